@@ -1,0 +1,161 @@
+/* diskrag_oracle.c -- CPU restatement of the reference's graph-search hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT. Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
+ * leg may load this library, and only as the checker / reported CPU baseline. The product path
+ * (diskrag_amd/, libdiskrag_hip.so) never links, imports or calls it and has no CPU fallback.
+ *
+ * What is restated (file:line into the reference, Jolara-ai/diskrag):
+ *   A1 exact squared L2            search_engine.py:374-379        np.sum(diff*diff): numpy pairwise order
+ *   A2 PQ distance table           pydiskann/pq/fast_pq.py:294-318 per-row np.sum, n = sub_dim
+ *   A3 ADC                         pydiskann/pq/fast_pq.py:320-333 sequential f32 sum over sub-quantisers, sqrt
+ *   A4 rerank policy               search_engine.py:381-397
+ *   M1 PQ-accelerated disk search  search_engine.py:398-506
+ *   M2 exact disk beam search      pydiskann/vamana_graph.py:719-760
+ *   M3 in-memory beam search       pydiskann/vamana_graph.py:535-605 (+ distance dispatch :301-329)
+ *   M4 in-memory greedy search     pydiskann/vamana_graph.py:607-640; Cython twin cython_utils.pyx:72-122
+ *   heapq                          CPython Lib/heapq.py (tie order of the returned lists depends on it, Q11)
+ *
+ * Parity pinning: every function here is checked in tests/test_oracle_golden.py against golden vectors that
+ * tests/golden/gen_golden.py produced by running the reference itself (imported from /root/reference in the
+ * dev container). M1 and M3-with-PQ are pinned bit-exactly (ids, float bits, counters). M2/M4 use
+ * np.linalg.norm -> BLAS sdot and M3-without-PQ uses a -ffast-math Cython loop; their summation order is
+ * library/compiler specific, so those are pinned on ids with a near-tie allowance and on distances to 1e-4
+ * relative ("parity unpinned at bit level" for those three distance functions only).
+ *
+ * Build: oracle/Makefile (gcc -O2 -ffp-contract=off; no -ffast-math, no FMA contraction).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_PAD 0xFFFFFFFFu
+#define ORC_M1 1u
+#define ORC_M2 2u
+#define ORC_M3 3u
+#define ORC_M4 4u
+#define ORC_F_USE_PQ 1u   /* M3: use_pq=True */
+#define ORC_F_CYTHON 2u   /* M4: greedy_search_cython twin (squared L2 via l2_distance_fast_cython) */
+#define ORC_F_QUERY_F64 4u
+
+typedef struct {
+    uint64_t N;
+    uint32_t D, R, m, medoid;
+    const float *vectors;    /* [N][D]                         index.dat records, vector part  */
+    const uint32_t *adj;     /* [N][R]  ORC_PAD slots skipped  index.dat records, neighbour part (0-padded on disk) */
+    const uint8_t *codes;    /* [N][m] or NULL                 pq_codes.bin */
+    const float *codebook;   /* [m][256][D/m] or NULL          kmeans_list[j].cluster_centers_ */
+} orc_index;
+
+static inline float sqrt_real_f32(float x) { return sqrtf(x); }
+static inline double sqrt_real_f64(double x) { return sqrt(x); }
+
+#define REAL float
+#define SFX f32
+#include "oracle_core.inc"
+#undef REAL
+#undef SFX
+
+#define REAL double
+#define SFX f64
+#include "oracle_core.inc"
+#undef REAL
+#undef SFX
+
+/* ------------------------------------------------------------------------------------------------ C API */
+
+/* numpy-order squared L2 between a stored vector and a query (A1). */
+float orc_sqdist_f32(const float *v, const float *q, uint32_t n) { return pw_sqdiff_f32(v, q, n); }
+double orc_sqdist_f64(const float *v, const double *q, uint32_t n) { return pw_sqdiff_f64(v, q, n); }
+
+/* A2: lut[m][256] */
+void orc_build_lut_f32(const float *codebook, const float *q, uint32_t m, uint32_t sd, float *lut)
+{ build_lut_f32(codebook, q, m, sd, lut); }
+void orc_build_lut_f64(const float *codebook, const double *q, uint32_t m, uint32_t sd, float *lut)
+{ build_lut_f64(codebook, q, m, sd, lut); }
+
+/* A3: squared ADC and its sqrt for n codes */
+void orc_adc(const float *lut, const uint8_t *codes, uint64_t n, uint32_t m, float *out_sq, float *out_sqrt)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        float s = 0.0f;
+        for (uint32_t j = 0; j < m; j++) s += lut[j * 256 + codes[i * m + j]];
+        if (out_sq) out_sq[i] = s;
+        if (out_sqrt) out_sqrt[i] = sqrtf(s);
+    }
+}
+
+/* Search a batch of queries. queries: float[nq][D] (or double when flags & ORC_F_QUERY_F64).
+ * out_ids[nq][k] (ORC_PAD padded), out_dist[nq][k] (double; NaN padded), out_count[nq],
+ * stats[nq][4] = {search_steps, nodes_visited, exact_distance_computations, pq_distance_computations}.
+ * nthreads > 1 runs queries on OpenMP threads (used only by bench.py's cpu_baseline). Returns 0 or <0. */
+int orc_search_batch(const float *vectors, const uint32_t *adj, const uint8_t *codes, const float *codebook,
+                     uint64_t N, uint32_t D, uint32_t R, uint32_t m, uint32_t medoid,
+                     const void *queries, uint32_t nq, uint32_t mode, uint32_t k, uint32_t L, uint32_t bw,
+                     uint32_t policy, uint32_t flags, int nthreads,
+                     uint32_t *out_ids, double *out_dist, uint32_t *out_count, uint32_t *stats)
+{
+    orc_index ix = { N, D, R, m, medoid, vectors, adj, codes, codebook };
+    int rc_all = 0;
+    if (mode < ORC_M1 || mode > ORC_M4) return -1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int64_t i = 0; i < (int64_t)nq; i++) {
+        int rc;
+        uint32_t *st = stats ? stats + (size_t)i * 4 : NULL;
+        if (flags & ORC_F_QUERY_F64)
+            rc = search_one_f64(&ix, (const double *)queries + (size_t)i * D, mode, k, L, bw, policy, flags,
+                                out_ids + (size_t)i * k, out_dist + (size_t)i * k, out_count + i, st);
+        else
+            rc = search_one_f32(&ix, (const float *)queries + (size_t)i * D, mode, k, L, bw, policy, flags,
+                                out_ids + (size_t)i * k, out_dist + (size_t)i * k, out_count + i, st);
+        if (rc) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+            rc_all = rc;
+        }
+    }
+    return rc_all;
+}
+
+/* brute-force ground truth (squared L2, numpy order), k smallest ids per query: used for recall */
+void orc_bruteforce_topk(const float *vectors, uint64_t N, uint32_t D, const float *queries, uint32_t nq,
+                         uint32_t k, int nthreads, uint32_t *out_ids)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int64_t qi = 0; qi < (int64_t)nq; qi++) {
+        const float *q = queries + (size_t)qi * D;
+        float *bd = (float *)malloc(k * sizeof(float));
+        uint32_t *bi = out_ids + (size_t)qi * k;
+        uint32_t cnt = 0;
+        for (uint64_t i = 0; i < N; i++) {
+            float d = pw_sqdiff_f32(vectors + i * D, q, D);
+            if (cnt < k || d < bd[cnt - 1]) {
+                uint32_t p = cnt < k ? cnt++ : k - 1;
+                while (p > 0 && bd[p - 1] > d) { bd[p] = bd[p - 1]; bi[p] = bi[p - 1]; p--; }
+                bd[p] = d; bi[p] = (uint32_t)i;
+            }
+        }
+        for (uint32_t j = cnt; j < k; j++) bi[j] = ORC_PAD;
+        free(bd);
+    }
+}
+
+/* C8 scalar kernels (cython_utils.pyx:18-24, :53-70): one f32 accumulator in index order. */
+float orc_l2_seq_f32(const float *x, const float *y, uint32_t n)
+{
+    float s = 0.0f;
+    for (uint32_t i = 0; i < n; i++) s += (x[i] - y[i]) * (x[i] - y[i]);
+    return s;
+}
+float orc_cosine_dist_f32(const float *x, const float *y, uint32_t n)
+{
+    float dot = 0.0f, nx = 0.0f, ny = 0.0f;
+    for (uint32_t i = 0; i < n; i++) { dot += x[i] * y[i]; nx += x[i] * x[i]; ny += y[i] * y[i]; }
+    if (nx == 0.0f || ny == 0.0f) return 0.0f;
+    return (float)(1.0 - ((double)dot / (sqrt((double)nx) * sqrt((double)ny))));
+}
