@@ -1,0 +1,259 @@
+"""ctypes binding of libdiskrag_hip.so (include/diskrag_hip.h).
+
+No PyTorch, no CPU fallback: if the shared library is missing or no HIP device is visible every call raises.
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libdiskrag_hip.so"
+
+PAD = 0xFFFFFFFF
+MODE_M1, MODE_M2, MODE_M3, MODE_M4 = 1, 2, 3, 4
+F_USE_PQ, F_SQDIST = 1, 2
+
+E_ARG, E_NODEVICE, E_IO, E_NOPQ, E_OVERFLOW, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+
+
+class DrStats(C.Structure):
+    _fields_ = [("steps", C.c_uint32), ("visited", C.c_uint32), ("exact", C.c_uint32), ("pq", C.c_uint32),
+                ("status", C.c_uint32), ("inserts", C.c_uint32)]
+
+
+class DrTiming(C.Structure):
+    _fields_ = [("h2d_ms", C.c_float), ("search_kernel_ms", C.c_float), ("finalize_kernel_ms", C.c_float),
+                ("d2h_ms", C.c_float), ("total_ms", C.c_float), ("grid", C.c_uint32), ("block", C.c_uint32),
+                ("lds_bytes", C.c_uint32), ("waves_per_cu", C.c_uint32)]
+
+
+STATS_DTYPE = np.dtype([("steps", "<u4"), ("visited", "<u4"), ("exact", "<u4"), ("pq", "<u4"), ("status", "<u4"),
+                        ("inserts", "<u4")])
+
+# every symbol include/diskrag_hip.h declares
+EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create", "dr_index_set_pq",
+           "dr_index_set_adjacency", "dr_search_batch", "dr_batch_upload", "dr_batch_run", "dr_batch_download",
+           "dr_get_timing", "dr_exact_distances", "dr_distance_table", "dr_adc", "dr_pq_scan",
+           "dr_bruteforce_topk", "dr_get_node", "dr_index_close"]
+
+_lib = None
+
+
+class DiskragHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libdiskrag_hip error {code}: {msg}")
+        self.code = code
+
+
+def load_library():
+    """Loads libdiskrag_hip.so. Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C diskrag_amd/csrc` "
+                          f"(or __graft_entry__.build()). There is no CPU fallback.")
+    L = C.CDLL(str(LIB_PATH))
+    vp, fp, u8p, u32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+    L.dr_device_count.restype = C.c_int
+    L.dr_device_count.argtypes = []
+    L.dr_last_error.restype = C.c_char_p
+    L.dr_last_error.argtypes = []
+    L.dr_index_open.restype = C.c_int
+    L.dr_index_open.argtypes = [C.POINTER(vp), C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.dr_index_create.restype = C.c_int
+    L.dr_index_create.argtypes = [C.POINTER(vp), fp, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.dr_index_set_pq.restype = C.c_int
+    L.dr_index_set_pq.argtypes = [vp, fp, u8p, C.c_uint32]
+    L.dr_index_set_adjacency.restype = C.c_int
+    L.dr_index_set_adjacency.argtypes = [vp, u32p]
+    L.dr_search_batch.restype = C.c_int
+    L.dr_search_batch.argtypes = [vp, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  C.c_uint32, u32p, fp, u32p, C.POINTER(DrStats)]
+    L.dr_batch_upload.restype = C.c_int
+    L.dr_batch_upload.argtypes = [vp, fp, C.c_uint32]
+    L.dr_batch_run.restype = C.c_int
+    L.dr_batch_run.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.dr_batch_download.restype = C.c_int
+    L.dr_batch_download.argtypes = [vp, u32p, fp, u32p, C.POINTER(DrStats)]
+    L.dr_get_timing.restype = C.c_int
+    L.dr_get_timing.argtypes = [vp, C.POINTER(DrTiming)]
+    L.dr_exact_distances.restype = C.c_int
+    L.dr_exact_distances.argtypes = [vp, fp, C.c_uint32, u32p, C.c_uint32, fp]
+    L.dr_distance_table.restype = C.c_int
+    L.dr_distance_table.argtypes = [vp, fp, C.c_uint32, fp]
+    L.dr_adc.restype = C.c_int
+    L.dr_adc.argtypes = [vp, fp, C.c_uint32, u32p, C.c_uint32, fp, fp]
+    L.dr_pq_scan.restype = C.c_int
+    L.dr_pq_scan.argtypes = [vp, fp, C.c_uint32, fp, fp]
+    L.dr_bruteforce_topk.restype = C.c_int
+    L.dr_bruteforce_topk.argtypes = [vp, fp, C.c_uint32, C.c_uint32, u32p, fp]
+    L.dr_get_node.restype = C.c_int
+    L.dr_get_node.argtypes = [vp, C.c_uint64, fp, u32p]
+    L.dr_index_close.restype = None
+    L.dr_index_close.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load_library().dr_last_error()
+        raise DiskragHipError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+class HipIndex:
+    """An index resident in HBM (handle of the C ABI)."""
+
+    def __init__(self, handle, N, D, R, medoid):
+        self._h = handle
+        self.N, self.D, self.R, self.medoid = int(N), int(D), int(R), int(medoid)
+        self.m = 0
+
+    # -- construction
+    @classmethod
+    def open(cls, index_dat, N, D, R, medoid, device=0):
+        L = load_library()
+        h = C.c_void_p()
+        _check(L.dr_index_open(C.byref(h), str(index_dat).encode(), int(N), int(D), int(R), int(medoid), int(device)))
+        return cls(h, N, D, R, medoid)
+
+    @classmethod
+    def create(cls, vectors, adj, medoid, device=0):
+        L = load_library()
+        vectors = np.ascontiguousarray(vectors, dtype=np.float32)
+        adj = np.ascontiguousarray(adj, dtype=np.uint32)
+        N, D = vectors.shape
+        if adj.shape[0] != N:
+            raise ValueError("adjacency rows != number of vectors")
+        h = C.c_void_p()
+        _check(L.dr_index_create(C.byref(h), _p(vectors, C.c_float), _p(adj, C.c_uint32), N, D, adj.shape[1],
+                                 int(medoid), int(device)))
+        return cls(h, N, D, adj.shape[1], medoid)
+
+    def set_pq(self, codebook, codes):
+        codebook = np.ascontiguousarray(codebook, dtype=np.float32)
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        m = codes.shape[1]
+        if codebook.shape != (m, 256, self.D // m) or codes.shape[0] != self.N:
+            raise ValueError(f"PQ shapes do not match the index: codebook {codebook.shape}, codes {codes.shape}")
+        _check(load_library().dr_index_set_pq(self._h, _p(codebook, C.c_float), _p(codes, C.c_uint8), m))
+        self.m = m
+
+    def set_adjacency(self, adj):
+        adj = np.ascontiguousarray(adj, dtype=np.uint32)
+        if adj.shape != (self.N, self.R):
+            raise ValueError("adjacency shape mismatch")
+        _check(load_library().dr_index_set_adjacency(self._h, _p(adj, C.c_uint32)))
+
+    def close(self):
+        if self._h:
+            load_library().dr_index_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- search
+    def _queries(self, queries):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.D:
+            raise ValueError(f"query dimension {q.shape[1]} != index dimension {self.D}")
+        return q
+
+    def search_batch(self, queries, k, L=100, beam_width=0, mode=MODE_M1, band_policy=0, flags=0):
+        q = self._queries(queries)
+        nq = q.shape[0]
+        ids = np.empty((nq, k), dtype=np.uint32)
+        dist = np.empty((nq, k), dtype=np.float32)
+        cnt = np.empty(nq, dtype=np.uint32)
+        stats = np.empty(nq, dtype=STATS_DTYPE)
+        _check(load_library().dr_search_batch(self._h, _p(q, C.c_float), nq, int(k), int(L), int(beam_width or 0),
+                                              int(mode), int(band_policy), int(flags), _p(ids, C.c_uint32),
+                                              _p(dist, C.c_float), _p(cnt, C.c_uint32),
+                                              stats.ctypes.data_as(C.POINTER(DrStats))))
+        return ids, dist, cnt, stats
+
+    def batch_upload(self, queries):
+        q = self._queries(queries)
+        _check(load_library().dr_batch_upload(self._h, _p(q, C.c_float), q.shape[0]))
+        self._nq = q.shape[0]
+
+    def batch_run(self, k, L=100, beam_width=0, mode=MODE_M1, band_policy=0, flags=0):
+        _check(load_library().dr_batch_run(self._h, int(k), int(L), int(beam_width or 0), int(mode),
+                                           int(band_policy), int(flags)))
+        self._k = int(k)
+
+    def batch_download(self):
+        nq, k = self._nq, self._k
+        ids = np.empty((nq, k), dtype=np.uint32)
+        dist = np.empty((nq, k), dtype=np.float32)
+        cnt = np.empty(nq, dtype=np.uint32)
+        stats = np.empty(nq, dtype=STATS_DTYPE)
+        _check(load_library().dr_batch_download(self._h, _p(ids, C.c_uint32), _p(dist, C.c_float),
+                                                _p(cnt, C.c_uint32), stats.ctypes.data_as(C.POINTER(DrStats))))
+        return ids, dist, cnt, stats
+
+    def timing(self):
+        t = DrTiming()
+        _check(load_library().dr_get_timing(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in DrTiming._fields_}
+
+    # -- kernel-level seams (B5)
+    def exact_distances(self, queries, node_ids):
+        q = self._queries(queries)
+        ids = np.ascontiguousarray(node_ids, dtype=np.uint32)
+        out = np.empty((q.shape[0], ids.size), dtype=np.float32)
+        _check(load_library().dr_exact_distances(self._h, _p(q, C.c_float), q.shape[0], _p(ids, C.c_uint32),
+                                                 ids.size, _p(out, C.c_float)))
+        return out
+
+    def distance_table(self, queries):
+        q = self._queries(queries)
+        out = np.empty((q.shape[0], self.m, 256), dtype=np.float32)
+        _check(load_library().dr_distance_table(self._h, _p(q, C.c_float), q.shape[0], _p(out, C.c_float)))
+        return out
+
+    def adc(self, queries, node_ids):
+        q = self._queries(queries)
+        ids = np.ascontiguousarray(node_ids, dtype=np.uint32)
+        sq = np.empty((q.shape[0], ids.size), dtype=np.float32)
+        rt = np.empty((q.shape[0], ids.size), dtype=np.float32)
+        _check(load_library().dr_adc(self._h, _p(q, C.c_float), q.shape[0], _p(ids, C.c_uint32), ids.size,
+                                     _p(sq, C.c_float), _p(rt, C.c_float)))
+        return sq, rt
+
+    def pq_scan(self, queries, want_output=True):
+        q = self._queries(queries)
+        out = np.empty((q.shape[0], self.N), dtype=np.float32) if want_output else None
+        ms = C.c_float(0)
+        _check(load_library().dr_pq_scan(self._h, _p(q, C.c_float), q.shape[0], _p(out, C.c_float), C.byref(ms)))
+        return out, ms.value
+
+    def bruteforce_topk(self, queries, k):
+        q = self._queries(queries)
+        ids = np.empty((q.shape[0], k), dtype=np.uint32)
+        dist = np.empty((q.shape[0], k), dtype=np.float32)
+        _check(load_library().dr_bruteforce_topk(self._h, _p(q, C.c_float), q.shape[0], int(k), _p(ids, C.c_uint32),
+                                                 _p(dist, C.c_float)))
+        return ids, dist
+
+    def get_node(self, node_id):
+        vec = np.empty(self.D, dtype=np.float32)
+        nbrs = np.empty(self.R, dtype=np.uint32)
+        _check(load_library().dr_get_node(self._h, int(node_id), _p(vec, C.c_float), _p(nbrs, C.c_uint32)))
+        return vec, nbrs
+
+
+def device_count():
+    return load_library().dr_device_count()

@@ -1,0 +1,79 @@
+// aux_kernels.hpp -- per-dimension template kernels besides the search kernel: exact distances for listed nodes
+// and brute-force top-k (recall ground truth). Instantiated in search_d<D>.hip.
+#pragma once
+#include "search_kernel.hpp"
+
+// ---- kernel-level entry points ----------------------------------------------------------------------------
+// exact squared distances out[q][i] for node_ids[i]; one wave scores 8 nodes per pass (same device function as
+// the search kernel).
+template <int D> __global__ __launch_bounds__(64) void exact_kernel(const float *__restrict__ vecp,
+        const float *__restrict__ queries_p, u32 nq, const u32 *__restrict__ ids, u32 n, float *__restrict__ out)
+{
+    constexpr bool QREG = (D <= 256);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *qperm = reinterpret_cast<float *>(smem);
+    const int lane = threadIdx.x & 63, j = lane & 7, oct = lane >> 3;
+    const u32 q = blockIdx.y;
+    const float *qpg = queries_p + (size_t)q * D;
+    QueryRegs<D> qreg;
+    if constexpr (QREG) load_query_regs<0, D, D>(qpg, j, qreg);
+    else { for (int i = lane; i < D; i += 64) qperm[i] = qpg[i]; }
+    WSYNC();
+    for (u32 base = blockIdx.x * 8; base < n; base += gridDim.x * 8) {
+        const u32 idx = min(base + (u32)oct, n - 1);
+        const float e = pw_row_stream<0, D, D, QREG>(vecp + (size_t)ids[idx] * D, &qreg, qperm, j);
+        if (j == 0 && base + oct < n) out[(size_t)q * n + base + oct] = e;
+    }
+}
+
+// brute-force exact top-k (recall ground truth). One wave per query streams all N stored vectors, 8 per pass,
+// and keeps the k best in LDS (k <= 64), ties broken towards the smaller id.
+template <int D> __global__ __launch_bounds__(64) void bruteforce_kernel(const float *__restrict__ vecp, u64 N,
+        const float *__restrict__ queries_p, u32 nq, u32 k, u32 *__restrict__ out_ids, float *__restrict__ out_dist)
+{
+    constexpr bool QREG = (D <= 256);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *qperm = reinterpret_cast<float *>(smem);
+    u64 *best = reinterpret_cast<u64 *>(smem + (QREG ? 0 : (size_t)D * 4));
+    const int lane = threadIdx.x & 63, j = lane & 7, oct = lane >> 3;
+    const u32 q = blockIdx.x;
+    if (q >= nq) return;
+    const float *qpg = queries_p + (size_t)q * D;
+    QueryRegs<D> qreg;
+    if constexpr (QREG) load_query_regs<0, D, D>(qpg, j, qreg);
+    else { for (int i = lane; i < D; i += 64) qperm[i] = qpg[i]; }
+    if (lane < (int)k) best[lane] = ~0ull;
+    WSYNC();
+    int bn = 0;
+    float W = __uint_as_float(0x7F800000u);
+    for (u64 base = 0; base < N; base += 8) {
+        const u64 row = base + oct < N ? base + oct : N - 1;
+        const float e = pw_row_stream<0, D, D, QREG>(vecp + row * D, &qreg, qperm, j);
+        const bool cand = (j == 0) && (base + oct < N) && (bn < (int)k || e < W);
+        u64 cm = __ballot(cand);
+        while (cm) {
+            const int f = __ffsll((long long)cm) - 1;
+            cm &= cm - 1;
+            const float ef = __shfl(e, f);
+            const u32 idf = (u32)(base + (f >> 3));
+            if (bn < (int)k || ef < W) {
+                const u64 key = ((u64)__float_as_uint(ef) << 32) | idf;
+                // insert into ascending list of at most k keys (one lane per slot)
+                const u64 mine = (lane < bn) ? best[lane] : ~0ull;
+                const int pos = __popcll(__ballot(lane < bn && mine < key));
+                WSYNC();
+                if (lane < bn && lane >= pos && lane + 1 < (int)k) best[lane + 1] = mine;
+                if (lane == 0 && pos < (int)k) best[pos] = key;
+                WSYNC();
+                if (bn < (int)k) bn++;
+                if (bn == (int)k) W = key_dist(best[k - 1]);
+            }
+        }
+    }
+    WSYNC();
+    if (lane < (int)k) {
+        const u64 key = lane < bn ? best[lane] : ~0ull;
+        out_ids[(size_t)q * k + lane] = lane < bn ? (u32)key : 0xFFFFFFFFu;
+        out_dist[(size_t)q * k + lane] = lane < bn ? key_dist(key) : __uint_as_float(0x7FC00000u);
+    }
+}

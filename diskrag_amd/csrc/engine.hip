@@ -1,0 +1,567 @@
+// engine.hip -- host side of libdiskrag_hip.so: the C ABI declared in include/diskrag_hip.h.
+//
+// Index data lives in HBM for the life of the handle:
+//   vecp   [N][D] f32, chain-major tiles (numerics.hpp)        from index.dat records (T1)
+//   adj    [N][R] u32 + first-occurrence masks [N][ceil(R/64)] from index.dat records (T1)
+//   codes  [N][m] u8, codebook [m][256][D/m] f32               pq_codes.bin (T2), cluster centres (T3)
+// Scratch (per handle, grown on demand): device query buffers, per-workgroup visited tables, per-query result
+// lists, insert logs, stats; one HIP stream per handle; calls on a handle are serialised by a mutex.
+#include <hip/hip_runtime.h>
+
+#include <fcntl.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/diskrag_hip.h"
+#include "engine_kernels.hpp"
+#include "variants.hpp"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(DR_E_NODEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+const DimKernels *dr_dim_kernels(int D)
+{
+    switch (D) {
+    case 32: return dr_dim_kernels_32();
+    case 64: return dr_dim_kernels_64();
+    case 96: return dr_dim_kernels_96();
+    case 128: return dr_dim_kernels_128();
+    case 256: return dr_dim_kernels_256();
+    case 768: return dr_dim_kernels_768();
+    case 960: return dr_dim_kernels_960();
+    case 1536: return dr_dim_kernels_1536();
+    default: return nullptr;
+    }
+}
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int reserve(size_t want, bool zero = false)
+    {
+        if (want <= n) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) return fail(DR_E_NODEVICE, "hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
+        n = want;
+        if (zero) { e = hipMemset(p, 0, want * sizeof(T)); if (e != hipSuccess) return fail(DR_E_NODEVICE, "hipMemset failed"); }
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct dr_index {
+    int device = 0;
+    uint64_t N = 0;
+    uint32_t D = 0, R = 0, medoid = 0, m = 0, sd = 0;
+    const DimKernels *kern = nullptr;
+    int num_cu = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    std::mutex mu;
+
+    DevBuf<float> vecp;
+    DevBuf<uint32_t> adj;
+    DevBuf<u64> first;
+    DevBuf<uint8_t> codes;
+    DevBuf<float> codebook;
+    DevBuf<uint32_t> perm;
+    std::vector<uint32_t> h_perm;
+
+    // batch scratch
+    uint32_t nq = 0;             // queries currently resident
+    DevBuf<float> q, qp;
+    DevBuf<u64> vis;
+    DevBuf<uint32_t> vis_gen, counter, res_n, tie, out_ids, out_count;
+    DevBuf<u64> res_keys, log, heap;
+    DevBuf<KStats> stats;
+    DevBuf<float> out_dist;
+    uint32_t vis_slots = 0, vis_grid = 0;
+    uint32_t last_k = 0;
+    dr_timing timing = {};
+};
+
+extern "C" int dr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *dr_last_error(void) { return g_err.c_str(); }
+
+static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, uint32_t medoid, int device)
+{
+    if (N == 0 || D == 0 || R == 0) return fail(DR_E_ARG, "N, D and R must be positive");
+    if (medoid >= N) return fail(DR_E_ARG, "medoid %u out of range (N=%llu)", medoid, (unsigned long long)N);
+    if (N >= 0xFFFFFFFFull) return fail(DR_E_UNSUPPORTED, "N must fit in 32-bit ids");
+    ix->kern = dr_dim_kernels((int)D);
+    if (!ix->kern) return fail(DR_E_UNSUPPORTED, "unsupported vector dimension %u (built: 32,64,96,128,256,768,960,1536)", D);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DR_E_NODEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(DR_E_ARG, "device %d out of range (%d devices)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    ix->num_cu = prop.multiProcessorCount;
+    ix->device = device; ix->N = N; ix->D = D; ix->R = R; ix->medoid = medoid;
+    HIPCHK(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+    for (auto &e : ix->ev) HIPCHK(hipEventCreate(&e));
+    ix->h_perm.resize(D);
+    pw_build_perm_rec(0, D, ix->h_perm.data());
+    if (ix->perm.reserve(D)) return DR_E_NODEVICE;
+    HIPCHK(hipMemcpy(ix->perm.p, ix->h_perm.data(), D * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (ix->vecp.reserve((size_t)N * D)) return DR_E_NODEVICE;
+    if (ix->adj.reserve((size_t)N * R)) return DR_E_NODEVICE;
+    if (ix->first.reserve((size_t)N * ((R + 63) / 64))) return DR_E_NODEVICE;
+    return 0;
+}
+
+static int build_first_masks(dr_index *ix)
+{
+    DevBuf<uint32_t> bad;
+    if (bad.reserve(1, true)) return DR_E_NODEVICE;
+    const uint64_t rows_per_block = 4;
+    const uint64_t blocks = (ix->N + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(first_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, ix->stream, ix->adj.p, ix->N, ix->R,
+                       ix->N, ix->first.p, bad.p);
+    HIPCHK(hipGetLastError());
+    uint32_t hbad = 0;
+    HIPCHK(hipMemcpyAsync(&hbad, bad.p, 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    bad.release();
+    if (hbad) return fail(DR_E_ARG, "adjacency holds %u neighbour ids >= N", hbad);
+    return 0;
+}
+
+// uploads `rows` records starting at row0; src points at (vectors | raw records)
+static int ingest_chunk(dr_index *ix, const void *src, uint64_t row0, uint64_t rows, uint32_t rec_words, bool with_adj,
+                        DevBuf<uint32_t> &staging)
+{
+    if (staging.reserve((size_t)rows * rec_words)) return DR_E_NODEVICE;
+    HIPCHK(hipMemcpyAsync(staging.p, src, (size_t)rows * rec_words * 4, hipMemcpyHostToDevice, ix->stream));
+    hipLaunchKernelGGL(ingest_records_kernel, dim3((unsigned)rows), dim3(64), 0, ix->stream, staging.p, rows, ix->D,
+                       ix->R, rec_words, ix->perm.p, ix->vecp.p + (size_t)row0 * ix->D,
+                       with_adj ? ix->adj.p + (size_t)row0 * ix->R : nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    return 0;
+}
+
+extern "C" int dr_index_create(dr_index **out, const float *vectors, const uint32_t *adj, uint64_t N, uint32_t D,
+                               uint32_t R, uint32_t medoid, int device)
+{
+    if (!out || !vectors || !adj) return fail(DR_E_ARG, "null argument");
+    dr_index *ix = new dr_index();
+    int rc = index_alloc_common(ix, N, D, R, medoid, device);
+    if (rc) { dr_index_close(ix); return rc; }
+    DevBuf<uint32_t> staging;
+    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / (D * 4));
+    for (uint64_t r0 = 0; r0 < N && !rc; r0 += chunk) {
+        const uint64_t rows = std::min(chunk, N - r0);
+        rc = ingest_chunk(ix, vectors + (size_t)r0 * D, r0, rows, D, false, staging);
+    }
+    staging.release();
+    if (!rc && hipMemcpy(ix->adj.p, adj, (size_t)N * R * 4, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(DR_E_NODEVICE, "adjacency upload failed");
+    if (!rc) rc = build_first_masks(ix);
+    if (rc) { dr_index_close(ix); return rc; }
+    *out = ix;
+    return 0;
+}
+
+extern "C" int dr_index_open(dr_index **out, const char *index_dat, uint64_t N, uint32_t D, uint32_t R,
+                             uint32_t medoid, int device)
+{
+    if (!out || !index_dat) return fail(DR_E_ARG, "null argument");
+    int fd = open(index_dat, O_RDONLY);
+    if (fd < 0) return fail(DR_E_IO, "cannot open %s", index_dat);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return fail(DR_E_IO, "cannot stat %s", index_dat); }
+    const uint64_t rec_bytes = 4ull * (D + R);
+    if ((uint64_t)st.st_size != N * rec_bytes) {
+        close(fd);
+        return fail(DR_E_IO, "%s: size %lld != N*4*(D+R) = %llu (N=%llu D=%u R=%u)", index_dat, (long long)st.st_size,
+                    (unsigned long long)(N * rec_bytes), (unsigned long long)N, D, R);
+    }
+    void *map = mmap(nullptr, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return fail(DR_E_IO, "mmap failed for %s", index_dat);
+    dr_index *ix = new dr_index();
+    int rc = index_alloc_common(ix, N, D, R, medoid, device);
+    DevBuf<uint32_t> staging;
+    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / rec_bytes);
+    for (uint64_t r0 = 0; r0 < N && !rc; r0 += chunk) {
+        const uint64_t rows = std::min(chunk, N - r0);
+        rc = ingest_chunk(ix, (const char *)map + r0 * rec_bytes, r0, rows, D + R, true, staging);
+    }
+    staging.release();
+    munmap(map, st.st_size);
+    if (!rc) rc = build_first_masks(ix);
+    if (rc) { dr_index_close(ix); return rc; }
+    *out = ix;
+    return 0;
+}
+
+extern "C" int dr_index_set_adjacency(dr_index *ix, const uint32_t *adj)
+{
+    if (!ix || !adj) return fail(DR_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipMemcpy(ix->adj.p, adj, (size_t)ix->N * ix->R * 4, hipMemcpyHostToDevice));
+    return build_first_masks(ix);
+}
+
+extern "C" int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_t *codes, uint32_t m)
+{
+    if (!ix || !codebook || !codes) return fail(DR_E_ARG, "null argument");
+    if (m == 0 || ix->D % m) return fail(DR_E_ARG, "n_subvectors %u must divide D=%u", m, ix->D);
+    if (ix->D / m > 128) return fail(DR_E_UNSUPPORTED, "sub_dim %u > 128", ix->D / m);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIPCHK(hipSetDevice(ix->device));
+    if (ix->codes.reserve((size_t)ix->N * m)) return DR_E_NODEVICE;
+    if (ix->codebook.reserve((size_t)256 * ix->D)) return DR_E_NODEVICE;
+    HIPCHK(hipMemcpy(ix->codes.p, codes, (size_t)ix->N * m, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ix->codebook.p, codebook, (size_t)256 * ix->D * 4, hipMemcpyHostToDevice));
+    ix->m = m; ix->sd = ix->D / m;
+    return 0;
+}
+
+extern "C" void dr_index_close(dr_index *ix)
+{
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release();
+    ix->perm.release(); ix->q.release(); ix->qp.release(); ix->vis.release(); ix->vis_gen.release();
+    ix->counter.release(); ix->res_n.release(); ix->tie.release(); ix->out_ids.release(); ix->out_count.release();
+    ix->res_keys.release(); ix->log.release(); ix->heap.release(); ix->stats.release(); ix->out_dist.release();
+    for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
+    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+// ------------------------------------------------------------------------------------------------ batches
+
+static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq)
+{
+    if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
+    HIPCHK(hipSetDevice(ix->device));
+    if (ix->q.reserve((size_t)nq * ix->D) || ix->qp.reserve((size_t)nq * ix->D)) return DR_E_NODEVICE;
+    HIPCHK(hipEventRecord(ix->ev[0], ix->stream));
+    HIPCHK(hipMemcpyAsync(ix->q.p, queries, (size_t)nq * ix->D * 4, hipMemcpyHostToDevice, ix->stream));
+    hipLaunchKernelGGL(permute_queries_kernel, dim3(nq), dim3(64), 0, ix->stream, ix->q.p, nq, ix->D, ix->perm.p,
+                       ix->qp.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    ix->nq = nq;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]);
+    ix->timing.h2d_ms = ms;
+    return 0;
+}
+
+static uint32_t next_pow2(uint64_t v)
+{
+    uint64_t p = 1;
+    while (p < v) p <<= 1;
+    return (uint32_t)p;
+}
+
+static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_t mode, uint32_t policy, uint32_t flags)
+{
+    if (ix->nq == 0) return fail(DR_E_ARG, "no queries uploaded");
+    if (mode < DR_MODE_M1 || mode > DR_MODE_M4) return fail(DR_E_ARG, "unknown mode %u", mode);
+    if (k == 0) return fail(DR_E_ARG, "k must be positive");
+    const bool use_pq = (mode == DR_MODE_M1) || (mode == DR_MODE_M3 && (flags & DR_F_USE_PQ));
+    if (use_pq && ix->m == 0) return fail(DR_E_NOPQ, "mode %u needs PQ data (dr_index_set_pq)", mode);
+    // result-list capacity: M1/M4 L, M2 beam_width, M3 k (search_engine.py:468-474; vamana_graph.py:746-750, :586-590)
+    const uint32_t cap = (mode == DR_MODE_M2) ? bw : (mode == DR_MODE_M3) ? k : L;
+    if (cap == 0) return fail(DR_E_ARG, "result-list capacity is zero (L / beam_width / k)");
+    if (cap > 512) return fail(DR_E_UNSUPPORTED, "result-list capacity %u > 512", cap);
+    HIPCHK(hipSetDevice(ix->device));
+
+    const int sc = cap <= 64 ? 0 : cap <= 128 ? 1 : cap <= 256 ? 2 : 3;
+    static const int NCHR[4] = { 1, 2, 4, 8 }, NCHC[4] = { 2, 4, 8, 16 };
+    const int kind = (mode == DR_MODE_M1) ? 0 : (mode == DR_MODE_M3 && use_pq) ? 2 : 1;
+    const void *kfn = ix->kern->search[kind][sc];
+
+    const bool need_lut = kind != 1;
+    size_t lds = (need_lut ? (size_t)ix->m * 256 * 4 : 0) + (size_t)ix->D * 4 + (ix->D > 256 ? (size_t)ix->D * 4 : 0) +
+                 (size_t)NCHR[sc] * 512 + (size_t)NCHC[sc] * 512 + 512;
+    if (lds > 160 * 1024) return fail(DR_E_UNSUPPORTED, "LDS footprint %zu B exceeds 160 KiB", lds);
+    HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 64, lds));
+    if (occ < 1) occ = 1;
+    const uint32_t nq = ix->nq;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)occ * ix->num_cu);
+
+    // visited-set sizing: M1 is capped at min(10L, N) expansions (search_engine.py:429); the other variants are
+    // bounded by N. Tables are 2x the bound (power of two) up to 2^21 slots; overflow is flagged per query.
+    uint64_t max_steps = (mode == DR_MODE_M1) ? std::min<uint64_t>((uint64_t)L * 10, ix->N) : 0xFFFFFFFFull;
+    uint64_t bound = (mode == DR_MODE_M1) ? max_steps * ix->R + 1 : (uint64_t)std::max<uint32_t>(cap * 10, 1000) * ix->R + 1;
+    bound = std::min<uint64_t>(bound, ix->N + 64);
+    uint32_t slots = next_pow2(std::max<uint64_t>(bound * 2, 1024));
+    if (slots > (1u << 21)) slots = 1u << 21;
+    if (slots != ix->vis_slots || grid > ix->vis_grid) {
+        ix->vis.release();
+        if (ix->vis.reserve((size_t)slots * grid, true)) return DR_E_NODEVICE;
+        ix->vis_gen.release();
+        if (ix->vis_gen.reserve(grid, true)) return DR_E_NODEVICE;
+        ix->vis_slots = slots; ix->vis_grid = grid;
+    }
+    const uint32_t logcap = 4096;
+    if (ix->counter.reserve(1) || ix->res_n.reserve(nq) || ix->tie.reserve(nq) || ix->stats.reserve(nq) ||
+        ix->res_keys.reserve((size_t)nq * 512) || ix->log.reserve((size_t)nq * logcap) ||
+        ix->heap.reserve((size_t)nq * 513) || ix->out_ids.reserve((size_t)nq * std::max<uint32_t>(k, 64)) ||
+        ix->out_dist.reserve((size_t)nq * std::max<uint32_t>(k, 64)) || ix->out_count.reserve(nq))
+        return DR_E_NODEVICE;
+
+    SearchParams p;
+    memset(&p, 0, sizeof p);
+    p.vecp = ix->vecp.p; p.adj = ix->adj.p; p.first = ix->first.p; p.codes = ix->codes.p; p.codebook = ix->codebook.p;
+    p.queries = ix->q.p; p.queries_p = ix->qp.p;
+    p.N = ix->N; p.D = ix->D; p.R = ix->R; p.m = ix->m; p.sd = ix->sd; p.medoid = ix->medoid; p.nq = nq;
+    p.mode = mode; p.k = k; p.cap = cap; p.L = L; p.bw = bw; p.policy = policy; p.flags = flags;
+    p.norm = (mode == DR_MODE_M2 || (mode == DR_MODE_M4 && !(flags & DR_F_SQDIST))) ? 1u : 0u;
+    p.max_steps = (uint32_t)std::min<uint64_t>(max_steps, 0xFFFFFFFFull);
+    p.capC = (uint32_t)NCHC[sc] * 64;
+    p.vis = ix->vis.p; p.vis_slots = slots; p.vis_limit = slots / 2 + slots / 4; p.vis_gen = ix->vis_gen.p;
+    p.counter = ix->counter.p;
+    p.res_keys = ix->res_keys.p; p.res_n = ix->res_n.p; p.stats = ix->stats.p; p.tie = ix->tie.p;
+    p.log = ix->log.p; p.logcap = logcap;
+
+    HIPCHK(hipMemsetAsync(ix->counter.p, 0, 4, ix->stream));
+    HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
+    void *args[] = { &p };
+    HIPCHK(hipLaunchKernel(kfn, dim3(grid), dim3(64), args, lds, ix->stream));
+    HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
+
+    FinalizeParams f;
+    f.res_keys = ix->res_keys.p; f.res_n = ix->res_n.p; f.tie = ix->tie.p; f.log = ix->log.p; f.stats = ix->stats.p;
+    f.logcap = logcap; f.cap = cap; f.k = k; f.mode = mode; f.nq = nq; f.heap = ix->heap.p;
+    f.out_ids = ix->out_ids.p; f.out_dist = ix->out_dist.p; f.out_count = ix->out_count.p;
+    hipLaunchKernelGGL(finalize_kernel, dim3((nq + 63) / 64), dim3(64), 0, ix->stream, f);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    float a = 0, b = 0;
+    (void)hipEventElapsedTime(&a, ix->ev[2], ix->ev[3]);
+    (void)hipEventElapsedTime(&b, ix->ev[3], ix->ev[4]);
+    ix->timing.search_kernel_ms = a; ix->timing.finalize_kernel_ms = b;
+    ix->timing.grid = grid; ix->timing.block = 64; ix->timing.lds_bytes = (uint32_t)lds; ix->timing.waves_per_cu = (uint32_t)occ;
+    ix->last_k = k;
+    return 0;
+}
+
+static int download_locked(dr_index *ix, uint32_t *out_ids, float *out_dist, uint32_t *out_count, dr_stats *stats)
+{
+    if (ix->nq == 0 || ix->last_k == 0) return fail(DR_E_ARG, "nothing to download");
+    HIPCHK(hipSetDevice(ix->device));
+    const uint32_t nq = ix->nq, k = ix->last_k;
+    HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
+    if (out_ids) HIPCHK(hipMemcpyAsync(out_ids, ix->out_ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
+    if (out_dist) HIPCHK(hipMemcpyAsync(out_dist, ix->out_dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
+    if (out_count) HIPCHK(hipMemcpyAsync(out_count, ix->out_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ix->stream));
+    static_assert(sizeof(dr_stats) == sizeof(KStats), "stats layout");
+    if (stats) HIPCHK(hipMemcpyAsync(stats, ix->stats.p, (size_t)nq * sizeof(KStats), hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipEventRecord(ix->ev[5], ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ix->ev[4], ix->ev[5]);
+    ix->timing.d2h_ms = ms;
+    ix->timing.total_ms = ix->timing.h2d_ms + ix->timing.search_kernel_ms + ix->timing.finalize_kernel_ms + ms;
+    return 0;
+}
+
+extern "C" int dr_batch_upload(dr_index *ix, const float *queries, uint32_t nq)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    return upload_queries_locked(ix, queries, nq);
+}
+
+extern "C" int dr_batch_run(dr_index *ix, uint32_t k, uint32_t L, uint32_t beam_width, uint32_t mode,
+                            uint32_t band_policy, uint32_t flags)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    return run_locked(ix, k, L, beam_width, mode, band_policy, flags);
+}
+
+extern "C" int dr_batch_download(dr_index *ix, uint32_t *out_ids, float *out_dist, uint32_t *out_count, dr_stats *stats)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    return download_locked(ix, out_ids, out_dist, out_count, stats);
+}
+
+extern "C" int dr_get_timing(dr_index *ix, dr_timing *out)
+{
+    if (!ix || !out) return fail(DR_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    *out = ix->timing;
+    return 0;
+}
+
+extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t L,
+                               uint32_t beam_width, uint32_t mode, uint32_t band_policy, uint32_t flags,
+                               uint32_t *out_ids, float *out_dist, uint32_t *out_count, dr_stats *stats)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    if (!out_ids || !out_dist || !out_count) return fail(DR_E_ARG, "null output buffer");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = upload_queries_locked(ix, queries, nq);
+    if (!rc) rc = run_locked(ix, k, L, beam_width, mode, band_policy, flags);
+    if (!rc) rc = download_locked(ix, out_ids, out_dist, out_count, stats);
+    return rc;
+}
+
+// --------------------------------------------------------------------------------- kernel-level entry points
+
+extern "C" int dr_exact_distances(dr_index *ix, const float *queries, uint32_t nq, const uint32_t *node_ids, uint32_t n,
+                                  float *out)
+{
+    if (!ix || !queries || !node_ids || !out || nq == 0 || n == 0) return fail(DR_E_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    for (uint32_t i = 0; i < n; i++) if (node_ids[i] >= ix->N) return fail(DR_E_ARG, "node id %u out of range", node_ids[i]);
+    int rc = upload_queries_locked(ix, queries, nq);
+    if (rc) return rc;
+    DevBuf<uint32_t> ids; DevBuf<float> o;
+    if (ids.reserve(n) || o.reserve((size_t)nq * n)) return DR_E_NODEVICE;
+    HIPCHK(hipMemcpyAsync(ids.p, node_ids, (size_t)n * 4, hipMemcpyHostToDevice, ix->stream));
+    const float *vecp = ix->vecp.p; const float *qp = ix->qp.p; const uint32_t *idp = ids.p; float *op = o.p;
+    void *args[] = { &vecp, &qp, &nq, &idp, &n, &op };
+    const unsigned gx = std::min<unsigned>((n + 7) / 8, 1024);
+    HIPCHK(hipLaunchKernel(ix->kern->exact, dim3(gx, nq), dim3(64), args, (size_t)ix->D * 4, ix->stream));
+    HIPCHK(hipMemcpyAsync(out, o.p, (size_t)nq * n * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    ids.release(); o.release();
+    return 0;
+}
+
+extern "C" int dr_distance_table(dr_index *ix, const float *queries, uint32_t nq, float *out)
+{
+    if (!ix || !queries || !out || nq == 0) return fail(DR_E_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->m == 0) return fail(DR_E_NOPQ, "no PQ data");
+    int rc = upload_queries_locked(ix, queries, nq);
+    if (rc) return rc;
+    DevBuf<float> o;
+    if (o.reserve((size_t)nq * ix->m * 256)) return DR_E_NODEVICE;
+    const size_t lds = (size_t)ix->D * 4 + (size_t)ix->m * 256 * 4;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&lut_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lut_kernel, dim3(nq), dim3(64), lds, ix->stream, ix->codebook.p, ix->q.p, ix->D, ix->m, ix->sd, o.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, o.p, (size_t)nq * ix->m * 256 * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    o.release();
+    return 0;
+}
+
+static int adc_common(dr_index *ix, const float *queries, uint32_t nq, const uint32_t *node_ids, uint64_t n,
+                      float *out_sq, float *out_sqrt, float *kernel_ms)
+{
+    if (ix->m == 0) return fail(DR_E_NOPQ, "no PQ data");
+    int rc = upload_queries_locked(ix, queries, nq);
+    if (rc) return rc;
+    DevBuf<uint32_t> ids; DevBuf<float> o1, o2;
+    if (node_ids) {
+        for (uint64_t i = 0; i < n; i++) if (node_ids[i] >= ix->N) return fail(DR_E_ARG, "node id out of range");
+        if (ids.reserve(n)) return DR_E_NODEVICE;
+        HIPCHK(hipMemcpyAsync(ids.p, node_ids, n * 4, hipMemcpyHostToDevice, ix->stream));
+    }
+    if (out_sq && o1.reserve((size_t)nq * n)) return DR_E_NODEVICE;
+    if (out_sqrt && o2.reserve((size_t)nq * n)) return DR_E_NODEVICE;
+    const size_t lds = (size_t)ix->D * 4 + (size_t)ix->m * 256 * 4;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&adc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned gx = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ix->num_cu * 8);
+    HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
+    hipLaunchKernelGGL(adc_kernel, dim3(gx, nq), dim3(256), lds, ix->stream, ix->codebook.p, ix->q.p, ix->codes.p,
+                       node_ids ? ids.p : nullptr, n, ix->D, ix->m, ix->sd, out_sq ? o1.p : nullptr, out_sqrt ? o2.p : nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
+    if (out_sq) HIPCHK(hipMemcpyAsync(out_sq, o1.p, (size_t)nq * n * 4, hipMemcpyDeviceToHost, ix->stream));
+    if (out_sqrt) HIPCHK(hipMemcpyAsync(out_sqrt, o2.p, (size_t)nq * n * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ix->ev[2], ix->ev[3]);
+    ids.release(); o1.release(); o2.release();
+    return 0;
+}
+
+extern "C" int dr_adc(dr_index *ix, const float *queries, uint32_t nq, const uint32_t *node_ids, uint32_t n,
+                      float *out_sq, float *out_sqrt)
+{
+    if (!ix || !queries || !node_ids || nq == 0 || n == 0) return fail(DR_E_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    return adc_common(ix, queries, nq, node_ids, n, out_sq, out_sqrt, nullptr);
+}
+
+extern "C" int dr_pq_scan(dr_index *ix, const float *queries, uint32_t nq, float *out_sq, float *kernel_ms)
+{
+    if (!ix || !queries || nq == 0) return fail(DR_E_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    return adc_common(ix, queries, nq, nullptr, ix->N, out_sq, nullptr, kernel_ms);
+}
+
+extern "C" int dr_bruteforce_topk(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t *out_ids,
+                                  float *out_dist)
+{
+    if (!ix || !queries || !out_ids || nq == 0 || k == 0 || k > 64) return fail(DR_E_ARG, "bad argument (k <= 64)");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    int rc = upload_queries_locked(ix, queries, nq);
+    if (rc) return rc;
+    DevBuf<uint32_t> oi; DevBuf<float> od;
+    if (oi.reserve((size_t)nq * k) || od.reserve((size_t)nq * k)) return DR_E_NODEVICE;
+    const float *vecp = ix->vecp.p; const float *qp = ix->qp.p; uint64_t N = ix->N; uint32_t *oip = oi.p; float *odp = od.p;
+    void *args[] = { &vecp, &N, &qp, &nq, &k, &oip, &odp };
+    const size_t lds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 64 * 8;
+    HIPCHK(hipLaunchKernel(ix->kern->bruteforce, dim3(nq), dim3(64), args, lds, ix->stream));
+    HIPCHK(hipMemcpyAsync(out_ids, oi.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
+    if (out_dist) HIPCHK(hipMemcpyAsync(out_dist, od.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    oi.release(); od.release();
+    return 0;
+}
+
+extern "C" int dr_get_node(dr_index *ix, uint64_t node_id, float *out_vec, uint32_t *out_nbrs)
+{
+    if (!ix || !out_vec || !out_nbrs) return fail(DR_E_ARG, "null argument");
+    if (node_id >= ix->N) return fail(DR_E_ARG, "node id out of range");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIPCHK(hipSetDevice(ix->device));
+    std::vector<float> tmp(ix->D);
+    HIPCHK(hipMemcpy(tmp.data(), ix->vecp.p + node_id * ix->D, (size_t)ix->D * 4, hipMemcpyDeviceToHost));
+    for (uint32_t e = 0; e < ix->D; e++) out_vec[e] = tmp[ix->h_perm[e]];
+    HIPCHK(hipMemcpy(out_nbrs, ix->adj.p + node_id * ix->R, (size_t)ix->R * 4, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -1,0 +1,209 @@
+// engine_kernels.hpp -- dimension-independent kernels: ingest (record split + chain-major permutation), adjacency
+// masks, result finalisation (heap replay for the reference's tie order), PQ table / ADC entry points.
+// Included by engine.hip only.
+#pragma once
+#include "search_kernel.hpp"
+
+// ---- ingest ---------------------------------------------------------------------------------------------
+// index.dat record i = D float32 then R uint32 (diskann_persist.py:17-24). rec_words = D + R when the source is
+// a raw record buffer; vectors-only sources pass rec_words = D and adj_off = 0 with adj_out = nullptr.
+__global__ void ingest_records_kernel(const u32 *__restrict__ rec, u64 n, u32 D, u32 R, u32 rec_words,
+                                      const u32 *__restrict__ perm, float *__restrict__ vecp_out,
+                                      u32 *__restrict__ adj_out)
+{
+    const u64 row = blockIdx.x;
+    if (row >= n) return;
+    const u32 *src = rec + row * rec_words;
+    for (u32 e = threadIdx.x; e < D; e += blockDim.x) vecp_out[row * D + perm[e]] = __uint_as_float(src[e]);
+    if (adj_out)
+        for (u32 s = threadIdx.x; s < R; s += blockDim.x) adj_out[row * R + s] = src[D + s];
+}
+
+__global__ void permute_queries_kernel(const float *__restrict__ q, u32 nq, u32 D, const u32 *__restrict__ perm,
+                                       float *__restrict__ qp)
+{
+    const u32 row = blockIdx.x;
+    if (row >= nq) return;
+    for (u32 e = threadIdx.x; e < D; e += blockDim.x) qp[(size_t)row * D + perm[e]] = q[(size_t)row * D + e];
+}
+
+// first[row][w] bit s: slot 64w+s holds a real id (not DR_PAD) that did not occur in an earlier slot of the row.
+// The reference walks a row in stored order and skips ids already in `visited` (search_engine.py:444-448), so a
+// repeated id (notably several 0 pads, Q3) is scored at its first position only. bad[0] counts ids >= N.
+__global__ void first_mask_kernel(const u32 *__restrict__ adj, u64 n, u32 R, u64 N, u64 *__restrict__ first,
+                                  u32 *__restrict__ bad)
+{
+    const u64 row = (u64)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const u32 lane = threadIdx.x & 63;
+    const u32 nw = (R + 63) / 64;
+    const u32 *a = adj + row * R;
+    for (u32 w = 0; w < nw; w++) {
+        const u32 s = w * 64 + lane;
+        const u32 id = (s < R) ? a[s] : 0xFFFFFFFFu;
+        bool ok = (s < R) && id != 0xFFFFFFFFu;
+        if (ok && id >= N) { atomicAdd(bad, 1u); ok = false; }
+        // earlier occurrence in previous words
+        for (u32 t = 0; t < w * 64 && ok; t++) if (a[t] == id) ok = false;
+        // earlier occurrence inside this word
+        for (u32 t = 0; t < 64; t++) {
+            const u32 other = __shfl(id, t);
+            if (t < lane && other == id) ok = false;
+        }
+        const u64 m = __ballot(ok);
+        if (lane == 0) first[row * nw + w] = m;
+    }
+}
+
+// ---- finalize -------------------------------------------------------------------------------------------
+// The reference returns `results` (a heapq array of (-dist, id)) after a STABLE sort on distance only
+// (search_engine.py:483-488; vamana_graph.py:596-598 for M3 with key sqrt(d); :640 for M4), so equal
+// distances come out in heap-array order. The search kernel keeps the list sorted; only when the first k
+// entries contain equal sort keys is the heap replayed from the accepted-insert log with CPython's exact
+// sift rules (Lib/heapq.py) to recover that order. M2 sorts full (dist, id) tuples (vamana_graph.py:758).
+struct FinalizeParams {
+    const u64 *res_keys; const u32 *res_n; const u32 *tie; const u64 *log; const KStats *stats;
+    u32 logcap, cap, k, mode, nq;
+    u64 *heap;            // [nq][cap + 1] scratch
+    u32 *out_ids; float *out_dist; u32 *out_count;
+};
+
+// python tuple (-d, id) "less than" on keys (dist bits << 32 | ~id): x < y  <=>  key(x) > key(y)
+DEV bool py_lt(u64 x, u64 y) { return x > y; }
+
+DEV void py_siftdown(u64 *h, int startpos, int pos)
+{
+    const u64 newitem = h[pos];
+    while (pos > startpos) {
+        const int parentpos = (pos - 1) >> 1;
+        const u64 parent = h[parentpos];
+        if (py_lt(newitem, parent)) { h[pos] = parent; pos = parentpos; continue; }
+        break;
+    }
+    h[pos] = newitem;
+}
+DEV void py_siftup(u64 *h, int n, int pos)
+{
+    const int endpos = n, startpos = pos;
+    const u64 newitem = h[pos];
+    int childpos = 2 * pos + 1;
+    while (childpos < endpos) {
+        const int rightpos = childpos + 1;
+        if (rightpos < endpos && !py_lt(h[childpos], h[rightpos])) childpos = rightpos;
+        h[pos] = h[childpos];
+        pos = childpos;
+        childpos = 2 * pos + 1;
+    }
+    h[pos] = newitem;
+    py_siftdown(h, startpos, pos);
+}
+
+DEV float sort_key(u64 key, u32 mode)
+{
+    const float d = key_dist(key);
+    return mode == 3u ? f_sqrt(d) : d;
+}
+
+__global__ void finalize_kernel(const FinalizeParams p)
+{
+    const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= p.nq) return;
+    const int n = (int)p.res_n[q];
+    const int cnt = n < (int)p.k ? n : (int)p.k;
+    const u64 *keys = p.res_keys + (size_t)q * p.cap;
+    u32 *oid = p.out_ids + (size_t)q * p.k;
+    float *od = p.out_dist + (size_t)q * p.k;
+    for (int i = 0; i < cnt; i++) {
+        oid[i] = ~(u32)keys[i];
+        od[i] = sort_key(keys[i], p.mode);
+    }
+    for (int i = cnt; i < (int)p.k; i++) { oid[i] = 0xFFFFFFFFu; od[i] = __uint_as_float(0x7FC00000u); }
+    p.out_count[q] = (u32)cnt;
+    if (!p.tie[q]) return;
+
+    u64 *h = p.heap + (size_t)q * (p.cap + 1);
+    int hn = 0;
+    if (p.mode != 2u) {
+        u32 nins = p.stats[q].inserts;
+        if (nins > p.logcap) return;   // log overflowed (status bit is already set): order stays as is
+        const u64 *lg = p.log + (size_t)q * p.logcap;
+        for (u32 t = 0; t < nins; t++) {
+            const u64 e = lg[t];
+            h[hn] = (e & 0xFFFFFFFF00000000ull) | (u32)(~(u32)e);
+            hn++;
+            py_siftdown(h, 0, hn - 1);                 // heappush
+            if (hn > (int)p.cap) {                     // heappop
+                const u64 last = h[--hn];
+                if (hn) { h[0] = last; py_siftup(h, hn, 0); }
+            }
+        }
+    }
+    // walk equal-key groups that intersect the first cnt positions
+    int i = 0;
+    while (i < cnt) {
+        const float ki = sort_key(keys[i], p.mode);
+        int e = i + 1;
+        while (e < n && sort_key(keys[e], p.mode) == ki) e++;
+        if (e - i > 1) {
+            if (p.mode == 2u) {
+                // full tuple order: id ascending; the list holds equal distances with id descending
+                for (int t = 0; i + t < cnt && t < e - i; t++) oid[i + t] = ~(u32)keys[e - 1 - t];
+            } else {
+                // heap-array order: pick group members by increasing heap index
+                int last = -1;
+                for (int pos = i; pos < cnt && pos < e; pos++) {
+                    int best = 0x7FFFFFFF; u64 bestkey = 0;
+                    for (int g = i; g < e; g++) {
+                        int hi = -1;
+                        for (int t = 0; t < hn; t++) if (h[t] == keys[g]) { hi = t; break; }
+                        if (hi > last && hi < best) { best = hi; bestkey = keys[g]; }
+                    }
+                    if (best == 0x7FFFFFFF) break;
+                    oid[pos] = ~(u32)bestkey;
+                    od[pos] = sort_key(bestkey, p.mode);
+                    last = best;
+                }
+            }
+        }
+        i = e;
+    }
+}
+
+// ---- PQ entry points
+__global__ __launch_bounds__(64) void lut_kernel(const float *__restrict__ codebook, const float *__restrict__ queries,
+                                                 u32 D, u32 m, u32 sd, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *q = reinterpret_cast<float *>(smem);
+    float *lut = q + D;
+    const u32 qi = blockIdx.x;
+    for (u32 i = threadIdx.x; i < D; i += 64) q[i] = queries[(size_t)qi * D + i];
+    WSYNC();
+    build_lut_wave(lut, codebook, q, m, sd);
+    WSYNC();
+    for (u32 e = threadIdx.x; e < m * 256; e += 64) out[(size_t)qi * m * 256 + e] = lut[e];
+}
+
+// ADC for listed nodes (ids != nullptr) or a flat scan of all N codes (ids == nullptr): the table sits in LDS,
+// each lane owns one code word and adds its m table entries in sub-quantiser order.
+__global__ __launch_bounds__(256) void adc_kernel(const float *__restrict__ codebook, const float *__restrict__ queries,
+        const u8 *__restrict__ codes, const u32 *__restrict__ ids, u64 n, u32 D, u32 m, u32 sd,
+        float *__restrict__ out_sq, float *__restrict__ out_sqrt)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *q = reinterpret_cast<float *>(smem);
+    float *lut = q + D;
+    const u32 qi = blockIdx.y;
+    for (u32 i = threadIdx.x; i < D; i += blockDim.x) q[i] = queries[(size_t)qi * D + i];
+    __syncthreads();
+    for (u32 e = threadIdx.x; e < m * 256; e += blockDim.x)
+        lut[e] = pw_run_lane(codebook + (size_t)e * sd, q + (e >> 8) * sd, (int)sd);
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 node = ids ? ids[i] : i;
+        const float s = adc_lane(lut, codes + node * m, m);
+        if (out_sq) out_sq[(size_t)qi * n + i] = s;
+        if (out_sqrt) out_sqrt[(size_t)qi * n + i] = f_sqrt(s);
+    }
+}
+

@@ -1,0 +1,207 @@
+// numerics.hpp -- float32 arithmetic in the reference's summation orders, for gfx950 wavefronts.
+//
+// The reference computes exact distances with np.sum(diff*diff) (search_engine.py:378-379) and PQ table rows
+// with np.sum(diff*diff, axis=1) (pydiskann/pq/fast_pq.py:315-316). numpy sums a contiguous run with its
+// pairwise routine: n < 8 sequential; n <= 128 eight interleaved accumulators r[j] += a[8t+j] combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); n > 128 split at n/2 rounded down to a multiple of 8, recursively.
+// Returned neighbour ids depend on exact float comparisons, so the device code reproduces that order bit for
+// bit: products are rounded before they are added (no FMA), chains are accumulated in t order, and the
+// combine tree is fixed.
+//
+// Device layout ("chain-major tiles"): a 64-lane wave scores 8 stored vectors at a time, 8 lanes (an octet)
+// per vector, lane j of the octet owning accumulator chain j. For that lane's elements 8t+j to arrive as
+// 16-byte loads, each leaf of the pairwise tree is stored in HBM with groups of four consecutive steps
+// transposed: position off + g*32 + j*4 + u holds original element off + 8*(4g+u) + j. One
+// global_load_dwordx4 per lane then reads 128 contiguous bytes per vector and 1 KiB per wave instruction,
+// fully coalesced, and the lane adds its four values in step order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+#define DEV __device__ __forceinline__
+
+DEV float f_sub(float a, float b) { return __fsub_rn(a, b); }
+DEV float f_mul(float a, float b) { return __fmul_rn(a, b); }
+DEV float f_add(float a, float b) { return __fadd_rn(a, b); }
+DEV float f_sqrt(float a) { return __fsqrt_rn(a); }
+DEV float sqd(float v, float q) { float d = f_sub(v, q); return f_mul(d, d); }
+
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) across the 8 lanes of an octet; every lane ends with the sum
+// (float addition is commutative, so both partners of each exchange compute identical bits).
+DEV float octet_combine(float r)
+{
+    r = f_add(r, __shfl_xor(r, 1));
+    r = f_add(r, __shfl_xor(r, 2));
+    r = f_add(r, __shfl_xor(r, 4));
+    return r;
+}
+
+// ---- host/device description of the pairwise tree -------------------------------------------------------
+// perm[e] = position of original element e in the chain-major layout (host side, used at ingest and for
+// queries). D must be a multiple of 8.
+static inline void pw_build_perm_rec(uint32_t off, uint32_t n, uint32_t *perm)
+{
+    if (n <= 128) {
+        uint32_t S = n / 8, G = S / 4, rem = S % 4;
+        for (uint32_t t = 0; t < S; t++)
+            for (uint32_t j = 0; j < 8; j++) {
+                uint32_t e = off + 8 * t + j, g = t / 4, u = t % 4;
+                perm[e] = (g < G) ? off + g * 32 + j * 4 + u : off + G * 32 + j * rem + (t - 4 * G);
+            }
+    } else {
+        uint32_t n2 = n / 2;
+        n2 -= n2 % 8;
+        pw_build_perm_rec(off, n2, perm);
+        pw_build_perm_rec(off + n2, n - n2, perm);
+    }
+}
+
+// ---- query accessors ----------------------------------------------------------------------------------
+// The query lives in the same chain-major layout. Small D: the lane's D/8 elements sit in registers;
+// large D: in LDS, read as ds_read_b128 (octets read the same addresses: broadcast).
+template <int D> struct QueryRegs {
+    float v[D / 8];   // lane j: its chain elements in load order (leaf by leaf, group by group)
+};
+
+template <int OFF, int N> struct LeafInfo {
+    static constexpr int S = N / 8, G = S / 4, REM = S % 4;
+};
+
+// number of per-lane floats consumed before leaf OFF starts = OFF/8 (each leaf of n elements gives n/8 per lane)
+
+// Loads this lane's D/8 query elements from a chain-major query in memory (global or LDS).
+template <int OFF, int N, int D> DEV void load_query_regs(const float *qp, int j, QueryRegs<D> &q)
+{
+    if constexpr (N <= 128) {
+        constexpr int S = N / 8, G = S / 4, REM = S % 4;
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) q.v[OFF / 8 + g * 4 + u] = qp[OFF + g * 32 + j * 4 + u];
+#pragma unroll
+        for (int u = 0; u < REM; u++) q.v[OFF / 8 + G * 4 + u] = qp[OFF + G * 32 + j * REM + u];
+    } else {
+        constexpr int N2 = (N / 2) - ((N / 2) % 8);
+        load_query_regs<OFF, N2, D>(qp, j, q);
+        load_query_regs<OFF + N2, N - N2, D>(qp, j, q);
+    }
+}
+
+// ---- streaming form: loads and arithmetic interleaved (any D % 8 == 0) ----------------------------------
+// row: chain-major stored vector (global). qreg != nullptr -> registers, else qlds (chain-major, LDS).
+template <int OFF, int N, int D, bool QREG>
+DEV float pw_row_stream(const float *__restrict__ row, const QueryRegs<D> *qreg, const float *qlds, int j)
+{
+    if constexpr (N <= 128) {
+        constexpr int S = N / 8, G = S / 4, REM = S % 4;
+        float r = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + OFF + g * 32 + j * 4);
+            float4 qq;
+            if constexpr (QREG) {
+                qq.x = qreg->v[OFF / 8 + g * 4 + 0]; qq.y = qreg->v[OFF / 8 + g * 4 + 1];
+                qq.z = qreg->v[OFF / 8 + g * 4 + 2]; qq.w = qreg->v[OFF / 8 + g * 4 + 3];
+            } else {
+                qq = *reinterpret_cast<const float4 *>(qlds + OFF + g * 32 + j * 4);
+            }
+            const float s0 = sqd(v.x, qq.x), s1 = sqd(v.y, qq.y), s2 = sqd(v.z, qq.z), s3 = sqd(v.w, qq.w);
+            r = (g == 0) ? s0 : f_add(r, s0);   // numpy: r[j] = a[j], then r[j] += a[8t+j]
+            r = f_add(r, s1);
+            r = f_add(r, s2);
+            r = f_add(r, s3);
+        }
+#pragma unroll
+        for (int u = 0; u < REM; u++) {
+            const float v = row[OFF + G * 32 + j * REM + u];
+            float qq;
+            if constexpr (QREG) qq = qreg->v[OFF / 8 + G * 4 + u];
+            else qq = qlds[OFF + G * 32 + j * REM + u];
+            const float s = sqd(v, qq);
+            r = (G == 0 && u == 0) ? s : f_add(r, s);
+        }
+        return octet_combine(r);
+    } else {
+        constexpr int N2 = (N / 2) - ((N / 2) % 8);
+        const float a = pw_row_stream<OFF, N2, D, QREG>(row, qreg, qlds, j);
+        const float b = pw_row_stream<OFF + N2, N - N2, D, QREG>(row, qreg, qlds, j);
+        return f_add(a, b);
+    }
+}
+
+// ---- split form for small D: all loads of several rows first, arithmetic after ---------------------------
+// Valid when every leaf has S % 4 == 0 (D = 96, 128, 256, ...): a row is D/32 float4 per lane.
+template <int D> struct RowRegs { float4 g[D / 32]; };
+
+template <int OFF, int N, int D> DEV void row_load(const float *__restrict__ row, int j, RowRegs<D> &rr)
+{
+    if constexpr (N <= 128) {
+        constexpr int G = (N / 8) / 4;
+        static_assert((N / 8) % 4 == 0, "split form needs whole groups");
+#pragma unroll
+        for (int g = 0; g < G; g++) rr.g[OFF / 32 + g] = *reinterpret_cast<const float4 *>(row + OFF + g * 32 + j * 4);
+    } else {
+        constexpr int N2 = (N / 2) - ((N / 2) % 8);
+        row_load<OFF, N2, D>(row, j, rr);
+        row_load<OFF + N2, N - N2, D>(row, j, rr);
+    }
+}
+
+template <int OFF, int N, int D> DEV float row_reduce(const RowRegs<D> &rr, const QueryRegs<D> &q)
+{
+    if constexpr (N <= 128) {
+        constexpr int G = (N / 8) / 4;
+        float r = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const float4 v = rr.g[OFF / 32 + g];
+            const float s0 = sqd(v.x, q.v[OFF / 8 + g * 4 + 0]), s1 = sqd(v.y, q.v[OFF / 8 + g * 4 + 1]);
+            const float s2 = sqd(v.z, q.v[OFF / 8 + g * 4 + 2]), s3 = sqd(v.w, q.v[OFF / 8 + g * 4 + 3]);
+            r = (g == 0) ? s0 : f_add(r, s0);
+            r = f_add(r, s1);
+            r = f_add(r, s2);
+            r = f_add(r, s3);
+        }
+        return octet_combine(r);
+    } else {
+        constexpr int N2 = (N / 2) - ((N / 2) % 8);
+        const float a = row_reduce<OFF, N2, D>(rr, q);
+        const float b = row_reduce<OFF + N2, N - N2, D>(rr, q);
+        return f_add(a, b);
+    }
+}
+
+template <int D> constexpr bool split_form_ok()
+{
+    // every leaf of the pairwise tree must have a multiple of 32 elements (S % 4 == 0)
+    if (D <= 128) return (D % 32) == 0;
+    return false;
+}
+template <> constexpr bool split_form_ok<256>() { return true; }
+
+// ---- one lane, one short contiguous run (PQ table rows, n = sub_dim <= 128), original element order -----
+// A2: DiskANNPQ.compute_distance_table, fast_pq.py:294-318.
+DEV float pw_run_lane(const float *__restrict__ c, const float *q, int n)
+{
+    if (n < 8) {
+        float res = 0.0f;
+        for (int i = 0; i < n; i++) res = f_add(res, sqd(c[i], q[i]));
+        return res;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = sqd(c[j], q[j]);
+    int i = 8;
+    const int lim = n - (n % 8);
+    for (; i < lim; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = f_add(r[j], sqd(c[i + j], q[i + j]));
+    }
+    float res = f_add(f_add(f_add(r[0], r[1]), f_add(r[2], r[3])), f_add(f_add(r[4], r[5]), f_add(r[6], r[7])));
+    for (; i < n; i++) res = f_add(res, sqd(c[i], q[i]));
+    return res;
+}

@@ -1,0 +1,130 @@
+/* diskrag_hip.h -- C ABI of libdiskrag_hip.so, the MI355X (gfx950) Vamana beam-search engine.
+ *
+ * The reference (Jolara-ai/diskrag) has no FFI for search: its seam is Python method calls. Each entry point
+ * below names the reference interface it stands behind (file:line into the reference tree). The Python host
+ * layer (diskrag_amd/search_engine.py) binds these with ctypes and mirrors SearchEngineCorrect.
+ *
+ * Conventions: every function returns 0 on success or a negative DR_E_* code; dr_last_error() returns a
+ * thread-local message for the last failure on the calling thread. The caller owns every host buffer; the
+ * library copies index data to HBM and owns device memory until dr_index_close(). Calls on one handle may
+ * come from several threads (the reference shares one engine across request threads, search_engine.py:879):
+ * they are serialised internally. There is NO CPU fallback: without a HIP device every call fails.
+ */
+#ifndef DISKRAG_HIP_H
+#define DISKRAG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DR_PAD 0xFFFFFFFFu /* empty neighbour slot (in-memory graphs) / empty output slot */
+
+/* search variants */
+#define DR_MODE_M1 1u /* SearchEngineCorrect._pq_accelerated_graph_search   search_engine.py:398-506 */
+#define DR_MODE_M2 2u /* beam_search_from_disk                              pydiskann/vamana_graph.py:719-760 */
+#define DR_MODE_M3 3u /* beam_search_with_pq                                pydiskann/vamana_graph.py:535-605 */
+#define DR_MODE_M4 4u /* greedy_search / greedy_search_cython               vamana_graph.py:607-640, cython_utils.pyx:72-122 */
+
+/* flags */
+#define DR_F_USE_PQ 1u /* M3: use_pq=True (ADC-only traversal, vamana_graph.py:318-320) */
+#define DR_F_SQDIST 2u /* M4: Cython twin metric, squared L2 (cython_utils.pyx:18-24) instead of the L2 norm */
+
+/* error codes */
+#define DR_OK 0
+#define DR_E_ARG (-1)        /* bad argument (ValueError in the reference facade) */
+#define DR_E_NODEVICE (-2)   /* no HIP device / HIP runtime failure */
+#define DR_E_IO (-3)         /* index file missing or of the wrong size (search_engine.py:29-30) */
+#define DR_E_NOPQ (-4)       /* mode needs PQ data but dr_index_set_pq was not called */
+#define DR_E_OVERFLOW (-5)   /* a per-query work area overflowed (see dr_stats.status) */
+#define DR_E_UNSUPPORTED (-6)
+
+typedef struct dr_index dr_index;
+
+/* per-query counters: the keys of the stats dict search_engine.py:497-504 returns */
+typedef struct {
+    uint32_t steps;   /* search_steps */
+    uint32_t visited; /* nodes_visited = len(visited) */
+    uint32_t exact;   /* exact_distance_computations */
+    uint32_t pq;      /* pq_distance_computations */
+    uint32_t status;  /* 0 ok; bit0 visited-set overflow, bit1 frontier overflow, bit2 insert-log overflow */
+    uint32_t inserts; /* accepted result-list inserts (engine counter, not in the reference) */
+} dr_stats;
+
+/* timing of the last dr_search_batch / dr_batch_run on a handle, measured with HIP events on the engine's
+ * own stream (bench.py's roofline uses search_kernel_ms) */
+typedef struct {
+    float h2d_ms, search_kernel_ms, finalize_kernel_ms, d2h_ms, total_ms;
+    uint32_t grid, block, lds_bytes, waves_per_cu;
+} dr_timing;
+
+int dr_device_count(void);
+const char *dr_last_error(void);
+
+/* Opens an index from the reference's on-disk record file (T1, pydiskann/io/diskann_persist.py:17-24 writer,
+ * :219-230 MMapNodeReader.get_node): N records of D float32 then R uint32, no header. Replaces
+ * MMapNodeReader(index_path, dim, R) + meta["medoid_idx"] in SearchEngineCorrect.__init__
+ * (search_engine.py:74-79). */
+int dr_index_open(dr_index **out, const char *index_dat, uint64_t N, uint32_t D, uint32_t R, uint32_t medoid,
+                  int device);
+
+/* Same, from host arrays: vectors[N][D], adj[N][R] (DR_PAD slots are skipped; disk files pad with 0, which
+ * is NOT skipped -- quirk Q3, diskann_persist.py:23). */
+int dr_index_create(dr_index **out, const float *vectors, const uint32_t *adj, uint64_t N, uint32_t D,
+                    uint32_t R, uint32_t medoid, int device);
+
+/* Attaches PQ data: codebook[m][256][D/m] (kmeans_list[j].cluster_centers_, T3) and codes[N][m]
+ * (pq_codes.bin, T2, diskann_persist.py:30-31,205-206). Replaces load_pq_codebook/load_pq_codes in
+ * search_engine.py:55-59. */
+int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_t *codes, uint32_t m);
+
+/* Replaces the adjacency (same N, R) -- used for the in-memory graph variants whose neighbour order is the
+ * Python set order (vamana_graph.py:581, :629). */
+int dr_index_set_adjacency(dr_index *ix, const uint32_t *adj);
+
+/* Searches a batch. queries[nq][D] float32 on the host. Outputs (host): out_ids[nq][k] (DR_PAD padded),
+ * out_dist[nq][k] (NaN padded; M1: squared L2, M2/M4: L2 norm, M3: sqrt of the traversal metric, Q7),
+ * out_count[nq] (results may be shorter than k), stats[nq] (may be NULL).
+ *   L           result-list size (M1, M4); ignored by M2 (Q6) and M3
+ *   beam_width  frontier trim (M1/M2: heapq.nsmallest, 0 = none; M3: pops the smallest, Q9); M2 list size
+ *   band_policy Q2: the reference flips a coin (np.random.random() < 0.2) in the 0.8-1.2 band; 0 = always
+ *               rerank, 1 = never (the two deterministic policies the golden vectors are generated with)
+ * Stands behind _pq_accelerated_graph_search(q,k,L,beam_width) (search_engine.py:398) and
+ * _exact_graph_search(q,k,L) (search_engine.py:508). */
+int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width,
+                    uint32_t mode, uint32_t band_policy, uint32_t flags, uint32_t *out_ids, float *out_dist,
+                    uint32_t *out_count, dr_stats *stats);
+
+/* HBM-resident batches (bench.py: inputs already on the device when the timed region starts).
+ * dr_batch_upload copies queries to the device; dr_batch_run launches the search + finalize kernels on the
+ * engine stream and waits for them; dr_batch_download copies results back. */
+int dr_batch_upload(dr_index *ix, const float *queries, uint32_t nq);
+int dr_batch_run(dr_index *ix, uint32_t k, uint32_t L, uint32_t beam_width, uint32_t mode, uint32_t band_policy,
+                 uint32_t flags);
+int dr_batch_download(dr_index *ix, uint32_t *out_ids, float *out_dist, uint32_t *out_count, dr_stats *stats);
+int dr_get_timing(dr_index *ix, dr_timing *out);
+
+/* Kernel-level entry points (B5 seams: reader.get_node + np.sum, pq_model.compute_distance_table,
+ * pq_model.asymmetric_distance; diskann_persist.py:219, fast_pq.py:294-333). They run the same device
+ * functions as the search kernel. */
+int dr_exact_distances(dr_index *ix, const float *queries, uint32_t nq, const uint32_t *node_ids, uint32_t n,
+                       float *out /*[nq][n] squared L2*/);
+int dr_distance_table(dr_index *ix, const float *queries, uint32_t nq, float *out /*[nq][m][256]*/);
+int dr_adc(dr_index *ix, const float *queries, uint32_t nq, const uint32_t *node_ids, uint32_t n,
+           float *out_sq /*[nq][n]*/, float *out_sqrt /*[nq][n]*/);
+/* Flat PQ scan of all N codes against each query's table (bandwidth ceiling of the LUT-accumulate loop). */
+int dr_pq_scan(dr_index *ix, const float *queries, uint32_t nq, float *out_sq /*[nq][N]*/, float *kernel_ms);
+/* Brute-force exact top-k (recall ground truth), squared L2 in the A1 summation order. */
+int dr_bruteforce_topk(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t *out_ids,
+                       float *out_dist);
+
+/* Reads node i back from HBM in the reference's (vector, neighbours) form -- MMapNodeReader.get_node. */
+int dr_get_node(dr_index *ix, uint64_t node_id, float *out_vec /*[D]*/, uint32_t *out_nbrs /*[R]*/);
+
+void dr_index_close(dr_index *ix);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -37,6 +37,8 @@
 #define ORC_F_USE_PQ 1u   /* M3: use_pq=True */
 #define ORC_F_CYTHON 2u   /* M4: greedy_search_cython twin (squared L2 via l2_distance_fast_cython) */
 #define ORC_F_QUERY_F64 4u
+#define ORC_F_PAIRWISE 8u  /* squared-L2 modes: use the numpy pairwise order (what the device computes) instead of the
+                             sequential Cython loop, whose -ffast-math order is unpinned anyway */
 
 typedef struct {
     uint64_t N;

@@ -13,7 +13,7 @@ HERE = Path(__file__).resolve().parent
 LIB_PATH = HERE / "libdiskrag_oracle.so"
 PAD = 0xFFFFFFFF
 M1, M2, M3, M4 = 1, 2, 3, 4
-F_USE_PQ, F_CYTHON, F_QUERY_F64 = 1, 2, 4
+F_USE_PQ, F_CYTHON, F_QUERY_F64, F_PAIRWISE = 1, 2, 4, 8
 
 _lib = None
 
