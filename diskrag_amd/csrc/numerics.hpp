@@ -24,10 +24,15 @@ typedef uint8_t u8;
 
 #define DEV __device__ __forceinline__
 
-DEV float f_sub(float a, float b) { return __fsub_rn(a, b); }
-DEV float f_mul(float a, float b) { return __fmul_rn(a, b); }
-DEV float f_add(float a, float b) { return __fadd_rn(a, b); }
-DEV float f_sqrt(float a) { return __fsqrt_rn(a); }
+// IEEE round-to-nearest f32 operations, never contracted into FMA (the pragma covers this whole header's
+// functions even if the build drops -ffp-contract=off). sqrt must be the correctly rounded one: HIP's
+// __fsqrt_rn lowers to the approximate native sqrt, __builtin_sqrtf to the IEEE sequence
+// (-fhip-fp32-correctly-rounded-divide-sqrt, on by default).
+#pragma clang fp contract(off)
+DEV float f_sub(float a, float b) { return a - b; }
+DEV float f_mul(float a, float b) { return a * b; }
+DEV float f_add(float a, float b) { return a + b; }
+DEV float f_sqrt(float a) { return __builtin_sqrtf(a); }
 DEV float sqd(float v, float q) { float d = f_sub(v, q); return f_mul(d, d); }
 
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) across the 8 lanes of an octet; every lane ends with the sum
