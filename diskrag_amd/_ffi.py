@@ -35,7 +35,8 @@ STATS_DTYPE = np.dtype([("steps", "<u4"), ("visited", "<u4"), ("exact", "<u4"), 
 EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create", "dr_index_set_pq",
            "dr_index_set_adjacency", "dr_search_batch", "dr_batch_upload", "dr_batch_run", "dr_batch_download",
            "dr_get_timing", "dr_exact_distances", "dr_distance_table", "dr_adc", "dr_pq_scan",
-           "dr_bruteforce_topk", "dr_get_node", "dr_index_close"]
+           "dr_bruteforce_topk", "dr_get_node", "dr_index_close", "dr_index_create_empty", "dr_build_vamana",
+           "dr_get_adjacency", "dr_pq_train", "dr_pq_encode"]
 
 _lib = None
 
@@ -91,6 +92,17 @@ def load_library():
     L.dr_bruteforce_topk.argtypes = [vp, fp, C.c_uint32, C.c_uint32, u32p, fp]
     L.dr_get_node.restype = C.c_int
     L.dr_get_node.argtypes = [vp, C.c_uint64, fp, u32p]
+    L.dr_index_create_empty.restype = C.c_int
+    L.dr_index_create_empty.argtypes = [C.POINTER(vp), fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
+    L.dr_build_vamana.restype = C.c_int
+    L.dr_build_vamana.argtypes = [vp, C.c_uint32, C.c_float, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
+                                  u32p, fp]
+    L.dr_get_adjacency.restype = C.c_int
+    L.dr_get_adjacency.argtypes = [vp, u32p]
+    L.dr_pq_train.restype = C.c_int
+    L.dr_pq_train.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, fp]
+    L.dr_pq_encode.restype = C.c_int
+    L.dr_pq_encode.argtypes = [vp, fp, C.c_uint32, u8p]
     L.dr_index_close.restype = None
     L.dr_index_close.argtypes = [vp]
     _lib = L
@@ -135,6 +147,43 @@ class HipIndex:
         _check(L.dr_index_create(C.byref(h), _p(vectors, C.c_float), _p(adj, C.c_uint32), N, D, adj.shape[1],
                                  int(medoid), int(device)))
         return cls(h, N, D, adj.shape[1], medoid)
+
+    @classmethod
+    def create_empty(cls, vectors, R, device=0):
+        """Vectors only; the graph is then built on the device with build_vamana()."""
+        L = load_library()
+        vectors = np.ascontiguousarray(vectors, dtype=np.float32)
+        N, D = vectors.shape
+        h = C.c_void_p()
+        _check(L.dr_index_create_empty(C.byref(h), _p(vectors, C.c_float), N, D, int(R), int(device)))
+        return cls(h, N, D, R, 0)
+
+    def build_vamana(self, L_build=100, alpha=1.2, passes=2, seed=1, pad_with_zero=True, max_batch=0):
+        med = C.c_uint32(0)
+        secs = C.c_float(0)
+        _check(load_library().dr_build_vamana(self._h, int(L_build), float(alpha), int(passes), int(seed),
+                                              1 if pad_with_zero else 0, int(max_batch), C.byref(med),
+                                              C.byref(secs)))
+        self.medoid = int(med.value)
+        return self.medoid, float(secs.value)
+
+    def get_adjacency(self):
+        out = np.empty((self.N, self.R), dtype=np.uint32)
+        _check(load_library().dr_get_adjacency(self._h, _p(out, C.c_uint32)))
+        return out
+
+    def pq_train(self, m, n_sample=100000, iters=10, seed=42):
+        cb = np.empty((m, 256, self.D // m), dtype=np.float32)
+        _check(load_library().dr_pq_train(self._h, int(m), int(n_sample), int(iters), int(seed), _p(cb, C.c_float)))
+        return cb
+
+    def pq_encode(self, codebook, want_codes=False):
+        cb = np.ascontiguousarray(codebook, dtype=np.float32)
+        m = cb.shape[0]
+        codes = np.empty((self.N, m), dtype=np.uint8) if want_codes else None
+        _check(load_library().dr_pq_encode(self._h, _p(cb, C.c_float), m, _p(codes, C.c_uint8)))
+        self.m = m
+        return codes
 
     def set_pq(self, codebook, codes):
         codebook = np.ascontiguousarray(codebook, dtype=np.float32)

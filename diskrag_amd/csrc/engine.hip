@@ -24,6 +24,7 @@
 
 #include "../../include/diskrag_hip.h"
 #include "engine_kernels.hpp"
+#include "build_kernels.hpp"
 #include "variants.hpp"
 
 static thread_local std::string g_err;
@@ -296,8 +297,14 @@ static uint32_t next_pow2(uint64_t v)
     return (uint32_t)p;
 }
 
-static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_t mode, uint32_t policy, uint32_t flags)
+// Builder override: search over the under-construction rows (RX slots, degree array instead of first-masks),
+// queries already resident in ix->q / ix->qp, no finalize.
+struct BuildOverride { const uint32_t *adjb; const uint32_t *deg; uint32_t RX; uint32_t nq; };
+
+static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_t mode, uint32_t policy, uint32_t flags,
+                      const BuildOverride *ov = nullptr)
 {
+    if (ov) ix->nq = ov->nq;
     if (ix->nq == 0) return fail(DR_E_ARG, "no queries uploaded");
     if (mode < DR_MODE_M1 || mode > DR_MODE_M4) return fail(DR_E_ARG, "unknown mode %u", mode);
     if (k == 0) return fail(DR_E_ARG, "k must be positive");
@@ -328,7 +335,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // visited-set sizing: M1 is capped at min(10L, N) expansions (search_engine.py:429); the other variants are
     // bounded by N. Tables are 2x the bound (power of two) up to 2^21 slots; overflow is flagged per query.
     uint64_t max_steps = (mode == DR_MODE_M1) ? std::min<uint64_t>((uint64_t)L * 10, ix->N) : 0xFFFFFFFFull;
-    uint64_t bound = (mode == DR_MODE_M1) ? max_steps * ix->R + 1 : (uint64_t)std::max<uint32_t>(cap * 10, 1000) * ix->R + 1;
+    const uint32_t Reff = ov ? ov->RX : ix->R;
+    uint64_t bound = (mode == DR_MODE_M1) ? max_steps * Reff + 1 : (uint64_t)std::max<uint32_t>(cap * 10, 1000) * Reff + 1;
     bound = std::min<uint64_t>(bound, ix->N + 64);
     uint32_t slots = next_pow2(std::max<uint64_t>(bound * 2, 1024));
     if (slots > (1u << 21)) slots = 1u << 21;
@@ -359,12 +367,14 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.counter = ix->counter.p;
     p.res_keys = ix->res_keys.p; p.res_n = ix->res_n.p; p.stats = ix->stats.p; p.tie = ix->tie.p;
     p.log = ix->log.p; p.logcap = logcap;
+    if (ov) { p.adj = ov->adjb; p.first = nullptr; p.deg = ov->deg; p.R = ov->RX; p.logcap = 0; }
 
     HIPCHK(hipMemsetAsync(ix->counter.p, 0, 4, ix->stream));
     HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
     void *args[] = { &p };
     HIPCHK(hipLaunchKernel(kfn, dim3(grid), dim3(64), args, lds, ix->stream));
     HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
+    if (ov) return 0;   // the builder consumes res_keys / res_n directly on the stream
 
     FinalizeParams f;
     f.res_keys = ix->res_keys.p; f.res_n = ix->res_n.p; f.tie = ix->tie.p; f.log = ix->log.p; f.stats = ix->stats.p;
@@ -563,5 +573,268 @@ extern "C" int dr_get_node(dr_index *ix, uint64_t node_id, float *out_vec, uint3
     HIPCHK(hipMemcpy(tmp.data(), ix->vecp.p + node_id * ix->D, (size_t)ix->D * 4, hipMemcpyDeviceToHost));
     for (uint32_t e = 0; e < ix->D; e++) out_vec[e] = tmp[ix->h_perm[e]];
     HIPCHK(hipMemcpy(out_nbrs, ix->adj.p + node_id * ix->R, (size_t)ix->R * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ builder
+
+extern "C" int dr_index_create_empty(dr_index **out, const float *vectors, uint64_t N, uint32_t D, uint32_t R, int device)
+{
+    if (!out || !vectors) return fail(DR_E_ARG, "null argument");
+    dr_index *ix = new dr_index();
+    int rc = index_alloc_common(ix, N, D, R, 0, device);
+    if (rc) { dr_index_close(ix); return rc; }
+    DevBuf<uint32_t> staging;
+    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / (D * 4));
+    for (uint64_t r0 = 0; r0 < N && !rc; r0 += chunk) {
+        const uint64_t rows = std::min(chunk, N - r0);
+        rc = ingest_chunk(ix, vectors + (size_t)r0 * D, r0, rows, D, false, staging);
+    }
+    staging.release();
+    if (!rc && hipMemset(ix->adj.p, 0xFF, (size_t)N * R * 4) != hipSuccess) rc = fail(DR_E_NODEVICE, "memset failed");
+    if (!rc && hipMemset(ix->first.p, 0, (size_t)N * ((R + 63) / 64) * 8) != hipSuccess) rc = fail(DR_E_NODEVICE, "memset failed");
+    if (rc) { dr_index_close(ix); return rc; }
+    *out = ix;
+    return 0;
+}
+
+extern "C" int dr_get_adjacency(dr_index *ix, uint32_t *out)
+{
+    if (!ix || !out) return fail(DR_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipMemcpy(out, ix->adj.p, (size_t)ix->N * ix->R * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static uint64_t splitmix64(uint64_t &x)
+{
+    uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint32_t passes, uint64_t seed,
+                               uint32_t pad_with_zero, uint32_t max_batch, uint32_t *out_medoid, float *out_seconds)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    if (L_build == 0 || L_build > 256) return fail(DR_E_ARG, "L_build must be in 1..256");
+    if (ix->R > 128) return fail(DR_E_UNSUPPORTED, "builder supports R <= 128");
+    if (passes == 0) passes = 2;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIPCHK(hipSetDevice(ix->device));
+    const uint64_t N = ix->N;
+    const uint32_t D = ix->D, R = ix->R;
+    const uint32_t RX = R + 64;                       // slack slots for reverse edges inside one batch
+    if (max_batch == 0) max_batch = 32768;
+    hipEvent_t t0, t1;
+    HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
+    HIPCHK(hipEventRecord(t0, ix->stream));
+
+    // ---- medoid: stored vector nearest to the centroid (the reference samples, cython_utils.pyx:210-263)
+    {
+        DevBuf<double> acc;
+        if (acc.reserve(D, true)) return DR_E_NODEVICE;
+        hipLaunchKernelGGL(column_sum_kernel, dim3(1024), dim3(128), 0, ix->stream, ix->vecp.p, N, D, acc.p);
+        HIPCHK(hipGetLastError());
+        std::vector<double> hacc(D);
+        HIPCHK(hipMemcpyAsync(hacc.data(), acc.p, D * sizeof(double), hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        acc.release();
+        // acc is in chain-major positions: upload as an already-permuted query
+        std::vector<float> cq(D);
+        for (uint32_t e = 0; e < D; e++) cq[e] = (float)(hacc[e] / (double)N);
+        if (ix->q.reserve(D) || ix->qp.reserve(D)) return DR_E_NODEVICE;
+        HIPCHK(hipMemcpyAsync(ix->qp.p, cq.data(), D * 4, hipMemcpyHostToDevice, ix->stream));
+        DevBuf<uint32_t> oi; DevBuf<float> od;
+        if (oi.reserve(1) || od.reserve(1)) return DR_E_NODEVICE;
+        const float *vecp = ix->vecp.p; const float *qp = ix->qp.p; uint64_t NN = N; uint32_t one = 1; uint32_t *oip = oi.p; float *odp = od.p;
+        void *args[] = { &vecp, &NN, &qp, &one, &one, &oip, &odp };
+        const size_t lds = (D > 256 ? (size_t)D * 4 : 0) + 64 * 8;
+        HIPCHK(hipLaunchKernel(ix->kern->bruteforce, dim3(1), dim3(64), args, lds, ix->stream));
+        uint32_t med = 0;
+        HIPCHK(hipMemcpyAsync(&med, oi.p, 4, hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        oi.release(); od.release();
+        ix->medoid = med;
+    }
+
+    DevBuf<uint32_t> adjb, deg, order, fwd, fwd_n, ovf_list, ovf_count;
+    if (adjb.reserve((size_t)N * RX) || deg.reserve(N, true) || order.reserve(N) || fwd.reserve((size_t)max_batch * R) ||
+        fwd_n.reserve(max_batch) || ovf_list.reserve(N) || ovf_count.reserve(1))
+        return DR_E_NODEVICE;
+    HIPCHK(hipMemsetAsync(adjb.p, 0xFF, (size_t)N * RX * 4, ix->stream));
+    if (ix->q.reserve((size_t)max_batch * D) || ix->qp.reserve((size_t)max_batch * D)) return DR_E_NODEVICE;
+
+    const size_t prune_lds = (D > 256 ? (size_t)D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024;
+    std::vector<uint32_t> horder(N);
+    uint64_t rng = seed ? seed : 1;
+    int rc = 0;
+    for (uint32_t pass = 0; pass < passes && !rc; pass++) {
+        for (uint64_t i = 0; i < N; i++) horder[i] = (uint32_t)i;
+        for (uint64_t i = N - 1; i > 0; i--) { uint64_t jx = splitmix64(rng) % (i + 1); std::swap(horder[i], horder[jx]); }
+        HIPCHK(hipMemcpyAsync(order.p, horder.data(), N * 4, hipMemcpyHostToDevice, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        const float a = (pass == 0 && passes > 1) ? 1.0f : alpha;      // cython_utils.pyx:312
+        uint64_t done = 0;
+        uint32_t bsz = 1;
+        while (done < N && !rc) {
+            // batch sizes double while the graph is small (pass 0); later passes run at the cap
+            uint32_t b = (pass == 0) ? std::min<uint64_t>(bsz, std::max<uint64_t>(1, done / 16 + 1)) : max_batch;
+            b = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(b, max_batch), N - done);
+            const uint32_t *pts = order.p + done;
+            // 1. queries = the batch points' own vectors (already chain-major)
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(b), dim3(64), 0, ix->stream, ix->vecp.p, pts, b, D, ix->qp.p);
+            BuildOverride ov = { adjb.p, deg.p, RX, b };
+            rc = run_locked(ix, 1, L_build, 0, DR_MODE_M4, 0, DR_F_SQDIST, &ov);
+            if (rc) break;
+            // 2. prune -> forward rows
+            PruneParams pp;
+            pp.vecp = ix->vecp.p; pp.adjb = adjb.p; pp.deg = deg.p; pp.RX = RX; pp.R = R; pp.alpha = a;
+            pp.points = pts; pp.npoints = b; pp.res_keys = ix->res_keys.p; pp.res_n = ix->res_n.p; pp.cap = L_build;
+            pp.fwd = fwd.p; pp.fwd_n = fwd_n.p;
+            {
+                void *args[] = { &pp };
+                const unsigned g = std::min<unsigned>(b, (unsigned)ix->num_cu * 16);
+                HIPCHK(hipLaunchKernel(ix->kern->prune, dim3(g), dim3(64), args, prune_lds, ix->stream));
+            }
+            // 3. reverse edges
+            HIPCHK(hipMemsetAsync(ovf_count.p, 0, 4, ix->stream));
+            {
+                const uint64_t threads = (uint64_t)b * R;
+                hipLaunchKernelGGL(reverse_edges_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ix->stream,
+                                   adjb.p, deg.p, RX, R, pts, b, fwd.p, fwd_n.p, ovf_list.p, ovf_count.p, (uint32_t)N);
+                HIPCHK(hipGetLastError());
+            }
+            uint32_t novf = 0;
+            HIPCHK(hipMemcpyAsync(&novf, ovf_count.p, 4, hipMemcpyDeviceToHost, ix->stream));
+            HIPCHK(hipStreamSynchronize(ix->stream));
+            // 4. re-prune rows that grew past R
+            if (novf) {
+                novf = (uint32_t)std::min<uint64_t>(novf, N);
+                PruneParams po = pp;
+                po.points = ovf_list.p; po.npoints = novf; po.res_keys = nullptr; po.res_n = nullptr; po.cap = 0;
+                po.fwd = nullptr; po.fwd_n = nullptr;
+                void *args[] = { &po };
+                const unsigned g = std::min<unsigned>(novf, (unsigned)ix->num_cu * 16);
+                HIPCHK(hipLaunchKernel(ix->kern->prune, dim3(g), dim3(64), args, prune_lds, ix->stream));
+            }
+            done += b;
+            if (bsz < max_batch) bsz *= 2;
+        }
+    }
+    if (!rc) {
+        const uint64_t total = N * R;
+        hipLaunchKernelGGL(compact_adj_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ix->stream, adjb.p,
+                           deg.p, N, RX, R, pad_with_zero ? 0u : 0xFFFFFFFFu, ix->adj.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        rc = build_first_masks(ix);
+    }
+    HIPCHK(hipEventRecord(t1, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, t0, t1);
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    adjb.release(); deg.release(); order.release(); fwd.release(); fwd_n.release(); ovf_list.release(); ovf_count.release();
+    ix->nq = 0;
+    if (out_medoid) *out_medoid = ix->medoid;
+    if (out_seconds) *out_seconds = ms / 1000.0f;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------ PQ build
+
+static int pq_assign(dr_index *ix, const uint32_t *d_ids, uint64_t n, uint32_t m, const float *d_codebook, uint8_t *d_out)
+{
+    const uint32_t sd = ix->D / m;
+    const size_t lds = (size_t)256 * sd * 4;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned gx = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ix->num_cu * 4);
+    hipLaunchKernelGGL(pq_assign_kernel, dim3(gx, m), dim3(256), lds, ix->stream, ix->vecp.p, ix->perm.p, d_ids, n, ix->D, m, sd,
+                       d_codebook, d_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int dr_pq_train(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t iters, uint64_t seed, float *out_codebook)
+{
+    if (!ix || !out_codebook) return fail(DR_E_ARG, "null argument");
+    if (m == 0 || ix->D % m || ix->D / m > 128) return fail(DR_E_ARG, "bad n_subvectors %u for D=%u", m, ix->D);
+    if (ix->N < 256) return fail(DR_E_ARG, "need at least 256 vectors (fast_pq.py:212-213)");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIPCHK(hipSetDevice(ix->device));
+    const uint32_t D = ix->D, sd = D / m;
+    const uint32_t ns = (uint32_t)std::min<uint64_t>(n_sample ? n_sample : 100000, ix->N);
+    if (iters == 0) iters = 10;
+    // sample without replacement (partial Fisher-Yates over ids)
+    std::vector<uint32_t> ids(ns);
+    {
+        uint64_t rng = seed ? seed : 42;
+        if (ns == ix->N) { for (uint32_t i = 0; i < ns; i++) ids[i] = i; }
+        else {
+            std::vector<uint32_t> all(ix->N);
+            for (uint64_t i = 0; i < ix->N; i++) all[i] = (uint32_t)i;
+            for (uint32_t i = 0; i < ns; i++) { uint64_t jx = i + splitmix64(rng) % (ix->N - i); std::swap(all[i], all[jx]); ids[i] = all[i]; }
+        }
+    }
+    DevBuf<uint32_t> d_ids; DevBuf<float> d_x, d_cb; DevBuf<uint8_t> d_assign;
+    if (d_ids.reserve(ns) || d_x.reserve((size_t)ns * D) || d_cb.reserve((size_t)256 * D) || d_assign.reserve((size_t)ns * m))
+        return DR_E_NODEVICE;
+    HIPCHK(hipMemcpyAsync(d_ids.p, ids.data(), (size_t)ns * 4, hipMemcpyHostToDevice, ix->stream));
+    hipLaunchKernelGGL(gather_subvectors_kernel, dim3(ns), dim3(64), 0, ix->stream, ix->vecp.p, ix->perm.p, d_ids.p, ns, D, d_x.p);
+    HIPCHK(hipGetLastError());
+    std::vector<float> x((size_t)ns * D);
+    HIPCHK(hipMemcpyAsync(x.data(), d_x.p, (size_t)ns * D * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    // init: 256 distinct sample rows per sub-quantiser
+    std::vector<float> cb((size_t)m * 256 * sd);
+    for (uint32_t jq = 0; jq < m; jq++)
+        for (uint32_t c = 0; c < 256; c++) {
+            const uint32_t r = (uint32_t)(((uint64_t)c * ns) / 256 + jq) % ns;
+            memcpy(&cb[((size_t)jq * 256 + c) * sd], &x[(size_t)r * D + jq * sd], sd * 4);
+        }
+    std::vector<uint8_t> assign((size_t)ns * m);
+    std::vector<double> sums((size_t)256 * sd);
+    std::vector<uint32_t> cnt(256);
+    for (uint32_t it = 0; it < iters; it++) {
+        HIPCHK(hipMemcpyAsync(d_cb.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice, ix->stream));
+        int rc = pq_assign(ix, d_ids.p, ns, m, d_cb.p, d_assign.p);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(assign.data(), d_assign.p, assign.size(), hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        for (uint32_t jq = 0; jq < m; jq++) {
+            std::fill(sums.begin(), sums.end(), 0.0);
+            std::fill(cnt.begin(), cnt.end(), 0u);
+            for (uint32_t i = 0; i < ns; i++) {
+                const uint32_t c = assign[(size_t)i * m + jq];
+                cnt[c]++;
+                const float *xi = &x[(size_t)i * D + jq * sd];
+                for (uint32_t t = 0; t < sd; t++) sums[(size_t)c * sd + t] += xi[t];
+            }
+            for (uint32_t c = 0; c < 256; c++)
+                if (cnt[c])
+                    for (uint32_t t = 0; t < sd; t++) cb[((size_t)jq * 256 + c) * sd + t] = (float)(sums[(size_t)c * sd + t] / cnt[c]);
+        }
+    }
+    memcpy(out_codebook, cb.data(), cb.size() * 4);
+    d_ids.release(); d_x.release(); d_cb.release(); d_assign.release();
+    return 0;
+}
+
+extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uint8_t *out_codes)
+{
+    if (!ix || !codebook) return fail(DR_E_ARG, "null argument");
+    if (m == 0 || ix->D % m || ix->D / m > 128) return fail(DR_E_ARG, "bad n_subvectors %u for D=%u", m, ix->D);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIPCHK(hipSetDevice(ix->device));
+    if (ix->codes.reserve((size_t)ix->N * m) || ix->codebook.reserve((size_t)256 * ix->D)) return DR_E_NODEVICE;
+    HIPCHK(hipMemcpyAsync(ix->codebook.p, codebook, (size_t)256 * ix->D * 4, hipMemcpyHostToDevice, ix->stream));
+    int rc = pq_assign(ix, nullptr, ix->N, m, ix->codebook.p, ix->codes.p);
+    if (rc) return rc;
+    if (out_codes) HIPCHK(hipMemcpyAsync(out_codes, ix->codes.p, (size_t)ix->N * m, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    ix->m = m; ix->sd = ix->D / m;
     return 0;
 }

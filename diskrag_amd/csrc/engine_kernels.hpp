@@ -207,3 +207,98 @@ __global__ __launch_bounds__(256) void adc_kernel(const float *__restrict__ code
     }
 }
 
+
+// ---- builder helpers (build_kernels.hpp has the per-dimension prune kernel) ---------------------------------
+__global__ void gather_rows_kernel(const float *__restrict__ src, const u32 *__restrict__ ids, u32 n, u32 D,
+                                   float *__restrict__ dst)
+{
+    const u32 row = blockIdx.x;
+    if (row >= n) return;
+    const float *s = src + (size_t)ids[row] * D;
+    for (u32 e = threadIdx.x; e < D; e += blockDim.x) dst[(size_t)row * D + e] = s[e];
+}
+
+// Adds p to the row of each of its selected neighbours (cython_utils.pyx:338-348). Rows have RX >= R slots;
+// the thread that takes slot R reports the row for re-pruning (:350-356).
+__global__ void reverse_edges_kernel(u32 *__restrict__ adjb, u32 *__restrict__ deg, u32 RX, u32 R,
+                                     const u32 *__restrict__ points, u32 npoints, const u32 *__restrict__ fwd,
+                                     const u32 *__restrict__ fwd_n, u32 *__restrict__ ovf_list,
+                                     u32 *__restrict__ ovf_count, u32 ovf_cap)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 pi = t / R, s = t % R;
+    if (pi >= npoints || s >= fwd_n[pi]) return;
+    const u32 pt = points[pi];
+    const u32 n = fwd[(size_t)pi * R + s];
+    if (n == 0xFFFFFFFFu || n == pt) return;
+    u32 *row = adjb + (size_t)n * RX;
+    const u32 dn = min(__hip_atomic_load(&deg[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), RX);
+    for (u32 i = 0; i < dn; i++)
+        if (__hip_atomic_load(&row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pt) return;
+    const u32 slot = atomicAdd(&deg[n], 1u);
+    if (slot < RX) __hip_atomic_store(&row[slot], pt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (slot == R) {
+        const u32 k = atomicAdd(ovf_count, 1u);
+        if (k < ovf_cap) ovf_list[k] = n;
+    }
+}
+
+// Final rows: the first min(deg, R) ids, then `padval` (0 reproduces the reference writer, diskann_persist.py:23).
+__global__ void compact_adj_kernel(const u32 *__restrict__ adjb, const u32 *__restrict__ deg, u64 N, u32 RX, u32 R,
+                                   u32 padval, u32 *__restrict__ adj)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * R) return;
+    const u64 row = i / R;
+    const u32 s = (u32)(i % R);
+    const u32 d = min(deg[row], R);
+    adj[i] = s < d ? adjb[row * RX + s] : padval;
+}
+
+__global__ void column_sum_kernel(const float *__restrict__ vecp, u64 N, u32 D, double *__restrict__ acc)
+{
+    // one block per chunk of rows; thread e sums dimension e (+blockDim strides)
+    const u64 rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+    const u64 r0 = (u64)blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    for (u32 e = threadIdx.x; e < D; e += blockDim.x) {
+        double s = 0.0;
+        for (u64 r = r0; r < r1; r++) s += (double)vecp[r * D + e];
+        atomicAdd(&acc[e], s);
+    }
+}
+
+// ---- PQ training / encoding (DiskANNPQ.fit / encode, pq/fast_pq.py:197-267) -----------------
+// Nearest centroid of sub-vector j of stored vector ids[i] (or i when ids == nullptr); one thread per (i, j).
+// Distances are plain squared L2 in element order; ties go to the lowest centroid index (argmin).
+__global__ void pq_assign_kernel(const float *__restrict__ vecp, const u32 *__restrict__ perm,
+                                 const u32 *__restrict__ ids, u64 n, u32 D, u32 m, u32 sd,
+                                 const float *__restrict__ codebook, u8 *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *cb = reinterpret_cast<float *>(smem);          // codebook of sub-quantiser blockIdx.y: [256][sd]
+    const u32 jq = blockIdx.y;
+    for (u32 e = threadIdx.x; e < 256 * sd; e += blockDim.x) cb[e] = codebook[(size_t)jq * 256 * sd + e];
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 node = ids ? ids[i] : i;
+        float x[128];
+        for (u32 t = 0; t < sd; t++) x[t] = vecp[node * D + perm[jq * sd + t]];
+        float best = 3.4e38f;
+        u32 bi = 0;
+        for (u32 c = 0; c < 256; c++) {
+            float s = 0.0f;
+            for (u32 t = 0; t < sd; t++) { const float d = x[t] - cb[c * sd + t]; s += d * d; }
+            if (s < best) { best = s; bi = c; }
+        }
+        out[i * m + jq] = (u8)bi;
+    }
+}
+
+__global__ void gather_subvectors_kernel(const float *__restrict__ vecp, const u32 *__restrict__ perm,
+                                         const u32 *__restrict__ ids, u32 n, u32 D, float *__restrict__ out)
+{
+    // original element order, for the host-side centroid update
+    const u32 row = blockIdx.x;
+    if (row >= n) return;
+    for (u32 e = threadIdx.x; e < D; e += blockDim.x) out[(size_t)row * D + e] = vecp[(size_t)ids[row] * D + perm[e]];
+}

@@ -39,6 +39,7 @@ struct SearchParams {
     const float *vecp;       // [N][D] chain-major
     const u32 *adj;          // [N][R]
     const u64 *first;        // [N][ceil(R/64)] bit s: slot s is a real id and its first occurrence in the row
+    const u32 *deg;          // build mode (first == nullptr): rows hold deg[i] distinct ids, the rest is DR_PAD
     const u8 *codes;         // [N][m]
     const float *codebook;   // [m][256][sd]
     const float *queries;    // [nq][D] original element order
@@ -312,8 +313,13 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchParams p)
                 const u32 slot = cbase + lane;
                 u32 nbid = 0xFFFFFFFFu;
                 if (slot < p.R) nbid = p.adj[(size_t)cur * p.R + slot];
-                const u64 fm = p.first[(size_t)cur * nwords + (cbase >> 6)];
-                const bool active = ((fm >> lane) & 1ull) != 0ull;
+                bool active;
+                if (p.first) {
+                    const u64 fm = p.first[(size_t)cur * nwords + (cbase >> 6)];
+                    active = ((fm >> lane) & 1ull) != 0ull;
+                } else {
+                    active = slot < min(p.deg[cur], p.R) && nbid != 0xFFFFFFFFu;
+                }
                 const bool isnew = wave_visit(vtab, vmask, gen, nbid, active);
                 const u64 newmask = __ballot(isnew);
                 const int nnew = __popcll(newmask);

@@ -11,6 +11,7 @@ struct DimKernels {
     const void *search[3][DR_NUM_SIZECLASS];
     const void *exact;
     const void *bruteforce;
+    const void *prune;
 };
 const DimKernels *dr_dim_kernels(int D);
 

@@ -122,6 +122,28 @@ int dr_bruteforce_topk(dr_index *ix, const float *queries, uint32_t nq, uint32_t
 /* Reads node i back from HBM in the reference's (vector, neighbours) form -- MMapNodeReader.get_node. */
 int dr_get_node(dr_index *ix, uint64_t node_id, float *out_vec /*[D]*/, uint32_t *out_nbrs /*[R]*/);
 
+/* ---- index construction on the device (offline in the reference) -------------------------
+ * dr_index_create_empty uploads vectors only (all neighbour slots DR_PAD, medoid 0).
+ * dr_build_vamana builds the graph in place: batched form of build_vamana_index_cython
+ * (pydiskann/cython_utils.pyx:269-369: `passes` passes, alpha = 1 in the first, then `alpha`; greedy search with
+ * list size L_build; robust prune to R; reverse edges with re-prune), medoid = stored vector nearest to the
+ * centroid. pad_with_zero != 0 pads short rows with 0 exactly as DiskANNPersist.save_index does
+ * (diskann_persist.py:23, quirk Q3), otherwise with DR_PAD. dr_get_adjacency reads the rows back (to write
+ * index.dat with the reference's record layout). */
+int dr_index_create_empty(dr_index **out, const float *vectors, uint64_t N, uint32_t D, uint32_t R, int device);
+int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint32_t passes, uint64_t seed,
+                    uint32_t pad_with_zero, uint32_t max_batch, uint32_t *out_medoid, float *out_seconds);
+int dr_get_adjacency(dr_index *ix, uint32_t *out /*[N][R]*/);
+
+/* PQ build on the device. dr_pq_train: m independent Lloyd k-means with 256 centroids on a
+ * sample of the stored vectors (DiskANNPQ.fit, pq/fast_pq.py:197-243; sklearn's k-means++ / n_init restarts are
+ * not reproduced: codebooks are not bit-comparable, golden fixtures ship reference codebooks instead).
+ * dr_pq_encode: nearest-centroid codes for all N vectors (DiskANNPQ.encode, fast_pq.py:245-267), attached to
+ * the index like dr_index_set_pq; out_codes may be NULL. */
+int dr_pq_train(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t iters, uint64_t seed,
+                float *out_codebook /*[m][256][D/m]*/);
+int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uint8_t *out_codes /*[N][m] or NULL*/);
+
 void dr_index_close(dr_index *ix);
 
 #ifdef __cplusplus
