@@ -8,7 +8,8 @@ from pathlib import Path
 import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libdiskrag_hip.so"
+import os as _os
+LIB_PATH = Path(_os.environ["DR_LIB"]) if _os.environ.get("DR_LIB") else PKG_DIR / "libdiskrag_hip.so"
 
 PAD = 0xFFFFFFFF
 MODE_M1, MODE_M2, MODE_M3, MODE_M4 = 1, 2, 3, 4
@@ -36,7 +37,7 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_index_set_adjacency", "dr_search_batch", "dr_batch_upload", "dr_batch_run", "dr_batch_download",
            "dr_get_timing", "dr_exact_distances", "dr_distance_table", "dr_adc", "dr_pq_scan",
            "dr_bruteforce_topk", "dr_get_node", "dr_index_close", "dr_index_create_empty", "dr_build_vamana",
-           "dr_get_adjacency", "dr_pq_train", "dr_pq_encode"]
+           "dr_get_adjacency", "dr_pq_train", "dr_pq_encode", "dr_debug_phase_cycles"]
 
 _lib = None
 
@@ -103,6 +104,8 @@ def load_library():
     L.dr_pq_train.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, fp]
     L.dr_pq_encode.restype = C.c_int
     L.dr_pq_encode.argtypes = [vp, fp, C.c_uint32, u8p]
+    L.dr_debug_phase_cycles.restype = C.c_int
+    L.dr_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_double)]
     L.dr_index_close.restype = None
     L.dr_index_close.argtypes = [vp]
     _lib = L
@@ -296,6 +299,11 @@ class HipIndex:
         _check(load_library().dr_bruteforce_topk(self._h, _p(q, C.c_float), q.shape[0], int(k), _p(ids, C.c_uint32),
                                                  _p(dist, C.c_float)))
         return ids, dist
+
+    def debug_phase_cycles(self):
+        out = (C.c_double * 8)()
+        _check(load_library().dr_debug_phase_cycles(self._h, out))
+        return list(out)
 
     def get_node(self, node_id):
         vec = np.empty(self.D, dtype=np.float32)

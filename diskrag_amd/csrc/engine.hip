@@ -12,6 +12,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -99,12 +100,12 @@ struct dr_index {
     // batch scratch
     uint32_t nq = 0;             // queries currently resident
     DevBuf<float> q, qp;
-    DevBuf<u64> vis;
-    DevBuf<uint32_t> vis_gen, counter, res_n, tie, out_ids, out_count;
-    DevBuf<u64> res_keys, log, heap;
+    DevBuf<uint32_t> vis, vlog, counter, res_n, tie, out_ids, out_count;
+    size_t vis_zeroed = 0;
+    DevBuf<u64> res_keys, log;
     DevBuf<KStats> stats;
     DevBuf<float> out_dist;
-    uint32_t vis_slots = 0, vis_grid = 0;
+    DevBuf<u64> phase;
     uint32_t last_k = 0;
     dr_timing timing = {};
 };
@@ -261,9 +262,9 @@ extern "C" void dr_index_close(dr_index *ix)
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release();
-    ix->perm.release(); ix->q.release(); ix->qp.release(); ix->vis.release(); ix->vis_gen.release();
+    ix->perm.release(); ix->q.release(); ix->qp.release(); ix->vis.release(); ix->vlog.release();
     ix->counter.release(); ix->res_n.release(); ix->tie.release(); ix->out_ids.release(); ix->out_count.release();
-    ix->res_keys.release(); ix->log.release(); ix->heap.release(); ix->stats.release(); ix->out_dist.release();
+    ix->res_keys.release(); ix->log.release(); ix->stats.release(); ix->out_dist.release();
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
@@ -298,8 +299,10 @@ static uint32_t next_pow2(uint64_t v)
 }
 
 // Builder override: search over the under-construction rows (RX slots, degree array instead of first-masks),
-// queries already resident in ix->q / ix->qp, no finalize.
+// queries already resident in ix->q / ix->qp, no outputs besides res_keys / res_n.
 struct BuildOverride { const uint32_t *adjb; const uint32_t *deg; uint32_t RX; uint32_t nq; };
+
+static int g_force_kind = -1;   // test/diagnostic hook: DR_FORCE_KIND environment variable
 
 static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_t mode, uint32_t policy, uint32_t flags,
                       const BuildOverride *ov = nullptr)
@@ -317,40 +320,49 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     HIPCHK(hipSetDevice(ix->device));
 
     const int sc = cap <= 64 ? 0 : cap <= 128 ? 1 : cap <= 256 ? 2 : 3;
-    static const int NCHR[4] = { 1, 2, 4, 8 }, NCHC[4] = { 2, 4, 8, 16 };
-    const int kind = (mode == DR_MODE_M1) ? 0 : (mode == DR_MODE_M3 && use_pq) ? 2 : 1;
+    // kernel variant (variants.hpp): codebook-in-LDS multi-wave workgroups when the codebook fits (D <= 128)
+    int kind = (mode == DR_MODE_M1) ? 0 : (mode == DR_MODE_M3 && use_pq) ? 2 : 1;
+    if (kind != 1 && ix->kern->search[3][sc] && (size_t)256 * ix->D * 4 <= 128 * 1024) kind = (kind == 0) ? 3 : 5;
+    {
+        static bool env_read = false;
+        if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e) g_force_kind = atoi(e); env_read = true; }
+        if (g_force_kind >= 0 && g_force_kind < DR_NUM_KINDS && ix->kern->search[g_force_kind][sc] &&
+            DR_KIND_PQ[g_force_kind] == (kind != 1) && ((g_force_kind == 2 || g_force_kind == 5) == (kind == 2 || kind == 5)))
+            kind = g_force_kind;
+    }
     const void *kfn = ix->kern->search[kind][sc];
+    const int NW = DR_KIND_NW[kind];
+    const bool cb = DR_KIND_CB[kind], pq = DR_KIND_PQ[kind];
 
-    const bool need_lut = kind != 1;
-    size_t lds = (need_lut ? (size_t)ix->m * 256 * 4 : 0) + (size_t)ix->D * 4 + (ix->D > 256 ? (size_t)ix->D * 4 : 0) +
-                 (size_t)NCHR[sc] * 512 + (size_t)NCHC[sc] * 512 + 512;
+    const size_t per_wave = ((pq && !cb) ? (size_t)ix->m * 256 * 4 : 0) + (size_t)ix->D * 4 + (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 512;
+    const size_t lds = ((pq && cb) ? (size_t)256 * ix->D * 4 : 0) + (size_t)NW * per_wave;
     if (lds > 160 * 1024) return fail(DR_E_UNSUPPORTED, "LDS footprint %zu B exceeds 160 KiB", lds);
     HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int occ = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 64, lds));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 64 * NW, lds));
     if (occ < 1) occ = 1;
     const uint32_t nq = ix->nq;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)occ * ix->num_cu);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nq + NW - 1) / NW, (uint64_t)occ * ix->num_cu);
+    const uint32_t slots = grid * NW;
 
-    // visited-set sizing: M1 is capped at min(10L, N) expansions (search_engine.py:429); the other variants are
-    // bounded by N. Tables are 2x the bound (power of two) up to 2^21 slots; overflow is flagged per query.
-    uint64_t max_steps = (mode == DR_MODE_M1) ? std::min<uint64_t>((uint64_t)L * 10, ix->N) : 0xFFFFFFFFull;
+    // visited set: one bitmap of N bits per wavefront slot + a log of the ids a query touched (for clearing).
+    // M1 is capped at min(10L, N) expansions (search_engine.py:429); the other variants are bounded by N.
     const uint32_t Reff = ov ? ov->RX : ix->R;
+    uint64_t max_steps = (mode == DR_MODE_M1) ? std::min<uint64_t>((uint64_t)L * 10, ix->N) : 0xFFFFFFFFull;
     uint64_t bound = (mode == DR_MODE_M1) ? max_steps * Reff + 1 : (uint64_t)std::max<uint32_t>(cap * 10, 1000) * Reff + 1;
-    bound = std::min<uint64_t>(bound, ix->N + 64);
-    uint32_t slots = next_pow2(std::max<uint64_t>(bound * 2, 1024));
-    if (slots > (1u << 21)) slots = 1u << 21;
-    if (slots != ix->vis_slots || grid > ix->vis_grid) {
-        ix->vis.release();
-        if (ix->vis.reserve((size_t)slots * grid, true)) return DR_E_NODEVICE;
-        ix->vis_gen.release();
-        if (ix->vis_gen.reserve(grid, true)) return DR_E_NODEVICE;
-        ix->vis_slots = slots; ix->vis_grid = grid;
+    bound = std::min<uint64_t>(bound, ix->N) + 64;
+    const uint32_t vis_words = (uint32_t)((ix->N + 31) / 32);
+    const uint32_t vis_limit = (uint32_t)bound;
+    if (ix->vis.reserve((size_t)slots * vis_words)) return DR_E_NODEVICE;
+    if (ix->vis_zeroed < (size_t)slots * vis_words) {
+        HIPCHK(hipMemsetAsync(ix->vis.p, 0, ix->vis.n * 4, ix->stream));
+        ix->vis_zeroed = ix->vis.n;
     }
+    if (ix->vlog.reserve((size_t)slots * vis_limit)) return DR_E_NODEVICE;
     const uint32_t logcap = 4096;
-    if (ix->counter.reserve(1) || ix->res_n.reserve(nq) || ix->tie.reserve(nq) || ix->stats.reserve(nq) ||
+    if (ix->counter.reserve(2) || ix->res_n.reserve((size_t)nq * 2) || ix->tie.reserve(nq) || ix->stats.reserve(nq) ||
         ix->res_keys.reserve((size_t)nq * 512) || ix->log.reserve((size_t)nq * logcap) ||
-        ix->heap.reserve((size_t)nq * 513) || ix->out_ids.reserve((size_t)nq * std::max<uint32_t>(k, 64)) ||
+        ix->out_ids.reserve((size_t)nq * std::max<uint32_t>(k, 64)) ||
         ix->out_dist.reserve((size_t)nq * std::max<uint32_t>(k, 64)) || ix->out_count.reserve(nq))
         return DR_E_NODEVICE;
 
@@ -362,33 +374,60 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.mode = mode; p.k = k; p.cap = cap; p.L = L; p.bw = bw; p.policy = policy; p.flags = flags;
     p.norm = (mode == DR_MODE_M2 || (mode == DR_MODE_M4 && !(flags & DR_F_SQDIST))) ? 1u : 0u;
     p.max_steps = (uint32_t)std::min<uint64_t>(max_steps, 0xFFFFFFFFull);
-    p.capC = (uint32_t)NCHC[sc] * 64;
-    p.vis = ix->vis.p; p.vis_slots = slots; p.vis_limit = slots / 2 + slots / 4; p.vis_gen = ix->vis_gen.p;
+    p.vis = ix->vis.p; p.vis_words = vis_words; p.vlog = ix->vlog.p; p.vis_limit = vis_limit;
     p.counter = ix->counter.p;
-    p.res_keys = ix->res_keys.p; p.res_n = ix->res_n.p; p.stats = ix->stats.p; p.tie = ix->tie.p;
+    p.res_keys = ix->res_keys.p; p.res_n = ix->res_n.p; p.stats = ix->stats.p;
+    p.tie_list = ix->tie.p; p.tie_count = ix->counter.p + 1;
     p.log = ix->log.p; p.logcap = logcap;
-    if (ov) { p.adj = ov->adjb; p.first = nullptr; p.deg = ov->deg; p.R = ov->RX; p.logcap = 0; }
+    p.out_ids = ix->out_ids.p; p.out_dist = ix->out_dist.p; p.out_count = ix->out_count.p;
+    p.phase = nullptr;
+#ifdef DR_PHASE_TIMING
+    if (!ov) { if (ix->phase.reserve((size_t)nq * 8, true)) return DR_E_NODEVICE; p.phase = ix->phase.p; }
+#endif
+    if (ov) {
+        p.adj = ov->adjb; p.first = nullptr; p.deg = ov->deg; p.R = ov->RX; p.logcap = 0;
+        p.tie_list = nullptr; p.out_ids = nullptr; p.out_dist = nullptr; p.out_count = nullptr;
+    }
 
-    HIPCHK(hipMemsetAsync(ix->counter.p, 0, 4, ix->stream));
+    static const bool dbg = getenv("DR_DEBUG") != nullptr;
+    if (dbg) { fprintf(stderr, "[dr] search kind=%d sc=%d NW=%d grid=%u lds=%zu occ=%d nq=%u cap=%u slots=%u vis_words=%u vis_limit=%u\n", kind, sc, NW, grid, lds, occ, nq, cap, slots, vis_words, vis_limit); fflush(stderr); }
+    HIPCHK(hipMemsetAsync(ix->counter.p, 0, 8, ix->stream));
+#ifdef DR_BOUNDED_TICKETS
+    HIPCHK(hipMemsetAsync(ix->res_n.p + nq, 0, (size_t)nq * 4, ix->stream));
+#endif
     HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
     void *args[] = { &p };
-    HIPCHK(hipLaunchKernel(kfn, dim3(grid), dim3(64), args, lds, ix->stream));
+    HIPCHK(hipLaunchKernel(kfn, dim3(grid), dim3(64 * NW), args, lds, ix->stream));
     HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
     if (ov) return 0;   // the builder consumes res_keys / res_n directly on the stream
+    if (dbg) { HIPCHK(hipStreamSynchronize(ix->stream)); fprintf(stderr, "[dr] search kernel done\n"); fflush(stderr); }
 
+    // tie replay for the queries the search kernel listed (usually few): one lane per query, heaps in LDS
     FinalizeParams f;
-    f.res_keys = ix->res_keys.p; f.res_n = ix->res_n.p; f.tie = ix->tie.p; f.log = ix->log.p; f.stats = ix->stats.p;
-    f.logcap = logcap; f.cap = cap; f.k = k; f.mode = mode; f.nq = nq; f.heap = ix->heap.p;
-    f.out_ids = ix->out_ids.p; f.out_dist = ix->out_dist.p; f.out_count = ix->out_count.p;
-    hipLaunchKernelGGL(finalize_kernel, dim3((nq + 63) / 64), dim3(64), 0, ix->stream, f);
+    f.res_keys = ix->res_keys.p; f.res_n = ix->res_n.p; f.tie_list = ix->tie.p; f.tie_count = ix->counter.p + 1;
+    f.log = ix->log.p; f.stats = ix->stats.p;
+    f.logcap = logcap; f.cap = cap; f.k = k; f.mode = mode;
+    f.qpb = cap <= 128 ? 64 : cap <= 256 ? 32 : 16;
+    f.out_ids = ix->out_ids.p; f.out_dist = ix->out_dist.p;
+    const size_t flds = (size_t)(cap + 1) * f.qpb * 8;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+    hipLaunchKernelGGL(finalize_kernel, dim3((nq + f.qpb - 1) / f.qpb), dim3(64), flds, ix->stream, f);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
+    if (dbg) { fprintf(stderr, "[dr] finalize done\n"); fflush(stderr); }
+#ifdef DR_BOUNDED_TICKETS
+    { std::vector<uint32_t> hc(nq + 2); HIPCHK(hipMemcpy(hc.data(), ix->res_n.p + nq, (size_t)nq * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(hc.data() + nq, ix->counter.p, 8, hipMemcpyDeviceToHost));
+      uint32_t mx = 0, mn = 1u << 30; for (uint32_t i = 0; i < nq; i++) { mx = std::max(mx, hc[i]); mn = std::min(mn, hc[i]); }
+      fprintf(stderr, "[dr] handed-out counts min=%u max=%u final counter=%u tie_count=%u\n", mn, mx, hc[nq], hc[nq + 1]); fflush(stderr); }
+#endif
     float a = 0, b = 0;
     (void)hipEventElapsedTime(&a, ix->ev[2], ix->ev[3]);
     (void)hipEventElapsedTime(&b, ix->ev[3], ix->ev[4]);
     ix->timing.search_kernel_ms = a; ix->timing.finalize_kernel_ms = b;
-    ix->timing.grid = grid; ix->timing.block = 64; ix->timing.lds_bytes = (uint32_t)lds; ix->timing.waves_per_cu = (uint32_t)occ;
+    ix->timing.grid = grid; ix->timing.block = 64 * NW; ix->timing.lds_bytes = (uint32_t)lds;
+    ix->timing.waves_per_cu = (uint32_t)(occ * NW);
     ix->last_k = k;
     return 0;
 }
@@ -837,4 +876,21 @@ extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uin
     HIPCHK(hipStreamSynchronize(ix->stream));
     ix->m = m; ix->sd = ix->D / m;
     return 0;
+}
+
+// Diagnostic: per-phase shader-clock sums of the last search (library built with -DDR_PHASE_TIMING only).
+extern "C" int dr_debug_phase_cycles(dr_index *ix, double *out8)
+{
+    if (!ix || !out8) return fail(DR_E_ARG, "null argument");
+#ifdef DR_PHASE_TIMING
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (!ix->phase.p || ix->nq == 0) return fail(DR_E_ARG, "no timed search yet");
+    std::vector<u64> h((size_t)ix->nq * 8);
+    HIPCHK(hipMemcpy(h.data(), ix->phase.p, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    for (size_t q = 0; q < ix->nq; q++) for (int i = 0; i < 8; i++) out8[i] += (double)h[q * 8 + i];
+    return 0;
+#else
+    return fail(DR_E_UNSUPPORTED, "library was not built with -DDR_PHASE_TIMING");
+#endif
 }

@@ -58,44 +58,47 @@ __global__ void first_mask_kernel(const u32 *__restrict__ adj, u64 n, u32 R, u64
 // ---- finalize -------------------------------------------------------------------------------------------
 // The reference returns `results` (a heapq array of (-dist, id)) after a STABLE sort on distance only
 // (search_engine.py:483-488; vamana_graph.py:596-598 for M3 with key sqrt(d); :640 for M4), so equal
-// distances come out in heap-array order. The search kernel keeps the list sorted; only when the first k
-// entries contain equal sort keys is the heap replayed from the accepted-insert log with CPython's exact
-// sift rules (Lib/heapq.py) to recover that order. M2 sorts full (dist, id) tuples (vamana_graph.py:758).
+// distances come out in heap-array order. The search kernel keeps the list sorted and writes the answer itself;
+// only queries whose first k entries hold equal sort keys are listed for this kernel, which replays the heap
+// from the accepted-insert log with CPython's exact sift rules (Lib/heapq.py) to recover that order.
+// M2 sorts full (dist, id) tuples (vamana_graph.py:758): ids ascending inside a tie, no replay.
+// One lane per listed query; the lanes' heaps sit interleaved in LDS (element i of lane l at h[i*QPB + l]).
 struct FinalizeParams {
-    const u64 *res_keys; const u32 *res_n; const u32 *tie; const u64 *log; const KStats *stats;
-    u32 logcap, cap, k, mode, nq;
-    u64 *heap;            // [nq][cap + 1] scratch
-    u32 *out_ids; float *out_dist; u32 *out_count;
+    const u64 *res_keys; const u32 *res_n; const u32 *tie_list; const u32 *tie_count; const u64 *log;
+    const KStats *stats;
+    u32 logcap, cap, k, mode, qpb;
+    u32 *out_ids; float *out_dist;
 };
 
 // python tuple (-d, id) "less than" on keys (dist bits << 32 | ~id): x < y  <=>  key(x) > key(y)
 DEV bool py_lt(u64 x, u64 y) { return x > y; }
 
-DEV void py_siftdown(u64 *h, int startpos, int pos)
+#define HP(i) h[(size_t)(i) * qpb]
+DEV void py_siftdown(u64 *h, u32 qpb, int startpos, int pos)
 {
-    const u64 newitem = h[pos];
+    const u64 newitem = HP(pos);
     while (pos > startpos) {
         const int parentpos = (pos - 1) >> 1;
-        const u64 parent = h[parentpos];
-        if (py_lt(newitem, parent)) { h[pos] = parent; pos = parentpos; continue; }
+        const u64 parent = HP(parentpos);
+        if (py_lt(newitem, parent)) { HP(pos) = parent; pos = parentpos; continue; }
         break;
     }
-    h[pos] = newitem;
+    HP(pos) = newitem;
 }
-DEV void py_siftup(u64 *h, int n, int pos)
+DEV void py_siftup(u64 *h, u32 qpb, int n, int pos)
 {
     const int endpos = n, startpos = pos;
-    const u64 newitem = h[pos];
+    const u64 newitem = HP(pos);
     int childpos = 2 * pos + 1;
     while (childpos < endpos) {
         const int rightpos = childpos + 1;
-        if (rightpos < endpos && !py_lt(h[childpos], h[rightpos])) childpos = rightpos;
-        h[pos] = h[childpos];
+        if (rightpos < endpos && !py_lt(HP(childpos), HP(rightpos))) childpos = rightpos;
+        HP(pos) = HP(childpos);
         pos = childpos;
         childpos = 2 * pos + 1;
     }
-    h[pos] = newitem;
-    py_siftdown(h, startpos, pos);
+    HP(pos) = newitem;
+    py_siftdown(h, qpb, startpos, pos);
 }
 
 DEV float sort_key(u64 key, u32 mode)
@@ -106,35 +109,32 @@ DEV float sort_key(u64 key, u32 mode)
 
 __global__ void finalize_kernel(const FinalizeParams p)
 {
-    const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= p.nq) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 qpb = p.qpb;
+    const u32 ntie = *p.tie_count;
+    const u32 t = blockIdx.x * qpb + threadIdx.x;
+    if (threadIdx.x >= qpb || t >= ntie) return;
+    const u32 q = p.tie_list[t];
+    u64 *h = reinterpret_cast<u64 *>(smem) + threadIdx.x;
     const int n = (int)p.res_n[q];
     const int cnt = n < (int)p.k ? n : (int)p.k;
     const u64 *keys = p.res_keys + (size_t)q * p.cap;
     u32 *oid = p.out_ids + (size_t)q * p.k;
     float *od = p.out_dist + (size_t)q * p.k;
-    for (int i = 0; i < cnt; i++) {
-        oid[i] = ~(u32)keys[i];
-        od[i] = sort_key(keys[i], p.mode);
-    }
-    for (int i = cnt; i < (int)p.k; i++) { oid[i] = 0xFFFFFFFFu; od[i] = __uint_as_float(0x7FC00000u); }
-    p.out_count[q] = (u32)cnt;
-    if (!p.tie[q]) return;
 
-    u64 *h = p.heap + (size_t)q * (p.cap + 1);
     int hn = 0;
     if (p.mode != 2u) {
-        u32 nins = p.stats[q].inserts;
+        const u32 nins = p.stats[q].inserts;
         if (nins > p.logcap) return;   // log overflowed (status bit is already set): order stays as is
         const u64 *lg = p.log + (size_t)q * p.logcap;
-        for (u32 t = 0; t < nins; t++) {
-            const u64 e = lg[t];
-            h[hn] = (e & 0xFFFFFFFF00000000ull) | (u32)(~(u32)e);
+        for (u32 i = 0; i < nins; i++) {
+            const u64 e = lg[i];
+            HP(hn) = (e & 0xFFFFFFFF00000000ull) | (u32)(~(u32)e);
             hn++;
-            py_siftdown(h, 0, hn - 1);                 // heappush
+            py_siftdown(h, qpb, 0, hn - 1);            // heappush
             if (hn > (int)p.cap) {                     // heappop
-                const u64 last = h[--hn];
-                if (hn) { h[0] = last; py_siftup(h, hn, 0); }
+                const u64 last = HP(--hn);
+                if (hn) { HP(0) = last; py_siftup(h, qpb, hn, 0); }
             }
         }
     }
@@ -147,7 +147,7 @@ __global__ void finalize_kernel(const FinalizeParams p)
         if (e - i > 1) {
             if (p.mode == 2u) {
                 // full tuple order: id ascending; the list holds equal distances with id descending
-                for (int t = 0; i + t < cnt && t < e - i; t++) oid[i + t] = ~(u32)keys[e - 1 - t];
+                for (int u = 0; i + u < cnt && u < e - i; u++) oid[i + u] = ~(u32)keys[e - 1 - u];
             } else {
                 // heap-array order: pick group members by increasing heap index
                 int last = -1;
@@ -155,7 +155,7 @@ __global__ void finalize_kernel(const FinalizeParams p)
                     int best = 0x7FFFFFFF; u64 bestkey = 0;
                     for (int g = i; g < e; g++) {
                         int hi = -1;
-                        for (int t = 0; t < hn; t++) if (h[t] == keys[g]) { hi = t; break; }
+                        for (int u = 0; u < hn; u++) if (HP(u) == keys[g]) { hi = u; break; }
                         if (hi > last && hi < best) { best = hi; bestkey = keys[g]; }
                     }
                     if (best == 0x7FFFFFFF) break;
@@ -168,6 +168,7 @@ __global__ void finalize_kernel(const FinalizeParams p)
         i = e;
     }
 }
+#undef HP
 
 // ---- PQ entry points
 __global__ __launch_bounds__(64) void lut_kernel(const float *__restrict__ codebook, const float *__restrict__ queries,
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void adc_kernel(const float *__restrict__ code
     __syncthreads();
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
         const u64 node = ids ? ids[i] : i;
-        const float s = adc_lane(lut, codes + node * m, m);
+        const float s = adc_lane<false>(lut, q, sd, codes + node * m, m);
         if (out_sq) out_sq[(size_t)qi * n + i] = s;
         if (out_sqrt) out_sqrt[(size_t)qi * n + i] = f_sqrt(s);
     }

@@ -1,4 +1,4 @@
-// search_kernel.hpp -- the beam-search kernel: one 64-lane wavefront per query, persistent workgroups.
+// search_kernel.hpp -- the beam-search kernel: one 64-lane wavefront per query, persistent wavefronts.
 //
 // Reference control flow restated (file:line into Jolara-ai/diskrag):
 //   M1 search_engine.py:398-506, M2 pydiskann/vamana_graph.py:719-760, M3 :535-605, M4 :607-640.
@@ -6,11 +6,17 @@
 // order, insert the accepted ones into a bounded result list and the frontier, optionally trim the frontier --
 // and differ in distance function, result-list capacity, stop rule and trim rule (SearchParams).
 //
-// Per-query state:
-//   LDS   PQ distance table T[m][256] f32 (A2), the query, result list and frontier as sorted arrays of
-//         64-bit keys (distance bits << 32 | id), a 64-entry staging area for one expansion
-//   HBM   exact visited set: open-addressed table of (generation << 32 | id) words per workgroup
-//         (generation tags make clearing unnecessary); accepted-insert log per query (tie replay)
+// Where a query's state lives:
+//   VGPRs  result list and frontier as sorted arrays of 64-bit keys (distance bits << 32 | id), one element per
+//          lane per 64-entry chunk; inserts are a ballot (position) plus one DPP wave shift per chunk -- no LDS
+//          round trips on the sequential path; the query (chain-major) for D <= 256
+//   LDS    PQ data for ADC: either the whole codebook shared by all wavefronts of the workgroup (D <= 128:
+//          4*256*D bytes <= 128 KiB; table entries T[j][c] are recomputed per neighbour in the reference's order,
+//          which lets 8-16 queries share a CU instead of the 4 that per-query tables allow), or the per-query
+//          table T[m][256] (larger D); the query in original order; a 64-entry staging area per expansion
+//   HBM    exact visited set: one bitmap per wavefront slot, tested-and-set with a single atomicOr per
+//          neighbour (one memory round trip), cleared after the query from a log of the touched ids;
+//          accepted-insert log per query (tie replay in finalize)
 //
 // Sequential semantics kept exactly: the neighbours of one expansion are scored in parallel (distances do not
 // depend on list state) and then DECIDED in stored order by a wave-uniform loop that runs once per accepted
@@ -19,17 +25,27 @@
 #pragma once
 #include "numerics.hpp"
 
-// A workgroup is ONE wavefront: LDS operations of a wave execute in issue order, so cross-lane hand-offs through
-// LDS only need the compiler not to reorder them. DR_HEAVY_SYNC swaps in a full barrier for debugging.
-#ifdef DR_HEAVY_SYNC
-#define WSYNC() __syncthreads()
-#else
+// A wavefront's LDS operations execute in issue order, so cross-lane hand-offs through LDS inside ONE wave only
+// need the compiler not to reorder them.
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// Diagnostic build (-DDR_PHASE_TIMING): per-phase shader-clock sums per query (SearchParams::phase). Each stamp
+// drains the wave's memory queues first, so the build is slower than the real one: read shares, not totals.
+#ifdef DR_PHASE_TIMING
+#define PH_STAMP(t) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory")
+#define PH_BEGIN() u64 ph_acc[8] = {0,0,0,0,0,0,0,0}; u64 ph_t0, ph_t1; PH_STAMP(ph_t0)
+#define PH(i) do { PH_STAMP(ph_t1); ph_acc[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; } while (0)
+#define PH_END(qi) do { if (lane == 0 && p.phase) for (int i_ = 0; i_ < 8; i_++) p.phase[(size_t)(qi) * 8 + i_] = ph_acc[i_]; } while (0)
+#else
+#define PH_BEGIN() do {} while (0)
+#define PH(i) do {} while (0)
+#define PH_END(qi) do {} while (0)
 #endif
 
 #define DR_ST_VIS_OVERFLOW 1u
 #define DR_ST_CAND_OVERFLOW 2u
 #define DR_ST_LOG_OVERFLOW 4u
+#define DR_ST_INTERNAL 8u      // a loop guard fired (never expected; bounds every loop so a bug cannot hang the GPU)
 
 enum DistKind { DIST_EXACT = 0, DIST_ADC_SQ = 2 };
 
@@ -49,194 +65,263 @@ struct SearchParams {
     u32 mode, k, cap, L, bw, policy, flags;
     u32 norm;                // 1: traversal metric is sqrt(squared L2) (M2, M4: np.linalg.norm)
     u32 max_steps;           // M1: min(10L, N); others: 0xFFFFFFFF
-    u32 capC;                // frontier ring capacity (power of two)
-    u64 *vis;                // [grid][vis_slots]
-    u32 vis_slots;           // power of two
-    u32 vis_limit;           // max entries before overflow is flagged
-    u32 *vis_gen;            // [grid]
-    u32 *counter;            // next query ticket
+    u32 *vis;                // [slots][vis_words] visited bitmaps (all zero between queries)
+    u32 vis_words;
+    u32 *vlog;               // [slots][vis_limit] ids set in the bitmap by the running query
+    u32 vis_limit;
+    u32 *counter;            // [2]: unused, tie-list length
     u64 *res_keys;           // [nq][cap] ascending (dist bits << 32 | ~id)
     u32 *res_n;              // [nq]
     KStats *stats;           // [nq]
-    u32 *tie;                // [nq] 1 = finalize must replay the heap
+    u32 *tie_list;           // queries whose first k results hold equal sort keys (finalize replays their heap)
+    u32 *tie_count;
     u64 *log;                // [nq][logcap] accepted inserts in order (dist bits << 32 | id)
     u32 logcap;
+    u32 *out_ids;            // [nq][k]   (nullptr in build mode)
+    float *out_dist;         // [nq][k]
+    u32 *out_count;          // [nq]
+    u64 *phase;              // [nq][8] cycle sums (DR_PHASE_TIMING builds only)
 };
 
 DEV u32 lane_id() { return threadIdx.x & 63; }
 DEV u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
-DEV u32 hash_id(u32 id) { return id * 2654435761u; }
+DEV float key_dist(u64 key) { return __uint_as_float((u32)(key >> 32)); }
 
-// ---- visited set ------------------------------------------------------------------------------------------
-// Lanes hold distinct ids (duplicates inside a row are removed by the `first` mask). Returns true when the id
-// was not in the set and has now been added.
-DEV bool wave_visit(u64 *tab, u32 mask, u32 gen, u32 id, bool active)
+// ---- cross-lane helpers -----------------------------------------------------------------------------------
+DEV u32 readlane32(u32 x, int l) { return (u32)__builtin_amdgcn_readlane((int)x, __builtin_amdgcn_readfirstlane(l)); }
+DEV u64 readlane64(u64 x, int l)
 {
-    bool isnew = false, done = !active;
-    u32 slot = (hash_id(id) >> 7) & mask;
-    const u64 mine = ((u64)gen << 32) | id;
-    while (__ballot(!done) != 0ull) {
-        if (!done) {
-            const u64 cur = __hip_atomic_load(&tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((u32)(cur >> 32) == gen) {
-                if ((u32)cur == id) done = true;
-                else slot = (slot + 1) & mask;
-            } else {
-                const u64 old = atomicCAS(&tab[slot], cur, mine);
-                if (old == cur) { done = true; isnew = true; }
-            }
-        }
-    }
-    return isnew;
+    const int ll = __builtin_amdgcn_readfirstlane(l);
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)x, ll);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(x >> 32), ll);
+    return ((u64)hi << 32) | lo;
+}
+// lane l <- x[l-1]; lane 0 <- carry   (DPP wave_shr:1, full-wave shift on GFX9)
+DEV u64 wave_shr1(u64 x, u64 carry)
+{
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp((int)(u32)carry, (int)(u32)x, 0x138, 0xf, 0xf, false);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp((int)(u32)(carry >> 32), (int)(u32)(x >> 32), 0x138, 0xf, 0xf, false);
+    return ((u64)hi << 32) | lo;
+}
+// lane l <- x[l+1]; lane 63 <- carry  (DPP wave_shl:1)
+DEV u64 wave_shl1(u64 x, u64 carry)
+{
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp((int)(u32)carry, (int)(u32)x, 0x130, 0xf, 0xf, false);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp((int)(u32)(carry >> 32), (int)(u32)(x >> 32), 0x130, 0xf, 0xf, false);
+    return ((u64)hi << 32) | lo;
 }
 
-// ---- sorted lists in LDS ---------------------------------------------------------------------------------
-// Result list: ascending linear array, key = dist bits << 32 | ~id, so the last element is the one heapq would
-// pop from the reference's max-heap of (-dist, id): largest distance, smallest id among equals.
-// Returns the new length. `evicted` receives the dropped key when the list was full.
-template <int NCH> DEV int res_insert(u64 *a, int n, int cap, u64 key, bool &did_evict)
+// ---- register-resident sorted lists -----------------------------------------------------------------------
+// Ascending array of NCH*64 keys; lane l of chunk c holds index c*64+l. Result list key = dist bits << 32 | ~id
+// (last element = what heapq pops from the reference's max-heap of (-dist, id): largest distance, smallest id
+// among equals); frontier key = dist bits << 32 | id (first element = heappop of the min-heap of (dist, id)).
+template <int NCH> struct RegList { u64 v[NCH]; };
+
+template <int NCH> DEV u64 list_get(const RegList<NCH> &L, int idx)
+{
+    u64 r = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+        if ((idx >> 6) == c) r = readlane64(L.v[c], idx & 63);
+    return r;
+}
+
+// Inserts key (n entries, capacity cap <= NCH*64). When full, the largest entry falls off the end (or the key
+// itself, if it is the largest): reported through dropped/did_drop. Returns the new length.
+template <int NCH> DEV int list_insert(RegList<NCH> &L, int n, int cap, u64 key, u64 &dropped, bool &did_drop)
 {
     const int lane = lane_id();
-    u64 v[NCH];
     int pos = 0;
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        const int i = c * 64 + lane;
-        v[c] = (i < n) ? a[i] : ~0ull;
-        pos += __popcll(__ballot(i < n && v[c] < key));
+    for (int c = 0; c < NCH; c++) pos += __popcll(__ballot((c * 64 + lane) < n && L.v[c] < key));
+    did_drop = (n == cap);
+    if (did_drop) {
+        if (pos >= cap) { dropped = key; return n; }
+        dropped = list_get<NCH>(L, cap - 1);
     }
-    did_evict = (n == cap);
 #pragma unroll
     for (int c = NCH - 1; c >= 0; c--) {
-        const int i = c * 64 + lane;
-        if (i < n && i >= pos && i + 1 < cap) a[i + 1] = v[c];
+        const u64 carry = (c > 0) ? readlane64(L.v[c > 0 ? c - 1 : 0], 63) : 0ull;
+        const u64 prev = wave_shr1(L.v[c], carry);
+        const int idx = c * 64 + lane;
+        const bool take_prev = idx > pos && idx <= n && idx < cap;
+        L.v[c] = (idx == pos) ? key : (take_prev ? prev : L.v[c]);
     }
-    if (lane == 0 && pos < cap) a[pos] = key;
     return n < cap ? n + 1 : cap;
 }
 
-// Frontier: ascending ring (key = dist bits << 32 | id), logical index i lives at (head + i) & (capC - 1).
-// Pop-min advances head; when full the largest entry falls off the end (caller checks it was junk).
-template <int NCH> DEV int cand_insert(u64 *a, int head, int n, int capC, u64 key, u64 &dropped, bool &did_drop)
+template <int NCH> DEV void list_pop_front(RegList<NCH> &L)
 {
-    const int lane = lane_id();
-    const int msk = capC - 1;
-    u64 v[NCH];
-    int pos = 0;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-        const int i = c * 64 + lane;
-        v[c] = (i < n) ? a[(head + i) & msk] : ~0ull;
-        pos += __popcll(__ballot(i < n && v[c] < key));
+        const u64 carry = (c + 1 < NCH) ? readlane64(L.v[c + 1 < NCH ? c + 1 : c], 0) : ~0ull;
+        L.v[c] = wave_shl1(L.v[c], carry);
     }
-    did_drop = false;
-    if (n == capC) {
-        // full: the largest element (logical n-1) is dropped, unless the new key is itself the largest
-        did_drop = true;
-        const int src = (head + n - 1) & msk;
-        dropped = a[src];
-        if (pos >= n) { dropped = key; return n; }
-        n = n - 1;
-    }
-#pragma unroll
-    for (int c = NCH - 1; c >= 0; c--) {
-        const int i = c * 64 + lane;
-        if (i < n && i >= pos) a[(head + i + 1) & msk] = v[c];
-    }
-    if (lane == 0) a[(head + pos) & msk] = key;
-    return n + 1;
 }
-
-DEV float key_dist(u64 key) { return __uint_as_float((u32)(key >> 32)); }
 
 // ---- PQ pieces -------------------------------------------------------------------------------------------
 // A2: whole table for one query, entries spread over the wave. q in original order (LDS).
 DEV void build_lut_wave(float *lut, const float *__restrict__ codebook, const float *q, u32 m, u32 sd)
 {
     const u32 total = m * 256;
+    if (sd == 4) {
+        // four entries per lane per trip: the codebook loads of a trip are independent and issue back to back
+        for (u32 e0 = lane_id() * 4; e0 < total; e0 += 256) {
+            const float4 *c4 = reinterpret_cast<const float4 *>(codebook + (size_t)e0 * 4);
+            const float4 a = c4[0], b = c4[1], c = c4[2], d = c4[3];
+            const float *qq = q + (e0 >> 8) * 4;
+            const float q0 = qq[0], q1 = qq[1], q2 = qq[2], q3 = qq[3];
+            float4 o;
+            o.x = f_add(f_add(f_add(f_add(0.0f, sqd(a.x, q0)), sqd(a.y, q1)), sqd(a.z, q2)), sqd(a.w, q3));
+            o.y = f_add(f_add(f_add(f_add(0.0f, sqd(b.x, q0)), sqd(b.y, q1)), sqd(b.z, q2)), sqd(b.w, q3));
+            o.z = f_add(f_add(f_add(f_add(0.0f, sqd(c.x, q0)), sqd(c.y, q1)), sqd(c.z, q2)), sqd(c.w, q3));
+            o.w = f_add(f_add(f_add(f_add(0.0f, sqd(d.x, q0)), sqd(d.y, q1)), sqd(d.z, q2)), sqd(d.w, q3));
+            *reinterpret_cast<float4 *>(lut + e0) = o;
+        }
+        return;
+    }
     for (u32 e = lane_id(); e < total; e += 64) {
         const u32 jq = e >> 8;
         lut[e] = pw_run_lane(codebook + (size_t)e * sd, q + jq * sd, (int)sd);
     }
 }
 
-// A3: squared ADC of one code word, strict sequential f32 order over the sub-quantisers (fast_pq.py:325-326).
-DEV float adc_lane(const float *lut, const u8 *__restrict__ code, u32 m)
+// A3 from a per-query table: T[j][code_j] summed in strict sub-quantiser order (fast_pq.py:325-326).
+DEV float adc_from_lut(const float *lut, u32 cw, u32 jbase, float s)
+{
+#pragma unroll
+    for (int b = 0; b < 4; b++) s = f_add(s, lut[(jbase + b) * 256 + ((cw >> (8 * b)) & 255u)]);
+    return s;
+}
+// A3 with the table entry recomputed from the codebook in LDS: same value as A2 would have stored (A2 order).
+// SD4: sub_dim == 4 (one ds_read_b128 per centroid); otherwise the generic run (numpy order for any sub_dim).
+template <bool SD4>
+DEV float adc_from_codebook(const float *cb, const float *q, u32 sd, u32 cw, u32 jbase, float s)
+{
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const u32 jq = jbase + b;
+        const u32 c = (cw >> (8 * b)) & 255u;
+        float t;
+        if constexpr (SD4) {
+            const float4 cv = *reinterpret_cast<const float4 *>(cb + ((size_t)jq * 256 + c) * 4);
+            const float4 qv = *reinterpret_cast<const float4 *>(q + jq * 4);
+            t = f_add(f_add(f_add(f_add(0.0f, sqd(cv.x, qv.x)), sqd(cv.y, qv.y)), sqd(cv.z, qv.z)), sqd(cv.w, qv.w));
+        } else {
+            t = pw_run_lane(cb + ((size_t)jq * 256 + c) * sd, q + jq * sd, (int)sd);
+        }
+        s = f_add(s, t);
+    }
+    return s;
+}
+
+// Squared ADC of one code word (m bytes at `code`). The code words are loaded first (they are the only global
+// loads), then consumed four sub-quantisers at a time by ROLLED loops: unrolling them lets the compiler hoist
+// every LDS read and costs ~190 VGPRs.
+template <bool CBLDS>
+DEV float adc_lane(const float *tab, const float *q, u32 sd, const u8 *__restrict__ code, u32 m)
 {
     float s = 0.0f;
-    if ((m & 15u) == 0) {
+    if ((m & 15u) == 0 && m <= 64) {
         const uint4 *c4 = reinterpret_cast<const uint4 *>(code);
-        for (u32 w = 0; w < m / 16; w++) {
-            const uint4 cw = c4[w];
-            const u32 ws[4] = { cw.x, cw.y, cw.z, cw.w };
-#pragma unroll
+        const int m16 = (int)(m / 16);
+        uint4 cw0 = c4[0], cw1 = cw0, cw2 = cw0, cw3 = cw0;
+        if (m16 > 1) cw1 = c4[1];
+        if (m16 > 2) cw2 = c4[2];
+        if (m16 > 3) cw3 = c4[3];
+        const bool sd4 = (sd == 4);
+#pragma unroll 1
+        for (int w = 0; w < m16; w++) {
+            const uint4 cw = (w == 0) ? cw0 : (w == 1) ? cw1 : (w == 2) ? cw2 : cw3;
+#pragma unroll 1
             for (int t = 0; t < 4; t++) {
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const u32 j = w * 16 + t * 4 + b;
-                    s = f_add(s, lut[j * 256 + ((ws[t] >> (8 * b)) & 255u)]);
+                const u32 word = (t == 0) ? cw.x : (t == 1) ? cw.y : (t == 2) ? cw.z : cw.w;
+                const u32 jbase = (u32)(w * 16 + t * 4);
+                if constexpr (CBLDS) {
+                    if (sd4) s = adc_from_codebook<true>(tab, q, sd, word, jbase, s);
+                    else s = adc_from_codebook<false>(tab, q, sd, word, jbase, s);
+                } else {
+                    s = adc_from_lut(tab, word, jbase, s);
                 }
             }
         }
     } else if ((m & 3u) == 0) {
         const u32 *c1 = reinterpret_cast<const u32 *>(code);
+#pragma unroll 1
         for (u32 w = 0; w < m / 4; w++) {
-            const u32 cw = c1[w];
-#pragma unroll
-            for (int b = 0; b < 4; b++) s = f_add(s, lut[(w * 4 + b) * 256 + ((cw >> (8 * b)) & 255u)]);
+            if constexpr (CBLDS) s = adc_from_codebook<false>(tab, q, sd, c1[w], w * 4, s);
+            else s = adc_from_lut(tab, c1[w], w * 4, s);
         }
     } else {
-        for (u32 j = 0; j < m; j++) s = f_add(s, lut[j * 256 + code[j]]);
+#pragma unroll 1
+        for (u32 jq = 0; jq < m; jq++) {
+            const u32 c = code[jq];
+            if constexpr (CBLDS) s = f_add(s, pw_run_lane(tab + ((size_t)jq * 256 + c) * sd, q + jq * sd, (int)sd));
+            else s = f_add(s, tab[jq * 256 + c]);
+        }
     }
     return s;
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------
-// D: vector dimension (compile time: the pairwise tree is unrolled). FILTER: M1's ADC + rerank policy.
-// KIND: traversal metric. NCHR/NCHC: result/frontier capacity in 64-entry chunks.
-template <int D, bool FILTER, int KIND, int NCHR, int NCHC>
-__global__ __launch_bounds__(64) void search_kernel(const SearchParams p)
+// D      vector dimension (compile time: the pairwise tree is unrolled)
+// FILTER M1's ADC + rerank policy            KIND   traversal metric
+// NCHR   result capacity in 64-entry chunks (frontier gets NCHR+1 chunks)
+// NW     wavefronts (= concurrent queries) per workgroup
+// CBLDS  ADC from the codebook shared in LDS (true) or from a per-query table (false)
+template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS>
+__global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
 {
+    constexpr int NCHC = NCHR + 1;
     constexpr bool QREG = (D <= 256);
     constexpr bool SPLIT = QREG && split_form_ok<D>();
-    constexpr int NP = SPLIT ? (D <= 128 ? 8 : 4) : 1;   // row passes (8 rows each) kept in flight
-    constexpr bool NEED_LUT = FILTER || KIND == DIST_ADC_SQ;
+    constexpr int NP = !SPLIT ? 1 : (NW >= 16 ? 1 : (NW >= 8 ? 2 : 4));   // row passes in flight
+    constexpr bool NEED_PQ = FILTER || KIND == DIST_ADC_SQ;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
     const int j = lane & 7, oct = lane >> 3;
 
-    // LDS carve-up (all offsets multiples of 16 bytes)
+    // ---- LDS carve-up: [shared codebook] then one region per wavefront (all offsets multiples of 16 bytes)
     size_t off = 0;
-    float *lut = reinterpret_cast<float *>(smem + off);
-    off += NEED_LUT ? (size_t)p.m * 256 * 4 : 0;
-    float *qorig = reinterpret_cast<float *>(smem + off);
-    off += (size_t)D * 4;
-    float *qperm = reinterpret_cast<float *>(smem + off);
-    off += QREG ? 0 : (size_t)D * 4;
-    u64 *rk = reinterpret_cast<u64 *>(smem + off);
-    off += (size_t)NCHR * 64 * 8;
-    u64 *ck = reinterpret_cast<u64 *>(smem + off);
-    off += (size_t)NCHC * 64 * 8;
-    u32 *nb_id = reinterpret_cast<u32 *>(smem + off);
-    off += 64 * 4;
-    float *nb_e = reinterpret_cast<float *>(smem + off);
-    off += 64 * 4;
+    float *cb_lds = reinterpret_cast<float *>(smem);
+    if constexpr (NEED_PQ && CBLDS) off += (size_t)256 * D * 4;
+    const size_t per_wave = ((NEED_PQ && !CBLDS) ? (size_t)p.m * 256 * 4 : 0) + (size_t)D * 4 + (QREG ? 0 : (size_t)D * 4) + 512;
+    unsigned char *wbase = smem + off + (size_t)wave * per_wave;
+    size_t woff = 0;
+    float *lut = reinterpret_cast<float *>(wbase);
+    if constexpr (NEED_PQ && !CBLDS) woff += (size_t)p.m * 256 * 4;
+    float *qorig = reinterpret_cast<float *>(wbase + woff);
+    woff += (size_t)D * 4;
+    float *qperm = reinterpret_cast<float *>(wbase + woff);
+    if constexpr (!QREG) woff += (size_t)D * 4;
+    u32 *nb_id = reinterpret_cast<u32 *>(wbase + woff);
+    woff += 256;
+    float *nb_e = reinterpret_cast<float *>(wbase + woff);
 
-    u64 *vtab = p.vis + (size_t)blockIdx.x * p.vis_slots;
-    const u32 vmask = p.vis_slots - 1;
-    u32 gen = p.vis_gen[blockIdx.x];
+    if constexpr (NEED_PQ && CBLDS) {
+        const float4 *src = reinterpret_cast<const float4 *>(p.codebook);
+        float4 *dst = reinterpret_cast<float4 *>(cb_lds);
+        for (u32 i = threadIdx.x; i < 64u * D; i += 64 * NW) dst[i] = src[i];
+        __syncthreads();
+    }
+    const float *pq_tab = CBLDS ? cb_lds : lut;
+
+    // Static query schedule: wavefront slot s takes queries s, s + slots, s + 2*slots, ... Every loop bound is a
+    // scalar, so the persistent loop is wave-uniform by construction (a ticket counter made the exit condition a
+    // divergent-loop mask that one hipcc build kept alive forever: ROCm 7.2, heavy SGPR spilling).
+    const u32 slot_id = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * NW + wave));
+    const u32 nslots = gridDim.x * NW;
+    u32 *vbm = p.vis + (size_t)slot_id * p.vis_words;
+    u32 *vlog = p.vlog + (size_t)slot_id * p.vis_limit;
     const int cap = (int)p.cap;
-    const int capC = (int)p.capC;
+    constexpr int capC = NCHC * 64;
     const u32 nwords = (p.R + 63) / 64;
 
-    for (;;) {
-        u32 qi = 0;
-        if (lane == 0) qi = atomicAdd(p.counter, 1u);
-        qi = __shfl(qi, 0);
-        if (qi >= p.nq) break;
-        gen++;
+    for (u32 qi = slot_id; qi < p.nq; qi += nslots) {
 
+        PH_BEGIN();
         // ---- per-query setup
         QueryRegs<D> qreg;
         {
@@ -249,64 +334,65 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchParams p)
             if constexpr (QREG) load_query_regs<0, D, D>(qpg, j, qreg);
         }
         WSYNC();
-        if constexpr (NEED_LUT) {
+        if constexpr (NEED_PQ && !CBLDS) {
             build_lut_wave(lut, p.codebook, qorig, p.m, p.sd);
             WSYNC();
         }
 
         u32 steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0, ninserts = 0;
-        int rn = 0, cn = 0, chead = 0;
-        u32 junk = 0;   // frontier entries dropped because they were worse than every result (see cand_insert)
+        int rn = 0, cn = 0;
+        u32 junk = 0;   // frontier entries that fell off the end while worse than every result
+        RegList<NCHR> rk;
+        RegList<NCHC> ck;
+#pragma unroll
+        for (int c = 0; c < NCHR; c++) rk.v[c] = ~0ull;
+#pragma unroll
+        for (int c = 0; c < NCHC; c++) ck.v[c] = ~0ull;
         u64 *qlog = p.log + (size_t)qi * p.logcap;
-
-        // distance of one node in the traversal metric, computed by octet 0, returned in every lane
-        auto node_dist = [&](u32 id) -> float {
-            float e;
-            if constexpr (KIND == DIST_ADC_SQ) {
-                e = adc_lane(lut, p.codes + (size_t)id * p.m, p.m);
-                npq++;
-            } else {
-                e = pw_row_stream<0, D, D, QREG>(p.vecp + (size_t)id * D, &qreg, qperm, j);
-                e = __shfl(e, 0);
-                if (p.norm) e = f_sqrt(e);
-                nexact++;
-            }
-            return e;
-        };
 
         // ---- start node (search_engine.py:416-426)
         {
             const u32 start = p.medoid;
-            wave_visit(vtab, vmask, gen, start, lane == 0);
+            if (lane == 0) { atomicOr(&vbm[start >> 5], 1u << (start & 31)); vlog[0] = start; }
             nvisited = 1;
-            const float d0 = node_dist(start);
-            const u32 db = __float_as_uint(d0);
-            if (lane == 0) {
-                rk[0] = ((u64)db << 32) | (u32)(~start);
-                ck[0] = ((u64)db << 32) | start;
-                if (p.logcap > 0) qlog[0] = ((u64)db << 32) | start;
+            float d0;
+            if constexpr (KIND == DIST_ADC_SQ) {
+                d0 = adc_lane<CBLDS>(pq_tab, qorig, p.sd, p.codes + (size_t)start * p.m, p.m);
+                npq++;
+            } else {
+                d0 = pw_row_stream<0, D, D, QREG>(p.vecp + (size_t)start * D, &qreg, qperm, j);
+                d0 = __uint_as_float(readlane32(__float_as_uint(d0), 0));
+                if (p.norm) d0 = f_sqrt(d0);
+                nexact++;
             }
-            rn = 1; cn = 1; chead = 0; ninserts = 1;
+            const u32 db = __float_as_uint(d0);
+            u64 dr; bool dd;
+            rn = list_insert<NCHR>(rk, 0, cap, ((u64)db << 32) | (u32)(~start), dr, dd);
+            cn = list_insert<NCHC>(ck, 0, capC, ((u64)db << 32) | start, dr, dd);
+            if (lane == 0 && p.logcap > 0) qlog[0] = ((u64)db << 32) | start;
+            ninserts = 1;
         }
-        WSYNC();
+        PH(0);
 
         // ---- main loop
         while ((cn > 0 || junk > 0) && steps < p.max_steps) {
+            if ((u64)steps > p.N + 8) { status |= DR_ST_INTERNAL; break; }   // every expansion pops a distinct node
             steps++;
             if (cn == 0) break;   // only junk left: the reference pops it and stops (it is worse than W)
-            const u64 ckey = ck[chead & (capC - 1)];
-            chead = (chead + 1) & (capC - 1);
+            const u64 ckey = readlane64(ck.v[0], 0);
+            list_pop_front<NCHC>(ck);
             cn--;
             const float cd = key_dist(ckey);
             const u32 cur = (u32)ckey;
             {
-                const float W = key_dist(rk[rn - 1]);
+                const float W = key_dist(list_get<NCHR>(rk, rn - 1));
                 bool stop;
                 if (p.mode == 3u) stop = (cd > W) && (rn == cap);
                 else if (p.mode == 4u) stop = (cd > W);
                 else stop = (rn >= cap) && (cd > W);
                 if (stop) break;
             }
+            PH(1);
 
             for (u32 cbase = 0; cbase < p.R; cbase += 64) {
                 if (nvisited + 64u > p.vis_limit) { status |= DR_ST_VIS_OVERFLOW; break; }
@@ -320,49 +406,60 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchParams p)
                 } else {
                     active = slot < min(p.deg[cur], p.R) && nbid != 0xFFFFFFFFu;
                 }
-                const bool isnew = wave_visit(vtab, vmask, gen, nbid, active);
+                PH(2);
+                // visited test-and-set: one atomic round trip; duplicates inside a row were removed by `first`
+                bool isnew = false;
+                if (active) {
+                    const u32 bit = 1u << (nbid & 31);
+                    isnew = (atomicOr(&vbm[nbid >> 5], bit) & bit) == 0u;
+                }
                 const u64 newmask = __ballot(isnew);
                 const int nnew = __popcll(newmask);
                 if (nnew == 0) continue;
-                if (isnew) nb_id[__popcll(newmask & lanemask_lt())] = nbid;
+                if (isnew) {
+                    const int rnk = __popcll(newmask & lanemask_lt());
+                    nb_id[rnk] = nbid;
+                    vlog[nvisited + rnk] = nbid;
+                }
                 nvisited += nnew;
                 WSYNC();
+                PH(3);
 
                 const u32 myid = nb_id[lane < nnew ? lane : 0];
                 float pq_d = 0.0f, e = 0.0f;
-                if constexpr (NEED_LUT) {
-                    float s = 0.0f;
-                    if (lane < nnew) s = adc_lane(lut, p.codes + (size_t)myid * p.m, p.m);
-                    if constexpr (FILTER) pq_d = f_sqrt(s);   // asymmetric_distance = sqrt (fast_pq.py:330-333)
-                    else e = s;
-                    npq += nnew;
-                }
+                // code words first, then the stored vectors: both are in flight while the ADC sums run
+                float adc_s = 0.0f;
                 if constexpr (KIND != DIST_ADC_SQ) {
-                    // exact distances: octet `oct` scores neighbour r*8+oct of pass r
                     if constexpr (SPLIT) {
                         RowRegs<D> rr[NP];
+                        for (int r0 = 0; r0 * 8 < nnew; r0 += NP) {
 #pragma unroll
-                        for (int r = 0; r < NP; r++) {
-                            if (r * 8 < nnew) {
-                                const int idx = min(r * 8 + oct, nnew - 1);
-                                row_load<0, D, D>(p.vecp + (size_t)nb_id[idx] * D, j, rr[r]);
+                            for (int r = 0; r < NP; r++) {
+                                if ((r0 + r) * 8 < nnew) {
+                                    const int idx = min((r0 + r) * 8 + oct, nnew - 1);
+                                    row_load<0, D, D>(p.vecp + (size_t)nb_id[idx] * D, j, rr[r]);
+                                }
                             }
-                        }
+                            if constexpr (NEED_PQ) {
+                                if (r0 == 0) {
+                                    if (lane < nnew) adc_s = adc_lane<CBLDS>(pq_tab, qorig, p.sd, p.codes + (size_t)myid * p.m, p.m);
+                                    PH(4);
+                                }
+                            }
 #pragma unroll
-                        for (int r = 0; r < NP; r++) {
-                            if (r * 8 < nnew) {
-                                float ev = row_reduce<0, D, D>(rr[r], qreg);
-                                if (p.norm) ev = f_sqrt(ev);
-                                if (j == 0 && r * 8 + oct < nnew) nb_e[r * 8 + oct] = ev;
+                            for (int r = 0; r < NP; r++) {
+                                if ((r0 + r) * 8 < nnew) {
+                                    float ev = row_reduce<0, D, D>(rr[r], qreg);
+                                    if (p.norm) ev = f_sqrt(ev);
+                                    if (j == 0 && (r0 + r) * 8 + oct < nnew) nb_e[(r0 + r) * 8 + oct] = ev;
+                                }
                             }
-                        }
-                        for (int r0 = NP; r0 * 8 < nnew; r0++) {   // only when NP*8 < 64
-                            const int idx = min(r0 * 8 + oct, nnew - 1);
-                            float ev = pw_row_stream<0, D, D, QREG>(p.vecp + (size_t)nb_id[idx] * D, &qreg, qperm, j);
-                            if (p.norm) ev = f_sqrt(ev);
-                            if (j == 0 && r0 * 8 + oct < nnew) nb_e[r0 * 8 + oct] = ev;
                         }
                     } else {
+                        if constexpr (NEED_PQ) {
+                            if (lane < nnew) adc_s = adc_lane<CBLDS>(pq_tab, qorig, p.sd, p.codes + (size_t)myid * p.m, p.m);
+                            PH(4);
+                        }
                         for (int r0 = 0; r0 * 8 < nnew; r0++) {
                             const int idx = min(r0 * 8 + oct, nnew - 1);
                             float ev = pw_row_stream<0, D, D, QREG>(p.vecp + (size_t)nb_id[idx] * D, &qreg, qperm, j);
@@ -372,12 +469,20 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchParams p)
                     }
                     WSYNC();
                     e = nb_e[lane < nnew ? lane : 0];
+                    if constexpr (FILTER) { pq_d = f_sqrt(adc_s); npq += nnew; }   // asymmetric_distance = sqrt (fast_pq.py:330-333)
+                } else {
+                    if (lane < nnew) adc_s = adc_lane<CBLDS>(pq_tab, qorig, p.sd, p.codes + (size_t)myid * p.m, p.m);
+                    e = adc_s;
+                    npq += nnew;
+                    PH(4);
                 }
+                PH(5);
 
                 // ---- decisions in stored order
                 bool pending = lane < nnew;
-                for (;;) {
-                    const float W = key_dist(rk[rn - 1]);
+                float W = key_dist(list_get<NCHR>(rk, rn - 1));
+                for (int guard = 0;; guard++) {
+                    if (guard > 64) { status |= DR_ST_INTERNAL; break; }   // at most one iteration per lane
                     bool pass = true;
                     if constexpr (FILTER) {
                         // _should_compute_exact_distance (search_engine.py:381-397); f32 products as numpy does
@@ -396,29 +501,25 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchParams p)
                     if constexpr (FILTER) nexact += __popcll(__ballot(upto && pass));
                     else if constexpr (KIND != DIST_ADC_SQ) nexact += __popcll(__ballot(upto));
                     pending = pending && lane > f;
-                    const float ef = __shfl(e, f);
-                    const u32 idf = __shfl(myid, f);
-                    const u32 eb = __float_as_uint(ef);
-                    bool ev;
-                    rn = res_insert<NCHR>(rk, rn, cap, ((u64)eb << 32) | (u32)(~idf), ev);
+                    const u32 eb = readlane32(__float_as_uint(e), f);
+                    const u32 idf = readlane32(myid, f);
+                    u64 rdrop; bool rdd;
+                    rn = list_insert<NCHR>(rk, rn, cap, ((u64)eb << 32) | (u32)(~idf), rdrop, rdd);
                     u64 dropped = 0; bool dd;
-                    cn = cand_insert<NCHC>(ck, chead, cn, capC, ((u64)eb << 32) | idf, dropped, dd);
-                    if (lane == 0) {
-                        if (ninserts < p.logcap) qlog[ninserts] = ((u64)eb << 32) | idf;
-                    }
-                    if (ninserts >= p.logcap) status |= DR_ST_LOG_OVERFLOW;
+                    cn = list_insert<NCHC>(ck, cn, capC, ((u64)eb << 32) | idf, dropped, dd);
+                    if (lane == 0 && ninserts < p.logcap) qlog[ninserts] = ((u64)eb << 32) | idf;
+                    if (ninserts >= p.logcap && p.logcap > 0) status |= DR_ST_LOG_OVERFLOW;
                     ninserts++;
-                    WSYNC();
+                    W = key_dist(list_get<NCHR>(rk, rn - 1));
                     if (dd) {
                         // the dropped frontier entry must be worse than every result, otherwise it could still
                         // have been expanded by the reference
-                        const float Wn = key_dist(rk[rn - 1]);
-                        if (rn >= cap && key_dist(dropped) > Wn) junk++;
+                        if (rn >= cap && key_dist(dropped) > W) junk++;
                         else status |= DR_ST_CAND_OVERFLOW;
                     }
                 }
             }
-
+            PH(6);
             if (status & DR_ST_VIS_OVERFLOW) break;
             // ---- frontier trim
             if (p.mode == 1u || p.mode == 2u) {
@@ -434,38 +535,54 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchParams p)
                 if ((u32)cn + junk > p.bw) {
                     u32 excess = (u32)cn + junk - p.bw;
                     const u32 rl = excess < (u32)cn ? excess : (u32)cn;
-                    chead = (chead + (int)rl) & (capC - 1);
+                    for (u32 t = 0; t < rl; t++) list_pop_front<NCHC>(ck);
                     cn -= (int)rl; excess -= rl;
                     junk -= excess;
                 }
             }
         }
 
+        // ---- clear the visited bits this query set (the bitmap is all zero between queries)
+        for (u32 i = lane; i < nvisited; i += 64) atomicExch(&vbm[vlog[i] >> 5], 0u);
+
         // ---- write results
-        WSYNC();
-        for (int i = lane; i < rn; i += 64) p.res_keys[(size_t)qi * cap + i] = rk[i];
-        // tie detection on the sort key of the final stable sort (distance; sqrt(distance) for M3)
+#pragma unroll
+        for (int c = 0; c < NCHR; c++) {
+            const int i = c * 64 + lane;
+            if (i < rn) p.res_keys[(size_t)qi * cap + i] = rk.v[c];
+        }
+        const int kout = min((int)p.k, rn);
         bool t = false;
-        {
-            const int lim = min((int)p.k, rn);
-            for (int i = lane; i < lim; i += 64) {
-                if (i + 1 < rn) {
-                    float a = key_dist(rk[i]), b = key_dist(rk[i + 1]);
-                    if (p.mode == 3u) { a = f_sqrt(a); b = f_sqrt(b); }
-                    if (a == b) t = true;
+#pragma unroll
+        for (int c = 0; c < NCHR; c++) {
+            const int i = c * 64 + lane;
+            // tie detection on the sort key of the final stable sort (distance; sqrt(distance) for M3)
+            const u64 nextk = wave_shl1(rk.v[c], (c + 1 < NCHR) ? readlane64(rk.v[c + 1 < NCHR ? c + 1 : c], 0) : ~0ull);
+            float a = key_dist(rk.v[c]), b = key_dist(nextk);
+            if (p.mode == 3u) { a = f_sqrt(a); b = f_sqrt(b); }
+            if (i < kout && i + 1 < rn && a == b) t = true;
+            if (p.out_ids) {
+                if (i < (int)p.k) {
+                    p.out_ids[(size_t)qi * p.k + i] = (i < kout) ? ~(u32)rk.v[c] : 0xFFFFFFFFu;
+                    p.out_dist[(size_t)qi * p.k + i] = (i < kout) ? a : __uint_as_float(0x7FC00000u);
                 }
             }
+        }
+        if (p.out_ids) for (int i = NCHR * 64 + lane; i < (int)p.k; i += 64) {
+            p.out_ids[(size_t)qi * p.k + i] = 0xFFFFFFFFu;
+            p.out_dist[(size_t)qi * p.k + i] = __uint_as_float(0x7FC00000u);
         }
         const bool anyt = __ballot(t) != 0ull;
         if (lane == 0) {
             p.res_n[qi] = (u32)rn;
-            p.tie[qi] = anyt ? 1u : 0u;
+            if (p.out_count) p.out_count[qi] = (u32)kout;
+            if (anyt && p.tie_list) p.tie_list[atomicAdd(p.tie_count, 1u)] = qi;
             KStats st;
             st.steps = steps; st.visited = nvisited; st.exact = nexact; st.pq = npq; st.status = status;
             st.inserts = ninserts;
             p.stats[qi] = st;
         }
-        WSYNC();
+        PH(7);
+        PH_END(qi);
     }
-    if (lane == 0) p.vis_gen[blockIdx.x] = gen;
 }

@@ -3,16 +3,27 @@
 #pragma once
 #include <stddef.h>
 
-// kind: 0 = M1 (ADC filter + exact), 1 = exact traversal (M2, M4, M3 without PQ), 2 = ADC-only traversal (M3)
+// kind: which search_kernel instantiation
+//   0 M1 (ADC filter + exact), per-query table in LDS, 1 wave per workgroup
+//   1 exact traversal (M2, M4, M3 without PQ, builder), 1 wave per workgroup
+//   2 ADC-only traversal (M3 with PQ), per-query table
+//   3 M1, codebook shared in LDS, 8 waves per workgroup      (D <= 128 only, else nullptr)
+//   4 M1, codebook shared in LDS, 16 waves per workgroup     (D <= 128 only)
+//   5 ADC-only traversal, codebook shared in LDS, 8 waves    (D <= 128 only)
 // sizeclass: result capacity <= 64 / 128 / 256 / 512
+#define DR_NUM_KINDS 6
 #define DR_NUM_SIZECLASS 4
 struct DimKernels {
     int D;
-    const void *search[3][DR_NUM_SIZECLASS];
+    const void *search[DR_NUM_KINDS][DR_NUM_SIZECLASS];
     const void *exact;
     const void *bruteforce;
     const void *prune;
 };
+static const int DR_KIND_NW[DR_NUM_KINDS] = { 1, 1, 1, 8, 16, 8 };
+static const bool DR_KIND_CB[DR_NUM_KINDS] = { false, false, false, true, true, true };
+static const bool DR_KIND_PQ[DR_NUM_KINDS] = { true, false, true, true, true, true };
+
 const DimKernels *dr_dim_kernels(int D);
 
 #define DR_DECLARE_DIM(DD) const DimKernels *dr_dim_kernels_##DD();

@@ -144,6 +144,10 @@ int dr_pq_train(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t iters, uin
                 float *out_codebook /*[m][256][D/m]*/);
 int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uint8_t *out_codes /*[N][m] or NULL*/);
 
+/* Diagnostic builds only (-DDR_PHASE_TIMING): shader-clock sums per phase of the last search, summed over queries:
+ * 0 setup+table, 1 pop/stop, 2 adjacency, 3 visited set, 4 ADC, 5 exact distances, 6 decisions/inserts, 7 output. */
+int dr_debug_phase_cycles(dr_index *ix, double *out8);
+
 void dr_index_close(dr_index *ix);
 
 #ifdef __cplusplus

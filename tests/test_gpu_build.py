@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 def built():
     from diskrag_amd import HipIndex
     from diskrag_amd.synth import sift_like
-    x, q = sift_like(20000, 128, n_queries=200, n_clusters=64, seed=5)
+    x, q = sift_like(20000, 128, n_queries=200, n_clusters=32, seed=5)
     ix = HipIndex.create_empty(x, R=32)
     medoid, secs = ix.build_vamana(L_build=64, alpha=1.2, passes=2, seed=3, pad_with_zero=False)
     cb = ix.pq_train(32, n_sample=10000, iters=6)
