@@ -120,7 +120,7 @@ def main():
 
     # ---------------------------------------------------------------- roofline of the dominant kernel
     # algorithmic bytes per query: B_q = 4D + S*4R + V*m + X*4D + 8k, counters from the engine
-    S, V, X = st["steps"].astype(np.float64), st["pq"].astype(np.float64), st["exact"].astype(np.float64)
+    S, V, X = st["steps"].astype(np.float64), st["pq_evaluated"].astype(np.float64), st["exact"].astype(np.float64)
     bytes_q = 4 * args.dim + S * 4 * args.R + V * args.m + X * 4 * args.dim + 8 * args.k
     alg_bytes = float(bytes_q.sum()) + 4 * 256 * args.dim       # + codebook once per batch
     k_ms = float(np.mean(kernel_ms))
@@ -138,7 +138,7 @@ def main():
                                % (args.n, args.dim, args.R, args.L, args.m, args.bw or None, args.k, args.nq),
                    "recall_at_10": recall, "build_seconds": build_s, "parallelism": "query-sharded replicas x%d" % world,
                    "qps_pcie_inclusive_rank0": pcie_qps,
-                   "per_query": {"expansions": float(S.mean()), "pq_distances": float(V.mean()),
+                   "per_query": {"expansions": float(S.mean()), "pq_distances": float(st["pq"].mean()), "pq_evaluated": float(V.mean()),
                                  "exact_distances": float(X.mean()), "algorithmic_bytes": float(bytes_q.mean())},
                    "launch": {k_: timing[k_] for k_ in ("grid", "block", "lds_bytes", "waves_per_cu")}},
         "roofline": {"bound": "hbm", "kernel": "search_kernel<128,M1>", "achieved": achieved, "peak": HBM_PEAK_GBPS,

@@ -49,7 +49,7 @@
 
 enum DistKind { DIST_EXACT = 0, DIST_ADC_SQ = 2 };
 
-struct KStats { u32 steps, visited, exact, pq, status, inserts; };
+struct KStats { u32 steps, visited, exact, pq, status, inserts, pq_evaluated, reserved; };
 
 struct SearchParams {
     const float *vecp;       // [N][D] chain-major
@@ -215,27 +215,42 @@ DEV float adc_from_codebook(const float *cb, const float *q, u32 sd, u32 cw, u32
     return s;
 }
 
-// Squared ADC of one code word (m bytes at `code`). The code words are loaded first (they are the only global
-// loads), then consumed four sub-quantisers at a time by ROLLED loops: unrolling them lets the compiler hoist
-// every LDS read and costs ~190 VGPRs.
-template <bool CBLDS>
-DEV float adc_lane(const float *tab, const float *q, u32 sd, const u8 *__restrict__ code, u32 m)
+// Squared ADC of one code word (m bytes at `code`), split in two so that the caller can put other loads between
+// the code-word loads and their use. The sums consume four sub-quantisers at a time in ROLLED loops: unrolling
+// them lets the compiler hoist every LDS read and costs ~190 VGPRs.
+DEV void adc_load_codes(uint4 &w0, uint4 &w1, uint4 &w2, uint4 &w3, const u8 *__restrict__ code, u32 m)
 {
-    float s = 0.0f;
     if ((m & 15u) == 0 && m <= 64) {
         const uint4 *c4 = reinterpret_cast<const uint4 *>(code);
         const int m16 = (int)(m / 16);
-        uint4 cw0 = c4[0], cw1 = cw0, cw2 = cw0, cw3 = cw0;
-        if (m16 > 1) cw1 = c4[1];
-        if (m16 > 2) cw2 = c4[2];
-        if (m16 > 3) cw3 = c4[3];
+        w0 = c4[0];
+        w1 = w0; w2 = w0; w3 = w0;
+        if (m16 > 1) w1 = c4[1];
+        if (m16 > 2) w2 = c4[2];
+        if (m16 > 3) w3 = c4[3];
+    }
+}
+
+template <bool CBLDS>
+DEV float adc_compute(const float *tab, const float *q, u32 sd, const uint4 c0, const uint4 c1v, const uint4 c2,
+                      const uint4 c3, const u8 *__restrict__ code, u32 m)
+{
+    float s = 0.0f;
+    if ((m & 15u) == 0 && m <= 64) {
+        const int m16 = (int)(m / 16);
         const bool sd4 = (sd == 4);
 #pragma unroll 1
         for (int w = 0; w < m16; w++) {
-            const uint4 cw = (w == 0) ? cw0 : (w == 1) ? cw1 : (w == 2) ? cw2 : cw3;
+            uint4 cw = c0;
+            if (w == 1) cw = c1v;
+            if (w == 2) cw = c2;
+            if (w == 3) cw = c3;
 #pragma unroll 1
             for (int t = 0; t < 4; t++) {
-                const u32 word = (t == 0) ? cw.x : (t == 1) ? cw.y : (t == 2) ? cw.z : cw.w;
+                u32 word = cw.x;
+                if (t == 1) word = cw.y;
+                if (t == 2) word = cw.z;
+                if (t == 3) word = cw.w;
                 const u32 jbase = (u32)(w * 16 + t * 4);
                 if constexpr (CBLDS) {
                     if (sd4) s = adc_from_codebook<true>(tab, q, sd, word, jbase, s);
@@ -261,6 +276,39 @@ DEV float adc_lane(const float *tab, const float *q, u32 sd, const u8 *__restric
         }
     }
     return s;
+}
+
+template <bool CBLDS>
+DEV float adc_lane(const float *tab, const float *q, u32 sd, const u8 *__restrict__ code, u32 m)
+{
+    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
+    adc_load_codes(w0, w1, w2, w3, code, m);
+    return adc_compute<CBLDS>(tab, q, sd, w0, w1, w2, w3, code, m);
+}
+
+// max over lanes, result in every lane
+DEV float wave_max(float x)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+    return x;
+}
+
+// sqrt(sum_j max_c T[j][c]) with the sum in A3's order: an upper bound of asymmetric_distance for any code word.
+template <bool CBLDS> DEV float adc_upper_bound(const float *tab, const float *q, u32 m, u32 sd)
+{
+    float s = 0.0f;
+    for (u32 jq = 0; jq < m; jq++) {
+        float mx = 0.0f;
+        for (u32 c = lane_id(); c < 256; c += 64) {
+            float t;
+            if constexpr (CBLDS) t = pw_run_lane(tab + ((size_t)jq * 256 + c) * sd, q + jq * sd, (int)sd);
+            else t = tab[jq * 256 + c];
+            mx = fmaxf(mx, t);
+        }
+        s = f_add(s, wave_max(mx));
+    }
+    return f_sqrt(s);
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------
@@ -338,7 +386,16 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
             build_lut_wave(lut, p.codebook, qorig, p.m, p.sd);
             WSYNC();
         }
+        // Upper bound of sqrt(ADC) over ALL code words for this query: sum_j max_c T[j][c] accumulated in the same
+        // j order as A3 (float addition and sqrt are monotone, so the bound holds in float arithmetic too). When
+        // it is below 0.8 * (a lower bound of the worst result distance during an expansion), the rerank policy A4
+        // returns True for every neighbour of that expansion and the ADC need not be evaluated -- on SIFT-scale
+        // data (squared distances ~1e4-1e5, sqrt(ADC) ~1e2) that is every expansion (quirk Q1). Exact: results and
+        // counters are unchanged; stats.pq_evaluated says how many ADC sums were really computed.
+        float pq_ub = __uint_as_float(0x7F800000u);
+        if constexpr (FILTER) pq_ub = adc_upper_bound<CBLDS>(pq_tab, qorig, p.m, p.sd);
 
+        u32 npq_eval = 0;
         u32 steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0, ninserts = 0;
         int rn = 0, cn = 0;
         u32 junk = 0;   // frontier entries that fell off the end while worse than every result
@@ -427,7 +484,22 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
 
                 const u32 myid = nb_id[lane < nnew ? lane : 0];
                 float pq_d = 0.0f, e = 0.0f;
-                // code words first, then the stored vectors: both are in flight while the ADC sums run
+                // Is the ADC value of this expansion's neighbours needed at all? (A4 is provably True for all of
+                // them when the list cannot fill up during the expansion, or when pq_ub clears the threshold for
+                // the smallest worst-distance the expansion can reach: at most nnew results get replaced.)
+                bool need_adc = NEED_PQ;
+                if constexpr (FILTER) {
+                    if (rn + nnew <= (int)p.L) need_adc = false;
+                    else if (rn == cap && cap - 1 - nnew >= 0) {
+                        const float Wlow = key_dist(list_get<NCHR>(rk, cap - 1 - nnew));
+                        if (pq_ub < f_mul(Wlow, 0.8f)) need_adc = false;
+                    }
+                }
+                const bool all_pass = !need_adc;
+                // code words first, then the stored vectors: the ADC sums run while the vectors are in flight
+                uint4 cw0 = make_uint4(0, 0, 0, 0), cw1 = cw0, cw2 = cw0, cw3 = cw0;
+                const u8 *mycode = p.codes + (size_t)myid * p.m;
+                if constexpr (NEED_PQ) { if (need_adc && lane < nnew) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m); }
                 float adc_s = 0.0f;
                 if constexpr (KIND != DIST_ADC_SQ) {
                     if constexpr (SPLIT) {
@@ -441,8 +513,8 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                                 }
                             }
                             if constexpr (NEED_PQ) {
-                                if (r0 == 0) {
-                                    if (lane < nnew) adc_s = adc_lane<CBLDS>(pq_tab, qorig, p.sd, p.codes + (size_t)myid * p.m, p.m);
+                                if (r0 == 0 && need_adc) {
+                                    if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
                                     PH(4);
                                 }
                             }
@@ -457,8 +529,10 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                         }
                     } else {
                         if constexpr (NEED_PQ) {
-                            if (lane < nnew) adc_s = adc_lane<CBLDS>(pq_tab, qorig, p.sd, p.codes + (size_t)myid * p.m, p.m);
-                            PH(4);
+                            if (need_adc) {
+                                if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
+                                PH(4);
+                            }
                         }
                         for (int r0 = 0; r0 * 8 < nnew; r0++) {
                             const int idx = min(r0 * 8 + oct, nnew - 1);
@@ -469,11 +543,15 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                     }
                     WSYNC();
                     e = nb_e[lane < nnew ? lane : 0];
-                    if constexpr (FILTER) { pq_d = f_sqrt(adc_s); npq += nnew; }   // asymmetric_distance = sqrt (fast_pq.py:330-333)
+                    if constexpr (FILTER) {
+                        pq_d = f_sqrt(adc_s);   // asymmetric_distance = sqrt (fast_pq.py:330-333)
+                        npq += nnew;            // the reference counts one PQ distance per new neighbour
+                        if (need_adc) npq_eval += nnew;
+                    }
                 } else {
-                    if (lane < nnew) adc_s = adc_lane<CBLDS>(pq_tab, qorig, p.sd, p.codes + (size_t)myid * p.m, p.m);
+                    if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
                     e = adc_s;
-                    npq += nnew;
+                    npq += nnew; npq_eval += nnew;
                     PH(4);
                 }
                 PH(5);
@@ -486,7 +564,7 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                     bool pass = true;
                     if constexpr (FILTER) {
                         // _should_compute_exact_distance (search_engine.py:381-397); f32 products as numpy does
-                        pass = (rn < (int)p.L) || (pq_d < f_mul(W, 0.8f)) ||
+                        pass = all_pass || (rn < (int)p.L) || (pq_d < f_mul(W, 0.8f)) ||
                                ((pq_d < f_mul(W, 1.2f)) && p.policy == 0u);
                     }
                     const bool acc = pending && pass && (rn < cap || e < W);
@@ -543,7 +621,16 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
         }
 
         // ---- clear the visited bits this query set (the bitmap is all zero between queries)
-        for (u32 i = lane; i < nvisited; i += 64) atomicExch(&vbm[vlog[i] >> 5], 0u);
+        // (four log reads in flight per trip; the swaps are fire-and-forget)
+        for (u32 i0 = 0; i0 < nvisited; i0 += 256) {
+            const u32 ia = i0 + lane, ib = ia + 64, ic = ia + 128, id_ = ia + 192;
+            const u32 va = (ia < nvisited) ? vlog[ia] : 0xFFFFFFFFu, vb = (ib < nvisited) ? vlog[ib] : 0xFFFFFFFFu;
+            const u32 vc = (ic < nvisited) ? vlog[ic] : 0xFFFFFFFFu, vd = (id_ < nvisited) ? vlog[id_] : 0xFFFFFFFFu;
+            if (va != 0xFFFFFFFFu) atomicExch(&vbm[va >> 5], 0u);
+            if (vb != 0xFFFFFFFFu) atomicExch(&vbm[vb >> 5], 0u);
+            if (vc != 0xFFFFFFFFu) atomicExch(&vbm[vc >> 5], 0u);
+            if (vd != 0xFFFFFFFFu) atomicExch(&vbm[vd >> 5], 0u);
+        }
 
         // ---- write results
 #pragma unroll
@@ -579,7 +666,7 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
             if (anyt && p.tie_list) p.tie_list[atomicAdd(p.tie_count, 1u)] = qi;
             KStats st;
             st.steps = steps; st.visited = nvisited; st.exact = nexact; st.pq = npq; st.status = status;
-            st.inserts = ninserts;
+            st.inserts = ninserts; st.pq_evaluated = npq_eval; st.reserved = 0;
             p.stats[qi] = st;
         }
         PH(7);

@@ -50,6 +50,9 @@ typedef struct {
     uint32_t pq;      /* pq_distance_computations */
     uint32_t status;  /* 0 ok; bit0 visited-set overflow, bit1 frontier overflow, bit2 insert-log overflow */
     uint32_t inserts; /* accepted result-list inserts (engine counter, not in the reference) */
+    uint32_t pq_evaluated; /* ADC sums actually computed: `pq` minus those whose outcome (rerank policy True) was
+                              proven from a per-query upper bound without reading the code words (engine counter) */
+    uint32_t reserved;
 } dr_stats;
 
 /* timing of the last dr_search_batch / dr_batch_run on a handle, measured with HIP events on the engine's

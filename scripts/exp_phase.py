@@ -1,4 +1,4 @@
-"""Diagnostic (GPU box): where one M1 expansion spends its cycles. Needs a -DDR_PHASE_TIMING build."""
+"""Diagnostic (GPU box): where one M1 expansion spends its cycles. Needs a -DDR_PHASE_TIMING build (DR_LIB)."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -14,6 +14,7 @@ for _ in range(2):
 ph = np.array(ix.debug_phase_cycles())
 names = ["setup+LUT", "pop/stop", "adjacency", "visited", "ADC", "exact", "decisions", "output"]
 tot = ph.sum()
-print("kernel_ms", ix.timing()["search_kernel_ms"], "steps", st["steps"].mean(), "visited", st["visited"].mean(), "inserts", st["inserts"].mean())
+t = ix.timing()
+print("kernel_ms", t["search_kernel_ms"], "finalize_ms", t["finalize_kernel_ms"], "steps", st["steps"].mean(), "visited", st["visited"].mean(), "inserts", st["inserts"].mean(), t)
 for nme, v in zip(names, ph):
     print(f"{nme:12s} {v/tot*100:6.2f}%  cycles/query {v/len(q):10.0f}  per-step {v/st['steps'].sum():8.0f}")
