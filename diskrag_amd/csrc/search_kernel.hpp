@@ -503,27 +503,30 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                 float adc_s = 0.0f;
                 if constexpr (KIND != DIST_ADC_SQ) {
                     if constexpr (SPLIT) {
+                        // rolling ring of NP row buffers: pass r is reduced while passes r+1 .. r+NP-1 are in flight
                         RowRegs<D> rr[NP];
-                        for (int r0 = 0; r0 * 8 < nnew; r0 += NP) {
 #pragma unroll
-                            for (int r = 0; r < NP; r++) {
-                                if ((r0 + r) * 8 < nnew) {
-                                    const int idx = min((r0 + r) * 8 + oct, nnew - 1);
-                                    row_load<0, D, D>(p.vecp + (size_t)nb_id[idx] * D, j, rr[r]);
-                                }
+                        for (int r = 0; r < NP; r++) {
+                            if (r * 8 < nnew) {
+                                const int idx = min(r * 8 + oct, nnew - 1);
+                                row_load<0, D, D>(p.vecp + (size_t)nb_id[idx] * D, j, rr[r]);
                             }
-                            if constexpr (NEED_PQ) {
-                                if (r0 == 0 && need_adc) {
-                                    if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
-                                    PH(4);
-                                }
+                        }
+                        if constexpr (NEED_PQ) {
+                            if (need_adc) {
+                                if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
+                                PH(4);
                             }
+                        }
 #pragma unroll
-                            for (int r = 0; r < NP; r++) {
-                                if ((r0 + r) * 8 < nnew) {
-                                    float ev = row_reduce<0, D, D>(rr[r], qreg);
-                                    if (p.norm) ev = f_sqrt(ev);
-                                    if (j == 0 && (r0 + r) * 8 + oct < nnew) nb_e[(r0 + r) * 8 + oct] = ev;
+                        for (int r = 0; r < 8; r++) {
+                            if (r * 8 < nnew) {
+                                float ev = row_reduce<0, D, D>(rr[r % NP], qreg);
+                                if (p.norm) ev = f_sqrt(ev);
+                                if (j == 0 && r * 8 + oct < nnew) nb_e[r * 8 + oct] = ev;
+                                if ((r + NP) * 8 < nnew) {
+                                    const int idx = min((r + NP) * 8 + oct, nnew - 1);
+                                    row_load<0, D, D>(p.vecp + (size_t)nb_id[idx] * D, j, rr[r % NP]);
                                 }
                             }
                         }
