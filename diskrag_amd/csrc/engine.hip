@@ -402,16 +402,19 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (ov) return 0;   // the builder consumes res_keys / res_n directly on the stream
     if (dbg) { HIPCHK(hipStreamSynchronize(ix->stream)); fprintf(stderr, "[dr] search kernel done\n"); fflush(stderr); }
 
-    // tie replay for the queries the search kernel listed (usually few): one lane per query, heaps in LDS
+    // tie replay for the queries the search kernel listed: one wavefront per query, heap in registers
     FinalizeParams f;
     f.res_keys = ix->res_keys.p; f.res_n = ix->res_n.p; f.tie_list = ix->tie.p; f.tie_count = ix->counter.p + 1;
     f.log = ix->log.p; f.stats = ix->stats.p;
     f.logcap = logcap; f.cap = cap; f.k = k; f.mode = mode;
-    f.qpb = cap <= 128 ? 64 : cap <= 256 ? 32 : 16;
     f.out_ids = ix->out_ids.p; f.out_dist = ix->out_dist.p;
-    const size_t flds = (size_t)(cap + 1) * f.qpb * 8;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-    hipLaunchKernelGGL(finalize_kernel, dim3((nq + f.qpb - 1) / f.qpb), dim3(64), flds, ix->stream, f);
+    {
+        const unsigned fgrid = (unsigned)std::min<uint64_t>(((uint64_t)nq + 3) / 4, (uint64_t)ix->num_cu * 8);
+        if (cap + 1 <= 64) hipLaunchKernelGGL(finalize_kernel<1>, dim3(fgrid), dim3(256), 0, ix->stream, f);
+        else if (cap + 1 <= 128) hipLaunchKernelGGL(finalize_kernel<2>, dim3(fgrid), dim3(256), 0, ix->stream, f);
+        else if (cap + 1 <= 256) hipLaunchKernelGGL(finalize_kernel<4>, dim3(fgrid), dim3(256), 0, ix->stream, f);
+        else hipLaunchKernelGGL(finalize_kernel<9>, dim3(fgrid), dim3(256), 0, ix->stream, f);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));

@@ -62,43 +62,50 @@ __global__ void first_mask_kernel(const u32 *__restrict__ adj, u64 n, u32 R, u64
 // only queries whose first k entries hold equal sort keys are listed for this kernel, which replays the heap
 // from the accepted-insert log with CPython's exact sift rules (Lib/heapq.py) to recover that order.
 // M2 sorts full (dist, id) tuples (vamana_graph.py:758): ids ascending inside a tie, no replay.
-// One lane per listed query; the lanes' heaps sit interleaved in LDS (element i of lane l at h[i*QPB + l]).
+// One WAVEFRONT per listed query: the heap array lives in registers (element i in lane i%64 of chunk i/64), the
+// sift indices are scalars, so every step is a v_readlane / masked move with no memory traffic.
 struct FinalizeParams {
     const u64 *res_keys; const u32 *res_n; const u32 *tie_list; const u32 *tie_count; const u64 *log;
     const KStats *stats;
-    u32 logcap, cap, k, mode, qpb;
+    u32 logcap, cap, k, mode;
     u32 *out_ids; float *out_dist;
 };
+
+template <int NCH> DEV void heap_set(RegList<NCH> &H, int idx, u64 v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int c = 0; c < NCH; c++) H.v[c] = (c == (idx >> 6) && lane == (idx & 63)) ? v : H.v[c];
+}
 
 // python tuple (-d, id) "less than" on keys (dist bits << 32 | ~id): x < y  <=>  key(x) > key(y)
 DEV bool py_lt(u64 x, u64 y) { return x > y; }
 
-#define HP(i) h[(size_t)(i) * qpb]
-DEV void py_siftdown(u64 *h, u32 qpb, int startpos, int pos)
+template <int NCH> DEV void py_siftdown(RegList<NCH> &H, int startpos, int pos)
 {
-    const u64 newitem = HP(pos);
+    const u64 newitem = list_get<NCH>(H, pos);
     while (pos > startpos) {
         const int parentpos = (pos - 1) >> 1;
-        const u64 parent = HP(parentpos);
-        if (py_lt(newitem, parent)) { HP(pos) = parent; pos = parentpos; continue; }
+        const u64 parent = list_get<NCH>(H, parentpos);
+        if (py_lt(newitem, parent)) { heap_set<NCH>(H, pos, parent); pos = parentpos; continue; }
         break;
     }
-    HP(pos) = newitem;
+    heap_set<NCH>(H, pos, newitem);
 }
-DEV void py_siftup(u64 *h, u32 qpb, int n, int pos)
+template <int NCH> DEV void py_siftup(RegList<NCH> &H, int n, int pos)
 {
     const int endpos = n, startpos = pos;
-    const u64 newitem = HP(pos);
+    const u64 newitem = list_get<NCH>(H, pos);
     int childpos = 2 * pos + 1;
     while (childpos < endpos) {
         const int rightpos = childpos + 1;
-        if (rightpos < endpos && !py_lt(HP(childpos), HP(rightpos))) childpos = rightpos;
-        HP(pos) = HP(childpos);
+        if (rightpos < endpos && !py_lt(list_get<NCH>(H, childpos), list_get<NCH>(H, rightpos))) childpos = rightpos;
+        heap_set<NCH>(H, pos, list_get<NCH>(H, childpos));
         pos = childpos;
         childpos = 2 * pos + 1;
     }
-    HP(pos) = newitem;
-    py_siftdown(h, qpb, startpos, pos);
+    heap_set<NCH>(H, pos, newitem);
+    py_siftdown<NCH>(H, startpos, pos);
 }
 
 DEV float sort_key(u64 key, u32 mode)
@@ -107,68 +114,80 @@ DEV float sort_key(u64 key, u32 mode)
     return mode == 3u ? f_sqrt(d) : d;
 }
 
-__global__ void finalize_kernel(const FinalizeParams p)
+// heap capacity NCH*64 - 1 >= cap + 1 entries
+template <int NCH> __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const u32 qpb = p.qpb;
+    const int lane = lane_id();
     const u32 ntie = *p.tie_count;
-    const u32 t = blockIdx.x * qpb + threadIdx.x;
-    if (threadIdx.x >= qpb || t >= ntie) return;
-    const u32 q = p.tie_list[t];
-    u64 *h = reinterpret_cast<u64 *>(smem) + threadIdx.x;
-    const int n = (int)p.res_n[q];
-    const int cnt = n < (int)p.k ? n : (int)p.k;
-    const u64 *keys = p.res_keys + (size_t)q * p.cap;
-    u32 *oid = p.out_ids + (size_t)q * p.k;
-    float *od = p.out_dist + (size_t)q * p.k;
+    const u32 nwaves = gridDim.x * (blockDim.x >> 6);
+    const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    for (u32 t = wave0; t < ntie; t += nwaves) {
+        const u32 q = p.tie_list[t];
+        const int n = (int)p.res_n[q];
+        const int cnt = n < (int)p.k ? n : (int)p.k;
+        const u64 *keys = p.res_keys + (size_t)q * p.cap;
+        u32 *oid = p.out_ids + (size_t)q * p.k;
+        float *od = p.out_dist + (size_t)q * p.k;
 
-    int hn = 0;
-    if (p.mode != 2u) {
-        const u32 nins = p.stats[q].inserts;
-        if (nins > p.logcap) return;   // log overflowed (status bit is already set): order stays as is
-        const u64 *lg = p.log + (size_t)q * p.logcap;
-        for (u32 i = 0; i < nins; i++) {
-            const u64 e = lg[i];
-            HP(hn) = (e & 0xFFFFFFFF00000000ull) | (u32)(~(u32)e);
-            hn++;
-            py_siftdown(h, qpb, 0, hn - 1);            // heappush
-            if (hn > (int)p.cap) {                     // heappop
-                const u64 last = HP(--hn);
-                if (hn) { HP(0) = last; py_siftup(h, qpb, hn, 0); }
-            }
-        }
-    }
-    // walk equal-key groups that intersect the first cnt positions
-    int i = 0;
-    while (i < cnt) {
-        const float ki = sort_key(keys[i], p.mode);
-        int e = i + 1;
-        while (e < n && sort_key(keys[e], p.mode) == ki) e++;
-        if (e - i > 1) {
-            if (p.mode == 2u) {
-                // full tuple order: id ascending; the list holds equal distances with id descending
-                for (int u = 0; i + u < cnt && u < e - i; u++) oid[i + u] = ~(u32)keys[e - 1 - u];
-            } else {
-                // heap-array order: pick group members by increasing heap index
-                int last = -1;
-                for (int pos = i; pos < cnt && pos < e; pos++) {
-                    int best = 0x7FFFFFFF; u64 bestkey = 0;
-                    for (int g = i; g < e; g++) {
-                        int hi = -1;
-                        for (int u = 0; u < hn; u++) if (HP(u) == keys[g]) { hi = u; break; }
-                        if (hi > last && hi < best) { best = hi; bestkey = keys[g]; }
+        RegList<NCH> H;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) H.v[c] = 0ull;
+        int hn = 0;
+        if (p.mode != 2u) {
+            const u32 nins = p.stats[q].inserts;
+            if (nins > p.logcap) continue;   // log overflowed (status bit is already set): order stays as is
+            const u64 *lg = p.log + (size_t)q * p.logcap;
+            for (u32 i0 = 0; i0 < nins; i0 += 64) {
+                // one coalesced read of 64 log entries, then consumed one by one through scalar broadcasts
+                const u64 mine = (i0 + lane < nins) ? lg[i0 + lane] : 0ull;
+                const int lim = (int)min(64u, nins - i0);
+                for (int u = 0; u < lim; u++) {
+                    const u64 e = readlane64(mine, u);
+                    heap_set<NCH>(H, hn, (e & 0xFFFFFFFF00000000ull) | (u32)(~(u32)e));
+                    hn++;
+                    py_siftdown<NCH>(H, 0, hn - 1);            // heappush
+                    if (hn > (int)p.cap) {                     // heappop
+                        const u64 last = list_get<NCH>(H, --hn);
+                        if (hn) { heap_set<NCH>(H, 0, last); py_siftup<NCH>(H, hn, 0); }
                     }
-                    if (best == 0x7FFFFFFF) break;
-                    oid[pos] = ~(u32)bestkey;
-                    od[pos] = sort_key(bestkey, p.mode);
-                    last = best;
                 }
             }
         }
-        i = e;
+        // walk equal-key groups that intersect the first cnt positions (keys: lane-strided copy of the sorted list)
+        int i = 0;
+        while (i < cnt) {
+            const float ki = sort_key(keys[i], p.mode);
+            int e = i + 1;
+            while (e < n && sort_key(keys[e], p.mode) == ki) e++;
+            if (e - i > 1) {
+                if (p.mode == 2u) {
+                    // full tuple order: id ascending; the list holds equal distances with id descending
+                    if (lane == 0) for (int u = 0; i + u < cnt && u < e - i; u++) oid[i + u] = ~(u32)keys[e - 1 - u];
+                } else {
+                    // heap-array order: pick group members by increasing heap index
+                    int last = -1;
+                    for (int pos = i; pos < cnt && pos < e; pos++) {
+                        int best = 0x7FFFFFFF; u64 bestkey = 0;
+                        for (int g = i; g < e; g++) {
+                            const u64 kg = keys[g];
+                            int hi = -1;
+#pragma unroll
+                            for (int c = 0; c < NCH; c++) {
+                                const u64 m = __ballot(c * 64 + lane < hn && H.v[c] == kg);
+                                if (m != 0ull && hi < 0) hi = c * 64 + __ffsll((long long)m) - 1;
+                            }
+                            if (hi > last && hi < best) { best = hi; bestkey = kg; }
+                        }
+                        if (best == 0x7FFFFFFF) break;
+                        if (lane == 0) { oid[pos] = ~(u32)bestkey; od[pos] = sort_key(bestkey, p.mode); }
+                        last = best;
+                    }
+                }
+            }
+            i = e;
+        }
     }
 }
-#undef HP
 
 // ---- PQ entry points
 __global__ __launch_bounds__(64) void lut_kernel(const float *__restrict__ codebook, const float *__restrict__ queries,

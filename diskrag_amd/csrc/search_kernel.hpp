@@ -111,6 +111,22 @@ DEV u64 wave_shl1(u64 x, u64 carry)
     return ((u64)hi << 32) | lo;
 }
 
+// min over the wave of a u32 (identity 0xFFFFFFFF), result broadcast: DPP inclusive scan (row_shr 1,2,4,8, then
+// row_bcast 15 / 31), total in lane 63.
+DEV u32 wave_min_u32(u32 x)
+{
+    const int idn = -1;
+#define DR_DPP_MIN(ctrl, rmask) x = min(x, (u32)__builtin_amdgcn_update_dpp(idn, (int)x, ctrl, rmask, 0xf, false))
+    DR_DPP_MIN(0x111, 0xf);
+    DR_DPP_MIN(0x112, 0xf);
+    DR_DPP_MIN(0x114, 0xf);
+    DR_DPP_MIN(0x118, 0xf);
+    DR_DPP_MIN(0x142, 0xa);
+    DR_DPP_MIN(0x143, 0xc);
+#undef DR_DPP_MIN
+    return readlane32(x, 63);
+}
+
 // ---- register-resident sorted lists -----------------------------------------------------------------------
 // Ascending array of NCH*64 keys; lane l of chunk c holds index c*64+l. Result list key = dist bits << 32 | ~id
 // (last element = what heapq pops from the reference's max-heap of (-dist, id): largest distance, smallest id
@@ -295,18 +311,27 @@ DEV float wave_max(float x)
 }
 
 // sqrt(sum_j max_c T[j][c]) with the sum in A3's order: an upper bound of asymmetric_distance for any code word.
+// Lane l scans half (l & 1) of the 256 centroids of sub-quantisers (l >> 1) + 32 t; the per-j maxima are then
+// added in j order through scalar broadcasts.
 template <bool CBLDS> DEV float adc_upper_bound(const float *tab, const float *q, u32 m, u32 sd)
 {
+    const u32 lane = lane_id();
     float s = 0.0f;
-    for (u32 jq = 0; jq < m; jq++) {
+    for (u32 j0 = 0; j0 < m; j0 += 32) {
+        const u32 jq = j0 + (lane >> 1);
         float mx = 0.0f;
-        for (u32 c = lane_id(); c < 256; c += 64) {
-            float t;
-            if constexpr (CBLDS) t = pw_run_lane(tab + ((size_t)jq * 256 + c) * sd, q + jq * sd, (int)sd);
-            else t = tab[jq * 256 + c];
-            mx = fmaxf(mx, t);
+        if (jq < m) {
+            const u32 c0 = (lane & 1u) * 128u;
+            for (u32 c = c0; c < c0 + 128u; c++) {
+                float t;
+                if constexpr (CBLDS) t = pw_run_lane(tab + ((size_t)jq * 256 + c) * sd, q + jq * sd, (int)sd);
+                else t = tab[jq * 256 + c];
+                mx = fmaxf(mx, t);
+            }
         }
-        s = f_add(s, wave_max(mx));
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        const u32 lim = (m - j0) < 32u ? (m - j0) : 32u;
+        for (u32 t = 0; t < lim; t++) s = f_add(s, __uint_as_float(readlane32(__float_as_uint(mx), (int)(2 * t))));
     }
     return f_sqrt(s);
 }
@@ -406,6 +431,10 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
 #pragma unroll
         for (int c = 0; c < NCHC; c++) ck.v[c] = ~0ull;
         u64 *qlog = p.log + (size_t)qi * p.logcap;
+        // speculative prefetch of the next node's adjacency row (chunk 0) into registers, issued before the
+        // sequential decision loop so that its latency hides behind it; verified against the real pop
+        u32 pf_node = 0xFFFFFFFFu, pf_nbid = 0xFFFFFFFFu;
+        u64 pf_aux = 0;
 
         // ---- start node (search_engine.py:416-426)
         {
@@ -455,14 +484,16 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                 if (nvisited + 64u > p.vis_limit) { status |= DR_ST_VIS_OVERFLOW; break; }
                 const u32 slot = cbase + lane;
                 u32 nbid = 0xFFFFFFFFu;
-                if (slot < p.R) nbid = p.adj[(size_t)cur * p.R + slot];
-                bool active;
-                if (p.first) {
-                    const u64 fm = p.first[(size_t)cur * nwords + (cbase >> 6)];
-                    active = ((fm >> lane) & 1ull) != 0ull;
+                u64 aux;
+                if (cbase == 0 && cur == pf_node) {
+                    nbid = pf_nbid; aux = pf_aux;
                 } else {
-                    active = slot < min(p.deg[cur], p.R) && nbid != 0xFFFFFFFFu;
+                    if (slot < p.R) nbid = p.adj[(size_t)cur * p.R + slot];
+                    aux = p.first ? p.first[(size_t)cur * nwords + (cbase >> 6)] : (u64)p.deg[cur];
                 }
+                bool active;
+                if (p.first) active = ((aux >> lane) & 1ull) != 0ull;
+                else active = slot < min((u32)aux, p.R) && nbid != 0xFFFFFFFFu;
                 PH(2);
                 // visited test-and-set: one atomic round trip; duplicates inside a row were removed by `first`
                 bool isnew = false;
@@ -559,6 +590,25 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                 }
                 PH(5);
 
+                // ---- predict the next pop: the closer of the frontier head and the best new neighbour; prefetch its row
+#ifdef DR_ADJ_PREFETCH   // measured 3% SLOWER on MI355X (extra VALU on a VALU-contended CU): kept for reference, off
+                if (cbase + 64 >= p.R) {
+                    const u32 ebits = (lane < nnew) ? __float_as_uint(e) : 0xFFFFFFFFu;
+                    const u32 emin = wave_min_u32(ebits);
+                    const u64 em = __ballot(lane < nnew && ebits == emin);
+                    u64 best = (cn > 0) ? readlane64(ck.v[0], 0) : ~0ull;
+                    if (em != 0ull) {
+                        const u64 nk = ((u64)emin << 32) | readlane32(myid, __ffsll((long long)em) - 1);
+                        if (nk < best) best = nk;
+                    }
+                    pf_node = (best == ~0ull) ? 0xFFFFFFFFu : (u32)best;
+                    if (pf_node != 0xFFFFFFFFu) {
+                        pf_nbid = (lane < (int)p.R) ? p.adj[(size_t)pf_node * p.R + lane] : 0xFFFFFFFFu;
+                        pf_aux = p.first ? p.first[(size_t)pf_node * nwords] : (u64)p.deg[pf_node];
+                    }
+                }
+#endif
+
                 // ---- decisions in stored order
                 bool pending = lane < nnew;
                 float W = key_dist(list_get<NCHR>(rk, rn - 1));
@@ -624,15 +674,15 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
         }
 
         // ---- clear the visited bits this query set (the bitmap is all zero between queries)
-        // (four log reads in flight per trip; the swaps are fire-and-forget)
+        // (four log reads in flight per trip; the stores bypass L1 like the atomics that will follow them)
         for (u32 i0 = 0; i0 < nvisited; i0 += 256) {
             const u32 ia = i0 + lane, ib = ia + 64, ic = ia + 128, id_ = ia + 192;
             const u32 va = (ia < nvisited) ? vlog[ia] : 0xFFFFFFFFu, vb = (ib < nvisited) ? vlog[ib] : 0xFFFFFFFFu;
             const u32 vc = (ic < nvisited) ? vlog[ic] : 0xFFFFFFFFu, vd = (id_ < nvisited) ? vlog[id_] : 0xFFFFFFFFu;
-            if (va != 0xFFFFFFFFu) atomicExch(&vbm[va >> 5], 0u);
-            if (vb != 0xFFFFFFFFu) atomicExch(&vbm[vb >> 5], 0u);
-            if (vc != 0xFFFFFFFFu) atomicExch(&vbm[vc >> 5], 0u);
-            if (vd != 0xFFFFFFFFu) atomicExch(&vbm[vd >> 5], 0u);
+            if (va != 0xFFFFFFFFu) __hip_atomic_store(&vbm[va >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (vb != 0xFFFFFFFFu) __hip_atomic_store(&vbm[vb >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (vc != 0xFFFFFFFFu) __hip_atomic_store(&vbm[vc >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (vd != 0xFFFFFFFFu) __hip_atomic_store(&vbm[vd >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 
         // ---- write results
