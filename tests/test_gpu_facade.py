@@ -1,0 +1,88 @@
+"""The drop-in facade (diskrag_amd.search_engine.SearchEngineCorrect) over a collection directory laid out and
+written exactly like the reference's (index.dat records, pq_codes.bin, meta.json; T1/T2/T4). Needs a GPU."""
+import json
+
+import numpy as np
+import pytest
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def write_collection(base, name, g, with_pq=True):
+    cdir = base / name
+    (cdir / "index").mkdir(parents=True)
+    n, d = g.vectors.shape
+    rec = np.empty((n, d + g.R), dtype=np.uint32)          # DiskANNPersist.save_index layout (diskann_persist.py:17-24)
+    rec[:, :d] = g.vectors.view(np.uint32)
+    rec[:, d:] = g.adj
+    rec.tofile(cdir / "index" / "index.dat")
+    meta = {"D": d, "R": g.R, "N": n, "medoid_idx": g.medoid, "use_pq": bool(with_pq and g.m), "n_subvectors": g.m}
+    (cdir / "index" / "meta.json").write_text(json.dumps(meta))
+    if with_pq and g.m:
+        g.codes.tofile(cdir / "index" / "pq_codes.bin")
+        g.codebook.astype(np.float32).tofile(cdir / "index" / "pq_codebook.f32")
+    (cdir / "collection_info.json").write_text(json.dumps({"name": name, "dimension": d, "num_vectors": n}))
+    return cdir
+
+
+def test_facade_m1_matches_reference_golden(tmp_path):
+    from diskrag_amd.search_engine import SearchEngineCorrect
+    g = load_golden("sift128_R64_m32")
+    write_collection(tmp_path, "c", g)
+    eng = SearchEngineCorrect("c", base_dir=tmp_path)
+    assert eng.use_pq and eng.n_subvectors == 32
+    c = g.case(1)   # L=100, beam_width=8 (the API default), k=10
+    for qi in range(6):
+        res, stats = eng._pq_accelerated_graph_search(g.queries[qi], k=10, L=100, beam_width=8)
+        assert [int(i) for _, i in res] == [int(i) for i in c["ids"][qi][:c["count"][qi]]]
+        assert np.array_equal(np.array([d for d, _ in res], dtype=np.float32).view(np.uint32),
+                              c["dist"][qi][:c["count"][qi]].view(np.uint32))
+        assert [stats["search_steps"], stats["nodes_visited"], stats["exact_distance_computations"],
+                stats["pq_distance_computations"]] == c["stats"][qi].tolist()
+        assert isinstance(res[0][0], np.float32) and isinstance(res[0][1], np.uint32)
+    # batched entry point == per-query calls
+    ids, dist, cnt, st = eng.search_batch(g.queries, k=10, L=100, beam_width=8)
+    assert np.array_equal(ids, c["ids"])
+    eng.close()
+
+
+def test_facade_search_and_faq_dedup(tmp_path):
+    from diskrag_amd.search_engine import SearchEngineCorrect
+    g = load_golden("randn128_R16_m32")
+    write_collection(tmp_path, "c", g)
+
+    def lookup(idx):   # every 3 consecutive vectors share a qa_id; odd ids are not FAQ rows
+        return f"text {idx}", {"type": "faq" if idx % 2 == 0 else "chunk", "qa_id": f"qa{idx // 6}"}
+
+    eng = SearchEngineCorrect("c", base_dir=tmp_path, text_lookup=lookup)
+    q = g.queries[0]
+    out = eng.search("hello", k=5, embedding_fn=lambda s: q)
+    assert [r["text"] for r in out["results"]] == [f"text {int(i)}" for i in g.case(2)["ids"][0][:5]]   # L=max(2k,20)=20, bw=8
+    assert out["stats"]["search_type"] == "pq_accelerated" and out["stats"]["L_search"] == 20
+    faq = eng.faq_search("hello", k=3, embedding_fn=lambda s: q)
+    qa = [r["metadata"]["qa_id"] for r in faq["results"]]
+    assert len(qa) == len(set(qa)) and all(r["metadata"]["type"] == "faq" for r in faq["results"])
+    assert faq["stats"]["total_results_before_dedup"] <= 9
+    with pytest.raises(ValueError):
+        eng.search("x", embedding_fn=None)
+    with pytest.raises(ValueError):
+        eng.search("x", embedding_fn=lambda s: np.zeros(7, dtype=np.float32))
+    eng.close()
+
+
+def test_facade_exact_mode_when_pq_missing(tmp_path):
+    """No PQ files -> the engine serves M2 with beam_width 8 (search_engine.py:49-51, 508-528; Q6: <= 8 hits)."""
+    from diskrag_amd.search_engine import SearchEngineCorrect
+    from oracle import pyoracle as orc
+    g = load_golden("randn128_R16_m32")
+    write_collection(tmp_path, "c", g, with_pq=False)
+    eng = SearchEngineCorrect("c", base_dir=tmp_path)
+    assert not eng.use_pq
+    res, st = eng._exact_graph_search(g.queries[0], k=15, L=100)
+    oids, odist, ocnt, _ = orc.search_batch(g.vectors, g.adj, g.queries[:1], g.medoid, orc.M2, 15, bw=8)
+    assert len(res) == int(ocnt[0]) <= 8
+    assert [int(i) for _, i in res] == oids[0, :ocnt[0]].tolist()
+    assert st["search_type"] == "exact_beam_search"
+    eng.close()
