@@ -126,6 +126,13 @@ def main():
     k_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
 
+    # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950
+    # read correction applied): measured offline on this same workload, committed under profiles/
+    traffic = None
+    pmc = ROOT / "profiles" / "r01" / "pmc_traffic.json"
+    if pmc.exists() and (args.n, args.nq, args.dim, args.R, args.L, args.m, args.bw) == (1_000_000, 10_000, 128, 64, 100, 32, 0):
+        traffic = json.loads(pmc.read_text())["search_kernel"]["hbm_bytes_per_launch"]
+
     total_q = args.nq * world * args.steps
     value = total_q / elapsed
     out = {
@@ -140,9 +147,10 @@ def main():
                    "qps_pcie_inclusive_rank0": pcie_qps,
                    "per_query": {"expansions": float(S.mean()), "pq_distances": float(st["pq"].mean()), "pq_evaluated": float(V.mean()),
                                  "exact_distances": float(X.mean()), "algorithmic_bytes": float(bytes_q.mean())},
-                   "launch": {k_: timing[k_] for k_ in ("grid", "block", "lds_bytes", "waves_per_cu")}},
+                   "launch": {k_: timing[k_] for k_ in ("grid", "block", "lds_bytes", "waves_per_cu")},
+                   "finalize_kernel_ms": timing["finalize_kernel_ms"]},
         "roofline": {"bound": "hbm", "kernel": "search_kernel<128,M1>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
     }
 
