@@ -175,6 +175,103 @@ template <int NCH> DEV void list_pop_front(RegList<NCH> &L)
     }
 }
 
+// Per-entry state of the result list: bit0 = expanded, bit1 = trimmed from the frontier ("dead"). The frontier of
+// the reference (a heap of (dist, id)) is the set of result entries with state 0, plus the few entries that were
+// evicted from the results while tied with the new worst distance (side list), plus a COUNT of evicted entries
+// that are worse than every result (they can only end the search). One sorted insert per accepted neighbour.
+template <int NCH> struct FlagList { u32 v[NCH]; };
+
+DEV u32 wave_shr1_u32(u32 x, u32 carry)
+{
+    return (u32)__builtin_amdgcn_update_dpp((int)carry, (int)x, 0x138, 0xf, 0xf, false);
+}
+template <int NCH> DEV u32 flag_get(const FlagList<NCH> &F, int idx)
+{
+    u32 r = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+        if ((idx >> 6) == c) r = readlane32(F.v[c], idx & 63);
+    return r;
+}
+template <int NCH> DEV void flag_or(FlagList<NCH> &F, int idx, u32 bits)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int c = 0; c < NCH; c++) F.v[c] |= (c == (idx >> 6) && lane == (idx & 63)) ? bits : 0u;
+}
+
+// list_insert for the flagged result list: the new entry gets state 0; reports the evicted entry and its state.
+template <int NCH>
+DEV int list_insert_f(RegList<NCH> &L, FlagList<NCH> &F, int n, int cap, u64 key, u64 &dropped, u32 &dflag, bool &did_drop)
+{
+    const int lane = lane_id();
+    int pos = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) pos += __popcll(__ballot((c * 64 + lane) < n && L.v[c] < key));
+    did_drop = (n == cap);
+    dflag = 0;
+    if (did_drop) {
+        if (pos >= cap) { dropped = key; return n; }
+        dropped = list_get<NCH>(L, cap - 1);
+        dflag = flag_get<NCH>(F, cap - 1);
+    }
+#pragma unroll
+    for (int c = NCH - 1; c >= 0; c--) {
+        const u64 carry = (c > 0) ? readlane64(L.v[c > 0 ? c - 1 : 0], 63) : 0ull;
+        const u32 carryf = (c > 0) ? readlane32(F.v[c > 0 ? c - 1 : 0], 63) : 0u;
+        const u64 prev = wave_shr1(L.v[c], carry);
+        const u32 prevf = wave_shr1_u32(F.v[c], carryf);
+        const int idx = c * 64 + lane;
+        const bool take_prev = idx > pos && idx <= n && idx < cap;
+        L.v[c] = (idx == pos) ? key : (take_prev ? prev : L.v[c]);
+        F.v[c] = (idx == pos) ? 0u : (take_prev ? prevf : F.v[c]);
+    }
+    return n < cap ? n + 1 : cap;
+}
+
+// Frontier order is (dist asc, id asc); the list is (dist asc, id DESC), so inside a run of equal distances the
+// frontier order is the list order reversed. Index of the first / last live entry in frontier order, or -1.
+template <int NCH> DEV int frontier_first(const RegList<NCH> &L, const FlagList<NCH> &F, int n)
+{
+    const int lane = lane_id();
+    int pidx = -1;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const u64 m = __ballot(c * 64 + lane < n && F.v[c] == 0u);
+        if (m != 0ull && pidx < 0) pidx = c * 64 + __ffsll((long long)m) - 1;
+    }
+    if (pidx < 0) return -1;
+    const u32 dp = (u32)(list_get<NCH>(L, pidx) >> 32);
+    int q = pidx;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const u64 m = __ballot(c * 64 + lane < n && F.v[c] == 0u && (u32)(L.v[c] >> 32) == dp);
+        if (m != 0ull) q = max(q, c * 64 + 63 - __clzll((long long)m));
+    }
+    return q;
+}
+template <int NCH> DEV int frontier_last(const RegList<NCH> &L, const FlagList<NCH> &F, int n)
+{
+    const int lane = lane_id();
+    int q = -1;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const u64 m = __ballot(c * 64 + lane < n && F.v[c] == 0u);
+        if (m != 0ull) q = c * 64 + 63 - __clzll((long long)m);
+    }
+    if (q < 0) return -1;
+    const u32 dq = (u32)(list_get<NCH>(L, q) >> 32);
+    int r = q;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const u64 m = __ballot(c * 64 + lane < n && F.v[c] == 0u && (u32)(L.v[c] >> 32) == dq);
+        if (m != 0ull) r = min(r, c * 64 + __ffsll((long long)m) - 1);
+    }
+    return r;
+}
+// result key (dist << 32 | ~id) -> frontier key (dist << 32 | id)
+DEV u64 fkey(u64 k) { return (k & 0xFFFFFFFF00000000ull) | (u32)(~(u32)k); }
+
 // ---- PQ pieces -------------------------------------------------------------------------------------------
 // A2: whole table for one query, entries spread over the wave. q in original order (LDS).
 DEV void build_lut_wave(float *lut, const float *__restrict__ codebook, const float *q, u32 m, u32 sd)
@@ -339,13 +436,12 @@ template <bool CBLDS> DEV float adc_upper_bound(const float *tab, const float *q
 // ---- the kernel -------------------------------------------------------------------------------------------
 // D      vector dimension (compile time: the pairwise tree is unrolled)
 // FILTER M1's ADC + rerank policy            KIND   traversal metric
-// NCHR   result capacity in 64-entry chunks (frontier gets NCHR+1 chunks)
+// NCHR   result capacity in 64-entry chunks
 // NW     wavefronts (= concurrent queries) per workgroup
 // CBLDS  ADC from the codebook shared in LDS (true) or from a per-query table (false)
 template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS>
 __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
 {
-    constexpr int NCHC = NCHR + 1;
     constexpr bool QREG = (D <= 256);
     constexpr bool SPLIT = QREG && split_form_ok<D>();
     constexpr int NP = !SPLIT ? 1 : (NW >= 16 ? 1 : (NW >= 8 ? 2 : 4));   // row passes in flight
@@ -389,7 +485,6 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
     u32 *vbm = p.vis + (size_t)slot_id * p.vis_words;
     u32 *vlog = p.vlog + (size_t)slot_id * p.vis_limit;
     const int cap = (int)p.cap;
-    constexpr int capC = NCHC * 64;
     const u32 nwords = (p.R + 63) / 64;
 
     for (u32 qi = slot_id; qi < p.nq; qi += nslots) {
@@ -422,19 +517,15 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
 
         u32 npq_eval = 0;
         u32 steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0, ninserts = 0;
-        int rn = 0, cn = 0;
-        u32 junk = 0;   // frontier entries that fell off the end while worse than every result
+        int rn = 0, cnT = 0, tn = 0;   // results; live (unexpanded, untrimmed) result entries; tie side list
+        u32 junk = 0;   // evicted frontier entries that are worse than every result (only their count matters)
         RegList<NCHR> rk;
-        RegList<NCHC> ck;
+        FlagList<NCHR> fl;
+        RegList<1> tl;   // frontier keys of entries evicted from the results while tied with the worst distance
 #pragma unroll
-        for (int c = 0; c < NCHR; c++) rk.v[c] = ~0ull;
-#pragma unroll
-        for (int c = 0; c < NCHC; c++) ck.v[c] = ~0ull;
+        for (int c = 0; c < NCHR; c++) { rk.v[c] = ~0ull; fl.v[c] = 0u; }
+        tl.v[0] = ~0ull;
         u64 *qlog = p.log + (size_t)qi * p.logcap;
-        // speculative prefetch of the next node's adjacency row (chunk 0) into registers, issued before the
-        // sequential decision loop so that its latency hides behind it; verified against the real pop
-        u32 pf_node = 0xFFFFFFFFu, pf_nbid = 0xFFFFFFFFu;
-        u64 pf_aux = 0;
 
         // ---- start node (search_engine.py:416-426)
         {
@@ -452,22 +543,28 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                 nexact++;
             }
             const u32 db = __float_as_uint(d0);
-            u64 dr; bool dd;
-            rn = list_insert<NCHR>(rk, 0, cap, ((u64)db << 32) | (u32)(~start), dr, dd);
-            cn = list_insert<NCHC>(ck, 0, capC, ((u64)db << 32) | start, dr, dd);
+            u64 dr; u32 df; bool dd;
+            rn = list_insert_f<NCHR>(rk, fl, 0, cap, ((u64)db << 32) | (u32)(~start), dr, df, dd);
+            cnT = 1;
             if (lane == 0 && p.logcap > 0) qlog[0] = ((u64)db << 32) | start;
             ninserts = 1;
         }
         PH(0);
 
         // ---- main loop
-        while ((cn > 0 || junk > 0) && steps < p.max_steps) {
+        while ((cnT + tn > 0 || junk > 0) && steps < p.max_steps) {
             if ((u64)steps > p.N + 8) { status |= DR_ST_INTERNAL; break; }   // every expansion pops a distinct node
             steps++;
-            if (cn == 0) break;   // only junk left: the reference pops it and stops (it is worse than W)
-            const u64 ckey = readlane64(ck.v[0], 0);
-            list_pop_front<NCHC>(ck);
-            cn--;
+            if (cnT + tn == 0) break;   // only junk left: the reference pops it and stops (it is worse than W)
+            // heappop(candidates): the smaller of the first live result entry and the side-list head
+            u64 ckey;
+            {
+                const int ia = frontier_first<NCHR>(rk, fl, rn);
+                const u64 ka = (ia >= 0) ? fkey(list_get<NCHR>(rk, ia)) : ~0ull;
+                const u64 kb = (tn > 0) ? readlane64(tl.v[0], 0) : ~0ull;
+                if (ka <= kb) { ckey = ka; flag_or<NCHR>(fl, ia, 1u); cnT--; }
+                else { ckey = kb; list_pop_front<1>(tl); tn--; }
+            }
             const float cd = key_dist(ckey);
             const u32 cur = (u32)ckey;
             {
@@ -484,13 +581,8 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                 if (nvisited + 64u > p.vis_limit) { status |= DR_ST_VIS_OVERFLOW; break; }
                 const u32 slot = cbase + lane;
                 u32 nbid = 0xFFFFFFFFu;
-                u64 aux;
-                if (cbase == 0 && cur == pf_node) {
-                    nbid = pf_nbid; aux = pf_aux;
-                } else {
-                    if (slot < p.R) nbid = p.adj[(size_t)cur * p.R + slot];
-                    aux = p.first ? p.first[(size_t)cur * nwords + (cbase >> 6)] : (u64)p.deg[cur];
-                }
+                if (slot < p.R) nbid = p.adj[(size_t)cur * p.R + slot];
+                const u64 aux = p.first ? p.first[(size_t)cur * nwords + (cbase >> 6)] : (u64)p.deg[cur];
                 bool active;
                 if (p.first) active = ((aux >> lane) & 1ull) != 0ull;
                 else active = slot < min((u32)aux, p.R) && nbid != 0xFFFFFFFFu;
@@ -591,23 +683,6 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                 PH(5);
 
                 // ---- predict the next pop: the closer of the frontier head and the best new neighbour; prefetch its row
-#ifdef DR_ADJ_PREFETCH   // measured 3% SLOWER on MI355X (extra VALU on a VALU-contended CU): kept for reference, off
-                if (cbase + 64 >= p.R) {
-                    const u32 ebits = (lane < nnew) ? __float_as_uint(e) : 0xFFFFFFFFu;
-                    const u32 emin = wave_min_u32(ebits);
-                    const u64 em = __ballot(lane < nnew && ebits == emin);
-                    u64 best = (cn > 0) ? readlane64(ck.v[0], 0) : ~0ull;
-                    if (em != 0ull) {
-                        const u64 nk = ((u64)emin << 32) | readlane32(myid, __ffsll((long long)em) - 1);
-                        if (nk < best) best = nk;
-                    }
-                    pf_node = (best == ~0ull) ? 0xFFFFFFFFu : (u32)best;
-                    if (pf_node != 0xFFFFFFFFu) {
-                        pf_nbid = (lane < (int)p.R) ? p.adj[(size_t)pf_node * p.R + lane] : 0xFFFFFFFFu;
-                        pf_aux = p.first ? p.first[(size_t)pf_node * nwords] : (u64)p.deg[pf_node];
-                    }
-                }
-#endif
 
                 // ---- decisions in stored order
                 bool pending = lane < nnew;
@@ -634,18 +709,20 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                     pending = pending && lane > f;
                     const u32 eb = readlane32(__float_as_uint(e), f);
                     const u32 idf = readlane32(myid, f);
-                    u64 rdrop; bool rdd;
-                    rn = list_insert<NCHR>(rk, rn, cap, ((u64)eb << 32) | (u32)(~idf), rdrop, rdd);
-                    u64 dropped = 0; bool dd;
-                    cn = list_insert<NCHC>(ck, cn, capC, ((u64)eb << 32) | idf, dropped, dd);
+                    u64 dropped = 0; u32 dflag = 0; bool dd;
+                    rn = list_insert_f<NCHR>(rk, fl, rn, cap, ((u64)eb << 32) | (u32)(~idf), dropped, dflag, dd);
+                    cnT++;
                     if (lane == 0 && ninserts < p.logcap) qlog[ninserts] = ((u64)eb << 32) | idf;
                     if (ninserts >= p.logcap && p.logcap > 0) status |= DR_ST_LOG_OVERFLOW;
                     ninserts++;
                     W = key_dist(list_get<NCHR>(rk, rn - 1));
-                    if (dd) {
-                        // the dropped frontier entry must be worse than every result, otherwise it could still
-                        // have been expanded by the reference
-                        if (rn >= cap && key_dist(dropped) > W) junk++;
+                    if (dd && dflag == 0u) {
+                        // a live entry left the results (search_engine.py:473-474) but stays in the reference's
+                        // frontier: worse than every result -> it can only end the search (count it);
+                        // tied with the new worst distance -> it can still be expanded (side list)
+                        cnT--;
+                        if (key_dist(dropped) > W) junk++;
+                        else if (tn < 64) { u64 d2; bool dd2; tn = list_insert<1>(tl, tn, 64, fkey(dropped), d2, dd2); }
                         else status |= DR_ST_CAND_OVERFLOW;
                     }
                 }
@@ -655,19 +732,32 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
             // ---- frontier trim
             if (p.mode == 1u || p.mode == 2u) {
                 // candidates = heapq.nsmallest(beam_width, candidates) (search_engine.py:477-479)
-                if (p.bw != 0u && (u32)cn + junk > p.bw) {
-                    u32 excess = (u32)cn + junk - p.bw;
+                if (p.bw != 0u && (u32)(cnT + tn) + junk > p.bw) {
+                    u32 excess = (u32)(cnT + tn) + junk - p.bw;
                     const u32 rj = excess < junk ? excess : junk;   // junk entries are the largest
                     junk -= rj; excess -= rj;
-                    cn -= (int)excess;
+                    for (u32 t = 0; t < excess; t++) {
+                        // drop the largest frontier entry: last live result entry or side-list tail
+                        const int ia = frontier_last<NCHR>(rk, fl, rn);
+                        const u64 ka = (ia >= 0) ? fkey(list_get<NCHR>(rk, ia)) : 0ull;
+                        const u64 kb = (tn > 0) ? readlane64(tl.v[0], tn - 1) : 0ull;
+                        if (ia >= 0 && (tn == 0 || ka > kb)) { flag_or<NCHR>(fl, ia, 2u); cnT--; }
+                        else tn--;
+                    }
                 }
             } else if (p.mode == 3u) {
-                // while len(beam) > beam_width: heappop(beam)   (vamana_graph.py:592-593, Q9)
-                if ((u32)cn + junk > p.bw) {
-                    u32 excess = (u32)cn + junk - p.bw;
-                    const u32 rl = excess < (u32)cn ? excess : (u32)cn;
-                    for (u32 t = 0; t < rl; t++) list_pop_front<NCHC>(ck);
-                    cn -= (int)rl; excess -= rl;
+                // while len(beam) > beam_width: heappop(beam)   (vamana_graph.py:592-593, Q9: pops the BEST)
+                if ((u32)(cnT + tn) + junk > p.bw) {
+                    u32 excess = (u32)(cnT + tn) + junk - p.bw;
+                    const u32 rl = excess < (u32)(cnT + tn) ? excess : (u32)(cnT + tn);
+                    for (u32 t = 0; t < rl; t++) {
+                        const int ia = frontier_first<NCHR>(rk, fl, rn);
+                        const u64 ka = (ia >= 0) ? fkey(list_get<NCHR>(rk, ia)) : ~0ull;
+                        const u64 kb = (tn > 0) ? readlane64(tl.v[0], 0) : ~0ull;
+                        if (ka <= kb) { flag_or<NCHR>(fl, ia, 2u); cnT--; }
+                        else { list_pop_front<1>(tl); tn--; }
+                    }
+                    excess -= rl;
                     junk -= excess;
                 }
             }
