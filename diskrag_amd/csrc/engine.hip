@@ -104,7 +104,7 @@ struct dr_index {
     size_t vis_zeroed = 0;
     DevBuf<u64> res_keys, log;
     DevBuf<KStats> stats;
-    DevBuf<float> out_dist;
+    DevBuf<float> out_dist, pq_ub;
     DevBuf<u64> phase;
     uint32_t last_k = 0;
     dr_timing timing = {};
@@ -264,7 +264,7 @@ extern "C" void dr_index_close(dr_index *ix)
     ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release();
     ix->perm.release(); ix->q.release(); ix->qp.release(); ix->vis.release(); ix->vlog.release();
     ix->counter.release(); ix->res_n.release(); ix->tie.release(); ix->out_ids.release(); ix->out_count.release();
-    ix->res_keys.release(); ix->log.release(); ix->stats.release(); ix->out_dist.release();
+    ix->res_keys.release(); ix->log.release(); ix->stats.release(); ix->out_dist.release(); ix->pq_ub.release(); ix->phase.release();
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
@@ -320,22 +320,30 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     HIPCHK(hipSetDevice(ix->device));
 
     const int sc = cap <= 64 ? 0 : cap <= 128 ? 1 : cap <= 256 ? 2 : 3;
-    // kernel variant (variants.hpp): codebook-in-LDS multi-wave workgroups when the codebook fits (D <= 128)
+    // kernel variant (variants.hpp). M1 at D = 128: vectors landed in LDS (kind 6); other D <= 128 with PQ: codebook
+    // shared in LDS (kinds 3 / 5); otherwise per-query table (0 / 2) or no PQ at all (1)
     int kind = (mode == DR_MODE_M1) ? 0 : (mode == DR_MODE_M3 && use_pq) ? 2 : 1;
     if (kind != 1 && ix->kern->search[3][sc] && (size_t)256 * ix->D * 4 <= 128 * 1024) kind = (kind == 0) ? 3 : 5;
+    if (kind == 3 && ix->kern->search[9][sc]) kind = 9;
+    if (kind == 1 && !ov && ix->kern->search[8][sc]) kind = 8;
     {
         static bool env_read = false;
         if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e) g_force_kind = atoi(e); env_read = true; }
-        if (g_force_kind >= 0 && g_force_kind < DR_NUM_KINDS && ix->kern->search[g_force_kind][sc] &&
-            DR_KIND_PQ[g_force_kind] == (kind != 1) && ((g_force_kind == 2 || g_force_kind == 5) == (kind == 2 || kind == 5)))
-            kind = g_force_kind;
+        const int g = g_force_kind;
+        if (g >= 0 && g < DR_NUM_KINDS && ix->kern->search[g][sc]) {
+            const bool g_m1 = (g == 0 || g == 3 || g == 4 || g == 6 || g == 7 || g == 9), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8);
+            const bool k_m1 = (mode == DR_MODE_M1), k_adc = (mode == DR_MODE_M3 && use_pq);
+            if ((g_m1 && k_m1) || (g_adc && k_adc) || (g_ex && !k_m1 && !k_adc)) kind = g;
+        }
     }
     const void *kfn = ix->kern->search[kind][sc];
     const int NW = DR_KIND_NW[kind];
-    const bool cb = DR_KIND_CB[kind], pq = DR_KIND_PQ[kind];
+    const bool cb = DR_KIND_CB[kind];
+    const int RB = DR_KIND_RB[kind];
 
-    const size_t per_wave = ((pq && !cb) ? (size_t)ix->m * 256 * 4 : 0) + (size_t)ix->D * 4 + (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 512;
-    const size_t lds = ((pq && cb) ? (size_t)256 * ix->D * 4 : 0) + (size_t)NW * per_wave;
+    const size_t per_wave = (DR_KIND_LUT[kind] ? (size_t)ix->m * 256 * 4 : 0) + (size_t)ix->D * 4 + (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 512 +
+                            (size_t)RB * ix->D * 4;
+    const size_t lds = (cb ? (size_t)256 * ix->D * 4 : 0) + (size_t)NW * per_wave;
     if (lds > 160 * 1024) return fail(DR_E_UNSUPPORTED, "LDS footprint %zu B exceeds 160 KiB", lds);
     HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int occ = 0;
@@ -381,6 +389,15 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.log = ix->log.p; p.logcap = logcap;
     p.out_ids = ix->out_ids.p; p.out_dist = ix->out_dist.p; p.out_count = ix->out_count.p;
     p.phase = nullptr;
+    p.pq_ub = nullptr;
+    if (mode == DR_MODE_M1 && RB > 0) {
+        // the codebook is not in LDS for this variant: per-query ADC upper bounds come from a small kernel
+        if (ix->pq_ub.reserve(nq)) return DR_E_NODEVICE;
+        hipLaunchKernelGGL(pq_bound_kernel, dim3(nq), dim3(256), (size_t)ix->D * 4 + 16, ix->stream, ix->codebook.p, ix->q.p,
+                           ix->D, ix->m, ix->sd, ix->pq_ub.p);
+        HIPCHK(hipGetLastError());
+        p.pq_ub = ix->pq_ub.p;
+    }
 #ifdef DR_PHASE_TIMING
     if (!ov) { if (ix->phase.reserve((size_t)nq * 8, true)) return DR_E_NODEVICE; p.phase = ix->phase.p; }
 #endif

@@ -322,3 +322,29 @@ __global__ void gather_subvectors_kernel(const float *__restrict__ vecp, const u
     if (row >= n) return;
     for (u32 e = threadIdx.x; e < D; e += blockDim.x) out[(size_t)row * D + e] = vecp[(size_t)ids[row] * D + perm[e]];
 }
+
+// sqrt(sum_j max_c T[j][c]) per query, sum in A3's order (see adc_upper_bound in search_kernel.hpp): one block of
+// 256 threads per query, thread c owns centroid c of every sub-quantiser (coalesced codebook reads).
+__global__ __launch_bounds__(256) void pq_bound_kernel(const float *__restrict__ codebook, const float *__restrict__ queries,
+                                                       u32 D, u32 m, u32 sd, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *q = reinterpret_cast<float *>(smem);
+    float *wmax = q + D;     // [4] per-wave maxima
+    const u32 qi = blockIdx.x, tid = threadIdx.x;
+    for (u32 i = tid; i < D; i += 256) q[i] = queries[(size_t)qi * D + i];
+    __syncthreads();
+    float s = 0.0f;
+    for (u32 jq = 0; jq < m; jq++) {
+        const float t = pw_run_lane(codebook + ((size_t)jq * 256 + tid) * sd, q + jq * sd, (int)sd);
+        float mx = t;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+        __syncthreads();
+        const float all = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        s = f_add(s, all);
+        __syncthreads();
+    }
+    if (tid == 0) out[qi] = f_sqrt(s);
+}

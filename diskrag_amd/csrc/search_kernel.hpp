@@ -81,6 +81,7 @@ struct SearchParams {
     float *out_dist;         // [nq][k]
     u32 *out_count;          // [nq]
     u64 *phase;              // [nq][8] cycle sums (DR_PHASE_TIMING builds only)
+    const float *pq_ub;      // [nq] precomputed sqrt-ADC upper bounds (pq_bound_kernel) or nullptr
 };
 
 DEV u32 lane_id() { return threadIdx.x & 63; }
@@ -439,11 +440,18 @@ template <bool CBLDS> DEV float adc_upper_bound(const float *tab, const float *q
 // NCHR   result capacity in 64-entry chunks
 // NW     wavefronts (= concurrent queries) per workgroup
 // CBLDS  ADC from the codebook shared in LDS (true) or from a per-query table (false)
-template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS>
+// RB     0, or: rows per burst of the LDS-landing variant -- the stored vectors of an expansion are moved HBM -> LDS
+//        by global_load_lds (no VGPR destination), RB rows in flight per wavefront with one wait, and the octets
+//        read their chain-major groups back with ds_read_b128. The codebook then stays in global memory (L2) and
+//        is only touched on the rare expansions whose ADC cannot be skipped (CBLDS must be true: the table
+//        entries are recomputed from the codebook, wherever it lives).
+template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0>
 __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
 {
     constexpr bool QREG = (D <= 256);
     constexpr bool SPLIT = QREG && split_form_ok<D>();
+    constexpr bool ROWLDS = RB > 0;
+    static_assert(!ROWLDS || (CBLDS && SPLIT && (64 % (D / 4)) == 0), "row landing needs whole rows per instruction");
     constexpr int NP = !SPLIT ? 1 : (NW >= 16 ? 1 : (NW >= 8 ? 2 : 4));   // row passes in flight
     constexpr bool NEED_PQ = FILTER || KIND == DIST_ADC_SQ;
 
@@ -455,8 +463,9 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
     // ---- LDS carve-up: [shared codebook] then one region per wavefront (all offsets multiples of 16 bytes)
     size_t off = 0;
     float *cb_lds = reinterpret_cast<float *>(smem);
-    if constexpr (NEED_PQ && CBLDS) off += (size_t)256 * D * 4;
-    const size_t per_wave = ((NEED_PQ && !CBLDS) ? (size_t)p.m * 256 * 4 : 0) + (size_t)D * 4 + (QREG ? 0 : (size_t)D * 4) + 512;
+    if constexpr (NEED_PQ && CBLDS && !ROWLDS) off += (size_t)256 * D * 4;
+    const size_t per_wave = ((NEED_PQ && !CBLDS) ? (size_t)p.m * 256 * 4 : 0) + (size_t)D * 4 + (QREG ? 0 : (size_t)D * 4) + 512 +
+                            (size_t)RB * D * 4;
     unsigned char *wbase = smem + off + (size_t)wave * per_wave;
     size_t woff = 0;
     float *lut = reinterpret_cast<float *>(wbase);
@@ -468,14 +477,16 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
     u32 *nb_id = reinterpret_cast<u32 *>(wbase + woff);
     woff += 256;
     float *nb_e = reinterpret_cast<float *>(wbase + woff);
+    woff += 256;
+    float *rowbuf = reinterpret_cast<float *>(wbase + woff);   // [RB][D] landing area (ROWLDS)
 
-    if constexpr (NEED_PQ && CBLDS) {
+    if constexpr (NEED_PQ && CBLDS && !ROWLDS) {
         const float4 *src = reinterpret_cast<const float4 *>(p.codebook);
         float4 *dst = reinterpret_cast<float4 *>(cb_lds);
         for (u32 i = threadIdx.x; i < 64u * D; i += 64 * NW) dst[i] = src[i];
         __syncthreads();
     }
-    const float *pq_tab = CBLDS ? cb_lds : lut;
+    const float *pq_tab = ROWLDS ? p.codebook : (CBLDS ? cb_lds : lut);
 
     // Static query schedule: wavefront slot s takes queries s, s + slots, s + 2*slots, ... Every loop bound is a
     // scalar, so the persistent loop is wave-uniform by construction (a ticket counter made the exit condition a
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
         // data (squared distances ~1e4-1e5, sqrt(ADC) ~1e2) that is every expansion (quirk Q1). Exact: results and
         // counters are unchanged; stats.pq_evaluated says how many ADC sums were really computed.
         float pq_ub = __uint_as_float(0x7F800000u);
-        if constexpr (FILTER) pq_ub = adc_upper_bound<CBLDS>(pq_tab, qorig, p.m, p.sd);
+        if constexpr (FILTER) pq_ub = p.pq_ub ? p.pq_ub[qi] : adc_upper_bound<CBLDS>(pq_tab, qorig, p.m, p.sd);
 
         u32 npq_eval = 0;
         u32 steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0, ninserts = 0;
@@ -625,7 +636,40 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                 if constexpr (NEED_PQ) { if (need_adc && lane < nnew) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m); }
                 float adc_s = 0.0f;
                 if constexpr (KIND != DIST_ADC_SQ) {
-                    if constexpr (SPLIT) {
+                    if constexpr (ROWLDS) {
+                        if constexpr (NEED_PQ) {
+                            if (need_adc) {
+                                if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
+                                PH(4);
+                            }
+                        }
+                        constexpr int LPR = D / 4;          // lanes (16-byte pieces) per row
+                        constexpr int RPI = 64 / LPR;       // rows per wave instruction (1 KiB)
+                        for (int b0 = 0; b0 < nnew; b0 += RB) {
+                            const int nb = min(RB, nnew - b0);
+                            // all rows of the burst in flight, no VGPR destination
+#pragma unroll
+                            for (int r = 0; r < RB; r += RPI) {
+                                if (r < nb) {
+                                    const int idx = min(b0 + r + lane / LPR, nnew - 1);
+                                    const float *g = p.vecp + (size_t)nb_id[idx] * D + (lane % LPR) * 4;
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                        (__attribute__((address_space(3))) void *)(rowbuf + (size_t)r * D), 16, 0, 0);
+                                }
+                            }
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            for (int r8 = 0; r8 < nb; r8 += 8) {
+                                const int row = min(r8 + oct, nb - 1);
+                                RowRegs<D> rr;
+                                row_load<0, D, D>(rowbuf + (size_t)row * D, j, rr);
+                                float ev = row_reduce<0, D, D>(rr, qreg);
+                                if (p.norm) ev = f_sqrt(ev);
+                                if (j == 0 && r8 + oct < nb) nb_e[b0 + r8 + oct] = ev;
+                            }
+                            // the landing area is rewritten by the next burst: its reads above have been consumed
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        }
+                    } else if constexpr (SPLIT) {
                         // rolling ring of NP row buffers: pass r is reduced while passes r+1 .. r+NP-1 are in flight
                         RowRegs<D> rr[NP];
 #pragma unroll

@@ -10,8 +10,12 @@
 //   3 M1, codebook shared in LDS, 8 waves per workgroup      (D <= 128 only, else nullptr)
 //   4 M1, codebook shared in LDS, 16 waves per workgroup     (D <= 128 only)
 //   5 ADC-only traversal, codebook shared in LDS, 8 waves    (D <= 128 only)
+//   6 M1, vectors landed in LDS by global_load_lds (32 rows/burst), codebook in global, 8 waves  (D = 128)
+//   7 same, 16 rows/burst, 16 waves                                                            (D = 128)
+//   8 exact traversal, vectors landed in LDS, 8 waves                                          (D = 128)
+//   9 M1, vectors landed in LDS, 24 rows/burst, 12 waves                                       (D = 128)
 // sizeclass: result capacity <= 64 / 128 / 256 / 512
-#define DR_NUM_KINDS 6
+#define DR_NUM_KINDS 10
 #define DR_NUM_SIZECLASS 4
 struct DimKernels {
     int D;
@@ -20,9 +24,11 @@ struct DimKernels {
     const void *bruteforce;
     const void *prune;
 };
-static const int DR_KIND_NW[DR_NUM_KINDS] = { 1, 1, 1, 8, 16, 8 };
-static const bool DR_KIND_CB[DR_NUM_KINDS] = { false, false, false, true, true, true };
-static const bool DR_KIND_PQ[DR_NUM_KINDS] = { true, false, true, true, true, true };
+static const int DR_KIND_NW[DR_NUM_KINDS] = { 1, 1, 1, 8, 16, 8, 8, 16, 8, 12 };
+static const bool DR_KIND_CB[DR_NUM_KINDS] = { false, false, false, true, true, true, false, false, false, false };   // codebook copied to LDS
+static const int DR_KIND_RB[DR_NUM_KINDS] = { 0, 0, 0, 0, 0, 0, 32, 16, 32, 24 };                                       // rows per LDS burst
+static const bool DR_KIND_LUT[DR_NUM_KINDS] = { true, false, true, false, false, false, false, false, false, false };     // per-query table in LDS
+static const bool DR_KIND_PQ[DR_NUM_KINDS] = { true, false, true, true, true, true, true, true, false, true };
 
 const DimKernels *dr_dim_kernels(int D);
 
