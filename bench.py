@@ -35,8 +35,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--num-vectors", dest="n", type=int, default=1_000_000)
+    ap.add_argument("--num-queries", dest="nq", type=int, default=10_000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--R", type=int, default=64)
     ap.add_argument("--L", type=int, default=100)
@@ -52,11 +52,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = os.environ.get("DR_BENCH_BACKEND", "nccl")     # "gloo" lets the N>1 path run where ranks share a GPU
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     import diskrag_amd
     from diskrag_amd import HipIndex, _ffi
@@ -70,7 +74,7 @@ def main():
     x, q = sift_like(args.n, args.dim, n_queries=args.nq, n_clusters=1024, seed=2024, query_seed=9000 + rank)
     log(f"synthetic data {x.shape} + {q.shape[0]} queries in {time.time() - t0:.1f}s")
     t0 = time.time()
-    ix = HipIndex.create_empty(x, R=args.R, device=local_rank)
+    ix = HipIndex.create_empty(x, R=args.R, device=local_rank % max(1, diskrag_amd.device_count()))
     medoid, build_s = ix.build_vamana(L_build=args.L_build, alpha=1.2, passes=2, seed=7, pad_with_zero=True)
     log(f"vamana graph built on device in {build_s:.1f}s (upload+build {time.time() - t0:.1f}s), medoid {medoid}")
     t0 = time.time()
@@ -88,7 +92,8 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
 
     # ---------------------------------------------------------------- warmup + timed region
     for _ in range(args.warmup):
@@ -103,7 +108,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

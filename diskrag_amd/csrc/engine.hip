@@ -309,6 +309,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
 {
     if (ov) ix->nq = ov->nq;
     if (ix->nq == 0) return fail(DR_E_ARG, "no queries uploaded");
+    if (ix->nq > 65536 && !ov) return fail(DR_E_UNSUPPORTED, "resident batches are limited to 65536 queries (dr_search_batch chunks larger ones)");
     if (mode < DR_MODE_M1 || mode > DR_MODE_M4) return fail(DR_E_ARG, "unknown mode %u", mode);
     if (k == 0) return fail(DR_E_ARG, "k must be positive");
     const bool use_pq = (mode == DR_MODE_M1) || (mode == DR_MODE_M3 && (flags & DR_F_USE_PQ));
@@ -502,17 +503,30 @@ extern "C" int dr_get_timing(dr_index *ix, dr_timing *out)
     return 0;
 }
 
+// Per-query scratch (insert log, result keys) is sized by the batch: very large batches are processed in chunks.
+static const uint32_t DR_MAX_CHUNK = 32768;
+
 extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t L,
                                uint32_t beam_width, uint32_t mode, uint32_t band_policy, uint32_t flags,
                                uint32_t *out_ids, float *out_dist, uint32_t *out_count, dr_stats *stats)
 {
     if (!ix) return fail(DR_E_ARG, "null index");
     if (!out_ids || !out_dist || !out_count) return fail(DR_E_ARG, "null output buffer");
+    if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
     std::lock_guard<std::mutex> lk(ix->mu);
-    int rc = upload_queries_locked(ix, queries, nq);
-    if (!rc) rc = run_locked(ix, k, L, beam_width, mode, band_policy, flags);
-    if (!rc) rc = download_locked(ix, out_ids, out_dist, out_count, stats);
-    return rc;
+    float h2d = 0, ker = 0, fin = 0, d2h = 0;
+    for (uint32_t q0 = 0; q0 < nq; q0 += DR_MAX_CHUNK) {
+        const uint32_t n = std::min(DR_MAX_CHUNK, nq - q0);
+        int rc = upload_queries_locked(ix, queries + (size_t)q0 * ix->D, n);
+        if (!rc) rc = run_locked(ix, k, L, beam_width, mode, band_policy, flags);
+        if (!rc) rc = download_locked(ix, out_ids + (size_t)q0 * k, out_dist + (size_t)q0 * k, out_count + q0,
+                                      stats ? stats + q0 : nullptr);
+        if (rc) return rc;
+        h2d += ix->timing.h2d_ms; ker += ix->timing.search_kernel_ms; fin += ix->timing.finalize_kernel_ms; d2h += ix->timing.d2h_ms;
+    }
+    ix->timing.h2d_ms = h2d; ix->timing.search_kernel_ms = ker; ix->timing.finalize_kernel_ms = fin; ix->timing.d2h_ms = d2h;
+    ix->timing.total_ms = h2d + ker + fin + d2h;
+    return 0;
 }
 
 // --------------------------------------------------------------------------------- kernel-level entry points

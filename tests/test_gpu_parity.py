@@ -217,3 +217,18 @@ def test_error_behaviour():
         HipIndex.create(g.vectors, bad, g.medoid)
     with pytest.raises(DiskragHipError):       # unsupported dimension
         HipIndex.create(np.zeros((4, 7), dtype=np.float32), np.zeros((4, 2), dtype=np.uint32), 0)
+
+
+def test_large_batch_is_chunked():
+    """dr_search_batch splits batches larger than its per-query scratch budget (32768) transparently."""
+    from diskrag_amd import _ffi
+    g = load_golden("sift128_R64_m32")
+    ix = get_index("sift128_R64_m32")
+    c = g.case(2)   # L=20, bw=8
+    reps = 40000 // len(g.queries) + 1
+    q = np.tile(g.queries, (reps, 1))[:40000]
+    ids, dist, cnt, st = ix.search_batch(q, 10, L=20, beam_width=8, mode=_ffi.MODE_M1)
+    want = np.tile(c["ids"], (reps, 1))[:40000]
+    assert (st["status"] == 0).all()
+    assert np.array_equal(ids, want)
+    assert np.array_equal(bits(dist), bits(np.tile(c["dist"], (reps, 1))[:40000]))
