@@ -37,7 +37,7 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_index_set_adjacency", "dr_search_batch", "dr_batch_upload", "dr_batch_run", "dr_batch_download",
            "dr_get_timing", "dr_exact_distances", "dr_distance_table", "dr_adc", "dr_pq_scan",
            "dr_bruteforce_topk", "dr_get_node", "dr_index_close", "dr_index_create_empty", "dr_build_vamana",
-           "dr_get_adjacency", "dr_pq_train", "dr_pq_encode", "dr_debug_phase_cycles"]
+           "dr_get_adjacency", "dr_pq_train", "dr_pq_encode", "dr_debug_phase_cycles", "dr_batch_sync"]
 
 _lib = None
 
@@ -77,6 +77,8 @@ def load_library():
     L.dr_batch_upload.argtypes = [vp, fp, C.c_uint32]
     L.dr_batch_run.restype = C.c_int
     L.dr_batch_run.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.dr_batch_sync.restype = C.c_int
+    L.dr_batch_sync.argtypes = [vp]
     L.dr_batch_download.restype = C.c_int
     L.dr_batch_download.argtypes = [vp, u32p, fp, u32p, C.POINTER(DrStats)]
     L.dr_get_timing.restype = C.c_int
@@ -245,6 +247,9 @@ class HipIndex:
         _check(load_library().dr_batch_run(self._h, int(k), int(L), int(beam_width or 0), int(mode),
                                            int(band_policy), int(flags)))
         self._k = int(k)
+
+    def batch_sync(self):
+        _check(load_library().dr_batch_sync(self._h))
 
     def batch_download(self):
         nq, k = self._nq, self._k

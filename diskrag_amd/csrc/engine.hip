@@ -100,11 +100,23 @@ struct dr_index {
     // batch scratch
     uint32_t nq = 0;             // queries currently resident
     DevBuf<float> q, qp;
-    DevBuf<uint32_t> vis, vlog, counter, res_n, tie, out_ids, out_count;
+    DevBuf<uint32_t> vis, vlog;
     size_t vis_zeroed = 0;
-    DevBuf<u64> res_keys, log;
-    DevBuf<KStats> stats;
-    DevBuf<float> out_dist, pq_ub;
+    // per-step outputs are double-buffered: the tie-order pass (finalize) of step i runs on its own stream while
+    // the search kernel of step i+1 fills the other set
+    struct BatchSet {
+        DevBuf<uint32_t> counter, res_n, tie, out_ids, out_count;
+        DevBuf<u64> res_keys, log;
+        DevBuf<KStats> stats;
+        DevBuf<float> out_dist;
+        hipEvent_t search_done = nullptr, fin_start = nullptr, fin_done = nullptr;
+        bool fin_pending = false;
+        void release() { counter.release(); res_n.release(); tie.release(); out_ids.release(); out_count.release();
+                         res_keys.release(); log.release(); stats.release(); out_dist.release(); }
+    } sets[2];
+    int parity = 0, last_set = 0;
+    hipStream_t fstream = nullptr;
+    DevBuf<float> pq_ub;
     DevBuf<u64> phase;
     uint32_t last_k = 0;
     dr_timing timing = {};
@@ -135,7 +147,9 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     ix->num_cu = prop.multiProcessorCount;
     ix->device = device; ix->N = N; ix->D = D; ix->R = R; ix->medoid = medoid;
     HIPCHK(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ix->fstream, hipStreamNonBlocking));
     for (auto &e : ix->ev) HIPCHK(hipEventCreate(&e));
+    for (auto &bs : ix->sets) { HIPCHK(hipEventCreate(&bs.search_done)); HIPCHK(hipEventCreate(&bs.fin_start)); HIPCHK(hipEventCreate(&bs.fin_done)); }
     ix->h_perm.resize(D);
     pw_build_perm_rec(0, D, ix->h_perm.data());
     if (ix->perm.reserve(D)) return DR_E_NODEVICE;
@@ -262,11 +276,18 @@ extern "C" void dr_index_close(dr_index *ix)
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release();
+    if (ix->fstream) (void)hipStreamSynchronize(ix->fstream);
     ix->perm.release(); ix->q.release(); ix->qp.release(); ix->vis.release(); ix->vlog.release();
-    ix->counter.release(); ix->res_n.release(); ix->tie.release(); ix->out_ids.release(); ix->out_count.release();
-    ix->res_keys.release(); ix->log.release(); ix->stats.release(); ix->out_dist.release(); ix->pq_ub.release(); ix->phase.release();
+    for (auto &bs : ix->sets) {
+        bs.release();
+        if (bs.search_done) (void)hipEventDestroy(bs.search_done);
+        if (bs.fin_start) (void)hipEventDestroy(bs.fin_start);
+        if (bs.fin_done) (void)hipEventDestroy(bs.fin_done);
+    }
+    ix->pq_ub.release(); ix->phase.release();
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    if (ix->fstream) (void)hipStreamDestroy(ix->fstream);
     delete ix;
 }
 
@@ -369,10 +390,17 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     }
     if (ix->vlog.reserve((size_t)slots * vis_limit)) return DR_E_NODEVICE;
     const uint32_t logcap = 4096;
-    if (ix->counter.reserve(2) || ix->res_n.reserve((size_t)nq * 2) || ix->tie.reserve(nq) || ix->stats.reserve(nq) ||
-        ix->res_keys.reserve((size_t)nq * 512) || ix->log.reserve((size_t)nq * logcap) ||
-        ix->out_ids.reserve((size_t)nq * std::max<uint32_t>(k, 64)) ||
-        ix->out_dist.reserve((size_t)nq * std::max<uint32_t>(k, 64)) || ix->out_count.reserve(nq))
+    const int set = ov ? 0 : ix->parity;
+    dr_index::BatchSet &bs = ix->sets[set];
+    if (bs.fin_pending) {
+        // this set's buffers may still be read by the tie-order pass of the step that used it last
+        if (ov) HIPCHK(hipStreamSynchronize(ix->fstream));
+        else HIPCHK(hipStreamWaitEvent(ix->stream, bs.fin_done, 0));
+    }
+    if (bs.counter.reserve(2) || bs.res_n.reserve(nq) || bs.tie.reserve(nq) || bs.stats.reserve(nq) ||
+        bs.res_keys.reserve((size_t)nq * cap) || bs.log.reserve((size_t)nq * logcap) ||
+        bs.out_ids.reserve((size_t)nq * std::max<uint32_t>(k, 64)) ||
+        bs.out_dist.reserve((size_t)nq * std::max<uint32_t>(k, 64)) || bs.out_count.reserve(nq))
         return DR_E_NODEVICE;
 
     SearchParams p;
@@ -384,11 +412,11 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.norm = (mode == DR_MODE_M2 || (mode == DR_MODE_M4 && !(flags & DR_F_SQDIST))) ? 1u : 0u;
     p.max_steps = (uint32_t)std::min<uint64_t>(max_steps, 0xFFFFFFFFull);
     p.vis = ix->vis.p; p.vis_words = vis_words; p.vlog = ix->vlog.p; p.vis_limit = vis_limit;
-    p.counter = ix->counter.p;
-    p.res_keys = ix->res_keys.p; p.res_n = ix->res_n.p; p.stats = ix->stats.p;
-    p.tie_list = ix->tie.p; p.tie_count = ix->counter.p + 1;
-    p.log = ix->log.p; p.logcap = logcap;
-    p.out_ids = ix->out_ids.p; p.out_dist = ix->out_dist.p; p.out_count = ix->out_count.p;
+    p.counter = bs.counter.p;
+    p.res_keys = bs.res_keys.p; p.res_n = bs.res_n.p; p.stats = bs.stats.p;
+    p.tie_list = bs.tie.p; p.tie_count = bs.counter.p + 1;
+    p.log = bs.log.p; p.logcap = logcap;
+    p.out_ids = bs.out_ids.p; p.out_dist = bs.out_dist.p; p.out_count = bs.out_count.p;
     p.phase = nullptr;
     p.pq_ub = nullptr;
     if (mode == DR_MODE_M1 && RB > 0) {
@@ -409,47 +437,58 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
 
     static const bool dbg = getenv("DR_DEBUG") != nullptr;
     if (dbg) { fprintf(stderr, "[dr] search kind=%d sc=%d NW=%d grid=%u lds=%zu occ=%d nq=%u cap=%u slots=%u vis_words=%u vis_limit=%u\n", kind, sc, NW, grid, lds, occ, nq, cap, slots, vis_words, vis_limit); fflush(stderr); }
-    HIPCHK(hipMemsetAsync(ix->counter.p, 0, 8, ix->stream));
-#ifdef DR_BOUNDED_TICKETS
-    HIPCHK(hipMemsetAsync(ix->res_n.p + nq, 0, (size_t)nq * 4, ix->stream));
-#endif
+    HIPCHK(hipMemsetAsync(bs.counter.p, 0, 8, ix->stream));
     HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
     void *args[] = { &p };
     HIPCHK(hipLaunchKernel(kfn, dim3(grid), dim3(64 * NW), args, lds, ix->stream));
     HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
     if (ov) return 0;   // the builder consumes res_keys / res_n directly on the stream
-    if (dbg) { HIPCHK(hipStreamSynchronize(ix->stream)); fprintf(stderr, "[dr] search kernel done\n"); fflush(stderr); }
 
-    // tie replay for the queries the search kernel listed: one wavefront per query, heap in registers
+    // tie replay for the queries the search kernel listed: one wavefront per query, heap in registers. It runs on
+    // its own stream so that it overlaps the NEXT step's search kernel (it needs 19 VGPRs and no LDS, so its
+    // wavefronts fit beside the search kernel's); dr_batch_sync / dr_batch_download wait for it.
+    HIPCHK(hipEventRecord(bs.search_done, ix->stream));
+    HIPCHK(hipStreamWaitEvent(ix->fstream, bs.search_done, 0));
     FinalizeParams f;
-    f.res_keys = ix->res_keys.p; f.res_n = ix->res_n.p; f.tie_list = ix->tie.p; f.tie_count = ix->counter.p + 1;
-    f.log = ix->log.p; f.stats = ix->stats.p;
+    f.res_keys = bs.res_keys.p; f.res_n = bs.res_n.p; f.tie_list = bs.tie.p; f.tie_count = bs.counter.p + 1;
+    f.log = bs.log.p; f.stats = bs.stats.p;
     f.logcap = logcap; f.cap = cap; f.k = k; f.mode = mode;
-    f.out_ids = ix->out_ids.p; f.out_dist = ix->out_dist.p;
+    f.out_ids = bs.out_ids.p; f.out_dist = bs.out_dist.p;
+    HIPCHK(hipEventRecord(bs.fin_start, ix->fstream));
     {
         const unsigned fgrid = (unsigned)std::min<uint64_t>(((uint64_t)nq + 3) / 4, (uint64_t)ix->num_cu * 8);
-        if (cap + 1 <= 64) hipLaunchKernelGGL(finalize_kernel<1>, dim3(fgrid), dim3(256), 0, ix->stream, f);
-        else if (cap + 1 <= 128) hipLaunchKernelGGL(finalize_kernel<2>, dim3(fgrid), dim3(256), 0, ix->stream, f);
-        else if (cap + 1 <= 256) hipLaunchKernelGGL(finalize_kernel<4>, dim3(fgrid), dim3(256), 0, ix->stream, f);
-        else hipLaunchKernelGGL(finalize_kernel<9>, dim3(fgrid), dim3(256), 0, ix->stream, f);
+        if (cap + 1 <= 64) hipLaunchKernelGGL(finalize_kernel<1>, dim3(fgrid), dim3(256), 0, ix->fstream, f);
+        else if (cap + 1 <= 128) hipLaunchKernelGGL(finalize_kernel<2>, dim3(fgrid), dim3(256), 0, ix->fstream, f);
+        else if (cap + 1 <= 256) hipLaunchKernelGGL(finalize_kernel<4>, dim3(fgrid), dim3(256), 0, ix->fstream, f);
+        else hipLaunchKernelGGL(finalize_kernel<9>, dim3(fgrid), dim3(256), 0, ix->fstream, f);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    if (dbg) { fprintf(stderr, "[dr] finalize done\n"); fflush(stderr); }
-#ifdef DR_BOUNDED_TICKETS
-    { std::vector<uint32_t> hc(nq + 2); HIPCHK(hipMemcpy(hc.data(), ix->res_n.p + nq, (size_t)nq * 4, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(hc.data() + nq, ix->counter.p, 8, hipMemcpyDeviceToHost));
-      uint32_t mx = 0, mn = 1u << 30; for (uint32_t i = 0; i < nq; i++) { mx = std::max(mx, hc[i]); mn = std::min(mn, hc[i]); }
-      fprintf(stderr, "[dr] handed-out counts min=%u max=%u final counter=%u tie_count=%u\n", mn, mx, hc[nq], hc[nq + 1]); fflush(stderr); }
-#endif
-    float a = 0, b = 0;
+    HIPCHK(hipEventRecord(bs.fin_done, ix->fstream));
+    bs.fin_pending = true;
+    HIPCHK(hipStreamSynchronize(ix->stream));      // the search kernel of this step has finished
+    if (dbg) { fprintf(stderr, "[dr] search done\n"); fflush(stderr); }
+    float a = 0;
     (void)hipEventElapsedTime(&a, ix->ev[2], ix->ev[3]);
-    (void)hipEventElapsedTime(&b, ix->ev[3], ix->ev[4]);
-    ix->timing.search_kernel_ms = a; ix->timing.finalize_kernel_ms = b;
+    ix->timing.search_kernel_ms = a;
     ix->timing.grid = grid; ix->timing.block = 64 * NW; ix->timing.lds_bytes = (uint32_t)lds;
     ix->timing.waves_per_cu = (uint32_t)(occ * NW);
     ix->last_k = k;
+    ix->last_set = set;
+    ix->parity ^= 1;
+    return 0;
+}
+
+// waits for every outstanding kernel of the handle (the overlapped tie-order pass included)
+static int sync_locked(dr_index *ix)
+{
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->fstream));
+    dr_index::BatchSet &bs = ix->sets[ix->last_set];
+    if (bs.fin_pending) {
+        float b = 0;
+        if (hipEventElapsedTime(&b, bs.fin_start, bs.fin_done) == hipSuccess) ix->timing.finalize_kernel_ms = b;
+    }
+    for (auto &x : ix->sets) x.fin_pending = false;
     return 0;
 }
 
@@ -457,13 +496,16 @@ static int download_locked(dr_index *ix, uint32_t *out_ids, float *out_dist, uin
 {
     if (ix->nq == 0 || ix->last_k == 0) return fail(DR_E_ARG, "nothing to download");
     HIPCHK(hipSetDevice(ix->device));
+    int rc = sync_locked(ix);
+    if (rc) return rc;
+    dr_index::BatchSet &bs = ix->sets[ix->last_set];
     const uint32_t nq = ix->nq, k = ix->last_k;
     HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
-    if (out_ids) HIPCHK(hipMemcpyAsync(out_ids, ix->out_ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
-    if (out_dist) HIPCHK(hipMemcpyAsync(out_dist, ix->out_dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
-    if (out_count) HIPCHK(hipMemcpyAsync(out_count, ix->out_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ix->stream));
+    if (out_ids) HIPCHK(hipMemcpyAsync(out_ids, bs.out_ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
+    if (out_dist) HIPCHK(hipMemcpyAsync(out_dist, bs.out_dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
+    if (out_count) HIPCHK(hipMemcpyAsync(out_count, bs.out_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ix->stream));
     static_assert(sizeof(dr_stats) == sizeof(KStats), "stats layout");
-    if (stats) HIPCHK(hipMemcpyAsync(stats, ix->stats.p, (size_t)nq * sizeof(KStats), hipMemcpyDeviceToHost, ix->stream));
+    if (stats) HIPCHK(hipMemcpyAsync(stats, bs.stats.p, (size_t)nq * sizeof(KStats), hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipEventRecord(ix->ev[5], ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
     float ms = 0;
@@ -471,6 +513,14 @@ static int download_locked(dr_index *ix, uint32_t *out_ids, float *out_dist, uin
     ix->timing.d2h_ms = ms;
     ix->timing.total_ms = ix->timing.h2d_ms + ix->timing.search_kernel_ms + ix->timing.finalize_kernel_ms + ms;
     return 0;
+}
+
+extern "C" int dr_batch_sync(dr_index *ix)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIPCHK(hipSetDevice(ix->device));
+    return sync_locked(ix);
 }
 
 extern "C" int dr_batch_upload(dr_index *ix, const float *queries, uint32_t nq)
@@ -765,7 +815,7 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
             // 2. prune -> forward rows
             PruneParams pp;
             pp.vecp = ix->vecp.p; pp.adjb = adjb.p; pp.deg = deg.p; pp.RX = RX; pp.R = R; pp.alpha = a;
-            pp.points = pts; pp.npoints = b; pp.res_keys = ix->res_keys.p; pp.res_n = ix->res_n.p; pp.cap = L_build;
+            pp.points = pts; pp.npoints = b; pp.res_keys = ix->sets[0].res_keys.p; pp.res_n = ix->sets[0].res_n.p; pp.cap = L_build;
             pp.fwd = fwd.p; pp.fwd_n = fwd_n.p;
             {
                 void *args[] = { &pp };

@@ -100,11 +100,15 @@ int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, uint32_t k,
                     uint32_t *out_count, dr_stats *stats);
 
 /* HBM-resident batches (bench.py: inputs already on the device when the timed region starts).
- * dr_batch_upload copies queries to the device; dr_batch_run launches the search + finalize kernels on the
- * engine stream and waits for them; dr_batch_download copies results back. */
+ * dr_batch_upload copies queries to the device. dr_batch_run launches one search step and returns when its
+ * search kernel has finished; the tie-order pass of that step (finalize: replays the reference's heap for the
+ * queries whose first k results hold equal distances) runs on a second stream and overlaps the NEXT step's
+ * search kernel (outputs are double-buffered). dr_batch_sync waits for everything outstanding;
+ * dr_batch_download syncs, then copies the last step's results back. */
 int dr_batch_upload(dr_index *ix, const float *queries, uint32_t nq);
 int dr_batch_run(dr_index *ix, uint32_t k, uint32_t L, uint32_t beam_width, uint32_t mode, uint32_t band_policy,
                  uint32_t flags);
+int dr_batch_sync(dr_index *ix);
 int dr_batch_download(dr_index *ix, uint32_t *out_ids, float *out_dist, uint32_t *out_count, dr_stats *stats);
 int dr_get_timing(dr_index *ix, dr_timing *out);
 
