@@ -117,6 +117,7 @@ struct dr_index {
     int parity = 0, last_set = 0;
     hipStream_t fstream = nullptr;
     DevBuf<float> pq_ub;
+    bool pq_ub_valid = false;     // pq_ub matches the resident queries and the attached codebook
     DevBuf<u64> phase;
     uint32_t last_k = 0;
     dr_timing timing = {};
@@ -267,6 +268,7 @@ extern "C" int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_
     HIPCHK(hipMemcpy(ix->codes.p, codes, (size_t)ix->N * m, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ix->codebook.p, codebook, (size_t)256 * ix->D * 4, hipMemcpyHostToDevice));
     ix->m = m; ix->sd = ix->D / m;
+    ix->pq_ub_valid = false;
     return 0;
 }
 
@@ -306,6 +308,7 @@ static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq
     HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
     ix->nq = nq;
+    ix->pq_ub_valid = false;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]);
     ix->timing.h2d_ms = ms;
@@ -419,12 +422,15 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.out_ids = bs.out_ids.p; p.out_dist = bs.out_dist.p; p.out_count = bs.out_count.p;
     p.phase = nullptr;
     p.pq_ub = nullptr;
-    if (mode == DR_MODE_M1 && RB > 0) {
-        // the codebook is not in LDS for this variant: per-query ADC upper bounds come from a small kernel
-        if (ix->pq_ub.reserve(nq)) return DR_E_NODEVICE;
-        hipLaunchKernelGGL(pq_bound_kernel, dim3(nq), dim3(256), (size_t)ix->D * 4 + 16, ix->stream, ix->codebook.p, ix->q.p,
-                           ix->D, ix->m, ix->sd, ix->pq_ub.p);
-        HIPCHK(hipGetLastError());
+    if (mode == DR_MODE_M1) {
+        // per-query ADC upper bounds: a function of (queries, codebook) only, computed once per uploaded batch
+        if (!ix->pq_ub_valid) {
+            if (ix->pq_ub.reserve(nq)) return DR_E_NODEVICE;
+            hipLaunchKernelGGL(pq_bound_kernel, dim3(nq), dim3(256), (size_t)ix->D * 4 + 16, ix->stream, ix->codebook.p, ix->q.p,
+                               ix->D, ix->m, ix->sd, ix->pq_ub.p);
+            HIPCHK(hipGetLastError());
+            ix->pq_ub_valid = true;
+        }
         p.pq_ub = ix->pq_ub.p;
     }
 #ifdef DR_PHASE_TIMING
@@ -959,6 +965,7 @@ extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uin
     if (out_codes) HIPCHK(hipMemcpyAsync(out_codes, ix->codes.p, (size_t)ix->N * m, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
     ix->m = m; ix->sd = ix->D / m;
+    ix->pq_ub_valid = false;
     return 0;
 }
 
