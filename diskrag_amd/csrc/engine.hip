@@ -415,6 +415,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.norm = (mode == DR_MODE_M2 || (mode == DR_MODE_M4 && !(flags & DR_F_SQDIST))) ? 1u : 0u;
     p.max_steps = (uint32_t)std::min<uint64_t>(max_steps, 0xFFFFFFFFull);
     p.vis = ix->vis.p; p.vis_words = vis_words; p.vlog = ix->vlog.p; p.vis_limit = vis_limit;
+    { const char *e = getenv("DR_VIS_STREAM"); p.vis_stream_clear = (e && atoi(e) && vis_words % 4 == 0 && (size_t)slots * vis_words % 4 == 0) ? 1u : 0u; }
     p.counter = bs.counter.p;
     p.res_keys = bs.res_keys.p; p.res_n = bs.res_n.p; p.stats = bs.stats.p;
     p.tie_list = bs.tie.p; p.tie_count = bs.counter.p + 1;

@@ -69,6 +69,7 @@ struct SearchParams {
     u32 vis_words;
     u32 *vlog;               // [slots][vis_limit] ids set in the bitmap by the running query
     u32 vis_limit;
+    u32 vis_stream_clear;    // 1: clear the whole slot bitmap with wide stores after a query (small N) instead of per id
     u32 *counter;            // [2]: unused, tie-list length
     u64 *res_keys;           // [nq][cap] ascending (dist bits << 32 | ~id)
     u32 *res_n;              // [nq]
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
         // ---- start node (search_engine.py:416-426)
         {
             const u32 start = p.medoid;
-            if (lane == 0) { atomicOr(&vbm[start >> 5], 1u << (start & 31)); vlog[0] = start; }
+            if (lane == 0) { atomicOr(&vbm[start >> 5], 1u << (start & 31)); if (!p.vis_stream_clear) vlog[0] = start; }
             nvisited = 1;
             float d0;
             if constexpr (KIND == DIST_ADC_SQ) {
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                 if (isnew) {
                     const int rnk = __popcll(newmask & lanemask_lt());
                     nb_id[rnk] = nbid;
-                    vlog[nvisited + rnk] = nbid;
+                    if (!p.vis_stream_clear) vlog[nvisited + rnk] = nbid;
                 }
                 nvisited += nnew;
                 WSYNC();
@@ -808,6 +809,14 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
         }
 
         // ---- clear the visited bits this query set (the bitmap is all zero between queries)
+        if (p.vis_stream_clear) {
+            // small N: the whole slot bitmap is a few hundred 1-KiB wave stores, cheaper than one 64-byte
+            // read-modify-write per visited id
+            uint4 *vb4 = reinterpret_cast<uint4 *>(vbm);
+            const u32 n4 = p.vis_words / 4;
+            for (u32 i = lane; i < n4; i += 64) vb4[i] = make_uint4(0, 0, 0, 0);
+            for (u32 i = n4 * 4 + lane; i < p.vis_words; i += 64) vbm[i] = 0u;
+        } else
         // (four log reads in flight per trip; the stores bypass L1 like the atomics that will follow them)
         for (u32 i0 = 0; i0 < nvisited; i0 += 256) {
             const u32 ia = i0 + lane, ib = ia + 64, ic = ia + 128, id_ = ia + 192;

@@ -36,16 +36,23 @@ def sift_like(n, d=128, n_queries=10000, n_clusters=1024, seed=2024, latent=32, 
     return x, q
 
 
-def unit_mixture(n, d=1536, n_queries=1000, n_clusters=256, seed=7, within=1.0):
-    """Unit-norm clustered vectors (text-embedding-like); L2^2 = 2 - 2*IP on these."""
+def unit_mixture(n, d=1536, n_queries=1000, n_clusters=256, seed=7, latent=64, within=1.0, noise=0.05):
+    """Unit-norm clustered vectors (text-embedding-like, low intrinsic dimension); L2^2 = 2 - 2*IP on these."""
     rs = np.random.RandomState(seed)
-    cent = rs.randn(n_clusters, d).astype(np.float32)
+    B = (rs.randn(latent, d) / np.sqrt(latent)).astype(np.float32)
+    cent = rs.randn(n_clusters, latent).astype(np.float32)
 
     def draw(cnt, r):
-        a = r.randint(0, n_clusters, size=cnt)
-        p = cent[a] + within * r.randn(cnt, d).astype(np.float32)
-        p /= np.linalg.norm(p, axis=1, keepdims=True)
-        return p.astype(np.float32)
+        out = np.empty((cnt, d), dtype=np.float32)
+        step = 1 << 15
+        for s in range(0, cnt, step):
+            e = min(cnt, s + step)
+            a = r.randint(0, n_clusters, size=e - s)
+            z = cent[a] + within * r.randn(e - s, latent).astype(np.float32)
+            p = z @ B + noise * r.randn(e - s, d).astype(np.float32)
+            p /= np.linalg.norm(p, axis=1, keepdims=True)
+            out[s:e] = p
+        return out
 
     return draw(n, rs), draw(n_queries, np.random.RandomState(seed + 1))
 
