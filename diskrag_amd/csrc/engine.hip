@@ -345,30 +345,36 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     HIPCHK(hipSetDevice(ix->device));
 
     const int sc = cap <= 64 ? 0 : cap <= 128 ? 1 : cap <= 256 ? 2 : 3;
-    // kernel variant (variants.hpp). M1 at D = 128: vectors landed in LDS (kind 6); other D <= 128 with PQ: codebook
-    // shared in LDS (kinds 3 / 5); otherwise per-query table (0 / 2) or no PQ at all (1)
-    int kind = (mode == DR_MODE_M1) ? 0 : (mode == DR_MODE_M3 && use_pq) ? 2 : 1;
-    if (kind != 1 && ix->kern->search[3][sc] && (size_t)256 * ix->D * 4 <= 128 * 1024) kind = (kind == 0) ? 3 : 5;
-    if (kind == 3 && ix->kern->search[9][sc]) kind = 9;
-    if (kind == 1 && !ov && ix->kern->search[8][sc]) kind = 8;
+    // kernel variant (variants.hpp): the first available variant of the mode's preference list whose LDS footprint
+    // fits. M1: vectors landed in LDS (9, 6) > codebook shared in LDS (3) > per-query table (0); ADC traversal:
+    // 5 > 2; exact traversal: 8 > 1 (the builder uses 1).
+    static const int NCHR_OF_SC[4] = { 1, 2, 4, 8 };
+    auto lds_of = [&](int kd) -> size_t {
+        const int rb = DR_KIND_RB[kd];
+        const size_t pw = (DR_KIND_LUT[kd] ? (size_t)ix->m * 256 * 4 : 0) + (size_t)ix->D * 4 + (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 512 +
+                          (rb ? (size_t)rb * ix->D * 4 : (size_t)NCHR_OF_SC[sc] * 64 * 12);
+        return (DR_KIND_CB[kd] ? (size_t)256 * ix->D * 4 : 0) + (size_t)DR_KIND_NW[kd] * pw;
+    };
+    auto usable = [&](int kd) { return ix->kern->search[kd][sc] != nullptr && lds_of(kd) <= 160 * 1024; };
+    static const int PREF_M1[] = { 9, 6, 3, 0 }, PREF_ADC[] = { 5, 2 }, PREF_EX[] = { 8, 1 }, PREF_BUILD[] = { 1 };
+    const bool k_m1 = (mode == DR_MODE_M1), k_adc = (mode == DR_MODE_M3 && use_pq);
+    const int *pref = k_m1 ? PREF_M1 : k_adc ? PREF_ADC : ov ? PREF_BUILD : PREF_EX;
+    const int npref = k_m1 ? 4 : k_adc ? 2 : ov ? 1 : 2;
+    int kind = -1;
+    for (int i = 0; i < npref && kind < 0; i++) if (usable(pref[i])) kind = pref[i];
     {
         static bool env_read = false;
         if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e) g_force_kind = atoi(e); env_read = true; }
         const int g = g_force_kind;
-        if (g >= 0 && g < DR_NUM_KINDS && ix->kern->search[g][sc]) {
+        if (g >= 0 && g < DR_NUM_KINDS && usable(g)) {
             const bool g_m1 = (g == 0 || g == 3 || g == 4 || g == 6 || g == 7 || g == 9), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8);
-            const bool k_m1 = (mode == DR_MODE_M1), k_adc = (mode == DR_MODE_M3 && use_pq);
             if ((g_m1 && k_m1) || (g_adc && k_adc) || (g_ex && !k_m1 && !k_adc)) kind = g;
         }
     }
+    if (kind < 0) return fail(DR_E_UNSUPPORTED, "no kernel variant fits in LDS (D=%u, m=%u, capacity %u)", ix->D, ix->m, cap);
     const void *kfn = ix->kern->search[kind][sc];
     const int NW = DR_KIND_NW[kind];
-    const bool cb = DR_KIND_CB[kind];
-    const int RB = DR_KIND_RB[kind];
-
-    const size_t per_wave = (DR_KIND_LUT[kind] ? (size_t)ix->m * 256 * 4 : 0) + (size_t)ix->D * 4 + (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 512 +
-                            (size_t)RB * ix->D * 4;
-    const size_t lds = (cb ? (size_t)256 * ix->D * 4 : 0) + (size_t)NW * per_wave;
+    const size_t lds = lds_of(kind);
     if (lds > 160 * 1024) return fail(DR_E_UNSUPPORTED, "LDS footprint %zu B exceeds 160 KiB", lds);
     HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int occ = 0;

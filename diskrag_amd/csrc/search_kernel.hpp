@@ -465,8 +465,10 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
     size_t off = 0;
     float *cb_lds = reinterpret_cast<float *>(smem);
     if constexpr (NEED_PQ && CBLDS && !ROWLDS) off += (size_t)256 * D * 4;
+    constexpr size_t MERGE_BYTES = (size_t)NCHR * 64 * 12;   // merge scratch: NCHR*64 keys (u64) + states (u32)
+    static_assert(!ROWLDS || (size_t)RB * D * 4 >= MERGE_BYTES, "the row landing area doubles as merge scratch");
     const size_t per_wave = ((NEED_PQ && !CBLDS) ? (size_t)p.m * 256 * 4 : 0) + (size_t)D * 4 + (QREG ? 0 : (size_t)D * 4) + 512 +
-                            (size_t)RB * D * 4;
+                            (ROWLDS ? (size_t)RB * D * 4 : MERGE_BYTES);
     unsigned char *wbase = smem + off + (size_t)wave * per_wave;
     size_t woff = 0;
     float *lut = reinterpret_cast<float *>(wbase);
@@ -480,6 +482,8 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
     float *nb_e = reinterpret_cast<float *>(wbase + woff);
     woff += 256;
     float *rowbuf = reinterpret_cast<float *>(wbase + woff);   // [RB][D] landing area (ROWLDS)
+    u64 *mk = reinterpret_cast<u64 *>(wbase + woff);           // merge scratch (shares the landing area: rows are
+    u32 *mf = reinterpret_cast<u32 *>(mk + NCHR * 64);         // consumed before the decisions start)
 
     if constexpr (NEED_PQ && CBLDS && !ROWLDS) {
         const float4 *src = reinterpret_cast<const float4 *>(p.codebook);
@@ -729,7 +733,126 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
 
                 // ---- predict the next pop: the closer of the frontier head and the best new neighbour; prefetch its row
 
-                // ---- decisions in stored order
+                // ---- decisions
+                // Batched form, used whenever acceptance depends on distances only (A4 proven True for the whole
+                // expansion, or a variant without A4). Sequential rule: neighbour i is accepted iff len < cap or
+                // e_i < W_i, W_i the worst distance after the earlier accepts. Equivalently: fewer than cap of
+                // (old list + earlier accepted) have distance <= e_i. So: (1) candidates = neighbours that beat
+                // the CURRENT worst distance (all of them while the list is not full), (2) walk only those, in
+                // stored order, with two ballots each, (3) ONE merge of the accepted set into the list through
+                // LDS. Entries pushed out of the list are accounted exactly as single inserts would.
+                bool batched = true;
+                if constexpr (FILTER) batched = all_pass;
+                if (batched) {
+                    if constexpr (KIND != DIST_ADC_SQ) nexact += nnew;
+                    const u32 ebits = __float_as_uint(e);
+                    const bool full0 = (rn == cap);
+                    const u32 W0b = (u32)(list_get<NCHR>(rk, rn - 1) >> 32);
+                    u64 cm = __ballot(lane < nnew && (!full0 || ebits < W0b));
+                    u32 acc_e = 0xFFFFFFFFu;   // lane s: distance bits of the s-th accepted neighbour
+                    int na = 0;
+                    u64 accmask = 0ull;
+                    while (cm != 0ull) {
+                        const int f = __ffsll((long long)cm) - 1;
+                        cm &= cm - 1ull;
+                        const u32 eb = readlane32(ebits, f);
+                        int c = 0;
+#pragma unroll
+                        for (int ch = 0; ch < NCHR; ch++)
+                            c += __popcll(__ballot(ch * 64 + lane < rn && (u32)(rk.v[ch] >> 32) <= eb));
+                        const int a = __popcll(__ballot(lane < na && acc_e <= eb));
+                        if (c + a < cap) {
+                            if (lane == na) acc_e = eb;
+                            na++;
+                            accmask |= 1ull << f;
+                        }
+                    }
+                    if (na > 0) {
+                        const bool isacc = ((accmask >> lane) & 1ull) != 0ull;
+                        const u64 mykey = ((u64)ebits << 32) | (u32)(~myid);
+                        // accepted-insert log, in stored order (finalize replays the reference's heap from it)
+                        {
+                            const u32 o = ninserts + (u32)__popcll(accmask & lanemask_lt());
+                            if (isacc && o < p.logcap) qlog[o] = ((u64)ebits << 32) | myid;
+                            if (ninserts + (u32)na > p.logcap && p.logcap > 0) status |= DR_ST_LOG_OVERFLOW;
+                            ninserts += (u32)na;
+                        }
+                        // ranks: rT = list keys below an accepted key, rA = accepted keys below it,
+                        //        sT[ch] = accepted keys below a list key
+                        int rT = 0, rA = 0;
+                        u32 sT[NCHR];
+#pragma unroll
+                        for (int ch = 0; ch < NCHR; ch++) sT[ch] = 0u;
+                        for (u64 am = accmask; am != 0ull; am &= am - 1ull) {
+                            const int f = __ffsll((long long)am) - 1;
+                            const u64 kf = readlane64(mykey, f);
+                            int cnt = 0;
+#pragma unroll
+                            for (int ch = 0; ch < NCHR; ch++) {
+                                const bool valid = ch * 64 + lane < rn;
+                                cnt += __popcll(__ballot(valid && rk.v[ch] < kf));
+                                sT[ch] += (valid && kf < rk.v[ch]) ? 1u : 0u;
+                            }
+                            if (lane == f) rT = cnt;
+                            rA += (isacc && kf < mykey) ? 1 : 0;
+                        }
+                        const int rn2 = min(rn + na, cap);
+                        // scatter to merged positions
+                        int npT[NCHR];
+#pragma unroll
+                        for (int ch = 0; ch < NCHR; ch++) {
+                            const int idx = ch * 64 + lane;
+                            npT[ch] = idx + (int)sT[ch];
+                            if (idx < rn && npT[ch] < cap) { mk[npT[ch]] = rk.v[ch]; mf[npT[ch]] = fl.v[ch]; }
+                        }
+                        const int npA = rT + rA;
+                        if (isacc && npA < cap) { mk[npA] = mykey; mf[npA] = 0u; }
+                        WSYNC();
+                        const u32 Wfb = (u32)(mk[rn2 - 1] >> 32);
+                        // entries pushed out: live ones stay in the reference's frontier (search_engine.py:469-474):
+                        // worse than every result -> only counted; tied with the new worst distance -> side list
+                        int nlive_out = 0;
+                        u64 tie_any = 0ull;
+#pragma unroll
+                        for (int ch = 0; ch < NCHR; ch++) {
+                            const bool out = (ch * 64 + lane < rn) && npT[ch] >= cap && fl.v[ch] == 0u;
+                            const u32 db = (u32)(rk.v[ch] >> 32);
+                            nlive_out += __popcll(__ballot(out));
+                            junk += (u32)__popcll(__ballot(out && db > Wfb));
+                            u64 tm = __ballot(out && db <= Wfb);
+                            tie_any |= tm;
+                            while (tm != 0ull) {
+                                const int f = __ffsll((long long)tm) - 1;
+                                tm &= tm - 1ull;
+                                if (tn < 64) { u64 d2; bool dd2; tn = list_insert<1>(tl, tn, 64, fkey(readlane64(rk.v[ch], f)), d2, dd2); }
+                                else status |= DR_ST_CAND_OVERFLOW;
+                            }
+                        }
+                        {
+                            const bool out = isacc && npA >= cap;
+                            const int nout = __popcll(__ballot(out));
+                            junk += (u32)__popcll(__ballot(out && ebits > Wfb));
+                            u64 tm = __ballot(out && ebits <= Wfb);
+                            while (tm != 0ull) {
+                                const int f = __ffsll((long long)tm) - 1;
+                                tm &= tm - 1ull;
+                                if (tn < 64) { u64 d2; bool dd2; tn = list_insert<1>(tl, tn, 64, fkey(readlane64(mykey, f)), d2, dd2); }
+                                else status |= DR_ST_CAND_OVERFLOW;
+                            }
+                            cnT += na - nout - nlive_out;
+                        }
+                        // gather the merged list back into registers
+#pragma unroll
+                        for (int ch = 0; ch < NCHR; ch++) {
+                            const int idx = ch * 64 + lane;
+                            rk.v[ch] = (idx < rn2) ? mk[idx] : ~0ull;
+                            fl.v[ch] = (idx < rn2) ? mf[idx] : 0u;
+                        }
+                        rn = rn2;
+                        WSYNC();
+                    }
+                } else {
+                // ---- sequential form (A4 live: it sees the worst distance in effect at each neighbour's position)
                 bool pending = lane < nnew;
                 float W = key_dist(list_get<NCHR>(rk, rn - 1));
                 for (int guard = 0;; guard++) {
@@ -770,6 +893,7 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                         else if (tn < 64) { u64 d2; bool dd2; tn = list_insert<1>(tl, tn, 64, fkey(dropped), d2, dd2); }
                         else status |= DR_ST_CAND_OVERFLOW;
                     }
+                }
                 }
             }
             PH(6);

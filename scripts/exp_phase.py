@@ -10,7 +10,7 @@ ix = HipIndex.create_empty(x, R=64)
 ix.build_vamana(L_build=100, alpha=1.2, passes=2, seed=7)
 cb = ix.pq_train(32, n_sample=20000, iters=3); ix.pq_encode(cb)
 for _ in range(2):
-    ids, dist, cnt, st = ix.search_batch(q, 10, L=100, beam_width=0, mode=_ffi.MODE_M1)
+    ids, dist, cnt, st = ix.search_batch(q, 10, L=100, beam_width=int(sys.argv[2]) if len(sys.argv) > 2 else 0, mode=_ffi.MODE_M1)
 ph = np.array(ix.debug_phase_cycles())
 names = ["setup+LUT", "pop/stop", "adjacency", "visited", "ADC", "exact", "decisions", "output"]
 tot = ph.sum()
