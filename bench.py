@@ -40,7 +40,8 @@ def main():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--R", type=int, default=64)
     ap.add_argument("--L", type=int, default=100)
-    ap.add_argument("--bw", type=int, default=0, help="beam_width; 0 = None (no frontier trim)")
+    ap.add_argument("--bw", type=int, default=8, help="beam_width: 8 = the reference default of search()/the API routes (search_engine.py:530, app.py:96); 0 = None (no frontier trim)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the beam_width=None secondary measurement")
     ap.add_argument("--m", type=int, default=32)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--L-build", type=int, default=100)
@@ -137,8 +138,31 @@ def main():
     # read correction applied): measured offline on this same workload, committed under profiles/
     traffic = None
     pmc = ROOT / "profiles" / "r01" / "pmc_traffic.json"
-    if pmc.exists() and (args.n, args.nq, args.dim, args.R, args.L, args.m, args.bw) == (1_000_000, 10_000, 128, 64, 100, 32, 0):
-        traffic = json.loads(pmc.read_text())["search_kernel"]["hbm_bytes_per_launch"]
+    if pmc.exists() and (args.n, args.nq, args.dim, args.R, args.L, args.m) == (1_000_000, 10_000, 128, 64, 100, 32):
+        rec = json.loads(pmc.read_text()).get("beam_width_%d" % args.bw)
+        if rec:
+            traffic = rec["hbm_bytes_per_launch"]
+
+    # secondary measurement (same index, same queries): beam_width=None, the reference's no-trim mode
+    secondary = None
+    if not args.no_secondary and args.bw != 0:
+        for _ in range(2):
+            ix.batch_run(args.k, L=args.L, beam_width=0, mode=mode)
+        ix.batch_sync()
+        sync_all()
+        t2 = time.perf_counter()
+        k2 = []
+        for _ in range(args.steps):
+            ix.batch_run(args.k, L=args.L, beam_width=0, mode=mode)
+            k2.append(ix.timing()["search_kernel_ms"])
+        ix.batch_sync()
+        el2 = time.perf_counter() - t2
+        ids2, _, _, st2 = ix.batch_download()
+        b2 = (4 * args.dim + st2["steps"].astype(np.float64) * 4 * args.R + st2["pq_evaluated"].astype(np.float64) * args.m +
+              st2["exact"].astype(np.float64) * 4 * args.dim + 8 * args.k).sum() + 4 * 256 * args.dim
+        secondary = {"beam_width": None, "qps_rank0": args.nq * args.steps / el2, "recall_at_10": recall_at_k(ids2, gt, args.k),
+                     "kernel_ms": float(np.mean(k2)), "roofline_frac": b2 / (float(np.mean(k2)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "exact_distances_per_query": float(st2["exact"].mean())}
 
     total_q = args.nq * world * args.steps
     value = total_q / elapsed
@@ -155,7 +179,7 @@ def main():
                    "per_query": {"expansions": float(S.mean()), "pq_distances": float(st["pq"].mean()), "pq_evaluated": float(V.mean()),
                                  "exact_distances": float(X.mean()), "algorithmic_bytes": float(bytes_q.mean())},
                    "launch": {k_: timing[k_] for k_ in ("grid", "block", "lds_bytes", "waves_per_cu")},
-                   "finalize_kernel_ms": timing["finalize_kernel_ms"]},
+                   "finalize_kernel_ms": timing["finalize_kernel_ms"], "secondary_no_trim": secondary},
         "roofline": {"bound": "hbm", "kernel": "search_kernel<128,M1>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},

@@ -905,6 +905,35 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                     u32 excess = (u32)(cnT + tn) + junk - p.bw;
                     const u32 rj = excess < junk ? excess : junk;   // junk entries are the largest
                     junk -= rj; excess -= rj;
+                    // drop the `excess` largest frontier entries. Common case (side list empty, the cut does not
+                    // fall inside a run of equal distances): mark the last `excess` live result entries in one
+                    // pass; otherwise one at a time (frontier order reverses the list order inside such runs).
+                    bool done_trim = false;
+                    if (tn == 0 && excess > 0 && (int)excess <= cnT) {
+                        const int keep = cnT - (int)excess;      // live entries that stay
+                        int base = 0;
+                        u32 kd[NCHR]; bool kill[NCHR];
+                        u32 d_lastkept = 0xFFFFFFFFu, d_firstkill = 0xFFFFFFFEu;
+#pragma unroll
+                        for (int ch = 0; ch < NCHR; ch++) {
+                            const bool live = (ch * 64 + lane < rn) && fl.v[ch] == 0u;
+                            const u64 lm = __ballot(live);
+                            const int rank = base + __popcll(lm & lanemask_lt());
+                            kill[ch] = live && rank >= keep;
+                            kd[ch] = (u32)(rk.v[ch] >> 32);
+                            const u64 m1 = __ballot(live && rank == keep - 1), m2 = __ballot(live && rank == keep);
+                            if (m1 != 0ull) d_lastkept = readlane32(kd[ch], __ffsll((long long)m1) - 1);
+                            if (m2 != 0ull) d_firstkill = readlane32(kd[ch], __ffsll((long long)m2) - 1);
+                            base += __popcll(lm);
+                        }
+                        if (keep == 0 || d_lastkept != d_firstkill) {
+#pragma unroll
+                            for (int ch = 0; ch < NCHR; ch++) fl.v[ch] |= kill[ch] ? 2u : 0u;
+                            cnT -= (int)excess;
+                            done_trim = true;
+                        }
+                    }
+                    if (!done_trim)
                     for (u32 t = 0; t < excess; t++) {
                         // drop the largest frontier entry: last live result entry or side-list tail
                         const int ia = frontier_last<NCHR>(rk, fl, rn);

@@ -11,10 +11,12 @@ ix = HipIndex.create_empty(x, R=64)
 ix.build_vamana(L_build=100, alpha=1.2, passes=2, seed=7)
 cb = ix.pq_train(32, n_sample=100000, iters=8); ix.pq_encode(cb)
 ix.bruteforce_topk(q[:1], 10)
+bw = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 ix.batch_upload(q)
 for _ in range(4):
-    ix.batch_run(10, L=100, beam_width=0, mode=_ffi.MODE_M1)
+    ix.batch_run(10, L=100, beam_width=bw, mode=_ffi.MODE_M1)
 ids, dist, cnt, st = ix.batch_download()
 S, V, X = st["steps"].astype(np.float64), st["pq_evaluated"].astype(np.float64), st["exact"].astype(np.float64)
 print("ALG_BYTES_PER_LAUNCH", float((4 * 128 + S * 4 * 64 + V * 32 + X * 4 * 128 + 80).sum() + 4 * 256 * 128))
 print("CALIB_BYTES", 1000000 * 128 * 4)
+print("BEAM_WIDTH", bw)

@@ -3,7 +3,30 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 scripts/pmc_target.py > $OUT/pmc_fetch.out 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 scripts/pmc_target.py > $OUT/pmc_write.out 2> $OUT/pmc_write.err
+for bw in 8 0; do
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_bw$bw -- python3 scripts/pmc_target.py $bw > $OUT/pmc_fetch_bw$bw.out 2> $OUT/pmc_fetch_bw$bw.err
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_bw$bw -- python3 scripts/pmc_target.py $bw > $OUT/pmc_write_bw$bw.out 2> $OUT/pmc_write_bw$bw.err
+done
 python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
-find $OUT -name "*.csv" | head -20; tail -2 $OUT/pmc_fetch.out; tail -3 $OUT/pmc_fetch.err
+python3 - <<'PY'
+import csv, glob, json
+def load(path): return list(csv.DictReader(open(path)))
+def vals(rows, c, sub): return [float(r['Counter_Value']) for r in rows if r['Counter_Name'] == c and sub in r['Kernel_Name']]
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on scripts/pmc_target.py <beam_width>, MI355X, ROCm 7.2",
+       "units": "FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes (MI355X_MICROARCH.md, HBM section): reads are doubled"}
+for bw in (8, 0):
+    f = load(glob.glob(f'gpurun_out/prof/pmc_fetch_bw{bw}/*/*_counter_collection.csv')[0])
+    w = load(glob.glob(f'gpurun_out/prof/pmc_write_bw{bw}/*/*_counter_collection.csv')[0])
+    alg = [float(l.split()[1]) for l in open(f'gpurun_out/prof/pmc_fetch_bw{bw}.out') if l.startswith('ALG_BYTES_PER_LAUNCH')][0]
+    fs, ws = vals(f, 'FETCH_SIZE', 'search_kernel<128, true'), vals(w, 'WRITE_SIZE', 'search_kernel<128, true')
+    cal = vals(f, 'FETCH_SIZE', 'bruteforce_kernel')
+    rd, wr = sum(fs) / len(fs) * 1024 * 2, sum(ws) / len(ws) * 1024
+    out[f"beam_width_{bw}"] = {"kernel": "search_kernel<128, true, 0, 2, 12, true, 24>", "FETCH_SIZE_KiB": fs, "WRITE_SIZE_KiB": ws,
+                               "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+                               "algorithmic_bytes_per_launch": alg,
+                               "calibration": {"kernel": "bruteforce_kernel<128>, 1 query", "known_bytes": 512000000, "FETCH_SIZE_KiB": cal[0],
+                                               "corrected_bytes": cal[0] * 1024 * 2}}
+json.dump(out, open('gpurun_out/prof/pmc_traffic.json', 'w'), indent=1)
+print(json.dumps({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if 'bytes' in kk}) for k, v in out.items()}, indent=1))
+PY
+cat $OUT/bench.json
