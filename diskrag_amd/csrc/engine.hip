@@ -356,10 +356,10 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         return (DR_KIND_CB[kd] ? (size_t)256 * ix->D * 4 : 0) + (size_t)DR_KIND_NW[kd] * pw;
     };
     auto usable = [&](int kd) { return ix->kern->search[kd][sc] != nullptr && lds_of(kd) <= 160 * 1024; };
-    static const int PREF_M1[] = { 9, 6, 3, 0 }, PREF_ADC[] = { 5, 2 }, PREF_EX[] = { 8, 1 }, PREF_BUILD[] = { 1 };
+    static const int PREF_M1[] = { 9, 6, 3, 0 }, PREF_ADC[] = { 5, 2 }, PREF_EX[] = { 8, 1 }, PREF_BUILD[] = { 1, 8 };
     const bool k_m1 = (mode == DR_MODE_M1), k_adc = (mode == DR_MODE_M3 && use_pq);
     const int *pref = k_m1 ? PREF_M1 : k_adc ? PREF_ADC : ov ? PREF_BUILD : PREF_EX;
-    const int npref = k_m1 ? 4 : k_adc ? 2 : ov ? 1 : 2;
+    const int npref = k_m1 ? 4 : k_adc ? 2 : 2;
     int kind = -1;
     for (int i = 0; i < npref && kind < 0; i++) if (usable(pref[i])) kind = pref[i];
     {

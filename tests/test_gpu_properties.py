@@ -1,0 +1,66 @@
+"""Size-independent properties of the search output on a device-built index that is too large for the oracle to
+sweep quickly (N = 200k): what the reference's result list must look like whatever the data. Needs a GPU."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+PAD = np.uint32(0xFFFFFFFF)
+
+
+@pytest.fixture(scope="module")
+def big():
+    from diskrag_amd import HipIndex
+    from diskrag_amd.synth import sift_like
+    x, q = sift_like(200000, 128, n_queries=3000, n_clusters=256, seed=77)
+    ix = HipIndex.create_empty(x, R=64)
+    ix.build_vamana(L_build=100, alpha=1.2, passes=2, seed=5, pad_with_zero=True)
+    cb = ix.pq_train(32, n_sample=50000, iters=5)
+    codes = ix.pq_encode(cb, want_codes=True)
+    return ix, x, q, cb, codes
+
+
+@pytest.mark.parametrize("mode,L,bw,k", [(1, 100, 8, 10), (1, 100, 0, 20), (1, 40, 8, 30), (2, 0, 32, 10), (4, 64, 0, 10)])
+def test_result_list_properties(big, mode, L, bw, k):
+    ix, x, q, cb, codes = big
+    ids, dist, cnt, st = ix.search_batch(q, k, L=L, beam_width=bw, mode=mode)
+    assert (st["status"] == 0).all()
+    cap = bw if mode == 2 else L
+    for i in range(0, len(q), 7):
+        n = int(cnt[i])
+        assert 1 <= n <= min(k, cap)
+        row, d = ids[i, :n], dist[i, :n]
+        assert (ids[i, n:] == PAD).all() and np.isnan(dist[i, n:]).all()
+        assert len(set(row.tolist())) == n                      # a node is returned once
+        assert (np.diff(d) >= 0).all()                           # ascending distances
+    # returned distances are the exact distances of the returned ids (A1 bits; sqrt for the norm modes)
+    sel = np.arange(0, len(q), 101)
+    for i in sel:
+        n = int(cnt[i])
+        ex = ix.exact_distances(q[i:i + 1], ids[i, :n])[0]
+        want = np.sqrt(ex) if mode in (2, 4) else ex
+        assert np.array_equal(dist[i, :n].view(np.uint32), want.astype(np.float32).view(np.uint32))
+    # idempotence: the same batch again gives the same bits (visited bitmaps and double buffers are reusable)
+    ids2, dist2, cnt2, st2 = ix.search_batch(q, k, L=L, beam_width=bw, mode=mode)
+    assert np.array_equal(ids, ids2) and np.array_equal(dist.view(np.uint32), dist2.view(np.uint32))
+    assert np.array_equal(st["steps"], st2["steps"]) and np.array_equal(st["visited"], st2["visited"])
+
+
+def test_counters_are_consistent(big):
+    ix, x, q, cb, codes = big
+    ids, dist, cnt, st = ix.search_batch(q, 10, L=100, beam_width=0, mode=1)
+    assert (st["visited"] == st["pq"] + 1).all()                 # every visited node but the start gets one ADC
+    assert (st["exact"] <= st["visited"]).all() and (st["pq_evaluated"] <= st["pq"]).all()
+    assert (st["steps"] <= 1000).all() and (st["inserts"] <= st["exact"]).all()
+
+
+def test_sample_matches_oracle_at_scale(big):
+    from oracle import pyoracle as orc
+    ix, x, q, cb, codes = big
+    adj = ix.get_adjacency()
+    for L, bw in ((100, 8), (100, 0)):
+        ids, dist, cnt, st = ix.search_batch(q[:300], 10, L=L, beam_width=bw, mode=1)
+        oids, odist, ocnt, ost = orc.search_batch(x, adj, q[:300], ix.medoid, orc.M1, 10, L=L, bw=bw, codes=codes,
+                                                  codebook=cb, nthreads=8)
+        assert np.array_equal(ids, oids)
+        assert np.array_equal(dist.view(np.uint32), odist.astype(np.float32).view(np.uint32))
+        assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), ost)
