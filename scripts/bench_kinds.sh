@@ -1,6 +1,6 @@
 #!/bin/bash
 # bench under each M1 kernel variant (0: per-query table, 1 wave/WG; 3: shared codebook 8 waves; 4: 16 waves)
-for kd in 9 0; do
+for kd in 9 6 7 3 4; do
   echo "== DR_FORCE_KIND=$kd"
   DR_FORCE_KIND=$kd timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "
 import sys,json
