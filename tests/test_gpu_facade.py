@@ -86,3 +86,31 @@ def test_facade_exact_mode_when_pq_missing(tmp_path):
     assert [int(i) for _, i in res] == oids[0, :ocnt[0]].tolist()
     assert st["search_type"] == "exact_beam_search"
     eng.close()
+
+
+def test_device_built_index_survives_the_reference_file_formats(tmp_path):
+    """N1+N2+N3 end to end: build graph and PQ on the device, write the reference's files (persist.write_index), open
+    them through the facade (dr_index_open on index.dat): same results as the index that never left HBM."""
+    import json as _json
+    from diskrag_amd import HipIndex, persist
+    from diskrag_amd.search_engine import SearchEngineCorrect
+    from diskrag_amd.synth import sift_like
+    x, q = sift_like(20000, 128, n_queries=64, n_clusters=64, seed=11, query_seed=12)
+    ix = HipIndex.create_empty(x, R=32)
+    medoid, _ = ix.build_vamana(L_build=60, alpha=1.2, passes=2, seed=3)
+    cb = ix.pq_train(32, n_sample=10000, iters=4)
+    codes = ix.pq_encode(cb, want_codes=True)
+    adj = ix.get_adjacency()
+    want = ix.search_batch(q, 10, L=50, beam_width=8)
+    cdir = tmp_path / "built"
+    meta = persist.write_index(cdir / "index", x, adj, medoid, codes=codes, codebook=cb,
+                               build_params={"L": 60, "alpha": 1.2}, pq_pickle=False)
+    assert meta["N"] == 20000 and meta["n_subvectors"] == 32 and meta["use_pq"]
+    (cdir / "collection_info.json").write_text(_json.dumps({"name": "built", "dimension": 128, "num_vectors": 20000}))
+    eng = SearchEngineCorrect("built", base_dir=tmp_path)
+    assert eng.use_pq and eng.medoid_idx == medoid
+    got = eng.search_batch(q, k=10, L=50, beam_width=8)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+    back = persist.read_index(cdir / "index")
+    assert np.array_equal(back.adjacency, adj) and np.array_equal(back.codes, codes)
+    eng.close(); ix.close()

@@ -40,7 +40,23 @@ def _worker(rank, world, port, ret):
                          dtype=np.float32)
         mids, mdist = parallel.allgather_merge_topk(lids, ldist, own.start, k)
         slow = parallel.max_over_ranks(1.0 + rank)
-        ret[rank] = (all_ids, mids, mdist, slow)
+        # --- the graph-sharded driver itself, two shards per rank, with the oracle standing in for the device index
+        from diskrag_amd.sharded import GraphShard, ShardedSearch
+
+        class OracleShard:   # HipIndex.search_batch's signature over a brute-force shard (host logic under test)
+            def __init__(self, vecs):
+                self.v = vecs
+
+            def search_batch(self, queries, k, L=100, beam_width=0, mode=0, band_policy=0, flags=0):
+                li = orc.bruteforce_topk(self.v, queries, k)
+                ld = np.array([[orc.sqdist(self.v[i], q) for i in row] for row, q in zip(li, queries)], dtype=np.float32)
+                st = np.zeros(len(queries), dtype=[("status", np.uint32)])
+                return li, ld, np.full(len(queries), k, dtype=np.uint32), st
+
+        quarters = [parallel.shard_slice(n, 2 * world, 2 * rank + j) for j in range(2)]
+        eng = ShardedSearch([GraphShard(OracleShard(g.vectors[sl]), sl.start) for sl in quarters])
+        sids, sdist, _ = eng.search_batch(g.queries, k)
+        ret[rank] = (all_ids, mids, mdist, slow, sids, sdist)
     finally:
         dist.destroy_process_group()
 
@@ -64,7 +80,9 @@ def test_two_rank_sharding_and_merge():
     gt = orc.bruteforce_topk(g.vectors, g.queries, 10)
     gt_d = np.array([[orc.sqdist(g.vectors[i], q) for i in row] for row, q in zip(gt, g.queries)], dtype=np.float32)
     for r in range(2):
-        all_ids, mids, mdist, slow = ret[r]
+        all_ids, mids, mdist, slow, sids, sdist = ret[r]
+        # 2 ranks x 2 local shards through ShardedSearch == the 2-shard exchange == brute force over everything
+        assert np.array_equal(sids, mids) and np.array_equal(sdist.view(np.uint32), mdist.view(np.uint32))
         assert np.array_equal(all_ids, want_ids)                  # query-sharded == unsharded
         assert np.array_equal(np.sort(mdist, axis=1).view(np.uint32), np.sort(gt_d, axis=1).view(np.uint32))
         assert slow == 2.0                                        # max over ranks
