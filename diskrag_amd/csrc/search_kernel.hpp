@@ -446,6 +446,20 @@ template <bool CBLDS> DEV float adc_upper_bound(const float *tab, const float *q
 //        read their chain-major groups back with ds_read_b128. The codebook then stays in global memory (L2) and
 //        is only touched on the rare expansions whose ADC cannot be skipped (CBLDS must be true: the table
 //        entries are recomputed from the codebook, wherever it lives).
+// A4 as a threshold on the worst distance: returns the bits of x = the largest float W >= 0 with f_mul(W, thr) <= pq.
+// f_mul(., thr) is monotone, so the reference's test `pq < thr * W` (search_engine.py:390-395) holds exactly for
+// W > x. `ok` is cleared if the fix-up did not reach the boundary (reported through stats.status, never silent).
+DEV u32 a4_threshold_bits(float pq, float thr, bool &ok) {
+    if (!(pq < __builtin_inff())) return 0x7F800000u;    // never passes
+    u32 cb = __float_as_uint(pq / thr);
+#pragma unroll 1
+    for (int it = 0; it < 8; it++) { if (f_mul(__uint_as_float(cb + 1u), thr) <= pq) cb++; else break; }
+#pragma unroll 1
+    for (int it = 0; it < 8; it++) { if (cb != 0u && f_mul(__uint_as_float(cb), thr) > pq) cb--; else break; }
+    ok = ok && f_mul(__uint_as_float(cb), thr) <= pq && f_mul(__uint_as_float(cb + 1u), thr) > pq;
+    return cb;
+}
+
 template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0>
 __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
 {
@@ -639,28 +653,48 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                     }
                 }
                 const bool all_pass = !need_adc;
-                // code words first, then the stored vectors: the ADC sums run while the vectors are in flight
+                // A4 live: ADC first. It turns into a per-neighbour threshold x on the worst result distance (A4 passes
+                // iff W > x), and while the list is full W only shrinks during the expansion, so a neighbour with
+                // x >= W now can never pass: its stored vector is not fetched at all (the reference would not score it
+                // either). The rows to score are compacted in stored order.
                 uint4 cw0 = make_uint4(0, 0, 0, 0), cw1 = cw0, cw2 = cw0, cw3 = cw0;
                 const u8 *mycode = p.codes + (size_t)myid * p.m;
                 if constexpr (NEED_PQ) { if (need_adc && lane < nnew) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m); }
                 float adc_s = 0.0f;
+                u32 xbits = 0u;               // bits of the A4 threshold; 0 when A4 is proven true
+                int nrow = nnew, myrow = lane;
+                bool rowlane = lane < nnew;
+                if constexpr (FILTER) {
+                    if (need_adc) {
+                        if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
+                        pq_d = f_sqrt(adc_s);   // asymmetric_distance = sqrt (fast_pq.py:330-333)
+                        bool ok = true;
+                        xbits = a4_threshold_bits(pq_d, p.policy == 0u ? 1.2f : 0.8f, ok);
+                        if (__ballot(lane < nnew && !ok) != 0ull) status |= DR_ST_INTERNAL;
+                        if (rn == cap) {
+                            const u32 W0b = (u32)(list_get<NCHR>(rk, rn - 1) >> 32);
+                            rowlane = lane < nnew && xbits < W0b;
+                            const u64 nm = __ballot(rowlane);
+                            nrow = __popcll(nm);
+                            myrow = __popcll(nm & lanemask_lt());
+                            WSYNC();            // every lane holds its id in a register: the id array can be rewritten
+                            if (rowlane) nb_id[myrow] = myid;
+                            WSYNC();
+                        }
+                        PH(4);
+                    }
+                }
                 if constexpr (KIND != DIST_ADC_SQ) {
                     if constexpr (ROWLDS) {
-                        if constexpr (NEED_PQ) {
-                            if (need_adc) {
-                                if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
-                                PH(4);
-                            }
-                        }
                         constexpr int LPR = D / 4;          // lanes (16-byte pieces) per row
                         constexpr int RPI = 64 / LPR;       // rows per wave instruction (1 KiB)
-                        for (int b0 = 0; b0 < nnew; b0 += RB) {
-                            const int nb = min(RB, nnew - b0);
+                        for (int b0 = 0; b0 < nrow; b0 += RB) {
+                            const int nb = min(RB, nrow - b0);
                             // all rows of the burst in flight, no VGPR destination
 #pragma unroll
                             for (int r = 0; r < RB; r += RPI) {
                                 if (r < nb) {
-                                    const int idx = min(b0 + r + lane / LPR, nnew - 1);
+                                    const int idx = min(b0 + r + lane / LPR, nrow - 1);
                                     const float *g = p.vecp + (size_t)nb_id[idx] * D + (lane % LPR) * 4;
                                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                         (__attribute__((address_space(3))) void *)(rowbuf + (size_t)r * D), 16, 0, 0);
@@ -683,47 +717,34 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                         RowRegs<D> rr[NP];
 #pragma unroll
                         for (int r = 0; r < NP; r++) {
-                            if (r * 8 < nnew) {
-                                const int idx = min(r * 8 + oct, nnew - 1);
+                            if (r * 8 < nrow) {
+                                const int idx = min(r * 8 + oct, nrow - 1);
                                 row_load<0, D, D>(p.vecp + (size_t)nb_id[idx] * D, j, rr[r]);
-                            }
-                        }
-                        if constexpr (NEED_PQ) {
-                            if (need_adc) {
-                                if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
-                                PH(4);
                             }
                         }
 #pragma unroll
                         for (int r = 0; r < 8; r++) {
-                            if (r * 8 < nnew) {
+                            if (r * 8 < nrow) {
                                 float ev = row_reduce<0, D, D>(rr[r % NP], qreg);
                                 if (p.norm) ev = f_sqrt(ev);
-                                if (j == 0 && r * 8 + oct < nnew) nb_e[r * 8 + oct] = ev;
-                                if ((r + NP) * 8 < nnew) {
-                                    const int idx = min((r + NP) * 8 + oct, nnew - 1);
+                                if (j == 0 && r * 8 + oct < nrow) nb_e[r * 8 + oct] = ev;
+                                if ((r + NP) * 8 < nrow) {
+                                    const int idx = min((r + NP) * 8 + oct, nrow - 1);
                                     row_load<0, D, D>(p.vecp + (size_t)nb_id[idx] * D, j, rr[r % NP]);
                                 }
                             }
                         }
                     } else {
-                        if constexpr (NEED_PQ) {
-                            if (need_adc) {
-                                if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
-                                PH(4);
-                            }
-                        }
-                        for (int r0 = 0; r0 * 8 < nnew; r0++) {
-                            const int idx = min(r0 * 8 + oct, nnew - 1);
+                        for (int r0 = 0; r0 * 8 < nrow; r0++) {
+                            const int idx = min(r0 * 8 + oct, nrow - 1);
                             float ev = pw_row_stream<0, D, D, QREG>(p.vecp + (size_t)nb_id[idx] * D, &qreg, qperm, j);
                             if (p.norm) ev = f_sqrt(ev);
-                            if (j == 0 && r0 * 8 + oct < nnew) nb_e[r0 * 8 + oct] = ev;
+                            if (j == 0 && r0 * 8 + oct < nrow) nb_e[r0 * 8 + oct] = ev;
                         }
                     }
                     WSYNC();
-                    e = nb_e[lane < nnew ? lane : 0];
+                    e = rowlane ? nb_e[myrow] : __builtin_inff();
                     if constexpr (FILTER) {
-                        pq_d = f_sqrt(adc_s);   // asymmetric_distance = sqrt (fast_pq.py:330-333)
                         npq += nnew;            // the reference counts one PQ distance per new neighbour
                         if (need_adc) npq_eval += nnew;
                     }
@@ -745,14 +766,23 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                 // the CURRENT worst distance (all of them while the list is not full), (2) walk only those, in
                 // stored order, with two ballots each, (3) ONE merge of the accepted set into the list through
                 // LDS. Entries pushed out of the list are accounted exactly as single inserts would.
+                // A4 live (FILTER, ADC evaluated): A4 passes iff W_i > x_i, so the neighbour is accepted iff fewer than
+                // cap of (old list + earlier accepted) have distance <= max(e_i, x_i), and it counts as an exact
+                // evaluation (the reference computes e_i before it knows the outcome) iff fewer than cap have
+                // distance <= x_i. The walk then covers every neighbour that can still pass.
+#ifdef DR_SEQ_A4
                 bool batched = true;
                 if constexpr (FILTER) batched = all_pass;
+#else
+                constexpr bool batched = true;
+#endif
                 if (batched) {
-                    if constexpr (KIND != DIST_ADC_SQ) nexact += nnew;
+                    const bool count_pass = FILTER && !all_pass;
+                    if constexpr (KIND != DIST_ADC_SQ) { if (!count_pass) nexact += nnew; }
                     const u32 ebits = __float_as_uint(e);
                     const bool full0 = (rn == cap);
                     const u32 W0b = (u32)(list_get<NCHR>(rk, rn - 1) >> 32);
-                    u64 cm = __ballot(lane < nnew && (!full0 || ebits < W0b));
+                    u64 cm = __ballot(lane < nnew && (!full0 || (count_pass ? xbits : ebits) < W0b));
                     u32 acc_e = 0xFFFFFFFFu;   // lane s: distance bits of the s-th accepted neighbour
                     int na = 0;
                     u64 accmask = 0ull;
@@ -760,16 +790,29 @@ __global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
                         const int f = __ffsll((long long)cm) - 1;
                         cm &= cm - 1ull;
                         const u32 eb = readlane32(ebits, f);
-                        int c = 0;
+                        u32 tb = eb;
+                        if (count_pass) {
+                            const u32 xb = readlane32(xbits, f);
+                            int cx = 0;
 #pragma unroll
-                        for (int ch = 0; ch < NCHR; ch++)
-                            c += __popcll(__ballot(ch * 64 + lane < rn && (u32)(rk.v[ch] >> 32) <= eb));
-                        const int a = __popcll(__ballot(lane < na && acc_e <= eb));
-                        if (c + a < cap) {
-                            if (lane == na) acc_e = eb;
-                            na++;
-                            accmask |= 1ull << f;
+                            for (int ch = 0; ch < NCHR; ch++)
+                                cx += __popcll(__ballot(ch * 64 + lane < rn && (u32)(rk.v[ch] >> 32) <= xb));
+                            cx += __popcll(__ballot(lane < na && acc_e <= xb));
+                            if (cx >= cap) continue;          // A4 is false at this position: never scored
+                            nexact++;
+                            if (eb <= xb) tb = 0xFFFFFFFFu;   // the count above already decides: accepted
                         }
+                        if (tb != 0xFFFFFFFFu) {
+                            int c = 0;
+#pragma unroll
+                            for (int ch = 0; ch < NCHR; ch++)
+                                c += __popcll(__ballot(ch * 64 + lane < rn && (u32)(rk.v[ch] >> 32) <= tb));
+                            const int a = __popcll(__ballot(lane < na && acc_e <= tb));
+                            if (c + a >= cap) continue;
+                        }
+                        if (lane == na) acc_e = eb;
+                        na++;
+                        accmask |= 1ull << f;
                     }
                     if (na > 0) {
                         const bool isacc = ((accmask >> lane) & 1ull) != 0ull;

@@ -1,0 +1,21 @@
+"""Diagnostic (GPU box): phase shares of one M1 expansion on c4-shaped A4-live data. Needs a -DDR_PHASE_TIMING build (DR_LIB)."""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+from diskrag_amd import HipIndex, _ffi
+from diskrag_amd.synth import unit_mixture
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000000
+bw = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+x, q = unit_mixture(n, 96, n_queries=10000, n_clusters=4096, seed=11, latent=32)
+ix = HipIndex.create_empty(x, R=64)
+ix.build_vamana(L_build=100, alpha=1.2, passes=2, seed=7)
+cb = ix.pq_train(16, n_sample=100000, iters=5); ix.pq_encode(cb)
+for _ in range(2):
+    ids, dist, cnt, st = ix.search_batch(q, 10, L=100, beam_width=bw, mode=_ffi.MODE_M1)
+ph = np.array(ix.debug_phase_cycles())
+names = ["setup+LUT", "pop/stop", "adjacency", "visited", "ADC", "exact", "decisions", "output"]
+tot = ph.sum()
+t = ix.timing()
+print("kernel_ms", t["search_kernel_ms"], "steps", st["steps"].mean(), "visited", st["visited"].mean(), "exact", st["exact"].mean(), "inserts", st["inserts"].mean(), t)
+for nme, v in zip(names, ph):
+    print(f"{nme:12s} {v/tot*100:6.2f}%  cycles/query {v/len(q):10.0f}  per-step {v/st['steps'].sum():8.0f}")
