@@ -37,7 +37,8 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_index_set_adjacency", "dr_search_batch", "dr_batch_upload", "dr_batch_run", "dr_batch_download",
            "dr_get_timing", "dr_exact_distances", "dr_distance_table", "dr_adc", "dr_pq_scan",
            "dr_bruteforce_topk", "dr_get_node", "dr_index_close", "dr_index_create_empty", "dr_build_vamana",
-           "dr_get_adjacency", "dr_pq_train", "dr_pq_encode", "dr_debug_phase_cycles", "dr_batch_sync"]
+           "dr_get_adjacency", "dr_pq_train", "dr_pq_encode", "dr_debug_phase_cycles", "dr_batch_sync",
+           "dr_debug_force_kind"]
 
 _lib = None
 
@@ -106,6 +107,8 @@ def load_library():
     L.dr_pq_train.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, fp]
     L.dr_pq_encode.restype = C.c_int
     L.dr_pq_encode.argtypes = [vp, fp, C.c_uint32, u8p]
+    L.dr_debug_force_kind.restype = C.c_int
+    L.dr_debug_force_kind.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.dr_debug_phase_cycles.restype = C.c_int
     L.dr_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_double)]
     L.dr_index_close.restype = None
@@ -304,6 +307,12 @@ class HipIndex:
         _check(load_library().dr_bruteforce_topk(self._h, _p(q, C.c_float), q.shape[0], int(k), _p(ids, C.c_uint32),
                                                  _p(dist, C.c_float)))
         return ids, dist
+
+    def debug_force_kind(self, kind):
+        """Pins the search-kernel variant (-1: engine's choice); returns the handle's A4 regime (1 live, 0 not, -1 unknown)."""
+        live = C.c_int(-1)
+        _check(load_library().dr_debug_force_kind(self._h, int(kind), C.byref(live)))
+        return int(live.value)
 
     def debug_phase_cycles(self):
         out = (C.c_double * 8)()

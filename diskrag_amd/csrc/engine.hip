@@ -118,6 +118,7 @@ struct dr_index {
     hipStream_t fstream = nullptr;
     DevBuf<float> pq_ub;
     bool pq_ub_valid = false;     // pq_ub matches the resident queries and the attached codebook
+    int adc_live = -1;            // M1 on this index: does the rerank policy A4 really consult the ADC? -1 = not probed yet
     DevBuf<u64> phase;
     uint32_t last_k = 0;
     dr_timing timing = {};
@@ -253,6 +254,7 @@ extern "C" int dr_index_set_adjacency(dr_index *ix, const uint32_t *adj)
     std::lock_guard<std::mutex> lk(ix->mu);
     HIPCHK(hipSetDevice(ix->device));
     HIPCHK(hipMemcpy(ix->adj.p, adj, (size_t)ix->N * ix->R * 4, hipMemcpyHostToDevice));
+    ix->adc_live = -1;
     return build_first_masks(ix);
 }
 
@@ -269,6 +271,7 @@ extern "C" int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_
     HIPCHK(hipMemcpy(ix->codebook.p, codebook, (size_t)256 * ix->D * 4, hipMemcpyHostToDevice));
     ix->m = m; ix->sd = ix->D / m;
     ix->pq_ub_valid = false;
+    ix->adc_live = -1;
     return 0;
 }
 
@@ -326,7 +329,9 @@ static uint32_t next_pow2(uint64_t v)
 // queries already resident in ix->q / ix->qp, no outputs besides res_keys / res_n.
 struct BuildOverride { const uint32_t *adjb; const uint32_t *deg; uint32_t RX; uint32_t nq; };
 
-static int g_force_kind = -1;   // test/diagnostic hook: DR_FORCE_KIND environment variable
+static int g_force_kind = -1;   // test/diagnostic hook: DR_FORCE_KIND environment variable / dr_debug_force_kind
+static bool g_force_kind_set = false;
+static int sync_locked(dr_index *ix);
 
 static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_t mode, uint32_t policy, uint32_t flags,
                       const BuildOverride *ov = nullptr)
@@ -357,14 +362,37 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     };
     auto usable = [&](int kd) { return ix->kern->search[kd][sc] != nullptr && lds_of(kd) <= 160 * 1024; };
     static const int PREF_M1[] = { 9, 6, 3, 0 }, PREF_ADC[] = { 5, 2 }, PREF_EX[] = { 8, 1 }, PREF_BUILD[] = { 1, 8 };
+    static const int PREF_M1_LIVE_LUT[] = { 0, 3, 9, 6 }, PREF_M1_LIVE_CB[] = { 3, 0, 9, 6 };
     const bool k_m1 = (mode == DR_MODE_M1), k_adc = (mode == DR_MODE_M3 && use_pq);
+    // M1 has two regimes. On SIFT-scale data the rerank policy A4 is provably true for almost every expansion (Q1),
+    // the ADC is skipped and the kernel is a pure row gather: vectors landed in LDS, table never built (9, 6).
+    // On unit-scale data A4 is live, every new neighbour's ADC is evaluated and the table wants to be in LDS: the
+    // per-query table (0) when 8 of them fit a CU, else the shared codebook (3). Which regime an index is in is
+    // MEASURED once per (graph, PQ) state on the first 64 queries it is asked (results do not depend on the variant).
+    if (k_m1 && !ov && ix->adc_live < 0) {
+        const uint32_t nq_all = ix->nq;
+        ix->adc_live = 0;
+        ix->nq = std::min<uint32_t>(nq_all, 64);
+        int rc = run_locked(ix, k, L, bw, mode, policy, flags, nullptr);
+        if (!rc) rc = sync_locked(ix);
+        std::vector<KStats> st(ix->nq);
+        if (!rc && hipMemcpy(st.data(), ix->sets[ix->last_set].stats.p, st.size() * sizeof(KStats), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(DR_E_NODEVICE, "probe: stats copy failed");
+        ix->nq = nq_all;
+        ix->pq_ub_valid = false;      // the probe computed bounds for its 64 queries only
+        if (rc) { ix->adc_live = -1; return rc; }
+        uint64_t evald = 0, all = 0;
+        for (const KStats &x : st) { evald += x.pq_evaluated; all += x.pq; }
+        ix->adc_live = (2 * evald > all) ? 1 : 0;
+    }
     const int *pref = k_m1 ? PREF_M1 : k_adc ? PREF_ADC : ov ? PREF_BUILD : PREF_EX;
     const int npref = k_m1 ? 4 : k_adc ? 2 : 2;
+    if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 8 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
     int kind = -1;
     for (int i = 0; i < npref && kind < 0; i++) if (usable(pref[i])) kind = pref[i];
     {
         static bool env_read = false;
-        if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e) g_force_kind = atoi(e); env_read = true; }
+        if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e && !g_force_kind_set) g_force_kind = atoi(e); env_read = true; }
         const int g = g_force_kind;
         if (g >= 0 && g < DR_NUM_KINDS && usable(g)) {
             const bool g_m1 = (g == 0 || g == 3 || g == 4 || g == 6 || g == 7 || g == 9), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8);
@@ -973,6 +1001,16 @@ extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uin
     HIPCHK(hipStreamSynchronize(ix->stream));
     ix->m = m; ix->sd = ix->D / m;
     ix->pq_ub_valid = false;
+    ix->adc_live = -1;
+    return 0;
+}
+
+extern "C" int dr_debug_force_kind(dr_index *ix, int kind, int *out_adc_live)
+{
+    if (kind >= DR_NUM_KINDS) return fail(DR_E_ARG, "unknown kernel variant %d", kind);
+    g_force_kind = kind < 0 ? -1 : kind;
+    g_force_kind_set = true;
+    if (ix && out_adc_live) { std::lock_guard<std::mutex> lk(ix->mu); *out_adc_live = ix->adc_live; }
     return 0;
 }
 

@@ -188,6 +188,33 @@ template <int D> constexpr bool split_form_ok()
 }
 template <> constexpr bool split_form_ok<256>() { return true; }
 
+// Same run with the centroid already in registers and a compile-time length (numpy order for n <= 128).
+template <int N>
+DEV float pw_run_regs(const float (&c)[N], const float *q)
+{
+    static_assert(N >= 1 && N <= 128, "sub_dim");
+    if constexpr (N < 8) {
+        float res = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; i++) res = f_add(res, sqd(c[i], q[i]));
+        return res;
+    } else {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = sqd(c[j], q[j]);
+        constexpr int lim = N - (N % 8);
+#pragma unroll
+        for (int i = 8; i < lim; i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = f_add(r[j], sqd(c[i + j], q[i + j]));
+        }
+        float res = f_add(f_add(f_add(r[0], r[1]), f_add(r[2], r[3])), f_add(f_add(r[4], r[5]), f_add(r[6], r[7])));
+#pragma unroll
+        for (int i = lim; i < N; i++) res = f_add(res, sqd(c[i], q[i]));
+        return res;
+    }
+}
+
 // ---- one lane, one short contiguous run (PQ table rows, n = sub_dim <= 128), original element order -----
 // A2: DiskANNPQ.compute_distance_table, fast_pq.py:294-318.
 DEV float pw_run_lane(const float *__restrict__ c, const float *q, int n)

@@ -275,25 +275,59 @@ template <int NCH> DEV int frontier_last(const RegList<NCH> &L, const FlagList<N
 DEV u64 fkey(u64 k) { return (k & 0xFFFFFFFF00000000ull) | (u32)(~(u32)k); }
 
 // ---- PQ pieces -------------------------------------------------------------------------------------------
+// A2 for a compile-time sub_dim: U table entries per lane per trip, every codebook load of a trip issued before the
+// first use (the per-entry loop of the generic form below exposes one memory round trip per element).
+template <int SD>
+DEV void build_lut_sd(float *lut, const float *__restrict__ codebook, const float *q, u32 total)
+{
+    constexpr int U = SD <= 8 ? 8 : (SD <= 16 ? 4 : (SD <= 32 ? 2 : 1));
+    for (u32 e0 = lane_id(); e0 < total; e0 += 64 * U) {
+        float c[U][SD];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u32 e = min(e0 + 64u * u, total - 1);
+            const float *src = codebook + (size_t)e * SD;
+            if constexpr (SD % 4 == 0) {
+#pragma unroll
+                for (int i = 0; i < SD; i += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src + i);
+                    c[u][i] = v.x; c[u][i + 1] = v.y; c[u][i + 2] = v.z; c[u][i + 3] = v.w;
+                }
+            } else if constexpr (SD % 2 == 0) {
+#pragma unroll
+                for (int i = 0; i < SD; i += 2) {
+                    const float2 v = *reinterpret_cast<const float2 *>(src + i);
+                    c[u][i] = v.x; c[u][i + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < SD; i++) c[u][i] = src[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u32 e = e0 + 64u * u;
+            if (e < total) lut[e] = pw_run_regs<SD>(c[u], q + (e >> 8) * SD);
+        }
+    }
+}
+
 // A2: whole table for one query, entries spread over the wave. q in original order (LDS).
 DEV void build_lut_wave(float *lut, const float *__restrict__ codebook, const float *q, u32 m, u32 sd)
 {
     const u32 total = m * 256;
-    if (sd == 4) {
-        // four entries per lane per trip: the codebook loads of a trip are independent and issue back to back
-        for (u32 e0 = lane_id() * 4; e0 < total; e0 += 256) {
-            const float4 *c4 = reinterpret_cast<const float4 *>(codebook + (size_t)e0 * 4);
-            const float4 a = c4[0], b = c4[1], c = c4[2], d = c4[3];
-            const float *qq = q + (e0 >> 8) * 4;
-            const float q0 = qq[0], q1 = qq[1], q2 = qq[2], q3 = qq[3];
-            float4 o;
-            o.x = f_add(f_add(f_add(f_add(0.0f, sqd(a.x, q0)), sqd(a.y, q1)), sqd(a.z, q2)), sqd(a.w, q3));
-            o.y = f_add(f_add(f_add(f_add(0.0f, sqd(b.x, q0)), sqd(b.y, q1)), sqd(b.z, q2)), sqd(b.w, q3));
-            o.z = f_add(f_add(f_add(f_add(0.0f, sqd(c.x, q0)), sqd(c.y, q1)), sqd(c.z, q2)), sqd(c.w, q3));
-            o.w = f_add(f_add(f_add(f_add(0.0f, sqd(d.x, q0)), sqd(d.y, q1)), sqd(d.z, q2)), sqd(d.w, q3));
-            *reinterpret_cast<float4 *>(lut + e0) = o;
-        }
-        return;
+    switch (sd) {
+    case 2: build_lut_sd<2>(lut, codebook, q, total); return;
+    case 3: build_lut_sd<3>(lut, codebook, q, total); return;
+    case 4: build_lut_sd<4>(lut, codebook, q, total); return;
+    case 6: build_lut_sd<6>(lut, codebook, q, total); return;
+    case 8: build_lut_sd<8>(lut, codebook, q, total); return;
+    case 12: build_lut_sd<12>(lut, codebook, q, total); return;
+    case 16: build_lut_sd<16>(lut, codebook, q, total); return;
+    case 24: build_lut_sd<24>(lut, codebook, q, total); return;
+    case 32: build_lut_sd<32>(lut, codebook, q, total); return;
+    case 48: build_lut_sd<48>(lut, codebook, q, total); return;
+    default: break;
     }
     for (u32 e = lane_id(); e < total; e += 64) {
         const u32 jq = e >> 8;
@@ -461,7 +495,7 @@ DEV u32 a4_threshold_bits(float pq, float thr, bool &ok) {
 }
 
 template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0>
-__global__ __launch_bounds__(64 * NW) void search_kernel(const SearchParams p)
+__global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const SearchParams p)
 {
     constexpr bool QREG = (D <= 256);
     constexpr bool SPLIT = QREG && split_form_ok<D>();

@@ -155,6 +155,13 @@ int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uint8_t *out_c
  * 0 setup+table, 1 pop/stop, 2 adjacency, 3 visited set, 4 ADC, 5 exact distances, 6 decisions/inserts, 7 output. */
 int dr_debug_phase_cycles(dr_index *ix, double *out8);
 
+/* Diagnostic/test hook: pin the search-kernel variant (variants.hpp index) for the modes it serves; -1 restores the
+ * engine's own choice. Every variant returns the same bits; the parity tests run all of them. Process-wide.
+ * When ix and out_adc_live are non-null, *out_adc_live receives the handle's measured M1 regime: 1 = the rerank
+ * policy A4 is live (ADC evaluated: unit-scale data), 0 = provably true almost always (SIFT-scale data, Q1),
+ * -1 = not probed yet (the probe runs on the first 64 queries of the next M1 call). */
+int dr_debug_force_kind(dr_index *ix, int kind, int *out_adc_live);
+
 void dr_index_close(dr_index *ix);
 
 #ifdef __cplusplus

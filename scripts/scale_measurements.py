@@ -13,7 +13,7 @@ from diskrag_amd.synth import unit_mixture, recall_at_k     # noqa: E402
 
 shape, n = sys.argv[1], int(sys.argv[2])
 nq = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
-D, m, ncl, latent = {"c3": (1536, 32, 4096, 64), "c4": (96, 16, 4096, 32)}[shape]
+D, m, ncl, latent = {"c3": (1536, 32, 4096, 64), "c4": (96, 16, 4096, 32), "u128": (128, 32, 4096, 32)}[shape]
 R = 64
 t0 = time.perf_counter()
 x, q = unit_mixture(n, D, n_queries=nq, n_clusters=ncl, seed=11, latent=latent)

@@ -1,0 +1,72 @@
+"""A4-live data (unit-norm: the rerank policy really consults the ADC) through every M1 kernel variant, against the
+oracle on the same device-built graph; and the engine's regime probe (unit-scale -> live, SIFT-scale -> not)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BLOCK = {0: 64, 3: 512, 6: 512, 9: 768}
+
+
+def _index(x, R, m):
+    from diskrag_amd import HipIndex
+    ix = HipIndex.create_empty(x, R=R)
+    medoid, _ = ix.build_vamana(L_build=60, alpha=1.2, passes=2, seed=3)
+    cb = ix.pq_train(m, n_sample=10000, iters=4)
+    codes = ix.pq_encode(cb, want_codes=True)
+    return ix, medoid, ix.get_adjacency(), cb, codes
+
+
+@pytest.mark.parametrize("D,m,kinds", [(128, 32, (0, 3, 9, 6)), (128, 16, (0, 3, 9)), (96, 16, (0, 3)), (64, 8, (0, 3))])
+def test_live_policy_every_variant_matches_oracle(D, m, kinds):
+    from diskrag_amd import _ffi
+    from diskrag_amd.synth import unit_mixture
+    from oracle import pyoracle as orc
+    x, q = unit_mixture(24000, D, n_queries=160, n_clusters=128, seed=31, latent=24)
+    ix, medoid, adj, cb, codes = _index(x, 32, m)
+    try:
+        ix.debug_force_kind(-1)
+        cases = [(100, 8, 0), (100, 0, 0), (100, 0, 1), (30, 8, 1), (64, 0, 0), (128, 8, 0)]
+        want = {}
+        for (L, bw, pol) in cases:
+            want[(L, bw, pol)] = orc.search_batch(x, adj, q, medoid, orc.M1, 10, L=L, bw=bw, policy=pol, codes=codes, codebook=cb,
+                                                    nthreads=8)
+        ran = set()
+        for kind in (-1,) + tuple(kinds):
+            ix.debug_force_kind(kind)
+            for (L, bw, pol) in cases:
+                ids, dist, cnt, st = ix.search_batch(q, 10, L=L, beam_width=bw, mode=_ffi.MODE_M1, band_policy=pol)
+                w_ids, w_dist, w_cnt, w_st = want[(L, bw, pol)]
+                assert int(st["status"].max()) == 0
+                assert np.array_equal(ids, w_ids), (kind, L, bw, pol)
+                valid = w_ids != 0xFFFFFFFF
+                assert np.array_equal(dist[valid].view(np.uint32), w_dist[valid].astype(np.float32).view(np.uint32))
+                assert np.array_equal(cnt, w_cnt)
+                assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), w_st), kind
+                if kind >= 0 and ix.timing()["block"] == BLOCK[kind]:
+                    ran.add(kind)
+        assert ix.debug_force_kind(-1) == 1                      # measured: the policy is live on this data
+        assert ran == set(kinds)                                 # every pinned variant really ran
+        # the policy is live: a good share of the visited neighbours was NOT exact-scored, and the ADC was evaluated
+        ids, dist, cnt, st = ix.search_batch(q, 10, L=100, beam_width=0, mode=_ffi.MODE_M1, band_policy=1)
+        assert st["exact"].sum() < 0.8 * st["visited"].sum() and st["pq_evaluated"].sum() > 0.5 * st["pq"].sum()
+    finally:
+        ix.debug_force_kind(-1)
+        ix.close()
+
+
+def test_regime_probe_on_sift_scale_data():
+    from diskrag_amd import _ffi
+    from diskrag_amd.synth import sift_like
+    x, q = sift_like(24000, 128, n_queries=96, n_clusters=64, seed=5, query_seed=6)
+    ix, medoid, adj, cb, codes = _index(x, 32, 32)
+    try:
+        assert ix.debug_force_kind(-1) == -1                     # not probed yet
+        ids, dist, cnt, st = ix.search_batch(q, 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
+        assert ix.debug_force_kind(-1) == 0                      # Q1: the policy is provably true, ADC skipped
+        assert st["pq_evaluated"].sum() < 0.1 * st["pq"].sum()
+        assert ix.timing()["block"] == 768                       # vectors landed in LDS, 12 waves per workgroup
+        ix.set_pq(cb, codes)                                     # a PQ change resets the probe
+        assert ix.debug_force_kind(-1) == -1
+    finally:
+        ix.close()
