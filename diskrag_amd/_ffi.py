@@ -38,7 +38,7 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_get_timing", "dr_exact_distances", "dr_distance_table", "dr_adc", "dr_pq_scan",
            "dr_bruteforce_topk", "dr_get_node", "dr_index_close", "dr_index_create_empty", "dr_build_vamana",
            "dr_get_adjacency", "dr_pq_train", "dr_pq_encode", "dr_debug_phase_cycles", "dr_batch_sync",
-           "dr_debug_force_kind"]
+           "dr_debug_force_kind", "dr_search_batch_f64"]
 
 _lib = None
 
@@ -107,6 +107,9 @@ def load_library():
     L.dr_pq_train.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, fp]
     L.dr_pq_encode.restype = C.c_int
     L.dr_pq_encode.argtypes = [vp, fp, C.c_uint32, u8p]
+    L.dr_search_batch_f64.restype = C.c_int
+    L.dr_search_batch_f64.argtypes = [vp, C.POINTER(C.c_double)] + [C.c_uint32] * 7 + [u32p, C.POINTER(C.c_double), u32p,
+                                                                                      C.POINTER(DrStats)]
     L.dr_debug_force_kind.restype = C.c_int
     L.dr_debug_force_kind.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.dr_debug_phase_cycles.restype = C.c_int
@@ -239,6 +242,24 @@ class HipIndex:
                                               int(mode), int(band_policy), int(flags), _p(ids, C.c_uint32),
                                               _p(dist, C.c_float), _p(cnt, C.c_uint32),
                                               stats.ctypes.data_as(C.POINTER(DrStats))))
+        return ids, dist, cnt, stats
+
+    def search_batch_f64(self, queries, k, L=100, beam_width=0, mode=MODE_M1, band_policy=0, flags=0):
+        """float64 queries (the CLI path, quirk Q8): M1 / M2, float64 distances back."""
+        q = np.ascontiguousarray(queries, dtype=np.float64)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.ndim != 2 or q.shape[1] != self.D:
+            raise ValueError(f"queries must be [nq, {self.D}], got {q.shape}")
+        nq = q.shape[0]
+        ids = np.empty((nq, k), dtype=np.uint32)
+        dist = np.empty((nq, k), dtype=np.float64)
+        cnt = np.empty(nq, dtype=np.uint32)
+        stats = np.empty(nq, dtype=STATS_DTYPE)
+        _check(load_library().dr_search_batch_f64(self._h, _p(q, C.c_double), nq, int(k), int(L), int(beam_width or 0),
+                                                  int(mode), int(band_policy), int(flags), _p(ids, C.c_uint32),
+                                                  _p(dist, C.c_double), _p(cnt, C.c_uint32),
+                                                  stats.ctypes.data_as(C.POINTER(DrStats))))
         return ids, dist, cnt, stats
 
     def batch_upload(self, queries):

@@ -25,6 +25,7 @@
 
 #include "../../include/diskrag_hip.h"
 #include "engine_kernels.hpp"
+#include "search_f64.hpp"
 #include "build_kernels.hpp"
 #include "variants.hpp"
 
@@ -618,6 +619,63 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
     ix->timing.h2d_ms = h2d; ix->timing.search_kernel_ms = ker; ix->timing.finalize_kernel_ms = fin; ix->timing.d2h_ms = d2h;
     ix->timing.total_ms = h2d + ker + fin + d2h;
     return 0;
+}
+
+// Float64 queries (the CLI hands np.array(list): diskrag.py:194, quirk Q8). M1 and M2 only -- the two searches the
+// CLI reaches (search_engine.py:566-573). One wavefront per query, at most 64 queries per launch; see search_f64.hpp.
+extern "C" int dr_search_batch_f64(dr_index *ix, const double *queries, uint32_t nq, uint32_t k, uint32_t L,
+                                   uint32_t beam_width, uint32_t mode, uint32_t band_policy, uint32_t flags,
+                                   uint32_t *out_ids, double *out_dist, uint32_t *out_count, dr_stats *stats)
+{
+    (void)flags;
+    if (!ix) return fail(DR_E_ARG, "null index");
+    if (!out_ids || !out_dist || !out_count) return fail(DR_E_ARG, "null output buffer");
+    if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
+    if (mode != DR_MODE_M1 && mode != DR_MODE_M2) return fail(DR_E_UNSUPPORTED, "float64 queries: modes M1 and M2 only");
+    if (k == 0) return fail(DR_E_ARG, "k must be positive");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (mode == DR_MODE_M1 && ix->m == 0) return fail(DR_E_NOPQ, "mode %u needs PQ data (dr_index_set_pq)", mode);
+    const uint32_t cap = (mode == DR_MODE_M2) ? beam_width : L;
+    if (cap == 0) return fail(DR_E_ARG, "result-list capacity is zero (L / beam_width)");
+    if (cap > 512) return fail(DR_E_UNSUPPORTED, "result-list capacity %u > 512", cap);
+    HIPCHK(hipSetDevice(ix->device));
+    const uint32_t D = ix->D, CH = 64;
+    const bool pq = (mode == DR_MODE_M1);
+    // LDS: 2 queries (f64), both heaps, per-expansion arrays, the table; the candidates heap takes what is left
+    const size_t fixed = (size_t)2 * D * 8 + (size_t)(cap + 1) * 12 + 64 * 8 + 64 * 4 + 64 * 4 + (pq ? (size_t)ix->m * 256 * 4 : 0) + 64;
+    if (fixed + 1024 * 12 > 160 * 1024) return fail(DR_E_UNSUPPORTED, "float64 search does not fit in LDS (D=%u, m=%u, capacity %u)", D, ix->m, cap);
+    const uint32_t cand_cap = (uint32_t)std::min<size_t>((160 * 1024 - fixed) / 12, 8192) & ~1u;
+    const size_t lds = fixed + (size_t)cand_cap * 12;
+    const void *kfn = ix->kern->search_f64;
+    HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t vis_words = (uint32_t)((ix->N + 31) / 32);
+    DevBuf<double> dq, dd; DevBuf<uint32_t> dids, dcnt, dvis; DevBuf<KStats> dst;
+    if (dq.reserve((size_t)CH * D) || dd.reserve((size_t)CH * k) || dids.reserve((size_t)CH * k) || dcnt.reserve(CH) ||
+        dst.reserve(CH) || dvis.reserve((size_t)CH * vis_words)) return DR_E_NODEVICE;
+    int rc = 0;
+    for (uint32_t q0 = 0; q0 < nq && !rc; q0 += CH) {
+        const uint32_t n = std::min(CH, nq - q0);
+        F64Params p;
+        memset(&p, 0, sizeof p);
+        p.vecp = ix->vecp.p; p.adj = ix->adj.p; p.first = ix->first.p; p.deg = nullptr; p.codes = ix->codes.p;
+        p.codebook = ix->codebook.p; p.perm = ix->perm.p; p.queries = dq.p;
+        p.N = ix->N; p.D = D; p.R = ix->R; p.m = ix->m; p.sd = ix->sd; p.medoid = ix->medoid; p.nq = n;
+        p.mode = mode; p.k = k; p.cap = cap; p.L = L; p.bw = beam_width; p.policy = band_policy;
+        p.max_steps = pq ? (uint32_t)std::min<uint64_t>((uint64_t)L * 10, ix->N) : 0xFFFFFFFFu;
+        p.vis = dvis.p; p.vis_words = vis_words; p.cand_cap = cand_cap;
+        p.out_ids = dids.p; p.out_dist = dd.p; p.out_count = dcnt.p; p.stats = dst.p;
+        if (hipMemcpyAsync(dq.p, queries + (size_t)q0 * D, (size_t)n * D * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+            hipMemsetAsync(dvis.p, 0, (size_t)n * vis_words * 4, ix->stream) != hipSuccess) { rc = fail(DR_E_NODEVICE, "float64 search: upload failed"); break; }
+        void *args[] = { &p };
+        if (hipLaunchKernel(kfn, dim3(n), dim3(64), args, lds, ix->stream) != hipSuccess) { rc = fail(DR_E_NODEVICE, "float64 search: launch failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        if (hipMemcpyAsync(out_ids + (size_t)q0 * k, dids.p, (size_t)n * k * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+            hipMemcpyAsync(out_dist + (size_t)q0 * k, dd.p, (size_t)n * k * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+            hipMemcpyAsync(out_count + q0, dcnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+            (stats && hipMemcpyAsync(stats + q0, dst.p, (size_t)n * sizeof(KStats), hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
+            hipStreamSynchronize(ix->stream) != hipSuccess) { rc = fail(DR_E_NODEVICE, "float64 search: %s", hipGetErrorString(hipGetLastError())); break; }
+    }
+    dq.release(); dd.release(); dids.release(); dcnt.release(); dvis.release(); dst.release();
+    return rc;
 }
 
 // --------------------------------------------------------------------------------- kernel-level entry points

@@ -237,3 +237,73 @@ DEV float pw_run_lane(const float *__restrict__ c, const float *q, int n)
     for (; i < n; i++) res = f_add(res, sqd(c[i], q[i]));
     return res;
 }
+
+// ---- float64 queries (the CLI path, diskrag.py:194: np.array(list) is float64) ------------------------------
+// vec (f32) - q (f64) promotes to f64 and np.sum runs the same pairwise routine on doubles
+// (search_engine.py:378-379 with a float64 query). Same chain-major layout, same tree, double arithmetic.
+DEV double d_sub(double a, double b) { return a - b; }
+DEV double d_mul(double a, double b) { return a * b; }
+DEV double d_add(double a, double b) { return a + b; }
+DEV double sqd64(float v, double q) { double d = d_sub((double)v, q); return d_mul(d, d); }
+
+DEV double octet_combine64(double r)
+{
+    r = d_add(r, __shfl_xor(r, 1));
+    r = d_add(r, __shfl_xor(r, 2));
+    r = d_add(r, __shfl_xor(r, 4));
+    return r;
+}
+
+// row: chain-major stored vector (global); qlds: chain-major float64 query (LDS). Lane j of the octet owns chain j.
+template <int OFF, int N, int D>
+DEV double pw_row_stream64(const float *__restrict__ row, const double *qlds, int j)
+{
+    if constexpr (N <= 128) {
+        constexpr int S = N / 8, G = S / 4, REM = S % 4;
+        double r = 0.0;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + OFF + g * 32 + j * 4);
+            const double *qq = qlds + OFF + g * 32 + j * 4;
+            const double s0 = sqd64(v.x, qq[0]), s1 = sqd64(v.y, qq[1]), s2 = sqd64(v.z, qq[2]), s3 = sqd64(v.w, qq[3]);
+            r = (g == 0) ? s0 : d_add(r, s0);
+            r = d_add(r, s1);
+            r = d_add(r, s2);
+            r = d_add(r, s3);
+        }
+#pragma unroll
+        for (int u = 0; u < REM; u++) {
+            const double s = sqd64(row[OFF + G * 32 + j * REM + u], qlds[OFF + G * 32 + j * REM + u]);
+            r = (G == 0 && u == 0) ? s : d_add(r, s);
+        }
+        return octet_combine64(r);
+    } else {
+        constexpr int N2 = (N / 2) - ((N / 2) % 8);
+        const double a = pw_row_stream64<OFF, N2, D>(row, qlds, j);
+        const double b = pw_row_stream64<OFF + N2, N - N2, D>(row, qlds, j);
+        return d_add(a, b);
+    }
+}
+
+// One lane, one short contiguous run in original element order, float64 query (A2 with a float64 query:
+// the table row is summed in f64 and stored as f32, fast_pq.py:307, 315-316).
+DEV double pw_run_lane64(const float *__restrict__ c, const double *q, int n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; i++) res = d_add(res, sqd64(c[i], q[i]));
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = sqd64(c[j], q[j]);
+    int i = 8;
+    const int lim = n - (n % 8);
+    for (; i < lim; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = d_add(r[j], sqd64(c[i + j], q[i + j]));
+    }
+    double res = d_add(d_add(d_add(r[0], r[1]), d_add(r[2], r[3])), d_add(d_add(r[4], r[5]), d_add(r[6], r[7])));
+    for (; i < n; i++) res = d_add(res, sqd64(c[i], q[i]));
+    return res;
+}

@@ -1,0 +1,246 @@
+// search_f64.hpp -- M1 / M2 for float64 queries: the `diskrag search` CLI path.
+//
+// diskrag.py:194 hands the engine `np.array(list_of_floats)`, a float64 query, so everything numpy computes from
+// it is float64 (quirk Q8): exact distances (search_engine.py:374-379), the table rows of A2 before they are
+// stored as float32 (fast_pq.py:307-316), the worst distance W and the 0.8 / 1.2 products of A4 (:390-395), the
+// heap keys, and the distances returned. The batched engine (search_kernel.hpp) packs a float32 distance and an
+// id into one 64-bit key; float64 distances do not fit, and the CLI asks one query at a time, so this path is a
+// separate, plain kernel: one wavefront per query, distances computed by the whole wavefront (octet per stored
+// vector, numpy's pairwise order in double), and the reference's two heaps kept literally -- CPython's heapq sift
+// rules on (key, id) tuples -- by lane 0 in LDS. Exact by construction, including the heap-array tie order of the
+// final stable sort (search_engine.py:483-488); throughput is not the point here (a query takes ~1 ms).
+#pragma once
+#include "search_kernel.hpp"
+
+struct F64Params {
+    const float *vecp; const u32 *adj; const u64 *first; const u32 *deg; const u8 *codes; const float *codebook;
+    const u32 *perm; const double *queries;
+    u64 N; u32 D, R, m, sd, medoid, nq;
+    u32 mode, k, cap, L, bw, policy, max_steps;
+    u32 *vis; u32 vis_words; u32 cand_cap;
+    u32 *out_ids; double *out_dist; u32 *out_count; KStats *stats;
+};
+
+// (key, id) tuple order: first differing element decides (ids are unique inside a heap)
+DEV bool tup_lt(double ka, u32 ia, double kb, u32 ib) { return ka < kb || (ka == kb && ia < ib); }
+
+// Lib/heapq.py _siftdown: bubble heap[pos] up towards startpos
+DEV void hq_siftdown(double *hk, u32 *hi, int startpos, int pos)
+{
+    const double nk = hk[pos]; const u32 ni = hi[pos];
+    while (pos > startpos) {
+        const int parent = (pos - 1) >> 1;
+        const double pk = hk[parent]; const u32 pi = hi[parent];
+        if (tup_lt(nk, ni, pk, pi)) { hk[pos] = pk; hi[pos] = pi; pos = parent; continue; }
+        break;
+    }
+    hk[pos] = nk; hi[pos] = ni;
+}
+// Lib/heapq.py _siftup: move the smaller child up until a leaf, then sift the item down from there
+DEV void hq_siftup(double *hk, u32 *hi, int n, int pos)
+{
+    const int startpos = pos;
+    const double nk = hk[pos]; const u32 ni = hi[pos];
+    int child = 2 * pos + 1;
+    while (child < n) {
+        const int right = child + 1;
+        if (right < n && !tup_lt(hk[child], hi[child], hk[right], hi[right])) child = right;
+        hk[pos] = hk[child]; hi[pos] = hi[child];
+        pos = child;
+        child = 2 * pos + 1;
+    }
+    hk[pos] = nk; hi[pos] = ni;
+    hq_siftdown(hk, hi, startpos, pos);
+}
+DEV void hq_push(double *hk, u32 *hi, int &n, double k, u32 id) { hk[n] = k; hi[n] = id; n++; hq_siftdown(hk, hi, 0, n - 1); }
+DEV void hq_pop(double *hk, u32 *hi, int &n, double &k, u32 &id)
+{
+    n--;
+    const double lk = hk[n]; const u32 li = hi[n];
+    if (n > 0) { k = hk[0]; id = hi[0]; hk[0] = lk; hi[0] = li; hq_siftup(hk, hi, n, 0); }
+    else { k = lk; id = li; }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void search_f64_kernel(const F64Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
+    const int lane = (int)lane_id();
+    const int oct = lane >> 3, j = lane & 7;
+    const u32 qi = blockIdx.x;
+    if (qi >= p.nq) return;
+    const bool pq = (p.mode == 1u);
+    // LDS carve-up
+    double *qperm = reinterpret_cast<double *>(smem64);              // chain-major query
+    double *qorig = qperm + D;                                       // original order (table rows)
+    double *res_k = qorig + D;                                       // results heap: keys = -distance
+    double *cand_k = res_k + (p.cap + 1);                            // candidates heap: keys = distance
+    double *nb_e = cand_k + p.cand_cap;
+    u32 *res_i = reinterpret_cast<u32 *>(nb_e + 64);
+    u32 *cand_i = res_i + (p.cap + 1);
+    u32 *nb_id = cand_i + p.cand_cap;
+    float *nb_pq = reinterpret_cast<float *>(nb_id + 64);
+    float *lut = nb_pq + 64;                                         // m*256 floats when pq
+    u32 *vbm = p.vis + (size_t)qi * p.vis_words;                     // zeroed by the host before the launch
+
+    for (int i = lane; i < D; i += 64) {
+        const double v = p.queries[(size_t)qi * D + i];
+        qorig[i] = v;
+        qperm[p.perm[i]] = v;
+    }
+    WSYNC();
+    if (pq) {
+        // A2 in float64, stored as float32 (fast_pq.py:307-316)
+        const u32 total = p.m * 256;
+        for (u32 e = lane; e < total; e += 64)
+            lut[e] = (float)pw_run_lane64(p.codebook + (size_t)e * p.sd, qorig + (e >> 8) * p.sd, (int)p.sd);
+        WSYNC();
+    }
+
+    u32 steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0;
+    int rn = 0, cn = 0;
+    const int cap = (int)p.cap;
+
+    // start node (search_engine.py:416-426, vamana_graph.py:724-729)
+    {
+        const u32 start = p.medoid;
+        if (lane == 0) atomicOr(&vbm[start >> 5], 1u << (start & 31));
+        nvisited = 1;
+        double d0 = pw_row_stream64<0, D, D>(p.vecp + (size_t)start * D, qperm, j);
+        if (!pq) d0 = __builtin_sqrt(d0);
+        nexact = 1;
+        if (lane == 0) { hq_push(cand_k, cand_i, cn, d0, start); hq_push(res_k, res_i, rn, -d0, start); }
+        cn = 1; rn = 1;
+        WSYNC();
+    }
+    const u32 nwords = (p.R + 63) / 64;
+    bool stop = false;
+    while (cn > 0 && steps < p.max_steps && !stop) {
+        steps++;
+        // pop + stop rule (search_engine.py:434-439, vamana_graph.py:731-735) by lane 0, broadcast through LDS
+        if (lane == 0) {
+            double ck; u32 ci; int n = cn;
+            hq_pop(cand_k, cand_i, n, ck, ci);
+            const double W = -res_k[0];
+            nb_id[0] = ci;
+            nb_id[1] = (rn >= cap && ck > W) ? 1u : 0u;
+        }
+        cn--;
+        WSYNC();
+        const u32 cur = nb_id[0];
+        stop = nb_id[1] != 0u;
+        WSYNC();
+        if (stop) break;
+        for (u32 cbase = 0; cbase < p.R; cbase += 64) {
+            const u32 slot = cbase + lane;
+            u32 nbid = 0xFFFFFFFFu;
+            if (slot < p.R) nbid = p.adj[(size_t)cur * p.R + slot];
+            const u64 aux = p.first ? p.first[(size_t)cur * nwords + (cbase >> 6)] : (u64)p.deg[cur];
+            bool active;
+            if (p.first) active = ((aux >> lane) & 1ull) != 0ull;
+            else active = slot < min((u32)aux, p.R) && nbid != 0xFFFFFFFFu;
+            bool isnew = false;
+            if (active) {
+                const u32 bit = 1u << (nbid & 31);
+                isnew = (atomicOr(&vbm[nbid >> 5], bit) & bit) == 0u;
+            }
+            const u64 newmask = __ballot(isnew);
+            const int nnew = __popcll(newmask);
+            if (nnew == 0) continue;
+            if (isnew) nb_id[__popcll(newmask & lanemask_lt())] = nbid;
+            nvisited += nnew;
+            WSYNC();
+            if (pq) {
+                // A3: strict sequential float32 sum over the sub-quantisers, then sqrt (fast_pq.py:320-333)
+                if (lane < nnew) {
+                    const u8 *code = p.codes + (size_t)nb_id[lane] * p.m;
+                    float s = 0.0f;
+                    for (u32 jj = 0; jj < p.m; jj++) s = f_add(s, lut[jj * 256 + code[jj]]);
+                    nb_pq[lane] = f_sqrt(s);
+                }
+                npq += nnew;
+            }
+            // exact distances of all new neighbours, 8 per pass (the reference scores only those A4 lets through;
+            // scoring the others changes nothing but work, the counter below follows the reference)
+            for (int r0 = 0; r0 < nnew; r0 += 8) {
+                const int idx = min(r0 + oct, nnew - 1);
+                double ev = pw_row_stream64<0, D, D>(p.vecp + (size_t)nb_id[idx] * D, qperm, j);
+                if (!pq) ev = __builtin_sqrt(ev);
+                if (j == 0 && r0 + oct < nnew) nb_e[r0 + oct] = ev;
+            }
+            WSYNC();
+            // the reference's neighbour loop, literally, on lane 0 (search_engine.py:449-474; vamana_graph.py:741-750)
+            if (lane == 0) {
+                int n_c = cn, n_r = rn;
+                u32 ex = 0;
+                for (int i = 0; i < nnew; i++) {
+                    const double W = -res_k[0];
+                    if (pq) {
+                        const double pd = (double)nb_pq[i];
+                        bool pass;
+                        if (n_r < (int)p.L) pass = true;
+                        else if (pd < d_mul(0.8, W)) pass = true;
+                        else if (pd < d_mul(1.2, W)) pass = (p.policy == 0u);
+                        else pass = false;
+                        if (!pass) continue;
+                    }
+                    ex++;
+                    const double e = nb_e[i];
+                    if (n_r < cap || e < W) {
+                        if (n_c >= (int)p.cand_cap) { status |= DR_ST_CAND_OVERFLOW; continue; }
+                        hq_push(cand_k, cand_i, n_c, e, nb_id[i]);
+                        hq_push(res_k, res_i, n_r, -e, nb_id[i]);
+                        if (n_r > cap) { double dk; u32 di; hq_pop(res_k, res_i, n_r, dk, di); }
+                    }
+                }
+                nb_id[0] = (u32)n_c; nb_id[1] = (u32)n_r; nb_id[2] = ex; nb_id[3] = status;
+            }
+            WSYNC();
+            cn = (int)nb_id[0]; rn = (int)nb_id[1]; nexact += nb_id[2]; status |= nb_id[3];
+            WSYNC();
+        }
+        // candidates = heapq.nsmallest(beam_width, candidates); heapify (search_engine.py:477-479,
+        // vamana_graph.py:753-755): the bw smallest tuples in ascending order, which already is a heap
+        if (p.bw != 0u && cn > (int)p.bw) {
+            if (lane == 0) {
+                for (int a = 0; a < (int)p.bw; a++) {
+                    int best = a;
+                    for (int b = a + 1; b < cn; b++)
+                        if (tup_lt(cand_k[b], cand_i[b], cand_k[best], cand_i[best])) best = b;
+                    const double tk = cand_k[a]; const u32 ti = cand_i[a];
+                    cand_k[a] = cand_k[best]; cand_i[a] = cand_i[best];
+                    cand_k[best] = tk; cand_i[best] = ti;
+                }
+            }
+            cn = (int)p.bw;
+            WSYNC();
+        }
+    }
+
+    // result extraction by lane 0: M1 stable sort of the heap ARRAY by distance only (search_engine.py:483-488);
+    // M2 sorted() on full (distance, id) tuples (vamana_graph.py:758)
+    if (lane == 0) {
+        for (int i = 0; i < rn; i++) res_k[i] = -res_k[i];
+        for (int i = 1; i < rn; i++) {        // insertion sort: stable
+            const double kk = res_k[i]; const u32 ii = res_i[i];
+            int b = i - 1;
+            while (b >= 0 && (pq ? (res_k[b] > kk) : tup_lt(kk, ii, res_k[b], res_i[b]))) {
+                res_k[b + 1] = res_k[b]; res_i[b + 1] = res_i[b]; b--;
+            }
+            res_k[b + 1] = kk; res_i[b + 1] = ii;
+        }
+    }
+    WSYNC();
+    const int kout = min(rn, (int)p.k);
+    for (int i = lane; i < (int)p.k; i += 64) {
+        p.out_ids[(size_t)qi * p.k + i] = (i < kout) ? res_i[i] : 0xFFFFFFFFu;
+        p.out_dist[(size_t)qi * p.k + i] = (i < kout) ? res_k[i] : __longlong_as_double(0x7FF8000000000000ll);
+    }
+    if (lane == 0) {
+        p.out_count[qi] = (u32)kout;
+        KStats st;
+        st.steps = steps; st.visited = nvisited; st.exact = nexact; st.pq = npq; st.status = status;
+        st.inserts = 0; st.pq_evaluated = npq; st.reserved = 0;
+        p.stats[qi] = st;
+    }
+}

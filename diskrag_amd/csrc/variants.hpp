@@ -23,6 +23,7 @@ struct DimKernels {
     const void *exact;
     const void *bruteforce;
     const void *prune;
+    const void *search_f64;   // M1 / M2 with float64 queries (the CLI path), search_f64.hpp
 };
 static const int DR_KIND_NW[DR_NUM_KINDS] = { 1, 1, 1, 8, 16, 8, 8, 16, 8, 12 };
 static const bool DR_KIND_CB[DR_NUM_KINDS] = { false, false, false, true, true, true, false, false, false, false };   // codebook copied to LDS

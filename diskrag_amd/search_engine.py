@@ -136,16 +136,26 @@ class SearchEngineCorrect:
             raise _ffi.DiskragHipError(_ffi.E_OVERFLOW, f"work-area overflow in {int(bad.sum())} queries "
                                        f"(status bits {int(np.bitwise_or.reduce(stats['status']))})")
 
+    @staticmethod
+    def _is_f64(query_vector) -> bool:
+        """The CLI hands np.array(list) = float64 (diskrag.py:194), the API float32 (app.py:45); the reference's numpy
+        arithmetic follows the query's dtype (quirk Q8), and so does the engine: float64 queries take the float64
+        kernel and get np.float64 distances back."""
+        return np.asarray(query_vector).dtype == np.float64
+
     def _pq_accelerated_graph_search(self, query_vector: np.ndarray, k: int = 10, L: int = 100,
                                      beam_width: Optional[int] = None, band_policy: int = 0
                                      ) -> Tuple[List[Tuple[float, int]], Dict]:
         t0 = time.time()
-        ids, dist, cnt, st = self.index.search_batch(query_vector, k, L=L, beam_width=beam_width or 0,
-                                                     mode=_ffi.MODE_M1, band_policy=band_policy)
+        f64 = self._is_f64(query_vector)
+        run = self.index.search_batch_f64 if f64 else self.index.search_batch
+        ids, dist, cnt, st = run(query_vector, k, L=L, beam_width=beam_width or 0, mode=_ffi.MODE_M1,
+                                 band_policy=band_policy)
         self._check_status(st)
         secs = time.time() - t0
         n = int(cnt[0])
-        results = [(np.float32(dist[0, i]), np.uint32(ids[0, i])) for i in range(n)]
+        ftype = np.float64 if f64 else np.float32
+        results = [(ftype(dist[0, i]), np.uint32(ids[0, i])) for i in range(n)]
         exact, pq = int(st["exact"][0]), int(st["pq"][0])
         self._bump(exact, pq, secs)
         stats = {"search_time": secs, "nodes_visited": int(st["visited"][0]), "exact_distance_computations": exact,
@@ -156,12 +166,15 @@ class SearchEngineCorrect:
     def _exact_graph_search(self, query_vector: np.ndarray, k: int = 10, L: int = 100
                             ) -> Tuple[List[Tuple[float, int]], Dict]:
         t0 = time.time()
+        f64 = self._is_f64(query_vector)
+        run = self.index.search_batch_f64 if f64 else self.index.search_batch
         # the reference hard-codes beam_width=8 here and ignores L (search_engine.py:513-519, Q6)
-        ids, dist, cnt, st = self.index.search_batch(query_vector, k, L=L, beam_width=8, mode=_ffi.MODE_M2)
+        ids, dist, cnt, st = run(query_vector, k, L=L, beam_width=8, mode=_ffi.MODE_M2)
         self._check_status(st)
         secs = time.time() - t0
         n = int(cnt[0])
-        results = [(np.float32(dist[0, i]), np.uint32(ids[0, i])) for i in range(n)]
+        ftype = np.float64 if f64 else np.float32
+        results = [(ftype(dist[0, i]), np.uint32(ids[0, i])) for i in range(n)]
         return results, {"search_time": secs, "exact_distance_computations": len(results) * 2,
                          "search_type": "exact_beam_search"}
 

@@ -99,6 +99,16 @@ int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, uint32_t k,
                     uint32_t mode, uint32_t band_policy, uint32_t flags, uint32_t *out_ids, float *out_dist,
                     uint32_t *out_count, dr_stats *stats);
 
+/* The same seam for FLOAT64 queries: `diskrag search` builds its query with np.array(list_of_floats)
+ * (diskrag.py:194), so the reference computes exact distances, table rows (before the float32 store), the worst
+ * distance and the 0.8/1.2 products of the rerank policy in float64 and returns float64 distances (quirk Q8).
+ * Modes DR_MODE_M1 and DR_MODE_M2 (the two searches the CLI reaches, search_engine.py:566-573); other arguments as
+ * dr_search_batch; out_dist is double[nq][k] (NaN padded). Bit-exact against the reference on ids, distances and
+ * counters for M1; M2 goes through np.linalg.norm (BLAS order, unpinned) and is held to 1e-4 like its f32 twin. */
+int dr_search_batch_f64(dr_index *ix, const double *queries, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width,
+                        uint32_t mode, uint32_t band_policy, uint32_t flags, uint32_t *out_ids, double *out_dist,
+                        uint32_t *out_count, dr_stats *stats);
+
 /* HBM-resident batches (bench.py: inputs already on the device when the timed region starts).
  * dr_batch_upload copies queries to the device. dr_batch_run launches one search step and returns when its
  * search kernel has finished; the tie-order pass of that step (finalize: replays the reference's heap for the

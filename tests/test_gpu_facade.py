@@ -114,3 +114,28 @@ def test_device_built_index_survives_the_reference_file_formats(tmp_path):
     back = persist.read_index(cdir / "index")
     assert np.array_equal(back.adjacency, adj) and np.array_equal(back.codes, codes)
     eng.close(); ix.close()
+
+
+def test_facade_float64_query_takes_the_float64_path(tmp_path):
+    """The CLI's query is float64 (diskrag.py:194): the facade must return the reference's float64 results for it."""
+    from diskrag_amd.search_engine import SearchEngineCorrect
+    g = load_golden("unit1536_R16_m32")
+    write_collection(tmp_path, "c", g)
+    eng = SearchEngineCorrect("c", base_dir=tmp_path)
+    ci = [i for i, c in enumerate(g.cases) if c.get("f64")][0]
+    c = g.case(ci)
+    for qi in range(len(c["queries"])):
+        res, stats = eng._pq_accelerated_graph_search(c["queries"][qi], k=c["k"], L=c["L"], beam_width=c["bw"] or None)
+        n = int(c["count"][qi])
+        assert [int(i) for _, i in res] == [int(i) for i in c["ids"][qi][:n]]
+        assert all(isinstance(d, np.float64) for d, _ in res)
+        assert np.array_equal(np.array([d for d, _ in res]).view(np.uint64), c["dist64"][qi][:n].view(np.uint64))
+        assert [stats["search_steps"], stats["nodes_visited"], stats["exact_distance_computations"],
+                stats["pq_distance_computations"]] == c["stats"][qi].tolist()
+    # the same vector as float32 takes the float32 kernel and returns np.float32 distances
+    res32, _ = eng._pq_accelerated_graph_search(c["queries"][0].astype(np.float32), k=c["k"], L=c["L"], beam_width=c["bw"] or None)
+    assert all(isinstance(d, np.float32) for d, _ in res32)
+    # search(): the CLI route, float64 from the embedding function
+    out = eng.search("q", k=3, embedding_fn=lambda s: np.array(c["queries"][0].tolist()), L_search=20)
+    assert out["stats"]["search_type"] == "pq_accelerated"
+    eng.close()
