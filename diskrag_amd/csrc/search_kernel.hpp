@@ -804,13 +804,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                 // cap of (old list + earlier accepted) have distance <= max(e_i, x_i), and it counts as an exact
                 // evaluation (the reference computes e_i before it knows the outcome) iff fewer than cap have
                 // distance <= x_i. The walk then covers every neighbour that can still pass.
-#ifdef DR_SEQ_A4
-                bool batched = true;
-                if constexpr (FILTER) batched = all_pass;
-#else
-                constexpr bool batched = true;
-#endif
-                if (batched) {
+                {
                     const bool count_pass = FILTER && !all_pass;
                     if constexpr (KIND != DIST_ADC_SQ) { if (!count_pass) nexact += nnew; }
                     const u32 ebits = __float_as_uint(e);
@@ -893,7 +887,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                         // entries pushed out: live ones stay in the reference's frontier (search_engine.py:469-474):
                         // worse than every result -> only counted; tied with the new worst distance -> side list
                         int nlive_out = 0;
-                        u64 tie_any = 0ull;
 #pragma unroll
                         for (int ch = 0; ch < NCHR; ch++) {
                             const bool out = (ch * 64 + lane < rn) && npT[ch] >= cap && fl.v[ch] == 0u;
@@ -901,7 +894,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                             nlive_out += __popcll(__ballot(out));
                             junk += (u32)__popcll(__ballot(out && db > Wfb));
                             u64 tm = __ballot(out && db <= Wfb);
-                            tie_any |= tm;
                             while (tm != 0ull) {
                                 const int f = __ffsll((long long)tm) - 1;
                                 tm &= tm - 1ull;
@@ -932,49 +924,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                         rn = rn2;
                         WSYNC();
                     }
-                } else {
-                // ---- sequential form (A4 live: it sees the worst distance in effect at each neighbour's position)
-                bool pending = lane < nnew;
-                float W = key_dist(list_get<NCHR>(rk, rn - 1));
-                for (int guard = 0;; guard++) {
-                    if (guard > 64) { status |= DR_ST_INTERNAL; break; }   // at most one iteration per lane
-                    bool pass = true;
-                    if constexpr (FILTER) {
-                        // _should_compute_exact_distance (search_engine.py:381-397); f32 products as numpy does
-                        pass = all_pass || (rn < (int)p.L) || (pq_d < f_mul(W, 0.8f)) ||
-                               ((pq_d < f_mul(W, 1.2f)) && p.policy == 0u);
-                    }
-                    const bool acc = pending && pass && (rn < cap || e < W);
-                    const u64 am = __ballot(acc);
-                    if (am == 0ull) {
-                        if constexpr (FILTER) nexact += __popcll(__ballot(pending && pass));
-                        else if constexpr (KIND != DIST_ADC_SQ) nexact += __popcll(__ballot(pending));
-                        break;
-                    }
-                    const int f = __ffsll((long long)am) - 1;
-                    const bool upto = pending && lane <= f;
-                    if constexpr (FILTER) nexact += __popcll(__ballot(upto && pass));
-                    else if constexpr (KIND != DIST_ADC_SQ) nexact += __popcll(__ballot(upto));
-                    pending = pending && lane > f;
-                    const u32 eb = readlane32(__float_as_uint(e), f);
-                    const u32 idf = readlane32(myid, f);
-                    u64 dropped = 0; u32 dflag = 0; bool dd;
-                    rn = list_insert_f<NCHR>(rk, fl, rn, cap, ((u64)eb << 32) | (u32)(~idf), dropped, dflag, dd);
-                    cnT++;
-                    if (lane == 0 && ninserts < p.logcap) qlog[ninserts] = ((u64)eb << 32) | idf;
-                    if (ninserts >= p.logcap && p.logcap > 0) status |= DR_ST_LOG_OVERFLOW;
-                    ninserts++;
-                    W = key_dist(list_get<NCHR>(rk, rn - 1));
-                    if (dd && dflag == 0u) {
-                        // a live entry left the results (search_engine.py:473-474) but stays in the reference's
-                        // frontier: worse than every result -> it can only end the search (count it);
-                        // tied with the new worst distance -> it can still be expanded (side list)
-                        cnT--;
-                        if (key_dist(dropped) > W) junk++;
-                        else if (tn < 64) { u64 d2; bool dd2; tn = list_insert<1>(tl, tn, 64, fkey(dropped), d2, dd2); }
-                        else status |= DR_ST_CAND_OVERFLOW;
-                    }
-                }
                 }
             }
             PH(6);

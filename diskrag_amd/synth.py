@@ -57,6 +57,42 @@ def unit_mixture(n, d=1536, n_queries=1000, n_clusters=256, seed=7, latent=64, w
     return draw(n, rs), draw(n_queries, np.random.RandomState(seed + 1))
 
 
+def unit_mixture_parallel(n, d=1536, n_queries=1000, n_clusters=256, seed=7, latent=64, within=1.0, noise=0.05,
+                          threads=32):
+    """The same family as unit_mixture, generated chunk-parallel with counter-based streams (one Philox stream per
+    32768-row chunk, float32 normals): 10M x 1536 in well under a minute on the GPU box's host cores. Not the same
+    numbers as unit_mixture(seed) -- a different, equally seeded dataset."""
+    from concurrent.futures import ThreadPoolExecutor
+    root = np.random.SeedSequence(seed)
+    g0 = np.random.Generator(np.random.Philox(root.spawn(1)[0]))
+    B = (g0.standard_normal((latent, d), dtype=np.float32) / np.float32(np.sqrt(latent)))
+    cent = g0.standard_normal((n_clusters, latent), dtype=np.float32)
+    step = 1 << 15
+
+    def draw(cnt, ss):
+        out = np.empty((cnt, d), dtype=np.float32)
+        starts = list(range(0, cnt, step))
+        seeds = ss.spawn(len(starts))
+
+        def fill(a):
+            s0, sq = a
+            e = min(cnt, s0 + step)
+            r = np.random.Generator(np.random.Philox(sq))
+            idx = r.integers(0, n_clusters, size=e - s0)
+            z = cent[idx] + np.float32(within) * r.standard_normal((e - s0, latent), dtype=np.float32)
+            p = z @ B
+            p += np.float32(noise) * r.standard_normal((e - s0, d), dtype=np.float32)
+            p /= np.linalg.norm(p, axis=1, keepdims=True)
+            out[s0:e] = p
+
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            list(ex.map(fill, zip(starts, seeds)))
+        return out
+
+    kids = root.spawn(3)
+    return draw(n, kids[1]), draw(n_queries, kids[2])
+
+
 def recall_at_k(ids, gt, k=10):
     """mean |pred[:k] & gt[:k]| / k (dataset_benchmark.py:120-124)."""
     hit = 0

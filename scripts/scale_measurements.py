@@ -9,14 +9,15 @@ import numpy as np
 
 sys.path.insert(0, ".")
 from diskrag_amd import HipIndex, _ffi                      # noqa: E402
-from diskrag_amd.synth import unit_mixture, recall_at_k     # noqa: E402
+from diskrag_amd.synth import unit_mixture, unit_mixture_parallel, recall_at_k     # noqa: E402
 
 shape, n = sys.argv[1], int(sys.argv[2])
 nq = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
 D, m, ncl, latent = {"c3": (1536, 32, 4096, 64), "c4": (96, 16, 4096, 32), "u128": (128, 32, 4096, 32)}[shape]
 R = 64
 t0 = time.perf_counter()
-x, q = unit_mixture(n, D, n_queries=nq, n_clusters=ncl, seed=11, latent=latent)
+gen = unit_mixture_parallel if n * D >= (1 << 32) else unit_mixture
+x, q = gen(n, D, n_queries=nq, n_clusters=ncl, seed=11, latent=latent)
 gen_s = time.perf_counter() - t0
 t0 = time.perf_counter()
 ix = HipIndex.create_empty(x, R=R)
@@ -27,7 +28,7 @@ cb = ix.pq_train(m, n_sample=100000, iters=5)
 ix.pq_encode(cb)
 pq_s = time.perf_counter() - t0
 gt, _ = ix.bruteforce_topk(q, 10)
-out = {"shape": shape, "N": n, "D": D, "R": R, "m": m, "nq": nq, "data": f"unit_mixture(latent={latent}, clusters={ncl})",
+out = {"shape": shape, "N": n, "D": D, "R": R, "m": m, "nq": nq, "data": f"{gen.__name__}(latent={latent}, clusters={ncl})",
        "generate_s": gen_s, "upload_s": up_s, "build_s": bsec, "pq_s": pq_s, "runs": {}}
 
 

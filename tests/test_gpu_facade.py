@@ -139,3 +139,39 @@ def test_facade_float64_query_takes_the_float64_path(tmp_path):
     out = eng.search("q", k=3, embedding_fn=lambda s: np.array(c["queries"][0].tolist()), L_search=20)
     assert out["stats"]["search_type"] == "pq_accelerated"
     eng.close()
+
+
+def test_concurrent_searches_on_one_handle():
+    """The reference engine is a shared singleton hit by several threads (search_engine.py:879, Q18): concurrent
+    dr_search_batch / dr_search_batch_f64 calls on one handle must each get their own answer."""
+    import threading
+    from diskrag_amd import _ffi
+    from tests.test_gpu_parity import get_index
+    g = load_golden("sift128_R64_m32")
+    ix = get_index("sift128_R64_m32")
+    cases = [(1, 100, 8), (1, 100, 0), (1, 20, 8), (2, 100, 8)]      # (mode, L, bw)
+    want = {c: ix.search_batch(g.queries, 10, L=c[1], beam_width=c[2], mode=c[0]) for c in cases}
+    q64 = g.queries[:8].astype(np.float64)
+    want64 = ix.search_batch_f64(q64, 10, L=50, beam_width=8)
+    errors = []
+
+    def worker(tid):
+        try:
+            for it in range(12):
+                c = cases[(tid + it) % len(cases)]
+                ids, dist, cnt, st = ix.search_batch(g.queries, 10, L=c[1], beam_width=c[2], mode=c[0])
+                if not (np.array_equal(ids, want[c][0]) and np.array_equal(dist.view(np.uint32), want[c][1].view(np.uint32))):
+                    errors.append((tid, it, c))
+                if it % 4 == tid % 4:
+                    i64, d64, _, _ = ix.search_batch_f64(q64, 10, L=50, beam_width=8)
+                    if not (np.array_equal(i64, want64[0]) and np.array_equal(d64.view(np.uint64), want64[1].view(np.uint64))):
+                        errors.append((tid, it, "f64"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors[:3]
