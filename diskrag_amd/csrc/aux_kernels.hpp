@@ -77,3 +77,33 @@ template <int D> __global__ __launch_bounds__(64) void bruteforce_kernel(const f
         out_dist[(size_t)q * k + lane] = lane < bn ? key_dist(key) : __uint_as_float(0x7FC00000u);
     }
 }
+
+// Nearest of P pivot rows for every stored vector (a coarse cluster label; used only to give the visited bitmap a
+// locality-preserving bit order, see engine.hip build_bit_order: any labelling is correct, a good one is fast).
+// One wavefront per stored vector, persistent over the rows; the pivots (P*D*4 bytes) stay L2-resident.
+template <int D> __global__ __launch_bounds__(64) void nearest_pivot_kernel(const float *__restrict__ vecp, u64 N,
+        const float *__restrict__ pivots_p, u32 P, u32 *__restrict__ label)
+{
+    constexpr bool QREG = (D <= 256);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *qperm = reinterpret_cast<float *>(smem);
+    const int lane = threadIdx.x & 63, j = lane & 7, oct = lane >> 3;
+    for (u64 row = blockIdx.x; row < N; row += gridDim.x) {
+        const float *qpg = vecp + row * D;
+        QueryRegs<D> qreg;
+        if constexpr (QREG) load_query_regs<0, D, D>(qpg, j, qreg);
+        else { WSYNC(); for (int i = lane; i < D; i += 64) qperm[i] = qpg[i]; WSYNC(); }
+        float best = __uint_as_float(0x7F800000u);
+        u32 besti = 0;
+        for (u32 base = 0; base < P; base += 8) {
+            const u32 pi = min(base + (u32)oct, P - 1);
+            const float e = pw_row_stream<0, D, D, QREG>(pivots_p + (size_t)pi * D, &qreg, qperm, j);
+            if (e < best) { best = e; besti = pi; }
+        }
+        // every lane of an octet holds the octet's result: reduce over the 8 octets
+        u64 key = ((u64)__float_as_uint(best) << 32) | besti;
+#pragma unroll
+        for (int sh = 8; sh < 64; sh <<= 1) { const u64 o = __shfl_xor(key, sh); key = o < key ? o : key; }
+        if (lane == 0) label[row] = (u32)key;
+    }
+}

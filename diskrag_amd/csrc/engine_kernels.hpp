@@ -348,3 +348,13 @@ __global__ __launch_bounds__(256) void pq_bound_kernel(const float *__restrict__
     }
     if (tid == 0) out[qi] = f_sqrt(s);
 }
+
+// adjr[i][s] = bit position of neighbour adj[i][s] in the visited bitmap (pad slots: 0)
+__global__ void map_adjacency_kernel(const u32 *__restrict__ adj, u64 total, u64 N, const u32 *__restrict__ rank,
+                                     u32 *__restrict__ adjr)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u32 nb = adj[i];
+        adjr[i] = nb < N ? rank[nb] : 0u;
+    }
+}

@@ -54,6 +54,7 @@ struct KStats { u32 steps, visited, exact, pq, status, inserts, pq_evaluated, re
 struct SearchParams {
     const float *vecp;       // [N][D] chain-major
     const u32 *adj;          // [N][R]
+    const u32 *adjr;         // [N][R] bit position of each neighbour in the visited bitmap (nullptr: the id itself)
     const u64 *first;        // [N][ceil(R/64)] bit s: slot s is a real id and its first occurrence in the row
     const u32 *deg;          // build mode (first == nullptr): rows hold deg[i] distinct ids, the rest is DR_PAD
     const u8 *codes;         // [N][m]
@@ -62,6 +63,7 @@ struct SearchParams {
     const float *queries_p;  // [nq][D] chain-major
     u64 N;
     u32 D, R, m, sd, medoid, nq;
+    u32 medoid_pos;          // bit position of the medoid
     u32 mode, k, cap, L, bw, policy, flags;
     u32 norm;                // 1: traversal metric is sqrt(squared L2) (M2, M4: np.linalg.norm)
     u32 max_steps;           // M1: min(10L, N); others: 0xFFFFFFFF
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
         // ---- start node (search_engine.py:416-426)
         {
             const u32 start = p.medoid;
-            if (lane == 0) { atomicOr(&vbm[start >> 5], 1u << (start & 31)); if (!p.vis_stream_clear) vlog[0] = start; }
+            if (lane == 0) { const u32 sp = p.adjr ? p.medoid_pos : start; atomicOr(&vbm[sp >> 5], 1u << (sp & 31)); if (!p.vis_stream_clear) vlog[0] = sp; }
             nvisited = 1;
             float d0;
             if constexpr (KIND == DIST_ADC_SQ) {
@@ -649,7 +651,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                 if (nvisited + 64u > p.vis_limit) { status |= DR_ST_VIS_OVERFLOW; break; }
                 const u32 slot = cbase + lane;
                 u32 nbid = 0xFFFFFFFFu;
-                if (slot < p.R) nbid = p.adj[(size_t)cur * p.R + slot];
+                // the visited bitmap is indexed by a locality-preserving bit order (neighbours of one node share a
+                // few cache lines instead of touching 64 different ones); the positions travel with the row
+                u32 nbpos = 0xFFFFFFFFu;
+                if (slot < p.R) { nbid = p.adj[(size_t)cur * p.R + slot]; nbpos = p.adjr ? p.adjr[(size_t)cur * p.R + slot] : nbid; }
                 const u64 aux = p.first ? p.first[(size_t)cur * nwords + (cbase >> 6)] : (u64)p.deg[cur];
                 bool active;
                 if (p.first) active = ((aux >> lane) & 1ull) != 0ull;
@@ -658,8 +663,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                 // visited test-and-set: one atomic round trip; duplicates inside a row were removed by `first`
                 bool isnew = false;
                 if (active) {
-                    const u32 bit = 1u << (nbid & 31);
-                    isnew = (atomicOr(&vbm[nbid >> 5], bit) & bit) == 0u;
+                    const u32 bit = 1u << (nbpos & 31);
+                    isnew = (atomicOr(&vbm[nbpos >> 5], bit) & bit) == 0u;
                 }
                 const u64 newmask = __ballot(isnew);
                 const int nnew = __popcll(newmask);
@@ -667,7 +672,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                 if (isnew) {
                     const int rnk = __popcll(newmask & lanemask_lt());
                     nb_id[rnk] = nbid;
-                    if (!p.vis_stream_clear) vlog[nvisited + rnk] = nbid;
+                    if (!p.vis_stream_clear) vlog[nvisited + rnk] = nbpos;
                 }
                 nvisited += nnew;
                 WSYNC();

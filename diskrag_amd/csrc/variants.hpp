@@ -23,6 +23,7 @@ struct DimKernels {
     const void *exact;
     const void *bruteforce;
     const void *prune;
+    const void *nearest_pivot;   // aux_kernels.hpp nearest_pivot_kernel (bit order of the visited bitmap)
     const void *search_f64;   // M1 / M2 with float64 queries (the CLI path), search_f64.hpp
 };
 static const int DR_KIND_NW[DR_NUM_KINDS] = { 1, 1, 1, 8, 16, 8, 8, 16, 8, 12 };
