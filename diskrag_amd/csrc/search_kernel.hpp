@@ -819,6 +819,60 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                     u32 acc_e = 0xFFFFFFFFu;   // lane s: distance bits of the s-th accepted neighbour
                     int na = 0;
                     u64 accmask = 0ull;
+                    const u64 mykey = ((u64)ebits << 32) | (u32)(~myid);
+                    int rT = 0, rA = 0;     // merge ranks: list keys below an accepted key, accepted keys below it
+                    u32 sT[NCHR];           // accepted keys below a list key
+#pragma unroll
+                    for (int ch = 0; ch < NCHR; ch++) sT[ch] = 0u;
+                    bool have_ranks = false;
+                    if (!count_pass && cm != 0ull) {
+                        // Without A4 in play the acceptance test needs no walk: a neighbour rejected earlier in the
+                        // row had e_j >= W_j >= W_i, so it can never be <= e_i of an accepted i, and counting ALL
+                        // earlier candidates gives the same verdict as counting the accepted ones:
+                        //   accept_i  <=>  #(old <= e_i) + #(candidates j < i with e_j <= e_i) < cap.
+                        // Both terms are lane-parallel: a binary search over the list (staged in the merge scratch)
+                        // and one pass over the candidate lanes that also collects, as bit masks, which candidate
+                        // keys lie below this lane's key / list keys -- the merge ranks fall out of the masks.
+#pragma unroll
+                        for (int ch = 0; ch < NCHR; ch++) if (ch * 64 + lane < rn) mk[ch * 64 + lane] = rk.v[ch];
+                        WSYNC();
+                        const bool iscand = ((cm >> lane) & 1ull) != 0ull;
+                        int lb_lo = 0, lb_hi = rn, ub_lo = 0, ub_hi = rn;
+                        const u64 key_ub = ((u64)ebits << 32) | 0xFFFFFFFFull;
+                        if (iscand) {
+                            constexpr int ITER = (NCHR == 1) ? 7 : (NCHR == 2) ? 8 : (NCHR == 4) ? 9 : 10;
+#pragma unroll
+                            for (int it = 0; it < ITER; it++) {
+                                const int m1 = (lb_lo + lb_hi) >> 1, m2 = (ub_lo + ub_hi) >> 1;
+                                const u64 v1 = mk[min(m1, rn - 1)], v2 = mk[min(m2, rn - 1)];
+                                if (lb_lo < lb_hi) { if (v1 < mykey) lb_lo = m1 + 1; else lb_hi = m1; }
+                                if (ub_lo < ub_hi) { if (v2 <= key_ub) ub_lo = m2 + 1; else ub_hi = m2; }
+                            }
+                        }
+                        u32 before = 0u;
+                        u64 lessm = 0ull, oldm[NCHR];
+#pragma unroll
+                        for (int ch = 0; ch < NCHR; ch++) oldm[ch] = 0ull;
+                        for (u64 mm = cm; mm != 0ull; mm &= mm - 1ull) {
+                            const int f = __ffsll((long long)mm) - 1;
+                            const u32 ef = readlane32(ebits, f);
+                            const u64 kf = readlane64(mykey, f);
+                            const u64 bit = 1ull << f;
+                            before += (f < lane && ef <= ebits) ? 1u : 0u;
+                            lessm |= (kf < mykey) ? bit : 0ull;
+#pragma unroll
+                            for (int ch = 0; ch < NCHR; ch++) oldm[ch] |= (kf < rk.v[ch]) ? bit : 0ull;
+                        }
+                        accmask = __ballot(iscand && (u32)ub_lo + before < (u32)cap);
+                        na = __popcll(accmask);
+                        rT = lb_lo;
+                        rA = __popcll(lessm & accmask);
+#pragma unroll
+                        for (int ch = 0; ch < NCHR; ch++) sT[ch] = (u32)__popcll(oldm[ch] & accmask);
+                        have_ranks = true;
+                        cm = 0ull;
+                        WSYNC();    // every search has read the staged list before the merge scatters over it
+                    }
                     while (cm != 0ull) {
                         const int f = __ffsll((long long)cm) - 1;
                         cm &= cm - 1ull;
@@ -849,7 +903,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                     }
                     if (na > 0) {
                         const bool isacc = ((accmask >> lane) & 1ull) != 0ull;
-                        const u64 mykey = ((u64)ebits << 32) | (u32)(~myid);
                         // accepted-insert log, in stored order (finalize replays the reference's heap from it)
                         {
                             const u32 o = ninserts + (u32)__popcll(accmask & lanemask_lt());
@@ -857,12 +910,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                             if (ninserts + (u32)na > p.logcap && p.logcap > 0) status |= DR_ST_LOG_OVERFLOW;
                             ninserts += (u32)na;
                         }
-                        // ranks: rT = list keys below an accepted key, rA = accepted keys below it,
-                        //        sT[ch] = accepted keys below a list key
-                        int rT = 0, rA = 0;
-                        u32 sT[NCHR];
-#pragma unroll
-                        for (int ch = 0; ch < NCHR; ch++) sT[ch] = 0u;
+                        if (!have_ranks)
                         for (u64 am = accmask; am != 0ull; am &= am - 1ull) {
                             const int f = __ffsll((long long)am) - 1;
                             const u64 kf = readlane64(mykey, f);
