@@ -941,7 +941,7 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
     }
 
     DevBuf<uint32_t> adjb, deg, order, fwd, fwd_n, ovf_list, ovf_count;
-    if (adjb.reserve((size_t)N * RX) || deg.reserve(N, true) || order.reserve(N) || fwd.reserve((size_t)max_batch * R) ||
+    if (adjb.reserve((size_t)N * RX) || deg.reserve(N + 2, true) || order.reserve(N) || fwd.reserve((size_t)max_batch * R) ||
         fwd_n.reserve(max_batch) || ovf_list.reserve(N) || ovf_count.reserve(1))
         return DR_E_NODEVICE;
     HIPCHK(hipMemsetAsync(adjb.p, 0xFF, (size_t)N * RX * 4, ix->stream));

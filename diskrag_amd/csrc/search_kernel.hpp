@@ -650,12 +650,22 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
             for (u32 cbase = 0; cbase < p.R; cbase += 64) {
                 if (nvisited + 64u > p.vis_limit) { status |= DR_ST_VIS_OVERFLOW; break; }
                 const u32 slot = cbase + lane;
-                u32 nbid = 0xFFFFFFFFu;
-                // the visited bitmap is indexed by a locality-preserving bit order (neighbours of one node share a
-                // few cache lines instead of touching 64 different ones); the positions travel with the row
-                u32 nbpos = 0xFFFFFFFFu;
-                if (slot < p.R) { nbid = p.adj[(size_t)cur * p.R + slot]; nbpos = p.adjr ? p.adjr[(size_t)cur * p.R + slot] : nbid; }
-                const u64 aux = p.first ? p.first[(size_t)cur * nwords + (cbase >> 6)] : (u64)p.deg[cur];
+                // One memory round trip for the whole row: ids, bit positions and the mask/degree word are loaded
+                // through pointers selected up front, so no load waits behind a branch on another load's register.
+                // The visited bitmap is indexed by a locality-preserving bit order (neighbours of one node share a
+                // few cache lines instead of touching 64 different ones); the positions travel with the row.
+                const u32 *idrow = p.adj + (size_t)cur * p.R;
+                const u32 *posrow = p.adjr ? p.adjr + (size_t)cur * p.R : idrow;
+                // (the degree array of the build mode is read as the aligned 8 bytes around deg[cur]: same load shape
+                // as the mask word, so the compiler keeps one straight-line group of loads; deg has N + 1 entries)
+                const u64 *auxp = p.first ? p.first + (size_t)cur * nwords + (cbase >> 6)
+                                          : reinterpret_cast<const u64 *>(p.deg + (cur & ~1u));
+                const u32 sl = min(slot, p.R - 1);
+                const u32 nbid_l = idrow[sl], nbpos_l = posrow[sl];
+                const u64 aux_w = auxp[0];
+                const u32 nbid = slot < p.R ? nbid_l : 0xFFFFFFFFu;
+                const u32 nbpos = slot < p.R ? nbpos_l : 0xFFFFFFFFu;
+                const u64 aux = p.first ? aux_w : (u64)(u32)(aux_w >> ((cur & 1u) * 32));
                 bool active;
                 if (p.first) active = ((aux >> lane) & 1ull) != 0ull;
                 else active = slot < min((u32)aux, p.R) && nbid != 0xFFFFFFFFu;
