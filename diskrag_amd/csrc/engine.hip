@@ -474,8 +474,10 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     const uint32_t Reff = ov ? ov->RX : ix->R;
     uint64_t max_steps = (mode == DR_MODE_M1) ? std::min<uint64_t>((uint64_t)L * 10, ix->N) : 0xFFFFFFFFull;
     uint64_t bound = (mode == DR_MODE_M1) ? max_steps * Reff + 1 : (uint64_t)std::max<uint32_t>(cap * 10, 1000) * Reff + 1;
-    bound = std::min<uint64_t>(bound, ix->N) + 64;
     const uint32_t vis_words = (uint32_t)((ix->N + 31) / 32);
+    // the log holds every tested slot (about R per expansion); past vis_words/4 entries a streamed clear of the whole
+    // bitmap moves fewer bytes than log + per-position clears, and the kernel switches to it when the log is full
+    bound = std::min<uint64_t>(bound, std::max<uint64_t>(vis_words / 4, 4096)) + 64;
     const uint32_t vis_limit = (uint32_t)bound;
     if (ix->vis.reserve((size_t)slots * vis_words)) return DR_E_NODEVICE;
     if (ix->vis_zeroed < (size_t)slots * vis_words) {

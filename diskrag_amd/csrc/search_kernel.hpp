@@ -42,7 +42,7 @@
 #define PH_END(qi) do {} while (0)
 #endif
 
-#define DR_ST_VIS_OVERFLOW 1u
+#define DR_ST_VIS_OVERFLOW 1u   // (retired: a full position log now switches the query to a whole-bitmap clear)
 #define DR_ST_CAND_OVERFLOW 2u
 #define DR_ST_LOG_OVERFLOW 4u
 #define DR_ST_INTERNAL 8u      // a loop guard fired (never expected; bounds every loop so a bug cannot hang the GPU)
@@ -69,7 +69,7 @@ struct SearchParams {
     u32 max_steps;           // M1: min(10L, N); others: 0xFFFFFFFF
     u32 *vis;                // [slots][vis_words] visited bitmaps (all zero between queries)
     u32 vis_words;
-    u32 *vlog;               // [slots][vis_limit] ids set in the bitmap by the running query
+    u32 *vlog;               // [slots][vis_limit] bit positions the running query may have set (every tested slot)
     u32 vis_limit;
     u32 vis_stream_clear;    // 1: clear the whole slot bitmap with wide stores after a query (small N) instead of per id
     u32 *counter;            // [2]: unused, tie-list length
@@ -587,6 +587,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
 
         u32 npq_eval = 0;
         u32 steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0, ninserts = 0;
+        u32 nlog = 0;            // entries of this query in the slot's position log
+        bool logfull = false;
         int rn = 0, cnT = 0, tn = 0;   // results; live (unexpanded, untrimmed) result entries; tie side list
         u32 junk = 0;   // evicted frontier entries that are worse than every result (only their count matters)
         RegList<NCHR> rk;
@@ -601,6 +603,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
         {
             const u32 start = p.medoid;
             if (lane == 0) { const u32 sp = p.adjr ? p.medoid_pos : start; atomicOr(&vbm[sp >> 5], 1u << (sp & 31)); if (!p.vis_stream_clear) vlog[0] = sp; }
+            nlog = 1;
             nvisited = 1;
             float d0;
             if constexpr (KIND == DIST_ADC_SQ) {
@@ -648,7 +651,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
             PH(1);
 
             for (u32 cbase = 0; cbase < p.R; cbase += 64) {
-                if (nvisited + 64u > p.vis_limit) { status |= DR_ST_VIS_OVERFLOW; break; }
                 const u32 slot = cbase + lane;
                 // One memory round trip for the whole row: ids, bit positions and the mask/degree word are loaded
                 // through pointers selected up front, so no load waits behind a branch on another load's register.
@@ -671,7 +673,18 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                 else active = slot < min((u32)aux, p.R) && nbid != 0xFFFFFFFFu;
                 PH(2);
                 // visited test-and-set: one atomic round trip; duplicates inside a row were removed by `first`
+                // The positions are logged for the end-of-query clear BEFORE the outcome is known (every tested slot,
+                // new or not: clearing a bit twice is harmless), so the store travels with the atomic instead of
+                // sitting between its result and the row loads. A log that fills up switches the query to a
+                // whole-bitmap clear: nothing can overflow.
                 bool isnew = false;
+                {
+                    const u64 actm = __ballot(active);
+                    const u32 nact = (u32)__popcll(actm);
+                    if (nlog + nact > p.vis_limit) logfull = true;
+                    if (active && !logfull && !p.vis_stream_clear) vlog[nlog + (u32)__popcll(actm & lanemask_lt())] = nbpos;
+                    if (!logfull) nlog += nact;
+                }
                 if (active) {
                     const u32 bit = 1u << (nbpos & 31);
                     isnew = (atomicOr(&vbm[nbpos >> 5], bit) & bit) == 0u;
@@ -682,7 +695,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                 if (isnew) {
                     const int rnk = __popcll(newmask & lanemask_lt());
                     nb_id[rnk] = nbid;
-                    if (!p.vis_stream_clear) vlog[nvisited + rnk] = nbpos;
                 }
                 nvisited += nnew;
                 WSYNC();
@@ -990,7 +1002,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                 }
             }
             PH(6);
-            if (status & DR_ST_VIS_OVERFLOW) break;
             // ---- frontier trim
             if (p.mode == 1u || p.mode == 2u) {
                 // candidates = heapq.nsmallest(beam_width, candidates) (search_engine.py:477-479)
@@ -1055,19 +1066,21 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
         }
 
         // ---- clear the visited bits this query set (the bitmap is all zero between queries)
-        if (p.vis_stream_clear) {
-            // small N: the whole slot bitmap is a few hundred 1-KiB wave stores, cheaper than one 64-byte
+        if (p.vis_stream_clear || logfull) {
+            // small N (or a full log): the whole slot bitmap is a few hundred 1-KiB wave stores, cheaper than one 64-byte
             // read-modify-write per visited id
-            uint4 *vb4 = reinterpret_cast<uint4 *>(vbm);
-            const u32 n4 = p.vis_words / 4;
-            for (u32 i = lane; i < n4; i += 64) vb4[i] = make_uint4(0, 0, 0, 0);
-            for (u32 i = n4 * 4 + lane; i < p.vis_words; i += 64) vbm[i] = 0u;
+            if ((p.vis_words & 3u) == 0u) {
+                uint4 *vb4 = reinterpret_cast<uint4 *>(vbm);
+                for (u32 i = lane; i < p.vis_words / 4; i += 64) vb4[i] = make_uint4(0, 0, 0, 0);
+            } else {
+                for (u32 i = lane; i < p.vis_words; i += 64) vbm[i] = 0u;
+            }
         } else
         // (four log reads in flight per trip; the stores bypass L1 like the atomics that will follow them)
-        for (u32 i0 = 0; i0 < nvisited; i0 += 256) {
+        for (u32 i0 = 0; i0 < nlog; i0 += 256) {
             const u32 ia = i0 + lane, ib = ia + 64, ic = ia + 128, id_ = ia + 192;
-            const u32 va = (ia < nvisited) ? vlog[ia] : 0xFFFFFFFFu, vb = (ib < nvisited) ? vlog[ib] : 0xFFFFFFFFu;
-            const u32 vc = (ic < nvisited) ? vlog[ic] : 0xFFFFFFFFu, vd = (id_ < nvisited) ? vlog[id_] : 0xFFFFFFFFu;
+            const u32 va = (ia < nlog) ? vlog[ia] : 0xFFFFFFFFu, vb = (ib < nlog) ? vlog[ib] : 0xFFFFFFFFu;
+            const u32 vc = (ic < nlog) ? vlog[ic] : 0xFFFFFFFFu, vd = (id_ < nlog) ? vlog[id_] : 0xFFFFFFFFu;
             if (va != 0xFFFFFFFFu) __hip_atomic_store(&vbm[va >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (vb != 0xFFFFFFFFu) __hip_atomic_store(&vbm[vb >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (vc != 0xFFFFFFFFu) __hip_atomic_store(&vbm[vc >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
