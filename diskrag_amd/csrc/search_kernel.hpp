@@ -751,12 +751,15 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                         constexpr int RPI = 64 / LPR;       // rows per wave instruction (1 KiB)
                         for (int b0 = 0; b0 < nrow; b0 += RB) {
                             const int nb = min(RB, nrow - b0);
-                            // all rows of the burst in flight, no VGPR destination
+                            // all rows of the burst in flight, no VGPR destination. The row ids of every instruction
+                            // are read first (one LDS wait for the burst instead of one per instruction).
+                            u32 rid[RB / RPI];
+#pragma unroll
+                            for (int r = 0; r < RB; r += RPI) rid[r / RPI] = nb_id[min(b0 + r + lane / LPR, nrow - 1)];
 #pragma unroll
                             for (int r = 0; r < RB; r += RPI) {
                                 if (r < nb) {
-                                    const int idx = min(b0 + r + lane / LPR, nrow - 1);
-                                    const float *g = p.vecp + (size_t)nb_id[idx] * D + (lane % LPR) * 4;
+                                    const float *g = p.vecp + (size_t)rid[r / RPI] * D + (lane % LPR) * 4;
                                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                         (__attribute__((address_space(3))) void *)(rowbuf + (size_t)r * D), 16, 0, 0);
                                 }
