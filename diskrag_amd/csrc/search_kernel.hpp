@@ -823,59 +823,58 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                 // ---- predict the next pop: the closer of the frontier head and the best new neighbour; prefetch its row
 
                 // ---- decisions
-                // Batched form, used whenever acceptance depends on distances only (A4 proven True for the whole
-                // expansion, or a variant without A4). Sequential rule: neighbour i is accepted iff len < cap or
-                // e_i < W_i, W_i the worst distance after the earlier accepts. Equivalently: fewer than cap of
-                // (old list + earlier accepted) have distance <= e_i. So: (1) candidates = neighbours that beat
-                // the CURRENT worst distance (all of them while the list is not full), (2) walk only those, in
-                // stored order, with two ballots each, (3) ONE merge of the accepted set into the list through
-                // LDS. Entries pushed out of the list are accounted exactly as single inserts would.
-                // A4 live (FILTER, ADC evaluated): A4 passes iff W_i > x_i, so the neighbour is accepted iff fewer than
-                // cap of (old list + earlier accepted) have distance <= max(e_i, x_i), and it counts as an exact
-                // evaluation (the reference computes e_i before it knows the outcome) iff fewer than cap have
-                // distance <= x_i. The walk then covers every neighbour that can still pass.
+                // The reference walks the new neighbours in stored order: i is scored iff A4 passes against the worst
+                // distance W_i in effect at its position, and accepted iff moreover e_i < W_i (or the list is not
+                // full); W_i = the cap-th smallest of S_i = old list + neighbours accepted before i. With
+                // x_i = A4's threshold (0 when A4 is proven true) and t_i = max(e_i, x_i):
+                //     scored_i   <=>  #(S_i <= x_i) < cap          accepted_i <=>  #(S_i <= t_i) < cap.
+                // No walk is needed. (1) #(old <= .) is a binary search over the list, staged in the merge scratch.
+                // (2) ONE pass over the candidate lanes records, as bit masks per lane, which earlier candidates j have
+                // e_j <= t_i (Mt) / <= x_i (Mx), and which candidate keys lie below this lane's key or list keys.
+                // (3) accepted = the unique fixed point of  A = { i : ub_t_i + |Mt_i & A| < cap }: the status of i
+                // depends on earlier lanes only, so iterating from "all candidates" is exact after at most
+                // (#candidates) rounds and in practice after two (without A4 the first round already is the answer:
+                // a neighbour rejected earlier had e_j >= W_j >= W_i > e_i). Each round is a popcount and a ballot.
+                // (4) the merge ranks are popcounts of the key masks against A. ONE merge through LDS follows.
                 {
                     const bool count_pass = FILTER && !all_pass;
                     if constexpr (KIND != DIST_ADC_SQ) { if (!count_pass) nexact += nnew; }
                     const u32 ebits = __float_as_uint(e);
+                    const u32 tbits = max(ebits, xbits);
                     const bool full0 = (rn == cap);
                     const u32 W0b = (u32)(list_get<NCHR>(rk, rn - 1) >> 32);
-                    u64 cm = __ballot(lane < nnew && (!full0 || (count_pass ? xbits : ebits) < W0b));
-                    u32 acc_e = 0xFFFFFFFFu;   // lane s: distance bits of the s-th accepted neighbour
+                    // lanes that can still be scored (superset of those that can be accepted)
+                    const u64 cm = __ballot(lane < nnew && (!full0 || (count_pass ? xbits : ebits) < W0b));
+                    const u64 mykey = ((u64)ebits << 32) | (u32)(~myid);
                     int na = 0;
                     u64 accmask = 0ull;
-                    const u64 mykey = ((u64)ebits << 32) | (u32)(~myid);
                     int rT = 0, rA = 0;     // merge ranks: list keys below an accepted key, accepted keys below it
                     u32 sT[NCHR];           // accepted keys below a list key
 #pragma unroll
                     for (int ch = 0; ch < NCHR; ch++) sT[ch] = 0u;
-                    bool have_ranks = false;
-                    if (!count_pass && cm != 0ull) {
-                        // Without A4 in play the acceptance test needs no walk: a neighbour rejected earlier in the
-                        // row had e_j >= W_j >= W_i, so it can never be <= e_i of an accepted i, and counting ALL
-                        // earlier candidates gives the same verdict as counting the accepted ones:
-                        //   accept_i  <=>  #(old <= e_i) + #(candidates j < i with e_j <= e_i) < cap.
-                        // Both terms are lane-parallel: a binary search over the list (staged in the merge scratch)
-                        // and one pass over the candidate lanes that also collects, as bit masks, which candidate
-                        // keys lie below this lane's key / list keys -- the merge ranks fall out of the masks.
+                    if (cm != 0ull) {
 #pragma unroll
                         for (int ch = 0; ch < NCHR; ch++) if (ch * 64 + lane < rn) mk[ch * 64 + lane] = rk.v[ch];
                         WSYNC();
                         const bool iscand = ((cm >> lane) & 1ull) != 0ull;
-                        int lb_lo = 0, lb_hi = rn, ub_lo = 0, ub_hi = rn;
-                        const u64 key_ub = ((u64)ebits << 32) | 0xFFFFFFFFull;
+                        int lb_lo = 0, lb_hi = rn, ut_lo = 0, ut_hi = rn, ux_lo = 0, ux_hi = rn;
+                        const u64 key_ut = ((u64)tbits << 32) | 0xFFFFFFFFull, key_ux = ((u64)xbits << 32) | 0xFFFFFFFFull;
                         if (iscand) {
                             constexpr int ITER = (NCHR == 1) ? 7 : (NCHR == 2) ? 8 : (NCHR == 4) ? 9 : 10;
 #pragma unroll
                             for (int it = 0; it < ITER; it++) {
-                                const int m1 = (lb_lo + lb_hi) >> 1, m2 = (ub_lo + ub_hi) >> 1;
+                                const int m1 = (lb_lo + lb_hi) >> 1, m2 = (ut_lo + ut_hi) >> 1;
                                 const u64 v1 = mk[min(m1, rn - 1)], v2 = mk[min(m2, rn - 1)];
                                 if (lb_lo < lb_hi) { if (v1 < mykey) lb_lo = m1 + 1; else lb_hi = m1; }
-                                if (ub_lo < ub_hi) { if (v2 <= key_ub) ub_lo = m2 + 1; else ub_hi = m2; }
+                                if (ut_lo < ut_hi) { if (v2 <= key_ut) ut_lo = m2 + 1; else ut_hi = m2; }
+                                if (count_pass) {
+                                    const int m3 = (ux_lo + ux_hi) >> 1;
+                                    const u64 v3 = mk[min(m3, rn - 1)];
+                                    if (ux_lo < ux_hi) { if (v3 <= key_ux) ux_lo = m3 + 1; else ux_hi = m3; }
+                                }
                             }
                         }
-                        u32 before = 0u;
-                        u64 lessm = 0ull, oldm[NCHR];
+                        u64 Mt = 0ull, Mx = 0ull, lessm = 0ull, oldm[NCHR];
 #pragma unroll
                         for (int ch = 0; ch < NCHR; ch++) oldm[ch] = 0ull;
                         for (u64 mm = cm; mm != 0ull; mm &= mm - 1ull) {
@@ -883,48 +882,29 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                             const u32 ef = readlane32(ebits, f);
                             const u64 kf = readlane64(mykey, f);
                             const u64 bit = 1ull << f;
-                            before += (f < lane && ef <= ebits) ? 1u : 0u;
+                            Mt |= (f < lane && ef <= tbits) ? bit : 0ull;
+                            if (count_pass) Mx |= (f < lane && ef <= xbits) ? bit : 0ull;
                             lessm |= (kf < mykey) ? bit : 0ull;
 #pragma unroll
                             for (int ch = 0; ch < NCHR; ch++) oldm[ch] |= (kf < rk.v[ch]) ? bit : 0ull;
                         }
-                        accmask = __ballot(iscand && (u32)ub_lo + before < (u32)cap);
+                        // a lane can be accepted only if its own exact distance beats the current worst (when full)
+                        const bool canacc = iscand && (!full0 || tbits < W0b);
+                        accmask = __ballot(canacc);
+                        for (int round = 0; round < 66; round++) {
+                            const u64 nxt = __ballot(canacc && (u32)ut_lo + (u32)__popcll(Mt & accmask) < (u32)cap);
+                            if (nxt == accmask) break;
+                            accmask = nxt;
+                            if (round == 65) status |= DR_ST_INTERNAL;
+                        }
                         na = __popcll(accmask);
+                        if (count_pass)
+                            nexact += (u32)__popcll(__ballot(iscand && (u32)ux_lo + (u32)__popcll(Mx & accmask) < (u32)cap));
                         rT = lb_lo;
                         rA = __popcll(lessm & accmask);
 #pragma unroll
                         for (int ch = 0; ch < NCHR; ch++) sT[ch] = (u32)__popcll(oldm[ch] & accmask);
-                        have_ranks = true;
-                        cm = 0ull;
                         WSYNC();    // every search has read the staged list before the merge scatters over it
-                    }
-                    while (cm != 0ull) {
-                        const int f = __ffsll((long long)cm) - 1;
-                        cm &= cm - 1ull;
-                        const u32 eb = readlane32(ebits, f);
-                        u32 tb = eb;
-                        if (count_pass) {
-                            const u32 xb = readlane32(xbits, f);
-                            int cx = 0;
-#pragma unroll
-                            for (int ch = 0; ch < NCHR; ch++)
-                                cx += __popcll(__ballot(ch * 64 + lane < rn && (u32)(rk.v[ch] >> 32) <= xb));
-                            cx += __popcll(__ballot(lane < na && acc_e <= xb));
-                            if (cx >= cap) continue;          // A4 is false at this position: never scored
-                            nexact++;
-                            if (eb <= xb) tb = 0xFFFFFFFFu;   // the count above already decides: accepted
-                        }
-                        if (tb != 0xFFFFFFFFu) {
-                            int c = 0;
-#pragma unroll
-                            for (int ch = 0; ch < NCHR; ch++)
-                                c += __popcll(__ballot(ch * 64 + lane < rn && (u32)(rk.v[ch] >> 32) <= tb));
-                            const int a = __popcll(__ballot(lane < na && acc_e <= tb));
-                            if (c + a >= cap) continue;
-                        }
-                        if (lane == na) acc_e = eb;
-                        na++;
-                        accmask |= 1ull << f;
                     }
                     if (na > 0) {
                         const bool isacc = ((accmask >> lane) & 1ull) != 0ull;
@@ -934,20 +914,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
                             if (isacc && o < p.logcap) qlog[o] = ((u64)ebits << 32) | myid;
                             if (ninserts + (u32)na > p.logcap && p.logcap > 0) status |= DR_ST_LOG_OVERFLOW;
                             ninserts += (u32)na;
-                        }
-                        if (!have_ranks)
-                        for (u64 am = accmask; am != 0ull; am &= am - 1ull) {
-                            const int f = __ffsll((long long)am) - 1;
-                            const u64 kf = readlane64(mykey, f);
-                            int cnt = 0;
-#pragma unroll
-                            for (int ch = 0; ch < NCHR; ch++) {
-                                const bool valid = ch * 64 + lane < rn;
-                                cnt += __popcll(__ballot(valid && rk.v[ch] < kf));
-                                sT[ch] += (valid && kf < rk.v[ch]) ? 1u : 0u;
-                            }
-                            if (lane == f) rT = cnt;
-                            rA += (isacc && kf < mykey) ? 1 : 0;
                         }
                         const int rn2 = min(rn + na, cap);
                         // scatter to merged positions
