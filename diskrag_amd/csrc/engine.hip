@@ -425,23 +425,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // the ADC is skipped and the kernel is a pure row gather: vectors landed in LDS, table never built (9, 6).
     // On unit-scale data A4 is live, every new neighbour's ADC is evaluated and the table wants to be in LDS: the
     // per-query table (0) when 8 of them fit a CU, else the shared codebook (3). Which regime an index is in is
-    // MEASURED once per (graph, PQ) state on the first 64 queries it is asked (results do not depend on the variant).
-    if (k_m1 && !ov && ix->adc_live < 0) {
-        const uint32_t nq_all = ix->nq;
-        ix->adc_live = 0;
-        ix->nq = std::min<uint32_t>(nq_all, 64);
-        int rc = run_locked(ix, k, L, bw, mode, policy, flags, nullptr);
-        if (!rc) rc = sync_locked(ix);
-        std::vector<KStats> st(ix->nq);
-        if (!rc && hipMemcpy(st.data(), ix->sets[ix->last_set].stats.p, st.size() * sizeof(KStats), hipMemcpyDeviceToHost) != hipSuccess)
-            rc = fail(DR_E_NODEVICE, "probe: stats copy failed");
-        ix->nq = nq_all;
-        ix->pq_ub_valid = false;      // the probe computed bounds for its 64 queries only
-        if (rc) { ix->adc_live = -1; return rc; }
-        uint64_t evald = 0, all = 0;
-        for (const KStats &x : st) { evald += x.pq_evaluated; all += x.pq; }
-        ix->adc_live = (2 * evald > all) ? 1 : 0;
-    }
+    // MEASURED on the first M1 batch an index state serves (its counters are read once that launch has finished, see
+    // the end of this function); until then the SIFT-scale preference applies. Results never depend on the variant.
     const int *pref = k_m1 ? PREF_M1 : k_adc ? PREF_ADC : ov ? PREF_BUILD : PREF_EX;
     const int npref = k_m1 ? 4 : k_adc ? 2 : 2;
     if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 8 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
@@ -574,6 +559,14 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     ix->timing.search_kernel_ms = a;
     ix->timing.grid = grid; ix->timing.block = 64 * NW; ix->timing.lds_bytes = (uint32_t)lds;
     ix->timing.waves_per_cu = (uint32_t)(occ * NW);
+    if (k_m1 && ix->adc_live < 0) {
+        // regime of this (graph, PQ) state: did the rerank policy really consult the ADC on this batch?
+        std::vector<KStats> st(std::min<uint32_t>(nq, 1024));
+        HIPCHK(hipMemcpy(st.data(), bs.stats.p, st.size() * sizeof(KStats), hipMemcpyDeviceToHost));
+        uint64_t evald = 0, all = 0;
+        for (const KStats &x : st) { evald += x.pq_evaluated; all += x.pq; }
+        ix->adc_live = (2 * evald > all) ? 1 : 0;
+    }
     ix->last_k = k;
     ix->last_set = set;
     ix->parity ^= 1;

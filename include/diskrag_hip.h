@@ -169,7 +169,7 @@ int dr_debug_phase_cycles(dr_index *ix, double *out8);
  * engine's own choice. Every variant returns the same bits; the parity tests run all of them. Process-wide.
  * When ix and out_adc_live are non-null, *out_adc_live receives the handle's measured M1 regime: 1 = the rerank
  * policy A4 is live (ADC evaluated: unit-scale data), 0 = provably true almost always (SIFT-scale data, Q1),
- * -1 = not probed yet (the probe runs on the first 64 queries of the next M1 call). */
+ * -1 = not measured yet (the first M1 batch served by an index state is the measurement). */
 int dr_debug_force_kind(dr_index *ix, int kind, int *out_adc_live);
 
 void dr_index_close(dr_index *ix);

@@ -7,7 +7,6 @@ for bw in 8 0; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_bw$bw -- python3 scripts/pmc_target.py $bw > $OUT/pmc_fetch_bw$bw.out 2> $OUT/pmc_fetch_bw$bw.err
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_bw$bw -- python3 scripts/pmc_target.py $bw > $OUT/pmc_write_bw$bw.out 2> $OUT/pmc_write_bw$bw.err
 done
-python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 python3 - <<'PY'
 import csv, glob, json
 def load(path): return list(csv.DictReader(open(path)))
@@ -29,4 +28,7 @@ for bw in (8, 0):
 json.dump(out, open('gpurun_out/prof/pmc_traffic.json', 'w'), indent=1)
 print(json.dumps({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if 'bytes' in kk}) for k, v in out.items()}, indent=1))
 PY
+# the bench line quotes roofline.traffic from profiles/r01/pmc_traffic.json: refresh it first, then run the bench
+cp $OUT/pmc_traffic.json profiles/r01/pmc_traffic.json
+python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
