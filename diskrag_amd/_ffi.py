@@ -38,7 +38,8 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_get_timing", "dr_exact_distances", "dr_distance_table", "dr_adc", "dr_pq_scan",
            "dr_bruteforce_topk", "dr_get_node", "dr_index_close", "dr_index_create_empty", "dr_build_vamana",
            "dr_get_adjacency", "dr_pq_train", "dr_pq_encode", "dr_debug_phase_cycles", "dr_batch_sync",
-           "dr_debug_force_kind", "dr_search_batch_f64"]
+           "dr_debug_force_kind", "dr_search_batch_f64",
+           "dr_index_create_codes", "dr_index_drop_vectors"]
 
 _lib = None
 
@@ -67,6 +68,11 @@ def load_library():
     L.dr_index_open.argtypes = [C.POINTER(vp), C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
     L.dr_index_create.restype = C.c_int
     L.dr_index_create.argtypes = [C.POINTER(vp), fp, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.dr_index_create_codes.restype = C.c_int
+    L.dr_index_create_codes.argtypes = [C.POINTER(vp), u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, fp, u8p,
+                                        C.c_uint32, C.c_int]
+    L.dr_index_drop_vectors.restype = C.c_int
+    L.dr_index_drop_vectors.argtypes = [vp]
     L.dr_index_set_pq.restype = C.c_int
     L.dr_index_set_pq.argtypes = [vp, fp, u8p, C.c_uint32]
     L.dr_index_set_adjacency.restype = C.c_int
@@ -168,6 +174,28 @@ class HipIndex:
         h = C.c_void_p()
         _check(L.dr_index_create_empty(C.byref(h), _p(vectors, C.c_float), N, D, int(R), int(device)))
         return cls(h, N, D, R, 0)
+
+    @classmethod
+    def create_codes(cls, adj, medoid, D, codebook, codes, device=0):
+        """PQ-only shard (config c5): adjacency + codes + codebook, no stored vectors (M3 with F_USE_PQ only)."""
+        L = load_library()
+        adj = np.ascontiguousarray(adj, dtype=np.uint32)
+        codebook = np.ascontiguousarray(codebook, dtype=np.float32)
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        N, R = adj.shape
+        m = codes.shape[1]
+        if codebook.shape != (m, 256, D // m) or codes.shape[0] != N:
+            raise ValueError(f"PQ shapes do not match the index: codebook {codebook.shape}, codes {codes.shape}")
+        h = C.c_void_p()
+        _check(L.dr_index_create_codes(C.byref(h), _p(adj, C.c_uint32), N, int(D), R, int(medoid), _p(codebook, C.c_float),
+                                       _p(codes, C.c_uint8), m, int(device)))
+        ix = cls(h, N, int(D), R, int(medoid))
+        ix.m = m
+        return ix
+
+    def drop_vectors(self):
+        """Frees the stored vectors: the index becomes a PQ-only shard (M3 with F_USE_PQ only)."""
+        _check(load_library().dr_index_drop_vectors(self._h))
 
     def build_vamana(self, L_build=100, alpha=1.2, passes=2, seed=1, pad_with_zero=True, max_batch=0):
         med = C.c_uint32(0)

@@ -91,6 +91,7 @@ struct dr_index {
     std::mutex mu;
 
     DevBuf<float> vecp;
+    bool has_vectors = true;      // false: a PQ-only shard (config c5): codes + adjacency, no stored vectors
     DevBuf<uint32_t> adj;
     DevBuf<u64> first;
     DevBuf<uint8_t> codes;
@@ -138,7 +139,7 @@ extern "C" int dr_device_count(void)
 
 extern "C" const char *dr_last_error(void) { return g_err.c_str(); }
 
-static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, uint32_t medoid, int device)
+static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, uint32_t medoid, int device, bool with_vectors = true)
 {
     if (N == 0 || D == 0 || R == 0) return fail(DR_E_ARG, "N, D and R must be positive");
     if (medoid >= N) return fail(DR_E_ARG, "medoid %u out of range (N=%llu)", medoid, (unsigned long long)N);
@@ -161,10 +162,17 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     pw_build_perm_rec(0, D, ix->h_perm.data());
     if (ix->perm.reserve(D)) return DR_E_NODEVICE;
     HIPCHK(hipMemcpy(ix->perm.p, ix->h_perm.data(), D * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (ix->vecp.reserve((size_t)N * D)) return DR_E_NODEVICE;
+    ix->has_vectors = with_vectors;
+    if (with_vectors && ix->vecp.reserve((size_t)N * D)) return DR_E_NODEVICE;
     if (ix->adj.reserve((size_t)N * R)) return DR_E_NODEVICE;
     if (ix->first.reserve((size_t)N * ((R + 63) / 64))) return DR_E_NODEVICE;
     return 0;
+}
+
+static int need_vectors(const dr_index *ix, const char *what)
+{
+    if (ix->has_vectors) return 0;
+    return fail(DR_E_UNSUPPORTED, "%s needs the stored vectors; this index holds PQ codes only", what);
 }
 
 static int build_first_masks(dr_index *ix)
@@ -281,6 +289,38 @@ extern "C" int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_
     return 0;
 }
 
+// PQ-only shard (config c5: the full vectors of 1e9 x 1536 points are never stored): adjacency + codes + codebook.
+// Serves the PQ-only traversal (DR_MODE_M3 with DR_F_USE_PQ = beam_search_with_pq, vamana_graph.py:535-605) and the
+// ADC entry points; everything that needs a stored vector answers DR_E_UNSUPPORTED.
+extern "C" int dr_index_create_codes(dr_index **out, const uint32_t *adj, uint64_t N, uint32_t D, uint32_t R,
+                                     uint32_t medoid, const float *codebook, const uint8_t *codes, uint32_t m, int device)
+{
+    if (!out || !adj || !codebook || !codes) return fail(DR_E_ARG, "null argument");
+    dr_index *ix = new dr_index();
+    int rc = index_alloc_common(ix, N, D, R, medoid, device, false);
+    if (!rc && hipMemcpy(ix->adj.p, adj, (size_t)N * R * 4, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(DR_E_NODEVICE, "adjacency upload failed");
+    if (!rc) rc = build_first_masks(ix);
+    if (!rc) rc = dr_index_set_pq(ix, codebook, codes, m);
+    if (rc) { dr_index_close(ix); return rc; }
+    *out = ix;
+    return 0;
+}
+
+// Turns a full index (built and encoded on the device) into a PQ-only shard: frees the N*D*4 bytes of vectors.
+extern "C" int dr_index_drop_vectors(dr_index *ix)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->m == 0) return fail(DR_E_NOPQ, "dropping the vectors of an index without PQ data would leave nothing to search");
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->fstream));
+    ix->vecp.release();
+    ix->has_vectors = false;
+    return 0;
+}
+
 extern "C" void dr_index_close(dr_index *ix)
 {
     if (!ix) return;
@@ -342,7 +382,7 @@ static int build_bit_order(dr_index *ix)
     static const bool off = getenv("DR_NO_BITORDER") != nullptr;
     ix->use_adjr = false;
     ix->adjr_valid = true;
-    if (off || ix->N < 32768) return 0;
+    if (off || ix->N < 32768 || !ix->has_vectors) return 0;
     const uint64_t N = ix->N;
     const uint32_t D = ix->D, R = ix->R;
     if (!ix->rank_valid) {
@@ -400,6 +440,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (k == 0) return fail(DR_E_ARG, "k must be positive");
     const bool use_pq = (mode == DR_MODE_M1) || (mode == DR_MODE_M3 && (flags & DR_F_USE_PQ));
     if (use_pq && ix->m == 0) return fail(DR_E_NOPQ, "mode %u needs PQ data (dr_index_set_pq)", mode);
+    if (!(mode == DR_MODE_M3 && use_pq)) { const int rcv = need_vectors(ix, "this search mode"); if (rcv) return rcv; }
     // result-list capacity: M1/M4 L, M2 beam_width, M3 k (search_engine.py:468-474; vamana_graph.py:746-750, :586-590)
     const uint32_t cap = (mode == DR_MODE_M2) ? bw : (mode == DR_MODE_M3) ? k : L;
     if (cap == 0) return fail(DR_E_ARG, "result-list capacity is zero (L / beam_width / k)");
@@ -687,6 +728,7 @@ extern "C" int dr_search_batch_f64(dr_index *ix, const double *queries, uint32_t
     if (mode != DR_MODE_M1 && mode != DR_MODE_M2) return fail(DR_E_UNSUPPORTED, "float64 queries: modes M1 and M2 only");
     if (k == 0) return fail(DR_E_ARG, "k must be positive");
     std::lock_guard<std::mutex> lk(ix->mu);
+    { const int rcv = need_vectors(ix, "float64 search"); if (rcv) return rcv; }
     if (mode == DR_MODE_M1 && ix->m == 0) return fail(DR_E_NOPQ, "mode %u needs PQ data (dr_index_set_pq)", mode);
     const uint32_t cap = (mode == DR_MODE_M2) ? beam_width : L;
     if (cap == 0) return fail(DR_E_ARG, "result-list capacity is zero (L / beam_width)");
@@ -738,6 +780,7 @@ extern "C" int dr_exact_distances(dr_index *ix, const float *queries, uint32_t n
 {
     if (!ix || !queries || !node_ids || !out || nq == 0 || n == 0) return fail(DR_E_ARG, "bad argument");
     std::lock_guard<std::mutex> lk(ix->mu);
+    { const int rcv = need_vectors(ix, "dr_exact_distances"); if (rcv) return rcv; }
     for (uint32_t i = 0; i < n; i++) if (node_ids[i] >= ix->N) return fail(DR_E_ARG, "node id %u out of range", node_ids[i]);
     int rc = upload_queries_locked(ix, queries, nq);
     if (rc) return rc;
@@ -823,6 +866,7 @@ extern "C" int dr_bruteforce_topk(dr_index *ix, const float *queries, uint32_t n
 {
     if (!ix || !queries || !out_ids || nq == 0 || k == 0 || k > 64) return fail(DR_E_ARG, "bad argument (k <= 64)");
     std::lock_guard<std::mutex> lk(ix->mu);
+    { const int rcv = need_vectors(ix, "dr_bruteforce_topk"); if (rcv) return rcv; }
     int rc = upload_queries_locked(ix, queries, nq);
     if (rc) return rc;
     DevBuf<uint32_t> oi; DevBuf<float> od;
@@ -843,6 +887,7 @@ extern "C" int dr_get_node(dr_index *ix, uint64_t node_id, float *out_vec, uint3
     if (!ix || !out_vec || !out_nbrs) return fail(DR_E_ARG, "null argument");
     if (node_id >= ix->N) return fail(DR_E_ARG, "node id out of range");
     std::lock_guard<std::mutex> lk(ix->mu);
+    { const int rcv = need_vectors(ix, "dr_get_node"); if (rcv) return rcv; }
     HIPCHK(hipSetDevice(ix->device));
     std::vector<float> tmp(ix->D);
     HIPCHK(hipMemcpy(tmp.data(), ix->vecp.p + node_id * ix->D, (size_t)ix->D * 4, hipMemcpyDeviceToHost));
@@ -898,6 +943,7 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
     if (ix->R > 128) return fail(DR_E_UNSUPPORTED, "builder supports R <= 128");
     if (passes == 0) passes = 2;
     std::lock_guard<std::mutex> lk(ix->mu);
+    { const int rcv = need_vectors(ix, "dr_build_vamana"); if (rcv) return rcv; }
     HIPCHK(hipSetDevice(ix->device));
     const uint64_t N = ix->N;
     const uint32_t D = ix->D, R = ix->R;
@@ -1039,6 +1085,7 @@ extern "C" int dr_pq_train(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t
     if (m == 0 || ix->D % m || ix->D / m > 128) return fail(DR_E_ARG, "bad n_subvectors %u for D=%u", m, ix->D);
     if (ix->N < 256) return fail(DR_E_ARG, "need at least 256 vectors (fast_pq.py:212-213)");
     std::lock_guard<std::mutex> lk(ix->mu);
+    { const int rcv = need_vectors(ix, "dr_pq_train"); if (rcv) return rcv; }
     HIPCHK(hipSetDevice(ix->device));
     const uint32_t D = ix->D, sd = D / m;
     const uint32_t ns = (uint32_t)std::min<uint64_t>(n_sample ? n_sample : 100000, ix->N);
@@ -1103,6 +1150,7 @@ extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uin
     if (!ix || !codebook) return fail(DR_E_ARG, "null argument");
     if (m == 0 || ix->D % m || ix->D / m > 128) return fail(DR_E_ARG, "bad n_subvectors %u for D=%u", m, ix->D);
     std::lock_guard<std::mutex> lk(ix->mu);
+    { const int rcv = need_vectors(ix, "dr_pq_encode"); if (rcv) return rcv; }
     HIPCHK(hipSetDevice(ix->device));
     if (ix->codes.reserve((size_t)ix->N * m) || ix->codebook.reserve((size_t)256 * ix->D)) return DR_E_NODEVICE;
     HIPCHK(hipMemcpyAsync(ix->codebook.p, codebook, (size_t)256 * ix->D * 4, hipMemcpyHostToDevice, ix->stream));

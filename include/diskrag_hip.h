@@ -84,6 +84,15 @@ int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_t *codes, u
 
 /* Replaces the adjacency (same N, R) -- used for the in-memory graph variants whose neighbour order is the
  * Python set order (vamana_graph.py:581, :629). */
+/* PQ-only shard (BASELINE config c5: 1e9 x 1536, the full vectors are never stored): adjacency + PQ codes + codebook,
+ * no vectors. Serves dr_search_batch mode DR_MODE_M3 with DR_F_USE_PQ (beam_search_with_pq, vamana_graph.py:535-605,
+ * the reference's only PQ-only traversal), dr_adc, dr_distance_table and dr_pq_scan; every entry point that needs a
+ * stored vector returns DR_E_UNSUPPORTED. dr_index_drop_vectors turns a full index (built and encoded on the
+ * device) into such a shard and frees its N*D*4 bytes. */
+int dr_index_create_codes(dr_index **out, const uint32_t *adj, uint64_t N, uint32_t D, uint32_t R, uint32_t medoid,
+                          const float *codebook, const uint8_t *codes, uint32_t m, int device);
+int dr_index_drop_vectors(dr_index *ix);
+
 int dr_index_set_adjacency(dr_index *ix, const uint32_t *adj);
 
 /* Searches a batch. queries[nq][D] float32 on the host. Outputs (host): out_ids[nq][k] (DR_PAD padded),

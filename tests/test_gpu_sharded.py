@@ -50,3 +50,45 @@ def test_four_shards_equal_the_merge_of_per_shard_oracle_runs():
     assert recall_at_k(ids, gt, k) > 0.15
     for sh in shards:
         sh.index.close()
+
+
+def test_pq_only_shard_without_vectors():
+    """c5's shards hold no vectors. A codes-only index serves the PQ-only traversal bit for bit like the full index
+    (and the reference golden), and refuses what needs a stored vector."""
+    from diskrag_amd import DiskragHipError, HipIndex, _ffi
+    from tests.conftest import load_golden
+    from tests.test_gpu_parity import get_index
+    name = "randn128_R16_m32"
+    g = load_golden(name)
+    ci = [i for i, c in enumerate(g.cases) if c["mode"] == "M3" and c.get("use_pq")][0]
+    c = g.case(ci)
+    full = get_index(name, mem=True)
+    want = full.search_batch(c["queries"], c["k"], L=c["k"], beam_width=c["bw"], mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
+    assert np.array_equal(want[0], c["ids"])                                   # the reference's own output
+    shard = HipIndex.create_codes(g.mem_adj, g.medoid, g.vectors.shape[1], g.codebook, g.codes)
+    got = shard.search_batch(c["queries"], c["k"], L=c["k"], beam_width=c["bw"], mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+    assert np.array_equal(shard.adc(g.queries[:3], np.arange(40, dtype=np.uint32)), full.adc(g.queries[:3], np.arange(40, dtype=np.uint32)))
+    for call in (lambda: shard.search_batch(g.queries, 10, L=50, mode=_ffi.MODE_M1),
+                 lambda: shard.search_batch(g.queries, 10, beam_width=8, mode=_ffi.MODE_M2),
+                 lambda: shard.search_batch(g.queries, 5, beam_width=8, mode=_ffi.MODE_M3),           # exact M3
+                 lambda: shard.search_batch_f64(g.queries.astype(np.float64), 10, L=50),
+                 lambda: shard.exact_distances(g.queries[:1], np.arange(4, dtype=np.uint32)),
+                 lambda: shard.bruteforce_topk(g.queries[:1], 5), lambda: shard.get_node(0),
+                 lambda: shard.build_vamana(), lambda: shard.pq_train(32)):
+        with pytest.raises(DiskragHipError):
+            call()
+    shard.close()
+    # a device-built index turned into a shard: same PQ-only answers before and after the vectors are freed
+    from diskrag_amd.synth import sift_like
+    x, q = sift_like(20000, 128, n_queries=64, n_clusters=64, seed=41, query_seed=42)
+    ix = HipIndex.create_empty(x, R=32)
+    ix.build_vamana(L_build=60, alpha=1.2, passes=2, seed=9, pad_with_zero=False)
+    ix.pq_encode(ix.pq_train(16, n_sample=8000, iters=4))
+    before = ix.search_batch(q, 10, L=10, beam_width=16, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
+    ix.drop_vectors()
+    after = ix.search_batch(q, 10, L=10, beam_width=16, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1].view(np.uint32), after[1].view(np.uint32))
+    with pytest.raises(DiskragHipError):
+        ix.search_batch(q, 10, L=50, mode=_ffi.MODE_M1)
+    ix.close()
