@@ -57,4 +57,9 @@ run("M1_L100_bw8_policy0", L=100, beam_width=8, mode=_ffi.MODE_M1, band_policy=0
 run("M1_L100_notrim_policy0", L=100, beam_width=0, mode=_ffi.MODE_M1, band_policy=0)
 run("M1_L100_notrim_policy1", L=100, beam_width=0, mode=_ffi.MODE_M1, band_policy=1)
 run("M2_bw8", L=100, beam_width=8, mode=_ffi.MODE_M2)
+# PQ-only traversal (the c5 path): result heap = k, Q9 trim; then the same with the vectors freed (a c5 shard)
+run("M3_PQ_k10_bw8", L=10, beam_width=8, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
+run("M3_PQ_k10_bw64", L=10, beam_width=64, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
+ix.drop_vectors()
+run("M3_PQ_k10_bw64_codes_only", L=10, beam_width=64, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
 print(json.dumps(out))
