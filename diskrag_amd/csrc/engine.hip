@@ -124,7 +124,7 @@ struct dr_index {
     hipStream_t fstream = nullptr;
     DevBuf<float> pq_ub;
     bool pq_ub_valid = false;     // pq_ub matches the resident queries and the attached codebook
-    int adc_live = -1;            // M1 on this index: does the rerank policy A4 really consult the ADC? -1 = not probed yet
+    int adc_live = -1;            // M1 on this index: does the rerank policy A4 really consult the ADC? -1 = not measured yet
     DevBuf<u64> phase;
     uint32_t last_k = 0;
     dr_timing timing = {};

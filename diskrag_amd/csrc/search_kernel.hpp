@@ -72,7 +72,7 @@ struct SearchParams {
     u32 *vlog;               // [slots][vis_limit] bit positions the running query may have set (every tested slot)
     u32 vis_limit;
     u32 vis_stream_clear;    // 1: clear the whole slot bitmap with wide stores after a query (small N) instead of per id
-    u32 *counter;            // [2]: unused, tie-list length
+    u32 *counter;            // [2]: query ticket counter (zeroed per launch), tie-list length
     u64 *res_keys;           // [nq][cap] ascending (dist bits << 32 | ~id)
     u32 *res_n;              // [nq]
     KStats *stats;           // [nq]
