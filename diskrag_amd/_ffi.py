@@ -39,7 +39,7 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_bruteforce_topk", "dr_get_node", "dr_index_close", "dr_index_create_empty", "dr_build_vamana",
            "dr_get_adjacency", "dr_pq_train", "dr_pq_encode", "dr_debug_phase_cycles", "dr_batch_sync",
            "dr_debug_force_kind", "dr_search_batch_f64",
-           "dr_index_create_codes", "dr_index_drop_vectors"]
+           "dr_index_create_codes", "dr_index_drop_vectors", "dr_pq_scan_best"]
 
 _lib = None
 
@@ -68,6 +68,8 @@ def load_library():
     L.dr_index_open.argtypes = [C.POINTER(vp), C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
     L.dr_index_create.restype = C.c_int
     L.dr_index_create.argtypes = [C.POINTER(vp), fp, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.dr_pq_scan_best.restype = C.c_int
+    L.dr_pq_scan_best.argtypes = [vp, fp, C.c_uint32, fp, u32p, fp, fp]
     L.dr_index_create_codes.restype = C.c_int
     L.dr_index_create_codes.argtypes = [C.POINTER(vp), u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, fp, u8p,
                                         C.c_uint32, C.c_int]
@@ -348,6 +350,18 @@ class HipIndex:
         ms = C.c_float(0)
         _check(load_library().dr_pq_scan(self._h, _p(q, C.c_float), q.shape[0], _p(out, C.c_float), C.byref(ms)))
         return out, ms.value
+
+    def pq_scan_best(self, queries, want_output=False):
+        """Flat scan of every code word: (nearest id, its squared ADC distance, kernel ms[, all distances])."""
+        q = self._queries(queries)
+        nq = q.shape[0]
+        out = np.empty((nq, self.N), dtype=np.float32) if want_output else None
+        bid = np.empty(nq, dtype=np.uint32)
+        bsq = np.empty(nq, dtype=np.float32)
+        ms = C.c_float(0)
+        _check(load_library().dr_pq_scan_best(self._h, _p(q, C.c_float), nq, _p(out, C.c_float), _p(bid, C.c_uint32),
+                                              _p(bsq, C.c_float), C.byref(ms)))
+        return (bid, bsq, ms.value, out) if want_output else (bid, bsq, ms.value)
 
     def bruteforce_topk(self, queries, k):
         q = self._queries(queries)

@@ -856,9 +856,53 @@ extern "C" int dr_adc(dr_index *ix, const float *queries, uint32_t nq, const uin
 
 extern "C" int dr_pq_scan(dr_index *ix, const float *queries, uint32_t nq, float *out_sq, float *kernel_ms)
 {
+    return dr_pq_scan_best(ix, queries, nq, out_sq, nullptr, nullptr, kernel_ms);
+}
+
+// Flat scan of all N code words per query (pq_scan_kernel): out_sq (optional) gets every squared ADC distance,
+// out_best_id / out_best_sq (optional) the nearest code word per query (smallest id among equal sums).
+extern "C" int dr_pq_scan_best(dr_index *ix, const float *queries, uint32_t nq, float *out_sq, uint32_t *out_best_id,
+                               float *out_best_sq, float *kernel_ms)
+{
     if (!ix || !queries || nq == 0) return fail(DR_E_ARG, "bad argument");
     std::lock_guard<std::mutex> lk(ix->mu);
-    return adc_common(ix, queries, nq, nullptr, ix->N, out_sq, nullptr, kernel_ms);
+    if (ix->m == 0) return fail(DR_E_NOPQ, "no PQ data");
+    const uint32_t m = ix->m;
+    if ((m & 15u) != 0 || m > 64) return adc_common(ix, queries, nq, nullptr, ix->N, out_sq, nullptr, kernel_ms);   // generic form
+    int rc = upload_queries_locked(ix, queries, nq);
+    if (rc) return rc;
+    const uint64_t n = ix->N;
+    DevBuf<float> o1; DevBuf<u64> best;
+    if (out_sq && o1.reserve((size_t)nq * n)) return DR_E_NODEVICE;
+    if (best.reserve(nq)) return DR_E_NODEVICE;
+    HIPCHK(hipMemsetAsync(best.p, 0xFF, (size_t)nq * 8, ix->stream));
+    const size_t lds = (size_t)ix->D * 4 + (size_t)m * 256 * 4;
+    const void *kfn = m == 16 ? reinterpret_cast<const void *>(&pq_scan_kernel<1>) : m == 32 ? reinterpret_cast<const void *>(&pq_scan_kernel<2>)
+                    : m == 48 ? reinterpret_cast<const void *>(&pq_scan_kernel<3>) : reinterpret_cast<const void *>(&pq_scan_kernel<4>);
+    HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 1;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds));
+    if (occ < 1) occ = 1;
+    // persistent blocks: the table is built once per block; with several queries in flight the rows share the chip
+    const unsigned per_q = (unsigned)std::max<uint64_t>(1, (uint64_t)occ * ix->num_cu / std::min<uint32_t>(nq, (uint32_t)occ * ix->num_cu));
+    const unsigned gx = (unsigned)std::min<uint64_t>((n + 255) / 256, per_q);
+    const float *cbp = ix->codebook.p; const float *qp = ix->q.p; const uint8_t *cdp = ix->codes.p; uint64_t nn = n;
+    uint32_t D = ix->D, sd = ix->sd; float *op = out_sq ? o1.p : nullptr; u64 *bp = best.p;
+    void *args[] = { &cbp, &qp, &cdp, &nn, &D, &sd, &op, &bp };
+    HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
+    HIPCHK(hipLaunchKernel(kfn, dim3(gx, nq), dim3(256), args, lds, ix->stream));
+    HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
+    std::vector<u64> hb(nq);
+    if (out_sq) HIPCHK(hipMemcpyAsync(out_sq, o1.p, (size_t)nq * n * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipMemcpyAsync(hb.data(), best.p, (size_t)nq * 8, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ix->ev[2], ix->ev[3]);
+    for (uint32_t i = 0; i < nq; i++) {
+        if (out_best_id) out_best_id[i] = (uint32_t)hb[i];
+        if (out_best_sq) { const uint32_t b = (uint32_t)(hb[i] >> 32); memcpy(&out_best_sq[i], &b, 4); }
+    }
+    o1.release(); best.release();
+    return 0;
 }
 
 extern "C" int dr_bruteforce_topk(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t *out_ids,

@@ -228,6 +228,74 @@ __global__ __launch_bounds__(256) void adc_kernel(const float *__restrict__ code
 }
 
 
+// Flat PQ scan (the isolated ADC kernel of SURVEY 8d): every code word of the table against one query per block
+// row, table in LDS, codes streamed from HBM with 16-byte loads (one code word per lane: a wavefront instruction
+// covers 64 consecutive code words). The m table reads of a lane are issued together and added in sub-quantiser
+// order (A3: strict sequential float sum, fast_pq.py:325-326), so the LDS pipeline -- not the latency of one read
+// -- sets the pace. Optionally writes every distance; always folds (distance, id) into the query's best key, so the
+// scan cannot be optimised away when the distances are not wanted.
+template <int M16>
+__global__ __launch_bounds__(256) void pq_scan_kernel(const float *__restrict__ codebook, const float *__restrict__ queries,
+        const u8 *__restrict__ codes, u64 n, u32 D, u32 sd, float *__restrict__ out_sq, u64 *__restrict__ out_best)
+{
+    constexpr u32 m = 16u * M16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *q = reinterpret_cast<float *>(smem);
+    float *lut = q + D;
+    const u32 qi = blockIdx.y;
+    for (u32 i = threadIdx.x; i < D; i += blockDim.x) q[i] = queries[(size_t)qi * D + i];
+    __syncthreads();
+    {
+        // each of the 4 wavefronts builds the table rows of a quarter of the sub-quantisers
+        const u32 w = threadIdx.x >> 6, j0 = w * (m / 4);
+        build_lut_wave(lut + j0 * 256, codebook + (size_t)j0 * 256 * sd, q + j0 * sd, m / 4, sd);
+    }
+    __syncthreads();
+    u64 best = ~0ull;
+    const uint4 *c4 = reinterpret_cast<const uint4 *>(codes);
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    uint4 cw[M16];
+    if (i < n) {
+#pragma unroll
+        for (int w = 0; w < M16; w++) cw[w] = c4[i * M16 + w];
+    }
+    while (i < n) {
+        uint4 nx[M16];
+        const u64 inext = i + stride;
+        if (inext < n) {      // next code word in flight while this one is looked up
+#pragma unroll
+            for (int w = 0; w < M16; w++) nx[w] = c4[inext * M16 + w];
+        }
+        float t[m];
+#pragma unroll
+        for (int w = 0; w < M16; w++) {
+            const u32 words[4] = { cw[w].x, cw[w].y, cw[w].z, cw[w].w };
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int jj = w * 16 + u * 4 + b;
+                    t[jj] = lut[jj * 256 + ((words[u] >> (8 * b)) & 255u)];
+                }
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < (int)m; jj++) s = f_add(s, t[jj]);
+        if (out_sq) out_sq[(size_t)qi * n + i] = s;
+        const u64 key = ((u64)__float_as_uint(s) << 32) | (u32)i;
+        best = key < best ? key : best;
+        i = inext;
+#pragma unroll
+        for (int w = 0; w < M16; w++) cw[w] = nx[w];
+    }
+    if (out_best) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const u64 other = __shfl_xor(best, o); best = other < best ? other : best; }
+        if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(reinterpret_cast<unsigned long long *>(out_best + qi), (unsigned long long)best);
+    }
+}
+
 // ---- builder helpers (build_kernels.hpp has the per-dimension prune kernel) ---------------------------------
 __global__ void gather_rows_kernel(const float *__restrict__ src, const u32 *__restrict__ ids, u32 n, u32 D,
                                    float *__restrict__ dst)

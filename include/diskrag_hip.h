@@ -141,6 +141,11 @@ int dr_adc(dr_index *ix, const float *queries, uint32_t nq, const uint32_t *node
            float *out_sq /*[nq][n]*/, float *out_sqrt /*[nq][n]*/);
 /* Flat PQ scan of all N codes against each query's table (bandwidth ceiling of the LUT-accumulate loop). */
 int dr_pq_scan(dr_index *ix, const float *queries, uint32_t nq, float *out_sq /*[nq][N]*/, float *kernel_ms);
+/* The same scan, also returning the nearest code word per query (smallest id among equal sums): the isolated
+ * ADC kernel of the path, benched against the HBM roofline on a code table far larger than the caches
+ * (scripts/bench_pq_scan.py). out_sq may be null. */
+int dr_pq_scan_best(dr_index *ix, const float *queries, uint32_t nq, float *out_sq, uint32_t *out_best_id,
+                    float *out_best_sq, float *kernel_ms);
 /* Brute-force exact top-k (recall ground truth), squared L2 in the A1 summation order. */
 int dr_bruteforce_topk(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t *out_ids,
                        float *out_dist);

@@ -232,3 +232,22 @@ def test_large_batch_is_chunked():
     assert (st["status"] == 0).all()
     assert np.array_equal(ids, want)
     assert np.array_equal(bits(dist), bits(np.tile(c["dist"], (reps, 1))[:40000]))
+
+
+@pytest.mark.parametrize("name", ["sift128_R64_m32", "randn128_R64_m16", "unit1536_R16_m64", "deep96_R32_m16"])
+def test_flat_pq_scan_matches_adc_and_finds_the_nearest_code(name):
+    """dr_pq_scan_best (the isolated ADC kernel): every distance == A3 of the reference (oracle), bit for bit, and
+    the folded best key is the argmin with the smallest id among equal sums."""
+    from oracle import pyoracle as orc
+    g = load_golden(name)
+    ix = get_index(name)
+    q = g.queries[:5]
+    bid, bsq, ms, allsq = ix.pq_scan_best(q, want_output=True)
+    for qi in range(len(q)):
+        lut = orc.build_lut(g.codebook, q[qi])
+        want = orc.adc(lut, g.codes)[0]
+        assert np.array_equal(bits(allsq[qi]), bits(want))
+        assert int(bid[qi]) == int(np.flatnonzero(want == want.min())[0])
+        assert bits(np.float32(bsq[qi])) == bits(want.min())
+    only_best = ix.pq_scan_best(q)
+    assert np.array_equal(only_best[0], bid) and np.array_equal(bits(only_best[1]), bits(bsq))
