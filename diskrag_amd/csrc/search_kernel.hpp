@@ -382,11 +382,35 @@ DEV void adc_load_codes(uint4 &w0, uint4 &w1, uint4 &w2, uint4 &w3, const u8 *__
     }
 }
 
+// A3 from the per-query table for one 16-byte code piece: all 16 table reads issued together, then the strict
+// sequential sum (one LDS wait per piece instead of one per 4 entries).
+DEV float adc_lut16(const float *lut, const uint4 cw, u32 jbase, float s)
+{
+    const u32 words[4] = { cw.x, cw.y, cw.z, cw.w };
+    float t[16];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) t[u * 4 + b] = lut[(jbase + u * 4 + b) * 256 + ((words[u] >> (8 * b)) & 255u)];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s = f_add(s, t[i]);
+    return s;
+}
+
 template <bool CBLDS>
 DEV float adc_compute(const float *tab, const float *q, u32 sd, const uint4 c0, const uint4 c1v, const uint4 c2,
                       const uint4 c3, const u8 *__restrict__ code, u32 m)
 {
     float s = 0.0f;
+    if constexpr (!CBLDS) {
+        if ((m & 15u) == 0 && m <= 64) {
+            s = adc_lut16(tab, c0, 0, s);
+            if (m > 16) s = adc_lut16(tab, c1v, 16, s);
+            if (m > 32) s = adc_lut16(tab, c2, 32, s);
+            if (m > 48) s = adc_lut16(tab, c3, 48, s);
+            return s;
+        }
+    }
     if ((m & 15u) == 0 && m <= 64) {
         const int m16 = (int)(m / 16);
         const bool sd4 = (sd == 4);
