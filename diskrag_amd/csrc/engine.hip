@@ -88,6 +88,12 @@ struct dr_index {
     int num_cu = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};
+    // search-kernel launches are timed with a ring of event pairs and harvested at the next sync: dr_batch_run does
+    // not wait for its kernel, consecutive steps queue back to back on the stream
+    static constexpr int KEV = 32;
+    hipEvent_t kev[KEV][2] = {};
+    int kev_pending = 0;
+    double kms_sum = 0.0; uint32_t kms_n = 0;
     std::mutex mu;
 
     DevBuf<float> vecp;
@@ -157,6 +163,7 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     HIPCHK(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ix->fstream, hipStreamNonBlocking));
     for (auto &e : ix->ev) HIPCHK(hipEventCreate(&e));
+    for (auto &pr : ix->kev) { HIPCHK(hipEventCreate(&pr[0])); HIPCHK(hipEventCreate(&pr[1])); }
     for (auto &bs : ix->sets) { HIPCHK(hipEventCreate(&bs.search_done)); HIPCHK(hipEventCreate(&bs.fin_start)); HIPCHK(hipEventCreate(&bs.fin_done)); }
     ix->h_perm.resize(D);
     pw_build_perm_rec(0, D, ix->h_perm.data());
@@ -337,6 +344,7 @@ extern "C" void dr_index_close(dr_index *ix)
     }
     ix->pq_ub.release(); ix->phase.release(); ix->rank.release(); ix->adjr.release();
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &pr : ix->kev) { if (pr[0]) (void)hipEventDestroy(pr[0]); if (pr[1]) (void)hipEventDestroy(pr[1]); }
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     if (ix->fstream) (void)hipStreamDestroy(ix->fstream);
     delete ix;
@@ -429,6 +437,21 @@ struct BuildOverride { const uint32_t *adjb; const uint32_t *deg; uint32_t RX; u
 static int g_force_kind = -1;   // test/diagnostic hook: DR_FORCE_KIND environment variable / dr_debug_force_kind
 static bool g_force_kind_set = false;
 static int sync_locked(dr_index *ix);
+
+// the search kernels of the pending launches have finished (caller synchronised the stream): collect their durations;
+// `publish` turns the sum since the last publication into timing.search_kernel_ms (mean per launch)
+static void harvest_kernel_times(dr_index *ix, bool publish)
+{
+    for (int i = 0; i < ix->kev_pending; i++) {
+        float a = 0;
+        if (hipEventElapsedTime(&a, ix->kev[i][0], ix->kev[i][1]) == hipSuccess) { ix->kms_sum += a; ix->kms_n++; }
+    }
+    ix->kev_pending = 0;
+    if (publish && ix->kms_n) {
+        ix->timing.search_kernel_ms = (float)(ix->kms_sum / ix->kms_n);
+        ix->kms_sum = 0.0; ix->kms_n = 0;
+    }
+}
 
 static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_t mode, uint32_t policy, uint32_t flags,
                       const BuildOverride *ov = nullptr)
@@ -566,11 +589,13 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     static const bool dbg = getenv("DR_DEBUG") != nullptr;
     if (dbg) { fprintf(stderr, "[dr] search kind=%d sc=%d NW=%d grid=%u lds=%zu occ=%d nq=%u cap=%u slots=%u vis_words=%u vis_limit=%u\n", kind, sc, NW, grid, lds, occ, nq, cap, slots, vis_words, vis_limit); fflush(stderr); }
     HIPCHK(hipMemsetAsync(bs.counter.p, 0, 8, ix->stream));
-    HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
+    if (!ov && ix->kev_pending == dr_index::KEV) { HIPCHK(hipStreamSynchronize(ix->stream)); harvest_kernel_times(ix, false); }
     void *args[] = { &p };
+    if (!ov) HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][0], ix->stream));
     HIPCHK(hipLaunchKernel(kfn, dim3(grid), dim3(64 * NW), args, lds, ix->stream));
-    HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
     if (ov) return 0;   // the builder consumes res_keys / res_n directly on the stream
+    HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][1], ix->stream));
+    ix->kev_pending++;
 
     // tie replay for the queries the search kernel listed: one wavefront per query, heap in registers. It runs on
     // its own stream so that it overlaps the NEXT step's search kernel (it needs 19 VGPRs and no LDS, so its
@@ -593,15 +618,13 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(bs.fin_done, ix->fstream));
     bs.fin_pending = true;
-    HIPCHK(hipStreamSynchronize(ix->stream));      // the search kernel of this step has finished
-    if (dbg) { fprintf(stderr, "[dr] search done\n"); fflush(stderr); }
-    float a = 0;
-    (void)hipEventElapsedTime(&a, ix->ev[2], ix->ev[3]);
-    ix->timing.search_kernel_ms = a;
+    // no host wait here: the next step may be queued right away (dr_batch_sync / dr_batch_download wait)
     ix->timing.grid = grid; ix->timing.block = 64 * NW; ix->timing.lds_bytes = (uint32_t)lds;
     ix->timing.waves_per_cu = (uint32_t)(occ * NW);
     if (k_m1 && ix->adc_live < 0) {
-        // regime of this (graph, PQ) state: did the rerank policy really consult the ADC on this batch?
+        // regime of this (graph, PQ) state: did the rerank policy really consult the ADC on this batch? (the one
+        // launch per index state that is waited for on the host)
+        HIPCHK(hipStreamSynchronize(ix->stream));
         std::vector<KStats> st(std::min<uint32_t>(nq, 1024));
         HIPCHK(hipMemcpy(st.data(), bs.stats.p, st.size() * sizeof(KStats), hipMemcpyDeviceToHost));
         uint64_t evald = 0, all = 0;
@@ -619,6 +642,7 @@ static int sync_locked(dr_index *ix)
 {
     HIPCHK(hipStreamSynchronize(ix->stream));
     HIPCHK(hipStreamSynchronize(ix->fstream));
+    harvest_kernel_times(ix, true);
     dr_index::BatchSet &bs = ix->sets[ix->last_set];
     if (bs.fin_pending) {
         float b = 0;

@@ -55,8 +55,10 @@ typedef struct {
     uint32_t reserved;
 } dr_stats;
 
-/* timing of the last dr_search_batch / dr_batch_run on a handle, measured with HIP events on the engine's
- * own stream (bench.py's roofline uses search_kernel_ms) */
+/* timing of the last dr_search_batch, or of the dr_batch_run calls since the previous dr_batch_sync /
+ * dr_batch_download, measured with HIP events on the engine's own stream. dr_batch_run queues its step and
+ * returns; search_kernel_ms is the MEAN search-kernel duration of the steps waited for by that sync (bench.py's
+ * roofline uses it), valid after the sync. */
 typedef struct {
     float h2d_ms, search_kernel_ms, finalize_kernel_ms, d2h_ms, total_ms;
     uint32_t grid, block, lds_bytes, waves_per_cu;
