@@ -114,8 +114,8 @@ struct dr_index {
     DevBuf<float> q, qp;
     DevBuf<uint32_t> vis, vlog;
     size_t vis_zeroed = 0;
-    // per-step outputs are double-buffered: the tie-order pass (finalize) of step i runs on its own stream while
-    // the search kernel of step i+1 fills the other set
+    // per-step outputs are triple-buffered: the tie-order pass (finalize) of step i runs on its own stream while
+    // the search kernels of steps i+1 and i+2 fill the other sets
     struct BatchSet {
         DevBuf<uint32_t> counter, res_n, tie, out_ids, out_count;
         DevBuf<u64> res_keys, log;
@@ -123,9 +123,12 @@ struct dr_index {
         DevBuf<float> out_dist;
         hipEvent_t search_done = nullptr, fin_start = nullptr, fin_done = nullptr;
         bool fin_pending = false;
+        bool counters_zeroed = false;
+        uint32_t ticket_base = 0;     // every launch draws exactly nq tickets from counter[0]: never reset
         void release() { counter.release(); res_n.release(); tie.release(); out_ids.release(); out_count.release();
                          res_keys.release(); log.release(); stats.release(); out_dist.release(); }
-    } sets[2];
+    } sets[3];      // three sets: the tie-order pass of step i only finds room in the TAILS of the next search kernels
+                    // (its 19 VGPRs do not fit beside 3 x 168 per SIMD), so it gets two steps to finish, not one
     int parity = 0, last_set = 0;
     hipStream_t fstream = nullptr;
     DevBuf<float> pq_ub;
@@ -588,11 +591,20 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
 
     static const bool dbg = getenv("DR_DEBUG") != nullptr;
     if (dbg) { fprintf(stderr, "[dr] search kind=%d sc=%d NW=%d grid=%u lds=%zu occ=%d nq=%u cap=%u slots=%u vis_words=%u vis_limit=%u\n", kind, sc, NW, grid, lds, occ, nq, cap, slots, vis_words, vis_limit); fflush(stderr); }
-    HIPCHK(hipMemsetAsync(bs.counter.p, 0, 8, ix->stream));
+    if (!bs.counters_zeroed) { HIPCHK(hipMemsetAsync(bs.counter.p, 0, 8, ix->stream)); bs.counters_zeroed = true; bs.ticket_base = 0; }
+    // Ticket counter: slot s starts on query s and every later query is a ticket; the started slots draw
+    // (nq - started) successful tickets plus one failing ticket each = exactly nq per launch, so the counter is
+    // monotonic and the launch only needs its starting value (no per-step memset on the search stream). The tie-list
+    // length (counter[1]) is zeroed on the tie-order stream after its consumer.
+    p.ticket_base = bs.ticket_base;
+    bs.ticket_base += nq;
     if (!ov && ix->kev_pending == dr_index::KEV) { HIPCHK(hipStreamSynchronize(ix->stream)); harvest_kernel_times(ix, false); }
     void *args[] = { &p };
     if (!ov) HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][0], ix->stream));
-    HIPCHK(hipLaunchKernel(kfn, dim3(grid), dim3(64 * NW), args, lds, ix->stream));
+    {
+        const hipError_t le = hipLaunchKernel(kfn, dim3(grid), dim3(64 * NW), args, lds, ix->stream);
+        if (le != hipSuccess) { bs.counters_zeroed = false; return fail(DR_E_NODEVICE, "search kernel launch failed: %s", hipGetErrorString(le)); }
+    }
     if (ov) return 0;   // the builder consumes res_keys / res_n directly on the stream
     HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][1], ix->stream));
     ix->kev_pending++;
@@ -608,6 +620,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     f.logcap = logcap; f.cap = cap; f.k = k; f.mode = mode;
     f.out_ids = bs.out_ids.p; f.out_dist = bs.out_dist.p;
     HIPCHK(hipEventRecord(bs.fin_start, ix->fstream));
+    static const bool skip_fin = getenv("DR_SKIP_FINALIZE") != nullptr;   // timing experiment only: tie order is then wrong
+    if (!skip_fin)
     {
         const unsigned fgrid = (unsigned)std::min<uint64_t>(((uint64_t)nq + 3) / 4, (uint64_t)ix->num_cu * 8);
         if (cap + 1 <= 64) hipLaunchKernelGGL(finalize_kernel<1>, dim3(fgrid), dim3(256), 0, ix->fstream, f);
@@ -616,6 +630,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         else hipLaunchKernelGGL(finalize_kernel<9>, dim3(fgrid), dim3(256), 0, ix->fstream, f);
     }
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(bs.counter.p + 1, 0, 4, ix->fstream));
     HIPCHK(hipEventRecord(bs.fin_done, ix->fstream));
     bs.fin_pending = true;
     // no host wait here: the next step may be queued right away (dr_batch_sync / dr_batch_download wait)
@@ -633,7 +648,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     }
     ix->last_k = k;
     ix->last_set = set;
-    ix->parity ^= 1;
+    ix->parity = (ix->parity + 1) % 3;
     return 0;
 }
 

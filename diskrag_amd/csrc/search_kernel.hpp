@@ -72,7 +72,8 @@ struct SearchParams {
     u32 *vlog;               // [slots][vis_limit] bit positions the running query may have set (every tested slot)
     u32 vis_limit;
     u32 vis_stream_clear;    // 1: clear the whole slot bitmap with wide stores after a query (small N) instead of per id
-    u32 *counter;            // [2]: query ticket counter (zeroed per launch), tie-list length
+    u32 *counter;            // [2]: query ticket counter (monotonic: a launch draws exactly nq tickets), tie-list length
+    u32 ticket_base;         // value of the ticket counter when this launch starts
     u64 *res_keys;           // [nq][cap] ascending (dist bits << 32 | ~id)
     u32 *res_n;              // [nq]
     KStats *stats;           // [nq]
@@ -521,7 +522,7 @@ DEV u32 a4_threshold_bits(float pq, float thr, bool &ok) {
 }
 
 template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const SearchParams p)
+DEV void search_body(const SearchParams &p)
 {
     constexpr bool QREG = (D <= 256);
     constexpr bool SPLIT = QREG && split_form_ok<D>();
@@ -1122,7 +1123,13 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const 
         {
             u32 t = 0;
             if (lane == 0) t = atomicAdd(p.counter, 1u);
-            qi = (u32)__builtin_amdgcn_readfirstlane((int)t) + nslots;
+            qi = (u32)__builtin_amdgcn_readfirstlane((int)t) - p.ticket_base + nslots;
         }
     }
+}
+
+template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const SearchParams p)
+{
+    search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB>(p);
 }
