@@ -64,3 +64,35 @@ def test_sample_matches_oracle_at_scale(big):
         assert np.array_equal(ids, oids)
         assert np.array_equal(dist.view(np.uint32), odist.astype(np.float32).view(np.uint32))
         assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), ost)
+
+
+def test_live_policy_sample_matches_oracle_at_scale():
+    """The A4-live regime (unit-norm data, ADC evaluated, rows fetched only for neighbours that can pass) at a size
+    where the locality bit order of the visited bitmap is active (N >= 32768): oracle sample, both band policies,
+    and the second batch (served by the variant the measured regime selects) equals the first."""
+    from diskrag_amd import HipIndex, _ffi
+    from diskrag_amd.synth import unit_mixture
+    from oracle import pyoracle as orc
+    x, q = unit_mixture(150000, 96, n_queries=400, n_clusters=512, seed=13, latent=32)
+    ix = HipIndex.create_empty(x, R=48)
+    medoid, _ = ix.build_vamana(L_build=80, alpha=1.2, passes=2, seed=4)
+    cb = ix.pq_train(16, n_sample=40000, iters=4)
+    codes = ix.pq_encode(cb, want_codes=True)
+    adj = ix.get_adjacency()
+    try:
+        for L, bw, pol in ((100, 8, 0), (100, 0, 1), (50, 8, 1)):
+            first = ix.search_batch(q, 10, L=L, beam_width=bw, mode=_ffi.MODE_M1, band_policy=pol)
+            again = ix.search_batch(q, 10, L=L, beam_width=bw, mode=_ffi.MODE_M1, band_policy=pol)
+            oi, od, oc, ost = orc.search_batch(x, adj, q, medoid, orc.M1, 10, L=L, bw=bw, policy=pol, codes=codes,
+                                               codebook=cb, nthreads=8)
+            for ids, dist, cnt, st in (first, again):
+                assert (st["status"] == 0).all()
+                assert np.array_equal(ids, oi) and np.array_equal(cnt, oc)
+                valid = oi != PAD
+                assert np.array_equal(dist[valid].view(np.uint32), od[valid].astype(np.float32).view(np.uint32))
+                assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), ost)
+        assert ix.debug_force_kind(-1) == 1          # measured: live
+        st = first[3]
+        assert st["exact"].sum() < 0.8 * st["visited"].sum()
+    finally:
+        ix.close()
