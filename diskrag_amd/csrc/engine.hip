@@ -131,6 +131,8 @@ struct dr_index {
                     // (its 19 VGPRs do not fit beside 3 x 168 per SIMD), so it gets two steps to finish, not one
     int parity = 0, last_set = 0;
     hipStream_t fstream = nullptr;
+    DevBuf<uint32_t> fin_stat;    // [1] largest tie-list length since the last sync (finalize_kernel)
+    uint32_t fin_hint = 0;        // tie-list length to size the tie-order launches for (0: not known yet -> full grid)
     DevBuf<float> pq_ub;
     bool pq_ub_valid = false;     // pq_ub matches the resident queries and the attached codebook
     int adc_live = -1;            // M1 on this index: does the rerank policy A4 really consult the ADC? -1 = not measured yet
@@ -345,7 +347,7 @@ extern "C" void dr_index_close(dr_index *ix)
         if (bs.fin_start) (void)hipEventDestroy(bs.fin_start);
         if (bs.fin_done) (void)hipEventDestroy(bs.fin_done);
     }
-    ix->pq_ub.release(); ix->phase.release(); ix->rank.release(); ix->adjr.release();
+    ix->pq_ub.release(); ix->phase.release(); ix->rank.release(); ix->adjr.release(); ix->fin_stat.release();
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
     for (auto &pr : ix->kev) { if (pr[0]) (void)hipEventDestroy(pr[0]); if (pr[1]) (void)hipEventDestroy(pr[1]); }
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -619,11 +621,18 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     f.log = bs.log.p; f.stats = bs.stats.p;
     f.logcap = logcap; f.cap = cap; f.k = k; f.mode = mode;
     f.out_ids = bs.out_ids.p; f.out_dist = bs.out_dist.p;
+    if (!ix->fin_stat.p) { if (ix->fin_stat.reserve(1, true)) return DR_E_NODEVICE; }
+    f.ntie_stat = ix->fin_stat.p;
     HIPCHK(hipEventRecord(bs.fin_start, ix->fstream));
     static const bool skip_fin = getenv("DR_SKIP_FINALIZE") != nullptr;   // timing experiment only: tie order is then wrong
     if (!skip_fin)
     {
-        const unsigned fgrid = (unsigned)std::min<uint64_t>(((uint64_t)nq + 3) / 4, (uint64_t)ix->num_cu * 8);
+        // One wavefront per tied query, 4 per workgroup, spread over the chip (packing 16 per CU slowed each replay by a
+        // third). Few queries tie (29 of 10 000 on the bench data), so the grid is sized for twice the largest tie list
+        // seen at the last sync (waves loop if there are more) instead of one wave slot per query of the batch. One
+        // replay takes ~0.85 ms of serial heap work: hidden behind the next search kernel, exposed once at the sync.
+        unsigned fgrid = (unsigned)std::min<uint64_t>(((uint64_t)nq + 3) / 4, (uint64_t)ix->num_cu * 8);
+        if (ix->fin_hint) fgrid = std::min<unsigned>(fgrid, (2 * ix->fin_hint + 64 + 3) / 4);
         if (cap + 1 <= 64) hipLaunchKernelGGL(finalize_kernel<1>, dim3(fgrid), dim3(256), 0, ix->fstream, f);
         else if (cap + 1 <= 128) hipLaunchKernelGGL(finalize_kernel<2>, dim3(fgrid), dim3(256), 0, ix->fstream, f);
         else if (cap + 1 <= 256) hipLaunchKernelGGL(finalize_kernel<4>, dim3(fgrid), dim3(256), 0, ix->fstream, f);
@@ -658,6 +667,12 @@ static int sync_locked(dr_index *ix)
     HIPCHK(hipStreamSynchronize(ix->stream));
     HIPCHK(hipStreamSynchronize(ix->fstream));
     harvest_kernel_times(ix, true);
+    if (ix->fin_stat.p) {
+        uint32_t mx = 0;
+        HIPCHK(hipMemcpy(&mx, ix->fin_stat.p, 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemset(ix->fin_stat.p, 0, 4));
+        ix->fin_hint = std::max<uint32_t>(mx, 16);
+    }
     dr_index::BatchSet &bs = ix->sets[ix->last_set];
     if (bs.fin_pending) {
         float b = 0;

@@ -69,6 +69,7 @@ struct FinalizeParams {
     const KStats *stats;
     u32 logcap, cap, k, mode;
     u32 *out_ids; float *out_dist;
+    u32 *ntie_stat;     // largest tie-list length seen since the host last looked (sizes the next launches)
 };
 
 template <int NCH> DEV void heap_set(RegList<NCH> &H, int idx, u64 v)
@@ -119,6 +120,7 @@ template <int NCH> __global__ __launch_bounds__(256) void finalize_kernel(const 
 {
     const int lane = lane_id();
     const u32 ntie = *p.tie_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.ntie_stat) atomicMax(p.ntie_stat, ntie);
     const u32 nwaves = gridDim.x * (blockDim.x >> 6);
     const u32 wave0 = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     for (u32 t = wave0; t < ntie; t += nwaves) {
