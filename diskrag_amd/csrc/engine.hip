@@ -922,7 +922,22 @@ extern "C" int dr_pq_scan_best(dr_index *ix, const float *queries, uint32_t nq, 
     std::lock_guard<std::mutex> lk(ix->mu);
     if (ix->m == 0) return fail(DR_E_NOPQ, "no PQ data");
     const uint32_t m = ix->m;
-    if ((m & 15u) != 0 || m > 64) return adc_common(ix, queries, nq, nullptr, ix->N, out_sq, nullptr, kernel_ms);   // generic form
+    if ((m & 15u) != 0 || m > 64) {
+        // generic form (any m): all distances through adc_kernel, the nearest code word picked on the host
+        std::vector<float> tmp;
+        float *all = out_sq;
+        if (!all && (out_best_id || out_best_sq)) { tmp.resize((size_t)nq * ix->N); all = tmp.data(); }
+        int rcg = adc_common(ix, queries, nq, nullptr, ix->N, all, nullptr, kernel_ms);
+        if (rcg || !all) return rcg;
+        for (uint32_t qi = 0; qi < nq; qi++) {
+            const float *row = all + (size_t)qi * ix->N;
+            uint64_t bi = 0;
+            for (uint64_t i = 1; i < ix->N; i++) if (row[i] < row[bi]) bi = i;
+            if (out_best_id) out_best_id[qi] = (uint32_t)bi;
+            if (out_best_sq) out_best_sq[qi] = row[bi];
+        }
+        return 0;
+    }
     int rc = upload_queries_locked(ix, queries, nq);
     if (rc) return rc;
     const uint64_t n = ix->N;

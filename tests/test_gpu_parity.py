@@ -251,3 +251,25 @@ def test_flat_pq_scan_matches_adc_and_finds_the_nearest_code(name):
         assert bits(np.float32(bsq[qi])) == bits(want.min())
     only_best = ix.pq_scan_best(q)
     assert np.array_equal(only_best[0], bid) and np.array_equal(bits(only_best[1]), bits(bsq))
+
+
+def test_flat_pq_scan_generic_m():
+    """m not a multiple of 16 (D=96, m=24): the generic scan path; same contract as the fast kernel."""
+    from diskrag_amd import HipIndex
+    from oracle import pyoracle as orc
+    rs = np.random.RandomState(3)
+    n, D, m = 3000, 96, 24
+    codes = rs.randint(0, 256, size=(n, m)).astype(np.uint8)
+    cb = rs.randn(m, 256, D // m).astype(np.float32)
+    q = rs.randn(4, D).astype(np.float32)
+    ix = HipIndex.create_codes(np.zeros((n, 1), dtype=np.uint32), 0, D, cb, codes)
+    try:
+        bid, bsq, ms, allsq = ix.pq_scan_best(q, want_output=True)
+        bid2, bsq2, _ = ix.pq_scan_best(q)
+        for qi in range(len(q)):
+            want = orc.adc(orc.build_lut(cb, q[qi]), codes)[0]
+            assert np.array_equal(bits(allsq[qi]), bits(want))
+            assert int(bid[qi]) == int(np.flatnonzero(want == want.min())[0]) == int(bid2[qi])
+            assert bits(np.float32(bsq[qi])) == bits(want.min()) == bits(np.float32(bsq2[qi]))
+    finally:
+        ix.close()
