@@ -69,7 +69,7 @@ struct SearchParams {
     u32 max_steps;           // M1: min(10L, N); others: 0xFFFFFFFF
     u32 *vis;                // [slots][vis_words] visited bitmaps (all zero between queries)
     u32 vis_words;
-    u32 *vlog;               // [slots][vis_limit] bit positions the running query may have set (every tested slot)
+    u32 *vlog;               // [slots][vis_limit] bit positions set in the bitmap by the running query
     u32 vis_limit;
     u32 vis_stream_clear;    // 1: clear the whole slot bitmap with wide stores after a query (small N) instead of per id
     u32 *counter;            // [2]: query ticket counter (monotonic: a launch draws exactly nq tickets), tie-list length
@@ -698,18 +698,7 @@ DEV void search_body(const SearchParams &p)
                 else active = slot < min((u32)aux, p.R) && nbid != 0xFFFFFFFFu;
                 PH(2);
                 // visited test-and-set: one atomic round trip; duplicates inside a row were removed by `first`
-                // The positions are logged for the end-of-query clear BEFORE the outcome is known (every tested slot,
-                // new or not: clearing a bit twice is harmless), so the store travels with the atomic instead of
-                // sitting between its result and the row loads. A log that fills up switches the query to a
-                // whole-bitmap clear: nothing can overflow.
                 bool isnew = false;
-                {
-                    const u64 actm = __ballot(active);
-                    const u32 nact = (u32)__popcll(actm);
-                    if (nlog + nact > p.vis_limit) logfull = true;
-                    if (active && !logfull && !p.vis_stream_clear) vlog[nlog + (u32)__popcll(actm & lanemask_lt())] = nbpos;
-                    if (!logfull) nlog += nact;
-                }
                 if (active) {
                     const u32 bit = 1u << (nbpos & 31);
                     isnew = (atomicOr(&vbm[nbpos >> 5], bit) & bit) == 0u;
@@ -717,10 +706,15 @@ DEV void search_body(const SearchParams &p)
                 const u64 newmask = __ballot(isnew);
                 const int nnew = __popcll(newmask);
                 if (nnew == 0) continue;
+                // the positions set by this query are logged for the end-of-query clear; a log that fills up switches
+                // the query to a whole-bitmap clear: nothing can overflow
+                if (nlog + (u32)nnew > p.vis_limit) logfull = true;
                 if (isnew) {
                     const int rnk = __popcll(newmask & lanemask_lt());
                     nb_id[rnk] = nbid;
+                    if (!logfull && !p.vis_stream_clear) vlog[nlog + rnk] = nbpos;
                 }
+                if (!logfull) nlog += (u32)nnew;
                 nvisited += nnew;
                 WSYNC();
                 PH(3);
