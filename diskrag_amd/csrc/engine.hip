@@ -630,13 +630,10 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         // One wavefront per tied query, 4 per workgroup, spread over the chip (packing 16 per CU slowed each replay by a
         // third). Few queries tie (29 of 10 000 on the bench data), so the grid is sized for twice the largest tie list
         // seen at the last sync (waves loop if there are more) instead of one wave slot per query of the batch. One
-        // replay takes ~0.85 ms of serial heap work: hidden behind the next search kernel, exposed once at the sync.
+        // replay takes ~0.6 ms of serial heap work: hidden behind the next search kernel, exposed once at the sync.
         unsigned fgrid = (unsigned)std::min<uint64_t>(((uint64_t)nq + 3) / 4, (uint64_t)ix->num_cu * 8);
         if (ix->fin_hint) fgrid = std::min<unsigned>(fgrid, (2 * ix->fin_hint + 64 + 3) / 4);
-        if (cap + 1 <= 64) hipLaunchKernelGGL(finalize_kernel<1>, dim3(fgrid), dim3(256), 0, ix->fstream, f);
-        else if (cap + 1 <= 128) hipLaunchKernelGGL(finalize_kernel<2>, dim3(fgrid), dim3(256), 0, ix->fstream, f);
-        else if (cap + 1 <= 256) hipLaunchKernelGGL(finalize_kernel<4>, dim3(fgrid), dim3(256), 0, ix->fstream, f);
-        else hipLaunchKernelGGL(finalize_kernel<9>, dim3(fgrid), dim3(256), 0, ix->fstream, f);
+        hipLaunchKernelGGL(finalize_kernel, dim3(fgrid), dim3(256), 4 * ((size_t)cap + 2 + 64) * 8, ix->fstream, f);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(bs.counter.p + 1, 0, 4, ix->fstream));
