@@ -193,7 +193,7 @@ static int build_first_masks(dr_index *ix)
     DevBuf<uint32_t> bad;
     if (bad.reserve(1, true)) return DR_E_NODEVICE;
     const uint64_t rows_per_block = 4;
-    const uint64_t blocks = (ix->N + rows_per_block - 1) / rows_per_block;
+    const uint64_t blocks = std::min<uint64_t>((ix->N + rows_per_block - 1) / rows_per_block, 1u << 20);   // grid-stride kernel
     hipLaunchKernelGGL(first_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, ix->stream, ix->adj.p, ix->N, ix->R,
                        ix->N, ix->first.p, bad.p);
     HIPCHK(hipGetLastError());
@@ -1157,7 +1157,7 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
     }
     if (!rc) {
         const uint64_t total = N * R;
-        hipLaunchKernelGGL(compact_adj_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ix->stream, adjb.p,
+        hipLaunchKernelGGL(compact_adj_kernel, dim3((unsigned)std::min<uint64_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, ix->stream, adjb.p,
                            deg.p, N, RX, R, pad_with_zero ? 0u : 0xFFFFFFFFu, ix->adj.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ix->stream));

@@ -33,10 +33,10 @@ __global__ void permute_queries_kernel(const float *__restrict__ q, u32 nq, u32 
 __global__ void first_mask_kernel(const u32 *__restrict__ adj, u64 n, u32 R, u64 N, u64 *__restrict__ first,
                                   u32 *__restrict__ bad)
 {
-    const u64 row = (u64)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    if (row >= n) return;
+    // grid-stride over the rows: a launch is limited to 2^32 - 1 work-items, N * 64 exceeds that from N = 6.7e7 on
     const u32 lane = threadIdx.x & 63;
     const u32 nw = (R + 63) / 64;
+    for (u64 row = (u64)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); row < n; row += (u64)gridDim.x * (blockDim.x / 64)) {
     const u32 *a = adj + row * R;
     for (u32 w = 0; w < nw; w++) {
         const u32 s = w * 64 + lane;
@@ -52,6 +52,7 @@ __global__ void first_mask_kernel(const u32 *__restrict__ adj, u64 n, u32 R, u64
         }
         const u64 m = __ballot(ok);
         if (lane == 0) first[row * nw + w] = m;
+    }
     }
 }
 
@@ -341,12 +342,12 @@ __global__ void reverse_edges_kernel(u32 *__restrict__ adjb, u32 *__restrict__ d
 __global__ void compact_adj_kernel(const u32 *__restrict__ adjb, const u32 *__restrict__ deg, u64 N, u32 RX, u32 R,
                                    u32 padval, u32 *__restrict__ adj)
 {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * R) return;
-    const u64 row = i / R;
-    const u32 s = (u32)(i % R);
-    const u32 d = min(deg[row], R);
-    adj[i] = s < d ? adjb[row * RX + s] : padval;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N * R; i += (u64)gridDim.x * blockDim.x) {   // (2^32 work-item limit)
+        const u64 row = i / R;
+        const u32 s = (u32)(i % R);
+        const u32 d = min(deg[row], R);
+        adj[i] = s < d ? adjb[row * RX + s] : padval;
+    }
 }
 
 __global__ void column_sum_kernel(const float *__restrict__ vecp, u64 N, u32 D, double *__restrict__ acc)
