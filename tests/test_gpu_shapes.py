@@ -70,3 +70,30 @@ def test_extreme_parameters_and_batch_sizes():
             assert np.array_equal(ids[sl], np.roll(ref[0], -off, axis=0)[:n])
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("D,m", [(32, 8), (64, 16), (256, 32), (768, 32), (960, 48)])
+def test_every_built_dimension(D, m):
+    """The pairwise tree and the chain-major layout are compiled per dimension: each built D (the goldens cover 96,
+    128 and 1536) against the oracle, SIFT-scale and unit-scale data, M1 / M2 / M3-PQ / M4."""
+    from diskrag_amd import HipIndex, _ffi
+    from diskrag_amd.synth import sift_like, unit_mixture
+    for gen in ("sift", "unit"):
+        if gen == "sift":
+            x, q = sift_like(6000, D, n_queries=40, n_clusters=32, seed=70 + D, query_seed=71 + D, latent=min(32, D))
+        else:
+            x, q = unit_mixture(6000, D, n_queries=40, n_clusters=32, seed=72 + D, latent=min(32, D))
+        ix = HipIndex.create_empty(x, R=32)
+        medoid, _ = ix.build_vamana(L_build=50, alpha=1.2, passes=2, seed=2, pad_with_zero=(gen == "sift"))
+        cb = ix.pq_train(m, n_sample=6000, iters=3)
+        codes = ix.pq_encode(cb, want_codes=True)
+        adj = ix.get_adjacency()
+        try:
+            if gen == "sift":       # 0-padded rows: the engine paths (M1, M2)
+                for (mode, k, L, bw, pol) in ((1, 10, 60, 8, 0), (1, 10, 60, 0, 1), (2, 8, 0, 8, 0)):
+                    _check(ix, x, adj, medoid, cb, codes, q, mode, k, L, bw, pol=pol)
+            else:                   # PAD-padded in-memory rows: M1 with the policy live, M3 with PQ, M4
+                for (mode, k, L, bw, pol, fl) in ((1, 10, 60, 8, 0, 0), (1, 10, 60, 0, 1, 0), (3, 5, 5, 8, 0, _ffi.F_USE_PQ), (4, 10, 40, 0, 0, 0)):
+                    _check(ix, x, adj, medoid, cb, codes, q, mode, k, L, bw, flags=fl, pol=pol)
+        finally:
+            ix.close()
