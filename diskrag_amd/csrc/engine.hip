@@ -132,6 +132,9 @@ struct dr_index {
     int parity = 0, last_set = 0;
     hipStream_t fstream = nullptr;
     DevBuf<uint32_t> fin_stat;    // [1] largest tie-list length since the last sync (finalize_kernel)
+    DevBuf<double> f64_q, f64_dist;                 // dr_search_batch_f64 scratch
+    DevBuf<uint32_t> f64_ids, f64_cnt, f64_vis;
+    DevBuf<KStats> f64_stats;
     uint32_t fin_hint = 0;        // tie-list length to size the tie-order launches for (0: not known yet -> full grid)
     DevBuf<float> pq_ub;
     bool pq_ub_valid = false;     // pq_ub matches the resident queries and the attached codebook
@@ -348,6 +351,7 @@ extern "C" void dr_index_close(dr_index *ix)
         if (bs.fin_done) (void)hipEventDestroy(bs.fin_done);
     }
     ix->pq_ub.release(); ix->phase.release(); ix->rank.release(); ix->adjr.release(); ix->fin_stat.release();
+    ix->f64_q.release(); ix->f64_dist.release(); ix->f64_ids.release(); ix->f64_cnt.release(); ix->f64_vis.release(); ix->f64_stats.release();
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
     for (auto &pr : ix->kev) { if (pr[0]) (void)hipEventDestroy(pr[0]); if (pr[1]) (void)hipEventDestroy(pr[1]); }
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -795,9 +799,12 @@ extern "C" int dr_search_batch_f64(dr_index *ix, const double *queries, uint32_t
     const void *kfn = ix->kern->search_f64;
     HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t vis_words = (uint32_t)((ix->N + 31) / 32);
-    DevBuf<double> dq, dd; DevBuf<uint32_t> dids, dcnt, dvis; DevBuf<KStats> dst;
-    if (dq.reserve((size_t)CH * D) || dd.reserve((size_t)CH * k) || dids.reserve((size_t)CH * k) || dcnt.reserve(CH) ||
-        dst.reserve(CH) || dvis.reserve((size_t)CH * vis_words)) return DR_E_NODEVICE;
+    // scratch kept on the handle (the CLI asks one query per call: no allocation on its path after the first)
+    DevBuf<double> &dq = ix->f64_q, &dd = ix->f64_dist; DevBuf<uint32_t> &dids = ix->f64_ids, &dcnt = ix->f64_cnt, &dvis = ix->f64_vis;
+    DevBuf<KStats> &dst = ix->f64_stats;
+    const uint32_t chq = std::min<uint32_t>(CH, nq);
+    if (dq.reserve((size_t)chq * D) || dd.reserve((size_t)chq * k) || dids.reserve((size_t)chq * k) || dcnt.reserve(chq) ||
+        dst.reserve(chq) || dvis.reserve((size_t)chq * vis_words)) return DR_E_NODEVICE;
     int rc = 0;
     for (uint32_t q0 = 0; q0 < nq && !rc; q0 += CH) {
         const uint32_t n = std::min(CH, nq - q0);
@@ -820,7 +827,6 @@ extern "C" int dr_search_batch_f64(dr_index *ix, const double *queries, uint32_t
             (stats && hipMemcpyAsync(stats + q0, dst.p, (size_t)n * sizeof(KStats), hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
             hipStreamSynchronize(ix->stream) != hipSuccess) { rc = fail(DR_E_NODEVICE, "float64 search: %s", hipGetErrorString(hipGetLastError())); break; }
     }
-    dq.release(); dd.release(); dids.release(); dcnt.release(); dvis.release(); dst.release();
     return rc;
 }
 
