@@ -96,3 +96,26 @@ def test_live_policy_sample_matches_oracle_at_scale():
         assert st["exact"].sum() < 0.8 * st["visited"].sum()
     finally:
         ix.close()
+
+
+def test_other_modes_sample_matches_oracle_at_scale(big):
+    """M2, M3 (exact and PQ-only) and M4 on the 200k index: oracle sample, bit for bit (the same 0-padded rows are
+    given to both, so the phantom neighbour 0 of short rows is a real neighbour for both)."""
+    from diskrag_amd import _ffi
+    from oracle import pyoracle as orc
+    ix, x, q, cb, codes = big
+    adj = ix.get_adjacency()
+    qs = q[:200]
+    P = orc.F_PAIRWISE
+    for (mode, omode, k, L, bw, fl, ofl) in ((2, orc.M2, 8, 0, 8, 0, P), (2, orc.M2, 10, 0, 64, 0, P),
+                                             (4, orc.M4, 10, 64, 0, _ffi.F_SQDIST, orc.F_CYTHON | P), (4, orc.M4, 10, 64, 0, 0, P),
+                                             (3, orc.M3, 10, 10, 32, _ffi.F_USE_PQ, orc.F_USE_PQ | P),
+                                             (3, orc.M3, 5, 5, 8, 0, P)):
+        ids, dist, cnt, st = ix.search_batch(qs, k, L=L, beam_width=bw, mode=mode, flags=fl)
+        oi, od, oc, ost = orc.search_batch(x, adj, qs, ix.medoid, omode, k, L=L, bw=bw, flags=ofl, codes=codes, codebook=cb,
+                                           nthreads=8)
+        assert (st["status"] == 0).all()
+        assert np.array_equal(ids, oi) and np.array_equal(cnt, oc), (mode, k, L, bw)
+        valid = oi != PAD
+        assert np.array_equal(dist[valid].view(np.uint32), od[valid].astype(np.float32).view(np.uint32)), (mode, k, L, bw)
+        assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), ost)
