@@ -106,6 +106,9 @@ struct dr_index {
     std::vector<uint32_t> h_perm;
     // bit order of the visited bitmaps (build_bit_order): rank[id] = bit position, adjr = rank of every adjacency slot
     DevBuf<uint32_t> rank, adjr;
+    // lossless byte copy of the vectors (integer-valued data, D = 128): 0 not checked yet, 1 present, -1 data does not qualify
+    DevBuf<uint8_t> vec8;
+    int vec8_state = 0;
     bool rank_valid = false, adjr_valid = false, use_adjr = false;
     uint32_t medoid_pos = 0;
 
@@ -332,6 +335,7 @@ extern "C" int dr_index_drop_vectors(dr_index *ix)
     HIPCHK(hipStreamSynchronize(ix->stream));
     HIPCHK(hipStreamSynchronize(ix->fstream));
     ix->vecp.release();
+    ix->vec8.release(); ix->vec8_state = -1;
     ix->has_vectors = false;
     return 0;
 }
@@ -350,7 +354,7 @@ extern "C" void dr_index_close(dr_index *ix)
         if (bs.fin_start) (void)hipEventDestroy(bs.fin_start);
         if (bs.fin_done) (void)hipEventDestroy(bs.fin_done);
     }
-    ix->pq_ub.release(); ix->phase.release(); ix->rank.release(); ix->adjr.release(); ix->fin_stat.release();
+    ix->pq_ub.release(); ix->phase.release(); ix->rank.release(); ix->adjr.release(); ix->fin_stat.release(); ix->vec8.release();
     ix->f64_q.release(); ix->f64_dist.release(); ix->f64_ids.release(); ix->f64_cnt.release(); ix->f64_vis.release(); ix->f64_stats.release();
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
     for (auto &pr : ix->kev) { if (pr[0]) (void)hipEventDestroy(pr[0]); if (pr[1]) (void)hipEventDestroy(pr[1]); }
@@ -439,6 +443,28 @@ static int build_bit_order(dr_index *ix)
     return 0;
 }
 
+// Byte rows (variant 10): SIFT-type descriptors are integers in [0, 255] held as float32. If EVERY component of the
+// index is such a value, a second copy as bytes (N*D bytes) lets the landing variant move a quarter of the row bytes
+// and take a whole expansion in one burst; v_cvt_f32_ubyte returns exactly the stored float, so distances are
+// bit-identical. Data that does not qualify (embeddings, un-rounded descriptors) keeps the float rows.
+static int build_byte_rows(dr_index *ix)
+{
+    static const bool off = getenv("DR_NO_BYTEROWS") != nullptr;
+    ix->vec8_state = -1;
+    if (off || ix->D != 128 || !ix->has_vectors) return 0;
+    DevBuf<uint32_t> bad;
+    if (bad.reserve(1, true) || ix->vec8.reserve((size_t)ix->N * ix->D)) return DR_E_NODEVICE;
+    hipLaunchKernelGGL(pack_u8_kernel, dim3((unsigned)std::min<uint64_t>((ix->N * ix->D + 255) / 256, 1u << 16)), dim3(256), 0, ix->stream,
+                       ix->vecp.p, ix->N, ix->D, ix->perm.p, ix->vec8.p, bad.p);
+    HIPCHK(hipGetLastError());
+    uint32_t hb = 1;
+    HIPCHK(hipMemcpyAsync(&hb, bad.p, 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    bad.release();
+    if (hb) ix->vec8.release(); else ix->vec8_state = 1;
+    return 0;
+}
+
 // Builder override: search over the under-construction rows (RX slots, degree array instead of first-masks),
 // queries already resident in ix->q / ix->qp, no outputs besides res_keys / res_n.
 struct BuildOverride { const uint32_t *adjb; const uint32_t *deg; uint32_t RX; uint32_t nq; };
@@ -487,12 +513,13 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     auto lds_of = [&](int kd) -> size_t {
         const int rb = DR_KIND_RB[kd];
         const size_t pw = (DR_KIND_LUT[kd] ? (size_t)ix->m * 256 * 4 : 0) + (size_t)ix->D * 4 + (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 512 +
-                          (rb ? (size_t)rb * ix->D * 4 : (size_t)NCHR_OF_SC[sc] * 64 * 12);
+                          (rb ? (size_t)rb * ix->D * (DR_KIND_U8[kd] ? 1 : 4) : (size_t)NCHR_OF_SC[sc] * 64 * 12);
         return (DR_KIND_CB[kd] ? (size_t)256 * ix->D * 4 : 0) + (size_t)DR_KIND_NW[kd] * pw;
     };
-    auto usable = [&](int kd) { return ix->kern->search[kd][sc] != nullptr && lds_of(kd) <= 160 * 1024; };
-    static const int PREF_M1[] = { 9, 6, 3, 0 }, PREF_ADC[] = { 5, 2 }, PREF_EX[] = { 8, 1 }, PREF_BUILD[] = { 1, 8 };
-    static const int PREF_M1_LIVE_LUT[] = { 0, 3, 9, 6 }, PREF_M1_LIVE_CB[] = { 3, 0, 9, 6 };
+    if (mode == DR_MODE_M1 && !ov && ix->vec8_state == 0) { const int rcb8 = build_byte_rows(ix); if (rcb8) return rcb8; }
+    auto usable = [&](int kd) { return ix->kern->search[kd][sc] != nullptr && lds_of(kd) <= 160 * 1024 && (!DR_KIND_U8[kd] || ix->vec8_state == 1); };
+    static const int PREF_M1[] = { 10, 9, 6, 3, 0 }, PREF_ADC[] = { 5, 2, -1, -1, -1 }, PREF_EX[] = { 8, 1, -1, -1, -1 }, PREF_BUILD[] = { 1, 8, -1, -1, -1 };
+    static const int PREF_M1_LIVE_LUT[] = { 0, 3, 10, 9, 6 }, PREF_M1_LIVE_CB[] = { 3, 0, 10, 9, 6 };
     const bool k_m1 = (mode == DR_MODE_M1), k_adc = (mode == DR_MODE_M3 && use_pq);
     // M1 has two regimes. On SIFT-scale data the rerank policy A4 is provably true for almost every expansion (Q1),
     // the ADC is skipped and the kernel is a pure row gather: vectors landed in LDS, table never built (9, 6).
@@ -501,7 +528,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // MEASURED on the first M1 batch an index state serves (its counters are read once that launch has finished, see
     // the end of this function); until then the SIFT-scale preference applies. Results never depend on the variant.
     const int *pref = k_m1 ? PREF_M1 : k_adc ? PREF_ADC : ov ? PREF_BUILD : PREF_EX;
-    const int npref = k_m1 ? 4 : k_adc ? 2 : 2;
+    const int npref = k_m1 ? 5 : k_adc ? 2 : 2;
     if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 8 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
     int kind = -1;
     for (int i = 0; i < npref && kind < 0; i++) if (usable(pref[i])) kind = pref[i];
@@ -510,7 +537,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e && !g_force_kind_set) g_force_kind = atoi(e); env_read = true; }
         const int g = g_force_kind;
         if (g >= 0 && g < DR_NUM_KINDS && usable(g)) {
-            const bool g_m1 = (g == 0 || g == 3 || g == 4 || g == 6 || g == 7 || g == 9), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8);
+            const bool g_m1 = (g == 0 || g == 3 || g == 4 || g == 6 || g == 7 || g == 9 || g == 10), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8);
             if ((g_m1 && k_m1) || (g_adc && k_adc) || (g_ex && !k_m1 && !k_adc)) kind = g;
         }
     }
@@ -562,6 +589,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (!ov && !ix->adjr_valid) { const int rcb = build_bit_order(ix); if (rcb) return rcb; }
     p.vecp = ix->vecp.p; p.adj = ix->adj.p; p.first = ix->first.p; p.codes = ix->codes.p; p.codebook = ix->codebook.p;
     p.adjr = (!ov && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
+    p.vec8 = ix->vec8_state == 1 ? ix->vec8.p : nullptr;
     p.queries = ix->q.p; p.queries_p = ix->qp.p;
     p.N = ix->N; p.D = ix->D; p.R = ix->R; p.m = ix->m; p.sd = ix->sd; p.medoid = ix->medoid; p.nq = nq;
     p.mode = mode; p.k = k; p.cap = cap; p.L = L; p.bw = bw; p.policy = policy; p.flags = flags;

@@ -433,3 +433,19 @@ __global__ void map_adjacency_kernel(const u32 *__restrict__ adj, u64 total, u64
         adjr[i] = nb < N ? rank[nb] : 0u;
     }
 }
+
+// Lossless byte copy of the vectors for the byte-row search variant (D = 128): out[row][j*16 + t] = element 8t + j
+// when that element is an integer in [0, 255]; any other value raises `bad` and the copy is discarded.
+__global__ void pack_u8_kernel(const float *__restrict__ vecp, u64 N, u32 D, const u32 *__restrict__ perm,
+                               u8 *__restrict__ out, u32 *__restrict__ bad)
+{
+    const u32 S = D / 8;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N * D; i += (u64)gridDim.x * blockDim.x) {
+        const u64 row = i / D;
+        const u32 e = (u32)(i % D);                       // original element index
+        const float v = vecp[row * D + perm[e]];
+        const float r = __builtin_rintf(v);
+        if (!(v == r && v >= 0.0f && v <= 255.0f)) { atomicOr(bad, 1u); continue; }
+        out[row * D + (e & 7u) * S + (e >> 3)] = (u8)(u32)r;
+    }
+}

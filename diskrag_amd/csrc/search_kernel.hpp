@@ -53,6 +53,7 @@ struct KStats { u32 steps, visited, exact, pq, status, inserts, pq_evaluated, re
 
 struct SearchParams {
     const float *vecp;       // [N][D] chain-major
+    const u8 *vec8;          // [N][D] the same vectors as bytes when every component is an integer in [0, 255] (else nullptr)
     const u32 *adj;          // [N][R]
     const u32 *adjr;         // [N][R] bit position of each neighbour in the visited bitmap (nullptr: the id itself)
     const u64 *first;        // [N][ceil(R/64)] bit s: slot s is a real id and its first occurrence in the row
@@ -521,7 +522,7 @@ DEV u32 a4_threshold_bits(float pq, float thr, bool &ok) {
     return cb;
 }
 
-template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0>
+template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false>
 DEV void search_body(const SearchParams &p)
 {
     constexpr bool QREG = (D <= 256);
@@ -541,9 +542,11 @@ DEV void search_body(const SearchParams &p)
     float *cb_lds = reinterpret_cast<float *>(smem);
     if constexpr (NEED_PQ && CBLDS && !ROWLDS) off += (size_t)256 * D * 4;
     constexpr size_t MERGE_BYTES = (size_t)NCHR * 64 * 12;   // merge scratch: NCHR*64 keys (u64) + states (u32)
-    static_assert(!ROWLDS || (size_t)RB * D * 4 >= MERGE_BYTES, "the row landing area doubles as merge scratch");
+    constexpr size_t ROW_BYTES = U8 ? (size_t)D : (size_t)D * 4;   // a landed row: bytes (lossless, see below) or floats
+    static_assert(!U8 || (ROWLDS && D == 128), "byte rows: the 12-wave landing variant at D = 128");
+    static_assert(!ROWLDS || (size_t)RB * ROW_BYTES >= MERGE_BYTES, "the row landing area doubles as merge scratch");
     const size_t per_wave = ((NEED_PQ && !CBLDS) ? (size_t)p.m * 256 * 4 : 0) + (size_t)D * 4 + (QREG ? 0 : (size_t)D * 4) + 512 +
-                            (ROWLDS ? (size_t)RB * D * 4 : MERGE_BYTES);
+                            (ROWLDS ? (size_t)RB * ROW_BYTES : MERGE_BYTES);
     unsigned char *wbase = smem + off + (size_t)wave * per_wave;
     size_t woff = 0;
     float *lut = reinterpret_cast<float *>(wbase);
@@ -765,7 +768,47 @@ DEV void search_body(const SearchParams &p)
                     }
                 }
                 if constexpr (KIND != DIST_ADC_SQ) {
-                    if constexpr (ROWLDS) {
+                    if constexpr (ROWLDS && U8) {
+                        // Byte rows. SIFT-type descriptors are integers in [0, 255] stored as float32: the engine
+                        // keeps a second, lossless copy as bytes (built only if EVERY component of the index
+                        // qualifies), laid out so that lane j of an octet finds the 16 steps of its accumulator
+                        // chain in one 16-byte piece (position j*16 + t = element 8t + j). A row is 128 bytes
+                        // instead of 512, a wavefront instruction lands 8 rows, and the whole expansion is ONE
+                        // burst. v_cvt_f32_ubyte gives back exactly the stored float, so the sum below is the same
+                        // arithmetic on the same values as the float path: bit-identical distances.
+                        const unsigned char *rowbuf8 = reinterpret_cast<const unsigned char *>(rowbuf);
+                        for (int b0 = 0; b0 < nrow; b0 += RB) {
+                            const int nb = min(RB, nrow - b0);
+                            u32 rid[RB / 8];
+#pragma unroll
+                            for (int r = 0; r < RB; r += 8) rid[r / 8] = nb_id[min(b0 + r + (lane >> 3), nrow - 1)];
+#pragma unroll
+                            for (int r = 0; r < RB; r += 8) {
+                                if (r < nb) {
+                                    const u8 *g = p.vec8 + (size_t)rid[r / 8] * D + (lane & 7) * 16;
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                        (__attribute__((address_space(3))) void *)(const_cast<unsigned char *>(rowbuf8) + (size_t)r * D), 16, 0, 0);
+                                }
+                            }
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            for (int r8 = 0; r8 < nb; r8 += 8) {
+                                const int row = min(r8 + oct, nb - 1);
+                                const uint4 w = *reinterpret_cast<const uint4 *>(rowbuf8 + (size_t)row * D + j * 16);
+                                const u32 words[4] = { w.x, w.y, w.z, w.w };
+                                float r = 0.0f;
+#pragma unroll
+                                for (int t = 0; t < 16; t++) {
+                                    const float v = (float)((words[t >> 2] >> (8 * (t & 3))) & 255u);
+                                    const float sq = sqd(v, qreg.v[t]);
+                                    r = (t == 0) ? sq : f_add(r, sq);
+                                }
+                                float ev = octet_combine(r);
+                                if (p.norm) ev = f_sqrt(ev);
+                                if (j == 0 && r8 + oct < nb) nb_e[b0 + r8 + oct] = ev;
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        }
+                    } else if constexpr (ROWLDS) {
                         constexpr int LPR = D / 4;          // lanes (16-byte pieces) per row
                         constexpr int RPI = 64 / LPR;       // rows per wave instruction (1 KiB)
                         for (int b0 = 0; b0 < nrow; b0 += RB) {
@@ -1122,8 +1165,8 @@ DEV void search_body(const SearchParams &p)
     }
 }
 
-template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0>
+template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const SearchParams p)
 {
-    search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB>(p);
+    search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB, U8>(p);
 }
