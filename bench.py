@@ -162,6 +162,24 @@ def main():
                      "kernel_ms": float(np.mean(k2)), "roofline_frac": b2 / (float(np.mean(k2)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "exact_distances_per_query": float(st2["exact"].mean())}
 
+    # the same step with float32 rows (variant 9): what the kernel does on data that is not integer-valued
+    float_rows = None
+    byte_rows = bool((timing["block"] == 768 and timing["lds_bytes"] < 140000) or timing["block"] == 1024)
+    if byte_rows and not args.no_secondary:
+        ix.debug_force_kind(9)
+        for _ in range(2):
+            ix.batch_run(args.k, L=args.L, beam_width=args.bw, mode=mode)
+        ix.batch_sync()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            ix.batch_run(args.k, L=args.L, beam_width=args.bw, mode=mode)
+        ix.batch_sync()
+        el3 = time.perf_counter() - t3
+        k3 = ix.timing()["search_kernel_ms"]
+        ix.debug_force_kind(-1)
+        float_rows = {"qps_rank0": args.nq * args.steps / el3, "kernel_ms": k3,
+                      "roofline_frac": alg_bytes / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+
     total_q = args.nq * world * args.steps
     value = total_q / elapsed
     out = {
@@ -177,7 +195,11 @@ def main():
                    "per_query": {"expansions": float(S.mean()), "pq_distances": float(st["pq"].mean()), "pq_evaluated": float(V.mean()),
                                  "exact_distances": float(X.mean()), "algorithmic_bytes": float(bytes_q.mean())},
                    "launch": {k_: timing[k_] for k_ in ("grid", "block", "lds_bytes", "waves_per_cu")},
-                   "finalize_kernel_ms": timing["finalize_kernel_ms"], "secondary_no_trim": secondary},
+                   "finalize_kernel_ms": timing["finalize_kernel_ms"], "secondary_no_trim": secondary,
+                   "row_storage": ("u8: lossless byte copy of the integer-valued vectors (every component checked; distances "
+                                   "bit-identical); roofline.achieved counts the reference's 4*D bytes per scored vector, "
+                                   "roofline.traffic is what HBM really moved") if byte_rows else "f32",
+                   "float32_rows": float_rows},
         "roofline": {"bound": "hbm", "kernel": "search_kernel<128,M1>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},

@@ -20,7 +20,7 @@ for bw in (8, 0):
     fs, ws = vals(f, 'FETCH_SIZE', 'search_kernel<128, true'), vals(w, 'WRITE_SIZE', 'search_kernel<128, true')
     cal = vals(f, 'FETCH_SIZE', 'bruteforce_kernel')
     rd, wr = sum(fs) / len(fs) * 1024 * 2, sum(ws) / len(ws) * 1024
-    out[f"beam_width_{bw}"] = {"kernel": "search_kernel<128, true, 0, 2, 12, true, 24>", "FETCH_SIZE_KiB": fs, "WRITE_SIZE_KiB": ws,
+    out[f"beam_width_{bw}"] = {"kernel": sorted({r['Kernel_Name'] for r in f if 'search_kernel<128, true' in r['Kernel_Name']})[0], "FETCH_SIZE_KiB": fs, "WRITE_SIZE_KiB": ws,
                                "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                                "algorithmic_bytes_per_launch": alg,
                                "calibration": {"kernel": "bruteforce_kernel<128>, 1 query", "known_bytes": 512000000, "FETCH_SIZE_KiB": cal[0],

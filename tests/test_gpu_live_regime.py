@@ -65,8 +65,49 @@ def test_regime_probe_on_sift_scale_data():
         ids, dist, cnt, st = ix.search_batch(q, 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
         assert ix.debug_force_kind(-1) == 0                      # Q1: the policy is provably true, ADC skipped
         assert st["pq_evaluated"].sum() < 0.1 * st["pq"].sum()
-        assert ix.timing()["block"] == 768                       # vectors landed in LDS, 12 waves per workgroup
+        assert ix.timing()["block"] == 1024                      # byte rows landed in LDS, 16 waves per workgroup
         ix.set_pq(cb, codes)                                     # a PQ change resets the probe
         assert ix.debug_force_kind(-1) == -1
     finally:
         ix.close()
+
+
+def test_byte_rows_are_lossless_and_only_for_integer_data():
+    """Variants 10 / 11 read a byte copy of the vectors, built only when every component is an integer in [0, 255]:
+    same bits as the float-row variant 9 and as the oracle; data that does not qualify never takes them."""
+    from diskrag_amd import _ffi
+    from diskrag_amd.synth import sift_like
+    from oracle import pyoracle as orc
+    x, q = sift_like(24000, 128, n_queries=128, n_clusters=64, seed=91, query_seed=92)
+    assert np.array_equal(x, np.rint(x)) and x.min() >= 0 and x.max() <= 255
+    ix, medoid, adj, cb, codes = _index(x, 32, 32)
+    try:
+        want = orc.search_batch(x, adj, q, medoid, orc.M1, 10, L=100, bw=8, codes=codes, codebook=cb, nthreads=8)
+        blocks = {}
+        for kind in (9, 10, 11, -1):
+            ix.debug_force_kind(kind)
+            for (L, bw) in ((100, 8), (100, 0), (300, 16), (20, 8)):
+                ids, dist, cnt, st = ix.search_batch(q, 10, L=L, beam_width=bw, mode=_ffi.MODE_M1)
+                w = want if (L, bw) == (100, 8) else orc.search_batch(x, adj, q, medoid, orc.M1, 10, L=L, bw=bw, codes=codes,
+                                                                      codebook=cb, nthreads=8)
+                assert np.array_equal(ids, w[0]) and np.array_equal(dist.view(np.uint32), w[1].astype(np.float32).view(np.uint32))
+                assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), w[3])
+            blocks[kind] = (ix.timing()["block"], ix.timing()["lds_bytes"])
+        assert blocks[9][0] == 768 and blocks[10][0] == 768 and blocks[10][1] < blocks[9][1] and blocks[11][0] == 1024
+        assert blocks[-1] == blocks[11]                         # the engine's own choice on integer data
+    finally:
+        ix.debug_force_kind(-1)
+        ix.close()
+    # the same descriptors shifted by a quarter: not integers any more -> float rows, still the oracle's bits
+    y = x + np.float32(0.25)
+    iy, medoid, adj, cb, codes = _index(y, 32, 32)
+    try:
+        for kind in (10, 11, -1):
+            iy.debug_force_kind(kind)
+            ids, dist, cnt, st = iy.search_batch(q, 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
+            assert iy.timing()["block"] == 768 and iy.timing()["lds_bytes"] > 140000      # variant 9
+            w = orc.search_batch(y, adj, q, medoid, orc.M1, 10, L=100, bw=8, codes=codes, codebook=cb, nthreads=8)
+            assert np.array_equal(ids, w[0]) and np.array_equal(dist.view(np.uint32), w[1].astype(np.float32).view(np.uint32))
+    finally:
+        iy.debug_force_kind(-1)
+        iy.close()
