@@ -531,6 +531,10 @@ DEV void search_body(const SearchParams &p)
     static_assert(!ROWLDS || (CBLDS && SPLIT && (64 % (D / 4)) == 0), "row landing needs whole rows per instruction");
     constexpr int NP = !SPLIT ? 1 : (NW >= 16 ? 1 : (NW >= 8 ? 2 : 4));   // row passes in flight
     constexpr bool NEED_PQ = FILTER || KIND == DIST_ADC_SQ;
+    // the rerank-policy kernels only ever serve M1 (squared distances, trim rule of search_engine.py:477-479): folding the
+    // mode at compile time drops the other variants' branches and their scalar registers from the hot loop
+    const u32 kmode = FILTER ? 1u : p.mode;
+    const u32 knorm = FILTER ? 0u : p.norm;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
@@ -640,7 +644,7 @@ DEV void search_body(const SearchParams &p)
             } else {
                 d0 = pw_row_stream<0, D, D, QREG>(p.vecp + (size_t)start * D, &qreg, qperm, j);
                 d0 = __uint_as_float(readlane32(__float_as_uint(d0), 0));
-                if (p.norm) d0 = f_sqrt(d0);
+                if (knorm) d0 = f_sqrt(d0);
                 nexact++;
             }
             const u32 db = __float_as_uint(d0);
@@ -671,8 +675,8 @@ DEV void search_body(const SearchParams &p)
             {
                 const float W = key_dist(list_get<NCHR>(rk, rn - 1));
                 bool stop;
-                if (p.mode == 3u) stop = (cd > W) && (rn == cap);
-                else if (p.mode == 4u) stop = (cd > W);
+                if (kmode == 3u) stop = (cd > W) && (rn == cap);
+                else if (kmode == 4u) stop = (cd > W);
                 else stop = (rn >= cap) && (cd > W);
                 if (stop) break;
             }
@@ -803,7 +807,7 @@ DEV void search_body(const SearchParams &p)
                                     r = (t == 0) ? sq : f_add(r, sq);
                                 }
                                 float ev = octet_combine(r);
-                                if (p.norm) ev = f_sqrt(ev);
+                                if (knorm) ev = f_sqrt(ev);
                                 if (j == 0 && r8 + oct < nb) nb_e[b0 + r8 + oct] = ev;
                             }
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -832,7 +836,7 @@ DEV void search_body(const SearchParams &p)
                                 RowRegs<D> rr;
                                 row_load<0, D, D>(rowbuf + (size_t)row * D, j, rr);
                                 float ev = row_reduce<0, D, D>(rr, qreg);
-                                if (p.norm) ev = f_sqrt(ev);
+                                if (knorm) ev = f_sqrt(ev);
                                 if (j == 0 && r8 + oct < nb) nb_e[b0 + r8 + oct] = ev;
                             }
                             // the landing area is rewritten by the next burst: its reads above have been consumed
@@ -852,7 +856,7 @@ DEV void search_body(const SearchParams &p)
                         for (int r = 0; r < 8; r++) {
                             if (r * 8 < nrow) {
                                 float ev = row_reduce<0, D, D>(rr[r % NP], qreg);
-                                if (p.norm) ev = f_sqrt(ev);
+                                if (knorm) ev = f_sqrt(ev);
                                 if (j == 0 && r * 8 + oct < nrow) nb_e[r * 8 + oct] = ev;
                                 if ((r + NP) * 8 < nrow) {
                                     const int idx = min((r + NP) * 8 + oct, nrow - 1);
@@ -864,7 +868,7 @@ DEV void search_body(const SearchParams &p)
                         for (int r0 = 0; r0 * 8 < nrow; r0++) {
                             const int idx = min(r0 * 8 + oct, nrow - 1);
                             float ev = pw_row_stream<0, D, D, QREG>(p.vecp + (size_t)nb_id[idx] * D, &qreg, qperm, j);
-                            if (p.norm) ev = f_sqrt(ev);
+                            if (knorm) ev = f_sqrt(ev);
                             if (j == 0 && r0 * 8 + oct < nrow) nb_e[r0 * 8 + oct] = ev;
                         }
                     }
@@ -1034,7 +1038,7 @@ DEV void search_body(const SearchParams &p)
             }
             PH(6);
             // ---- frontier trim
-            if (p.mode == 1u || p.mode == 2u) {
+            if (kmode == 1u || kmode == 2u) {
                 // candidates = heapq.nsmallest(beam_width, candidates) (search_engine.py:477-479)
                 if (p.bw != 0u && (u32)(cnT + tn) + junk > p.bw) {
                     u32 excess = (u32)(cnT + tn) + junk - p.bw;
@@ -1078,7 +1082,7 @@ DEV void search_body(const SearchParams &p)
                         else tn--;
                     }
                 }
-            } else if (p.mode == 3u) {
+            } else if (kmode == 3u) {
                 // while len(beam) > beam_width: heappop(beam)   (vamana_graph.py:592-593, Q9: pops the BEST)
                 if ((u32)(cnT + tn) + junk > p.bw) {
                     u32 excess = (u32)(cnT + tn) + junk - p.bw;
@@ -1132,7 +1136,7 @@ DEV void search_body(const SearchParams &p)
             // tie detection on the sort key of the final stable sort (distance; sqrt(distance) for M3)
             const u64 nextk = wave_shl1(rk.v[c], (c + 1 < NCHR) ? readlane64(rk.v[c + 1 < NCHR ? c + 1 : c], 0) : ~0ull);
             float a = key_dist(rk.v[c]), b = key_dist(nextk);
-            if (p.mode == 3u) { a = f_sqrt(a); b = f_sqrt(b); }
+            if (kmode == 3u) { a = f_sqrt(a); b = f_sqrt(b); }
             if (i < kout && i + 1 < rn && a == b) t = true;
             if (p.out_ids) {
                 if (i < (int)p.k) {
