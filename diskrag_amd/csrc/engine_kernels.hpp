@@ -398,7 +398,7 @@ __global__ void gather_subvectors_kernel(const float *__restrict__ vecp, const u
     for (u32 e = threadIdx.x; e < D; e += blockDim.x) out[(size_t)row * D + e] = vecp[(size_t)ids[row] * D + perm[e]];
 }
 
-// sqrt(sum_j max_c T[j][c]) per query, sum in A3's order (see adc_upper_bound in search_kernel.hpp): one block of
+// sqrt(sum_j max_c T[j][c]) per query, sum in A3's order (an upper bound of asymmetric_distance for any code word; its use is described in search_kernel.hpp): one block of
 // 256 threads per query, thread c owns centroid c of every sub-quantiser (coalesced codebook reads).
 __global__ __launch_bounds__(256) void pq_bound_kernel(const float *__restrict__ codebook, const float *__restrict__ queries,
                                                        u32 D, u32 m, u32 sd, float *__restrict__ out)

@@ -471,32 +471,6 @@ DEV float wave_max(float x)
     return x;
 }
 
-// sqrt(sum_j max_c T[j][c]) with the sum in A3's order: an upper bound of asymmetric_distance for any code word.
-// Lane l scans half (l & 1) of the 256 centroids of sub-quantisers (l >> 1) + 32 t; the per-j maxima are then
-// added in j order through scalar broadcasts.
-template <bool CBLDS> DEV float adc_upper_bound(const float *tab, const float *q, u32 m, u32 sd)
-{
-    const u32 lane = lane_id();
-    float s = 0.0f;
-    for (u32 j0 = 0; j0 < m; j0 += 32) {
-        const u32 jq = j0 + (lane >> 1);
-        float mx = 0.0f;
-        if (jq < m) {
-            const u32 c0 = (lane & 1u) * 128u;
-            for (u32 c = c0; c < c0 + 128u; c++) {
-                float t;
-                if constexpr (CBLDS) t = pw_run_lane(tab + ((size_t)jq * 256 + c) * sd, q + jq * sd, (int)sd);
-                else t = tab[jq * 256 + c];
-                mx = fmaxf(mx, t);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 1));
-        const u32 lim = (m - j0) < 32u ? (m - j0) : 32u;
-        for (u32 t = 0; t < lim; t++) s = f_add(s, __uint_as_float(readlane32(__float_as_uint(mx), (int)(2 * t))));
-    }
-    return f_sqrt(s);
-}
-
 // ---- the kernel -------------------------------------------------------------------------------------------
 // D      vector dimension (compile time: the pairwise tree is unrolled)
 // FILTER M1's ADC + rerank policy            KIND   traversal metric
@@ -508,6 +482,8 @@ template <bool CBLDS> DEV float adc_upper_bound(const float *tab, const float *q
 //        read their chain-major groups back with ds_read_b128. The codebook then stays in global memory (L2) and
 //        is only touched on the rare expansions whose ADC cannot be skipped (CBLDS must be true: the table
 //        entries are recomputed from the codebook, wherever it lives).
+// U8     the landing variant on the lossless byte copy of integer-valued vectors (D = 128): 128-byte rows, a whole
+//        expansion per burst.
 // A4 as a threshold on the worst distance: returns the bits of x = the largest float W >= 0 with f_mul(W, thr) <= pq.
 // f_mul(., thr) is monotone, so the reference's test `pq < thr * W` (search_engine.py:390-395) holds exactly for
 // W > x. `ok` is cleared if the fix-up did not reach the boundary (reported through stats.status, never silent).
@@ -535,6 +511,11 @@ DEV void search_body(const SearchParams &p)
     // mode at compile time drops the other variants' branches and their scalar registers from the hot loop
     const u32 kmode = FILTER ? 1u : p.mode;
     const u32 knorm = FILTER ? 0u : p.norm;
+    // (they are never used by the builder either: first-occurrence masks, outputs, tie list and the per-query ADC bounds
+    // are always there)
+    const bool has_first = FILTER ? true : (p.first != nullptr);
+    const bool has_out = FILTER ? true : (p.out_ids != nullptr);
+    const bool has_ties = FILTER ? true : (p.tie_list != nullptr);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
@@ -615,7 +596,7 @@ DEV void search_body(const SearchParams &p)
         // data (squared distances ~1e4-1e5, sqrt(ADC) ~1e2) that is every expansion (quirk Q1). Exact: results and
         // counters are unchanged; stats.pq_evaluated says how many ADC sums were really computed.
         float pq_ub = __uint_as_float(0x7F800000u);
-        if constexpr (FILTER) pq_ub = p.pq_ub ? p.pq_ub[qi] : adc_upper_bound<CBLDS>(pq_tab, qorig, p.m, p.sd);
+        if constexpr (FILTER) pq_ub = p.pq_ub[qi];   // pq_bound_kernel, once per uploaded batch
 
         u32 npq_eval = 0;
         u32 steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0, ninserts = 0;
@@ -692,16 +673,16 @@ DEV void search_body(const SearchParams &p)
                 const u32 *posrow = p.adjr ? p.adjr + (size_t)cur * p.R : idrow;
                 // (the degree array of the build mode is read as the aligned 8 bytes around deg[cur]: same load shape
                 // as the mask word, so the compiler keeps one straight-line group of loads; deg has N + 1 entries)
-                const u64 *auxp = p.first ? p.first + (size_t)cur * nwords + (cbase >> 6)
+                const u64 *auxp = has_first ? p.first + (size_t)cur * nwords + (cbase >> 6)
                                           : reinterpret_cast<const u64 *>(p.deg + (cur & ~1u));
                 const u32 sl = min(slot, p.R - 1);
                 const u32 nbid_l = idrow[sl], nbpos_l = posrow[sl];
                 const u64 aux_w = auxp[0];
                 const u32 nbid = slot < p.R ? nbid_l : 0xFFFFFFFFu;
                 const u32 nbpos = slot < p.R ? nbpos_l : 0xFFFFFFFFu;
-                const u64 aux = p.first ? aux_w : (u64)(u32)(aux_w >> ((cur & 1u) * 32));
+                const u64 aux = has_first ? aux_w : (u64)(u32)(aux_w >> ((cur & 1u) * 32));
                 bool active;
-                if (p.first) active = ((aux >> lane) & 1ull) != 0ull;
+                if (has_first) active = ((aux >> lane) & 1ull) != 0ull;
                 else active = slot < min((u32)aux, p.R) && nbid != 0xFFFFFFFFu;
                 PH(2);
                 // visited test-and-set: one atomic round trip; duplicates inside a row were removed by `first`
@@ -1138,14 +1119,14 @@ DEV void search_body(const SearchParams &p)
             float a = key_dist(rk.v[c]), b = key_dist(nextk);
             if (kmode == 3u) { a = f_sqrt(a); b = f_sqrt(b); }
             if (i < kout && i + 1 < rn && a == b) t = true;
-            if (p.out_ids) {
+            if (has_out) {
                 if (i < (int)p.k) {
                     p.out_ids[(size_t)qi * p.k + i] = (i < kout) ? ~(u32)rk.v[c] : 0xFFFFFFFFu;
                     p.out_dist[(size_t)qi * p.k + i] = (i < kout) ? a : __uint_as_float(0x7FC00000u);
                 }
             }
         }
-        if (p.out_ids) for (int i = NCHR * 64 + lane; i < (int)p.k; i += 64) {
+        if (has_out) for (int i = NCHR * 64 + lane; i < (int)p.k; i += 64) {
             p.out_ids[(size_t)qi * p.k + i] = 0xFFFFFFFFu;
             p.out_dist[(size_t)qi * p.k + i] = __uint_as_float(0x7FC00000u);
         }
@@ -1153,7 +1134,7 @@ DEV void search_body(const SearchParams &p)
         if (lane == 0) {
             p.res_n[qi] = (u32)rn;
             if (p.out_count) p.out_count[qi] = (u32)kout;
-            if (anyt && p.tie_list) p.tie_list[atomicAdd(p.tie_count, 1u)] = qi;
+            if (anyt && has_ties) p.tie_list[atomicAdd(p.tie_count, 1u)] = qi;
             KStats st;
             st.steps = steps; st.visited = nvisited; st.exact = nexact; st.pq = npq; st.status = status;
             st.inserts = ninserts; st.pq_evaluated = npq_eval; st.reserved = 0;
