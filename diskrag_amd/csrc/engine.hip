@@ -516,9 +516,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
                           (rb ? (size_t)rb * ix->D * (DR_KIND_U8[kd] ? 1 : 4) : (size_t)NCHR_OF_SC[sc] * 64 * 12);
         return (DR_KIND_CB[kd] ? (size_t)256 * ix->D * 4 : 0) + (size_t)DR_KIND_NW[kd] * pw;
     };
-    if (mode == DR_MODE_M1 && !ov && ix->vec8_state == 0) { const int rcb8 = build_byte_rows(ix); if (rcb8) return rcb8; }
+    if (!ov && ix->vec8_state == 0) { const int rcb8 = build_byte_rows(ix); if (rcb8) return rcb8; }
     auto usable = [&](int kd) { return ix->kern->search[kd][sc] != nullptr && lds_of(kd) <= 160 * 1024 && (!DR_KIND_U8[kd] || ix->vec8_state == 1); };
-    static const int PREF_M1[] = { 11, 10, 9, 6, 3, 0 }, PREF_ADC[] = { 5, 2, -1, -1, -1, -1 }, PREF_EX[] = { 8, 1, -1, -1, -1, -1 }, PREF_BUILD[] = { 1, 8, -1, -1, -1, -1 };
+    static const int PREF_M1[] = { 11, 10, 9, 6, 3, 0 }, PREF_ADC[] = { 5, 2, -1, -1, -1, -1 }, PREF_EX[] = { 12, 8, 1, -1, -1, -1 }, PREF_BUILD[] = { 1, 8, -1, -1, -1, -1 };
     static const int PREF_M1_LIVE_LUT[] = { 0, 3, 11, 10, 9, 6 }, PREF_M1_LIVE_CB[] = { 3, 0, 11, 10, 9, 6 };
     const bool k_m1 = (mode == DR_MODE_M1), k_adc = (mode == DR_MODE_M3 && use_pq);
     // M1 has two regimes. On SIFT-scale data the rerank policy A4 is provably true for almost every expansion (Q1),
@@ -528,7 +528,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // MEASURED on the first M1 batch an index state serves (its counters are read once that launch has finished, see
     // the end of this function); until then the SIFT-scale preference applies. Results never depend on the variant.
     const int *pref = k_m1 ? PREF_M1 : k_adc ? PREF_ADC : ov ? PREF_BUILD : PREF_EX;
-    const int npref = k_m1 ? 6 : k_adc ? 2 : 2;
+    const int npref = k_m1 ? 6 : k_adc ? 2 : ov ? 2 : 3;
     if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 8 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
     int kind = -1;
     for (int i = 0; i < npref && kind < 0; i++) if (usable(pref[i])) kind = pref[i];
@@ -537,7 +537,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e && !g_force_kind_set) g_force_kind = atoi(e); env_read = true; }
         const int g = g_force_kind;
         if (g >= 0 && g < DR_NUM_KINDS && usable(g)) {
-            const bool g_m1 = (g == 0 || g == 3 || g == 4 || g == 6 || g == 7 || g == 9 || g == 10 || g == 11), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8);
+            const bool g_m1 = (g == 0 || g == 3 || g == 4 || g == 6 || g == 7 || g == 9 || g == 10 || g == 11), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8 || g == 12);
             if ((g_m1 && k_m1) || (g_adc && k_adc) || (g_ex && !k_m1 && !k_adc)) kind = g;
         }
     }

@@ -95,6 +95,14 @@ def test_byte_rows_are_lossless_and_only_for_integer_data():
             blocks[kind] = (ix.timing()["block"], ix.timing()["lds_bytes"])
         assert blocks[9][0] == 768 and blocks[10][0] == 768 and blocks[10][1] < blocks[9][1] and blocks[11][0] == 1024
         assert blocks[-1] == blocks[11]                         # the engine's own choice on integer data
+        # the exact traversals: float rows (8) == byte rows (12) == oracle
+        for (mode, omode, k, L, bw, fl, ofl) in ((2, orc.M2, 8, 0, 8, 0, orc.F_PAIRWISE), (4, orc.M4, 10, 50, 0, _ffi.F_SQDIST, orc.F_CYTHON | orc.F_PAIRWISE)):
+            w = orc.search_batch(x, adj, q, medoid, omode, k, L=L, bw=bw, flags=ofl, nthreads=8)
+            for kind, blk in ((8, 512), (12, 1024), (-1, 1024)):
+                ix.debug_force_kind(kind)
+                ids, dist, cnt, st = ix.search_batch(q, k, L=L, beam_width=bw, mode=mode, flags=fl)
+                assert ix.timing()["block"] == blk
+                assert np.array_equal(ids, w[0]) and np.array_equal(dist.view(np.uint32), w[1].astype(np.float32).view(np.uint32))
     finally:
         ix.debug_force_kind(-1)
         ix.close()
