@@ -530,14 +530,18 @@ DEV void search_body(const SearchParams &p)
     constexpr size_t ROW_BYTES = U8 ? (size_t)D : (size_t)D * 4;   // a landed row: bytes (lossless, see below) or floats
     static_assert(!U8 || (ROWLDS && D == 128), "byte rows: the 12-wave landing variant at D = 128");
     static_assert(!ROWLDS || (size_t)RB * ROW_BYTES >= MERGE_BYTES, "the row landing area doubles as merge scratch");
-    const size_t per_wave = ((NEED_PQ && !CBLDS) ? (size_t)p.m * 256 * 4 : 0) + (size_t)D * 4 + (QREG ? 0 : (size_t)D * 4) + 512 +
+    // the query in its original element order is needed in LDS only where table entries are recomputed per neighbour
+    // from the codebook; the per-query table is built once, straight from global memory (at D = 1536, m = 32 that is
+    // the 6 KiB between three and four wavefronts per CU)
+    constexpr bool QORIG_LDS = NEED_PQ && CBLDS;
+    const size_t per_wave = ((NEED_PQ && !CBLDS) ? (size_t)p.m * 256 * 4 : 0) + (QORIG_LDS ? (size_t)D * 4 : 0) + (QREG ? 0 : (size_t)D * 4) + 512 +
                             (ROWLDS ? (size_t)RB * ROW_BYTES : MERGE_BYTES);
     unsigned char *wbase = smem + off + (size_t)wave * per_wave;
     size_t woff = 0;
     float *lut = reinterpret_cast<float *>(wbase);
     if constexpr (NEED_PQ && !CBLDS) woff += (size_t)p.m * 256 * 4;
     float *qorig = reinterpret_cast<float *>(wbase + woff);
-    woff += (size_t)D * 4;
+    if constexpr (QORIG_LDS) woff += (size_t)D * 4;
     float *qperm = reinterpret_cast<float *>(wbase + woff);
     if constexpr (!QREG) woff += (size_t)D * 4;
     u32 *nb_id = reinterpret_cast<u32 *>(wbase + woff);
@@ -579,14 +583,14 @@ DEV void search_body(const SearchParams &p)
             const float *qg = p.queries + (size_t)qi * D;
             const float *qpg = p.queries_p + (size_t)qi * D;
             for (int i = lane; i < D; i += 64) {
-                qorig[i] = qg[i];
+                if constexpr (QORIG_LDS) qorig[i] = qg[i];
                 if constexpr (!QREG) qperm[i] = qpg[i];
             }
             if constexpr (QREG) load_query_regs<0, D, D>(qpg, j, qreg);
         }
         WSYNC();
         if constexpr (NEED_PQ && !CBLDS) {
-            build_lut_wave(lut, p.codebook, qorig, p.m, p.sd);
+            build_lut_wave(lut, p.codebook, p.queries + (size_t)qi * D, p.m, p.sd);
             WSYNC();
         }
         // Upper bound of sqrt(ADC) over ALL code words for this query: sum_j max_c T[j][c] accumulated in the same
