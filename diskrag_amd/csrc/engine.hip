@@ -19,6 +19,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -135,6 +136,7 @@ struct dr_index {
     int parity = 0, last_set = 0;
     hipStream_t fstream = nullptr;
     DevBuf<uint32_t> fin_stat;    // [1] largest tie-list length since the last sync (finalize_kernel)
+    std::map<std::pair<const void *, size_t>, int> occ_cache;
     DevBuf<double> f64_q, f64_dist;                 // dr_search_batch_f64 scratch
     DevBuf<uint32_t> f64_ids, f64_cnt, f64_vis;
     DevBuf<KStats> f64_stats;
@@ -547,10 +549,18 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     const int NW = DR_KIND_NW[kind];
     const size_t lds = lds_of(kind);
     if (lds > 160 * 1024) return fail(DR_E_UNSUPPORTED, "LDS footprint %zu B exceeds 160 KiB", lds);
-    HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // (kernel attribute + occupancy are asked once per (variant, LDS size): a single-query call is all overhead)
     int occ = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 64 * NW, lds));
-    if (occ < 1) occ = 1;
+    {
+        auto it = ix->occ_cache.find(std::make_pair(kfn, lds));
+        if (it != ix->occ_cache.end()) occ = it->second;
+        else {
+            HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 64 * NW, lds));
+            if (occ < 1) occ = 1;
+            ix->occ_cache[std::make_pair(kfn, lds)] = occ;
+        }
+    }
     const uint32_t nq = ix->nq;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nq + NW - 1) / NW, (uint64_t)occ * ix->num_cu);
     const uint32_t slots = grid * NW;
