@@ -95,7 +95,7 @@ def test_device_built_index_survives_the_reference_file_formats(tmp_path):
     from diskrag_amd import HipIndex, persist
     from diskrag_amd.search_engine import SearchEngineCorrect
     from diskrag_amd.synth import sift_like
-    x, q = sift_like(20000, 128, n_queries=64, n_clusters=64, seed=11, query_seed=12)
+    x, q = sift_like(40000, 128, n_queries=64, n_clusters=64, seed=11, query_seed=12)   # > 32768: the locality bit order is on
     ix = HipIndex.create_empty(x, R=32)
     medoid, _ = ix.build_vamana(L_build=60, alpha=1.2, passes=2, seed=3)
     cb = ix.pq_train(32, n_sample=10000, iters=4)
@@ -105,8 +105,8 @@ def test_device_built_index_survives_the_reference_file_formats(tmp_path):
     cdir = tmp_path / "built"
     meta = persist.write_index(cdir / "index", x, adj, medoid, codes=codes, codebook=cb,
                                build_params={"L": 60, "alpha": 1.2}, pq_pickle=False)
-    assert meta["N"] == 20000 and meta["n_subvectors"] == 32 and meta["use_pq"]
-    (cdir / "collection_info.json").write_text(_json.dumps({"name": "built", "dimension": 128, "num_vectors": 20000}))
+    assert meta["N"] == 40000 and meta["n_subvectors"] == 32 and meta["use_pq"]
+    (cdir / "collection_info.json").write_text(_json.dumps({"name": "built", "dimension": 128, "num_vectors": 40000}))
     eng = SearchEngineCorrect("built", base_dir=tmp_path)
     assert eng.use_pq and eng.medoid_idx == medoid
     got = eng.search_batch(q, k=10, L=50, beam_width=8)
