@@ -137,6 +137,7 @@ struct dr_index {
     hipStream_t fstream = nullptr;
     DevBuf<uint32_t> fin_stat;    // [1] largest tie-list length since the last sync (finalize_kernel)
     std::map<std::pair<const void *, size_t>, int> occ_cache;
+    void *pinned = nullptr; size_t pinned_bytes = 0;      // host slab for result downloads
     DevBuf<double> f64_q, f64_dist;                 // dr_search_batch_f64 scratch
     DevBuf<uint32_t> f64_ids, f64_cnt, f64_vis;
     DevBuf<KStats> f64_stats;
@@ -358,6 +359,7 @@ extern "C" void dr_index_close(dr_index *ix)
     }
     ix->pq_ub.release(); ix->phase.release(); ix->rank.release(); ix->adjr.release(); ix->fin_stat.release(); ix->vec8.release();
     ix->f64_q.release(); ix->f64_dist.release(); ix->f64_ids.release(); ix->f64_cnt.release(); ix->f64_vis.release(); ix->f64_stats.release();
+    if (ix->pinned) (void)hipHostFree(ix->pinned);
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
     for (auto &pr : ix->kev) { if (pr[0]) (void)hipEventDestroy(pr[0]); if (pr[1]) (void)hipEventDestroy(pr[1]); }
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -730,14 +732,29 @@ static int download_locked(dr_index *ix, uint32_t *out_ids, float *out_dist, uin
     if (rc) return rc;
     dr_index::BatchSet &bs = ix->sets[ix->last_set];
     const uint32_t nq = ix->nq, k = ix->last_k;
-    HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
-    if (out_ids) HIPCHK(hipMemcpyAsync(out_ids, bs.out_ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
-    if (out_dist) HIPCHK(hipMemcpyAsync(out_dist, bs.out_dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
-    if (out_count) HIPCHK(hipMemcpyAsync(out_count, bs.out_count.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ix->stream));
+    // results go through a pinned host slab: four asynchronous copies and one wait, then plain memcpys into the caller's
+    // (pageable) arrays -- a pageable destination makes every hipMemcpyAsync a blocking staged copy of its own
     static_assert(sizeof(dr_stats) == sizeof(KStats), "stats layout");
-    if (stats) HIPCHK(hipMemcpyAsync(stats, bs.stats.p, (size_t)nq * sizeof(KStats), hipMemcpyDeviceToHost, ix->stream));
+    const size_t b_ids = (size_t)nq * k * 4, b_cnt = (size_t)nq * 4, b_st = (size_t)nq * sizeof(KStats);
+    const size_t need = 2 * b_ids + b_cnt + b_st;
+    if (ix->pinned_bytes < need) {
+        if (ix->pinned) (void)hipHostFree(ix->pinned);
+        ix->pinned = nullptr; ix->pinned_bytes = 0;
+        if (hipHostMalloc(&ix->pinned, need, hipHostMallocDefault) != hipSuccess) return fail(DR_E_NODEVICE, "hipHostMalloc(%zu) failed", need);
+        ix->pinned_bytes = need;
+    }
+    unsigned char *hp = static_cast<unsigned char *>(ix->pinned);
+    HIPCHK(hipEventRecord(ix->ev[4], ix->stream));
+    if (out_ids) HIPCHK(hipMemcpyAsync(hp, bs.out_ids.p, b_ids, hipMemcpyDeviceToHost, ix->stream));
+    if (out_dist) HIPCHK(hipMemcpyAsync(hp + b_ids, bs.out_dist.p, b_ids, hipMemcpyDeviceToHost, ix->stream));
+    if (out_count) HIPCHK(hipMemcpyAsync(hp + 2 * b_ids, bs.out_count.p, b_cnt, hipMemcpyDeviceToHost, ix->stream));
+    if (stats) HIPCHK(hipMemcpyAsync(hp + 2 * b_ids + b_cnt, bs.stats.p, b_st, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipEventRecord(ix->ev[5], ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
+    if (out_ids) memcpy(out_ids, hp, b_ids);
+    if (out_dist) memcpy(out_dist, hp + b_ids, b_ids);
+    if (out_count) memcpy(out_count, hp + 2 * b_ids, b_cnt);
+    if (stats) memcpy(stats, hp + 2 * b_ids + b_cnt, b_st);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ix->ev[4], ix->ev[5]);
     ix->timing.d2h_ms = ms;
@@ -860,11 +877,25 @@ extern "C" int dr_search_batch_f64(dr_index *ix, const double *queries, uint32_t
             hipMemsetAsync(dvis.p, 0, (size_t)n * vis_words * 4, ix->stream) != hipSuccess) { rc = fail(DR_E_NODEVICE, "float64 search: upload failed"); break; }
         void *args[] = { &p };
         if (hipLaunchKernel(kfn, dim3(n), dim3(64), args, lds, ix->stream) != hipSuccess) { rc = fail(DR_E_NODEVICE, "float64 search: launch failed: %s", hipGetErrorString(hipGetLastError())); break; }
-        if (hipMemcpyAsync(out_ids + (size_t)q0 * k, dids.p, (size_t)n * k * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
-            hipMemcpyAsync(out_dist + (size_t)q0 * k, dd.p, (size_t)n * k * 8, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
-            hipMemcpyAsync(out_count + q0, dcnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
-            (stats && hipMemcpyAsync(stats + q0, dst.p, (size_t)n * sizeof(KStats), hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
+        // results through the pinned host slab (see download_locked)
+        const size_t b_ids = (size_t)n * k * 4, b_d = (size_t)n * k * 8, b_cnt = (size_t)n * 4, b_st = (size_t)n * sizeof(KStats);
+        const size_t need = b_d + b_ids + b_cnt + b_st;
+        if (ix->pinned_bytes < need) {
+            if (ix->pinned) (void)hipHostFree(ix->pinned);
+            ix->pinned = nullptr; ix->pinned_bytes = 0;
+            if (hipHostMalloc(&ix->pinned, need, hipHostMallocDefault) != hipSuccess) { rc = fail(DR_E_NODEVICE, "hipHostMalloc(%zu) failed", need); break; }
+            ix->pinned_bytes = need;
+        }
+        unsigned char *hp = static_cast<unsigned char *>(ix->pinned);
+        if (hipMemcpyAsync(hp, dd.p, b_d, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+            hipMemcpyAsync(hp + b_d, dids.p, b_ids, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+            hipMemcpyAsync(hp + b_d + b_ids, dcnt.p, b_cnt, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
+            (stats && hipMemcpyAsync(hp + b_d + b_ids + b_cnt, dst.p, b_st, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
             hipStreamSynchronize(ix->stream) != hipSuccess) { rc = fail(DR_E_NODEVICE, "float64 search: %s", hipGetErrorString(hipGetLastError())); break; }
+        memcpy(out_dist + (size_t)q0 * k, hp, b_d);
+        memcpy(out_ids + (size_t)q0 * k, hp + b_d, b_ids);
+        memcpy(out_count + q0, hp + b_d + b_ids, b_cnt);
+        if (stats) memcpy(stats + q0, hp + b_d + b_ids + b_cnt, b_st);
     }
     return rc;
 }
