@@ -138,6 +138,7 @@ struct dr_index {
     DevBuf<uint32_t> fin_stat;    // [1] largest tie-list length since the last sync (finalize_kernel)
     std::map<std::pair<const void *, size_t>, int> occ_cache;
     void *pinned = nullptr; size_t pinned_bytes = 0;      // host slab for result downloads
+    bool h2d_pending = false;
     DevBuf<double> f64_q, f64_dist;                 // dr_search_batch_f64 scratch
     DevBuf<uint32_t> f64_ids, f64_cnt, f64_vis;
     DevBuf<KStats> f64_stats;
@@ -369,7 +370,7 @@ extern "C" void dr_index_close(dr_index *ix)
 
 // ------------------------------------------------------------------------------------------------ batches
 
-static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq)
+static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq, bool wait = true)
 {
     if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
     HIPCHK(hipSetDevice(ix->device));
@@ -380,12 +381,13 @@ static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq
                        ix->qp.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
+    // dr_search_batch does not wait here: what consumes the queries is queued behind them on the same stream and the call
+    // only returns after its download; the copy's duration is read at the next sync. An explicit dr_batch_upload waits,
+    // so that the caller's buffer is free on return whatever kind of host memory it is.
+    if (wait) HIPCHK(hipStreamSynchronize(ix->stream));
     ix->nq = nq;
     ix->pq_ub_valid = false;
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]);
-    ix->timing.h2d_ms = ms;
+    ix->h2d_pending = true;
     return 0;
 }
 
@@ -709,6 +711,11 @@ static int sync_locked(dr_index *ix)
     HIPCHK(hipStreamSynchronize(ix->stream));
     HIPCHK(hipStreamSynchronize(ix->fstream));
     harvest_kernel_times(ix, true);
+    if (ix->h2d_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) ix->timing.h2d_ms = ms;
+        ix->h2d_pending = false;
+    }
     if (ix->fin_stat.p && ix->nq >= 1024) {     // (small batches launch a small pass anyway: no blocking readback for them)
         uint32_t mx = 0;
         HIPCHK(hipMemcpy(&mx, ix->fin_stat.p, 4, hipMemcpyDeviceToHost));
@@ -814,7 +821,7 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
     float h2d = 0, ker = 0, fin = 0, d2h = 0;
     for (uint32_t q0 = 0; q0 < nq; q0 += DR_MAX_CHUNK) {
         const uint32_t n = std::min(DR_MAX_CHUNK, nq - q0);
-        int rc = upload_queries_locked(ix, queries + (size_t)q0 * ix->D, n);
+        int rc = upload_queries_locked(ix, queries + (size_t)q0 * ix->D, n, false);
         if (!rc) rc = run_locked(ix, k, L, beam_width, mode, band_policy, flags);
         if (!rc) rc = download_locked(ix, out_ids + (size_t)q0 * k, out_dist + (size_t)q0 * k, out_count + q0,
                                       stats ? stats + q0 : nullptr);
