@@ -7,9 +7,10 @@
 // and differ in distance function, result-list capacity, stop rule and trim rule (SearchParams).
 //
 // Where a query's state lives:
-//   VGPRs  result list and frontier as sorted arrays of 64-bit keys (distance bits << 32 | id), one element per
-//          lane per 64-entry chunk; inserts are a ballot (position) plus one DPP wave shift per chunk -- no LDS
-//          round trips on the sequential path; the query (chain-major) for D <= 256
+//   VGPRs  result list (which doubles as the frontier: a per-entry "popped" flag) as a sorted array of 64-bit keys
+//          (distance bits << 32 | ~id), one element per lane per 64-entry chunk; a whole expansion's accepted
+//          neighbours enter it with ONE scatter/gather merge through LDS; single inserts (start node, tie side
+//          list) are a ballot plus one wave shift per chunk; the query (chain-major) for D <= 256
 //   LDS    PQ data for ADC: either the whole codebook shared by all wavefronts of the workgroup (D <= 128:
 //          4*256*D bytes <= 128 KiB; table entries T[j][c] are recomputed per neighbour in the reference's order,
 //          which lets 8-16 queries share a CU instead of the 4 that per-query tables allow), or the per-query
@@ -19,9 +20,10 @@
 //          accepted-insert log per query (tie replay in finalize)
 //
 // Sequential semantics kept exactly: the neighbours of one expansion are scored in parallel (distances do not
-// depend on list state) and then DECIDED in stored order by a wave-uniform loop that runs once per accepted
-// insert; lanes between two accepted inserts evaluate the rerank policy A4 (search_engine.py:381-397) with
-// the worst-distance W in effect at their position.
+// depend on list state); which of them the reference would have scored and accepted, walking them in stored order
+// with the worst distance W in effect at each position and the rerank policy A4 (search_engine.py:381-397), is
+// then computed without a walk -- see "decisions" in the main loop: counts against the old list by binary search,
+// counts against earlier neighbours by bit masks, and a fixed point that converges in one or two ballots.
 #pragma once
 #include "numerics.hpp"
 
@@ -870,8 +872,6 @@ DEV void search_body(const SearchParams &p)
                     PH(4);
                 }
                 PH(5);
-
-                // ---- predict the next pop: the closer of the frontier head and the best new neighbour; prefetch its row
 
                 // ---- decisions
                 // The reference walks the new neighbours in stored order: i is scored iff A4 passes against the worst
