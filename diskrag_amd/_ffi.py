@@ -26,7 +26,7 @@ class DrStats(C.Structure):
 class DrTiming(C.Structure):
     _fields_ = [("h2d_ms", C.c_float), ("search_kernel_ms", C.c_float), ("finalize_kernel_ms", C.c_float),
                 ("d2h_ms", C.c_float), ("total_ms", C.c_float), ("grid", C.c_uint32), ("block", C.c_uint32),
-                ("lds_bytes", C.c_uint32), ("waves_per_cu", C.c_uint32)]
+                ("lds_bytes", C.c_uint32), ("waves_per_cu", C.c_uint32), ("variant", C.c_uint32)]
 
 
 STATS_DTYPE = np.dtype([("steps", "<u4"), ("visited", "<u4"), ("exact", "<u4"), ("pq", "<u4"), ("status", "<u4"),

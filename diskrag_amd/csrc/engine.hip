@@ -110,6 +110,7 @@ struct dr_index {
     // lossless byte copy of the vectors (integer-valued data, D = 128): 0 not checked yet, 1 present, -1 data does not qualify
     DevBuf<uint8_t> vec8;
     int vec8_state = 0;
+    bool q_u8 = false;           // every component of the resident queries is an integer in [0, 255] (byte-query variants 13/14)
     bool rank_valid = false, adjr_valid = false, use_adjr = false;
     uint32_t medoid_pos = 0;
 
@@ -388,6 +389,19 @@ static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq
     ix->nq = nq;
     ix->pq_ub_valid = false;
     ix->h2d_pending = true;
+    // byte queries? (only asked when byte rows exist; non-integer data leaves at the first element)
+    ix->q_u8 = false;
+    if (ix->vec8_state == 1 || (ix->vec8_state == 0 && ix->D == 128)) {
+        const size_t n = (size_t)nq * ix->D;
+        bool ok = true;
+        for (size_t b = 0; b < n && ok; b += 4096) {
+            const size_t e = std::min(n, b + 4096);
+            int bad = 0;
+            for (size_t i = b; i < e; i++) { const float v = queries[i]; bad |= !(v >= 0.0f && v <= 255.0f && v == (float)(int)v); }
+            ok = !bad;
+        }
+        ix->q_u8 = ok;
+    }
     return 0;
 }
 
@@ -513,8 +527,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
 
     const int sc = cap <= 64 ? 0 : cap <= 128 ? 1 : cap <= 256 ? 2 : 3;
     // kernel variant (variants.hpp): the first available variant of the mode's preference list whose LDS footprint
-    // fits. M1: vectors landed in LDS (9, 6) > codebook shared in LDS (3) > per-query table (0); ADC traversal:
-    // 5 > 2; exact traversal: 8 > 1 (the builder uses 1).
+    // fits. M1: byte rows with byte queries (13) > byte rows (11, 10) > float rows landed in LDS (9, 6) > codebook
+    // shared in LDS (3) > per-query table (0); ADC traversal: 5 > 2; exact traversal: 14 > 12 > 8 > 1 (the builder
+    // uses 1). The byte variants need integer-valued data / queries and are skipped otherwise.
     static const int NCHR_OF_SC[4] = { 1, 2, 4, 8 };
     auto lds_of = [&](int kd) -> size_t {
         const int rb = DR_KIND_RB[kd];
@@ -524,9 +539,10 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         return (DR_KIND_CB[kd] ? (size_t)256 * ix->D * 4 : 0) + (size_t)DR_KIND_NW[kd] * pw;
     };
     if (!ov && ix->vec8_state == 0) { const int rcb8 = build_byte_rows(ix); if (rcb8) return rcb8; }
-    auto usable = [&](int kd) { return ix->kern->search[kd][sc] != nullptr && lds_of(kd) <= 160 * 1024 && (!DR_KIND_U8[kd] || ix->vec8_state == 1); };
-    static const int PREF_M1[] = { 11, 10, 9, 6, 3, 0 }, PREF_ADC[] = { 5, 2, -1, -1, -1, -1 }, PREF_EX[] = { 12, 8, 1, -1, -1, -1 }, PREF_BUILD[] = { 1, 8, -1, -1, -1, -1 };
-    static const int PREF_M1_LIVE_LUT[] = { 0, 3, 11, 10, 9, 6 }, PREF_M1_LIVE_CB[] = { 3, 0, 11, 10, 9, 6 };
+    auto usable = [&](int kd) { return ix->kern->search[kd][sc] != nullptr && lds_of(kd) <= 160 * 1024 && (!DR_KIND_U8[kd] || ix->vec8_state == 1) &&
+                                       (!DR_KIND_QB[kd] || (ix->q_u8 && !ov)); };
+    static const int PREF_M1[] = { 13, 11, 10, 9, 6, 3, 0 }, PREF_ADC[] = { 5, 2 }, PREF_EX[] = { 14, 12, 8, 1 }, PREF_BUILD[] = { 1, 8 };
+    static const int PREF_M1_LIVE_LUT[] = { 0, 3, 13, 11, 10, 9, 6 }, PREF_M1_LIVE_CB[] = { 3, 0, 13, 11, 10, 9, 6 };
     const bool k_m1 = (mode == DR_MODE_M1), k_adc = (mode == DR_MODE_M3 && use_pq);
     // M1 has two regimes. On SIFT-scale data the rerank policy A4 is provably true for almost every expansion (Q1),
     // the ADC is skipped and the kernel is a pure row gather: vectors landed in LDS, table never built (9, 6).
@@ -535,7 +551,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // MEASURED on the first M1 batch an index state serves (its counters are read once that launch has finished, see
     // the end of this function); until then the SIFT-scale preference applies. Results never depend on the variant.
     const int *pref = k_m1 ? PREF_M1 : k_adc ? PREF_ADC : ov ? PREF_BUILD : PREF_EX;
-    const int npref = k_m1 ? 6 : k_adc ? 2 : ov ? 2 : 3;
+    const int npref = k_m1 ? 7 : k_adc ? 2 : ov ? 2 : 4;
     if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 8 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
     int kind = -1;
     for (int i = 0; i < npref && kind < 0; i++) if (usable(pref[i])) kind = pref[i];
@@ -544,7 +560,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e && !g_force_kind_set) g_force_kind = atoi(e); env_read = true; }
         const int g = g_force_kind;
         if (g >= 0 && g < DR_NUM_KINDS && usable(g)) {
-            const bool g_m1 = (g == 0 || g == 3 || g == 4 || g == 6 || g == 7 || g == 9 || g == 10 || g == 11), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8 || g == 12);
+            const bool g_m1 = (g == 0 || g == 3 || g == 4 || g == 6 || g == 7 || g == 9 || g == 10 || g == 11 || g == 13), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
             if ((g_m1 && k_m1) || (g_adc && k_adc) || (g_ex && !k_m1 && !k_adc)) kind = g;
         }
     }
@@ -688,7 +704,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     bs.fin_pending = true;
     // no host wait here: the next step may be queued right away (dr_batch_sync / dr_batch_download wait)
     ix->timing.grid = grid; ix->timing.block = 64 * NW; ix->timing.lds_bytes = (uint32_t)lds;
-    ix->timing.waves_per_cu = (uint32_t)(occ * NW);
+    ix->timing.waves_per_cu = (uint32_t)(occ * NW); ix->timing.variant = (uint32_t)kind;
     if (k_m1 && ix->adc_live < 0) {
         // regime of this (graph, PQ) state: did the rerank policy really consult the ADC on this batch? (the one
         // launch per index state that is waited for on the host)

@@ -486,6 +486,8 @@ DEV float wave_max(float x)
 //        entries are recomputed from the codebook, wherever it lives).
 // U8     the landing variant on the lossless byte copy of integer-valued vectors (D = 128): 128-byte rows, a whole
 //        expansion per burst.
+// QB     byte rows AND byte queries (integer-valued queries in [0, 255], checked per batch by the engine): distances
+//        by v_dot4_u32_u8 -- the integer sum equals the reference's float32 sum bit for bit (see the burst code).
 // A4 as a threshold on the worst distance: returns the bits of x = the largest float W >= 0 with f_mul(W, thr) <= pq.
 // f_mul(., thr) is monotone, so the reference's test `pq < thr * W` (search_engine.py:390-395) holds exactly for
 // W > x. `ok` is cleared if the fix-up did not reach the boundary (reported through stats.status, never silent).
@@ -500,7 +502,7 @@ DEV u32 a4_threshold_bits(float pq, float thr, bool &ok) {
     return cb;
 }
 
-template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false>
+template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false>
 DEV void search_body(const SearchParams &p)
 {
     constexpr bool QREG = (D <= 256);
@@ -531,6 +533,7 @@ DEV void search_body(const SearchParams &p)
     constexpr size_t MERGE_BYTES = (size_t)NCHR * 64 * 12;   // merge scratch: NCHR*64 keys (u64) + states (u32)
     constexpr size_t ROW_BYTES = U8 ? (size_t)D : (size_t)D * 4;   // a landed row: bytes (lossless, see below) or floats
     static_assert(!U8 || (ROWLDS && D == 128), "byte rows: the 12-wave landing variant at D = 128");
+    static_assert(!QB || U8, "byte queries go with byte rows");
     static_assert(!ROWLDS || (size_t)RB * ROW_BYTES >= MERGE_BYTES, "the row landing area doubles as merge scratch");
     // the query in its original element order is needed in LDS only where table entries are recomputed per neighbour
     // from the codebook; the per-query table is built once, straight from global memory (at D = 1536, m = 32 that is
@@ -589,6 +592,19 @@ DEV void search_body(const SearchParams &p)
                 if constexpr (!QREG) qperm[i] = qpg[i];
             }
             if constexpr (QREG) load_query_regs<0, D, D>(qpg, j, qreg);
+        }
+        // Byte queries (the engine selects this variant only when EVERY component of EVERY query of the batch is an
+        // integer in [0, 255], like the rows): the same 16 chain steps of lane j packed into four words, and sum q^2.
+        u32 qb[4] = { 0u, 0u, 0u, 0u };
+        int qq = 0;
+        if constexpr (QB) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) qb[t >> 2] |= ((u32)qreg.v[t] & 255u) << (8 * (t & 3));
+            u32 s2 = 0u;
+#pragma unroll
+            for (int w = 0; w < 4; w++) s2 = __builtin_amdgcn_udot4(qb[w], qb[w], s2, false);
+            qq = (int)s2;
+            qq += __shfl_xor(qq, 1); qq += __shfl_xor(qq, 2); qq += __shfl_xor(qq, 4);
         }
         WSYNC();
         if constexpr (NEED_PQ && !CBLDS) {
@@ -786,14 +802,31 @@ DEV void search_body(const SearchParams &p)
                                 const int row = min(r8 + oct, nb - 1);
                                 const uint4 w = *reinterpret_cast<const uint4 *>(rowbuf8 + (size_t)row * D + j * 16);
                                 const u32 words[4] = { w.x, w.y, w.z, w.w };
-                                float r = 0.0f;
+                                float ev;
+                                if constexpr (QB) {
+                                    // Integers in [0, 255] on both sides: every difference, square and partial sum
+                                    // of the reference's float32 computation is an integer below 128 * 255^2 < 2^24,
+                                    // i.e. exact in ANY order, so its result is float(sum (x - q)^2) -- computed here
+                                    // as x.x - 2 q.x + q.q with 8 byte dot products instead of 63 float operations.
+                                    u32 qx = 0u, xx = 0u;
 #pragma unroll
-                                for (int t = 0; t < 16; t++) {
-                                    const float v = (float)((words[t >> 2] >> (8 * (t & 3))) & 255u);
-                                    const float sq = sqd(v, qreg.v[t]);
-                                    r = (t == 0) ? sq : f_add(r, sq);
+                                    for (int w4 = 0; w4 < 4; w4++) {
+                                        qx = __builtin_amdgcn_udot4(words[w4], qb[w4], qx, false);
+                                        xx = __builtin_amdgcn_udot4(words[w4], words[w4], xx, false);
+                                    }
+                                    int part = (int)xx - 2 * (int)qx;
+                                    part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
+                                    ev = (float)(part + qq);
+                                } else {
+                                    float r = 0.0f;
+#pragma unroll
+                                    for (int t = 0; t < 16; t++) {
+                                        const float v = (float)((words[t >> 2] >> (8 * (t & 3))) & 255u);
+                                        const float sq = sqd(v, qreg.v[t]);
+                                        r = (t == 0) ? sq : f_add(r, sq);
+                                    }
+                                    ev = octet_combine(r);
                                 }
-                                float ev = octet_combine(r);
                                 if (knorm) ev = f_sqrt(ev);
                                 if (j == 0 && r8 + oct < nb) nb_e[b0 + r8 + oct] = ev;
                             }
@@ -1154,8 +1187,8 @@ DEV void search_body(const SearchParams &p)
     }
 }
 
-template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false>
+template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const SearchParams p)
 {
-    search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB, U8>(p);
+    search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB, U8, QB>(p);
 }

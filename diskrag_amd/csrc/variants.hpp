@@ -17,8 +17,10 @@
 //  10 M1, BYTE vectors landed in LDS (lossless copy of integer-valued data), 64 rows/burst, 12 waves (D = 128)
 //  11 same, 16 waves (128 VGPRs: a few spilled dwords, 7 % faster than 12 waves once the row bytes are quartered)
 //  12 exact traversal (M2, M4, M3 without PQ) on BYTE vectors, 64 rows/burst, 16 waves          (D = 128)
+//  13 = 11 with BYTE queries as well (every component of the batch an integer in [0, 255]): v_dot4_u32_u8 distances
+//  14 = 12 with byte queries
 // sizeclass: result capacity <= 64 / 128 / 256 / 512
-#define DR_NUM_KINDS 13
+#define DR_NUM_KINDS 15
 #define DR_NUM_SIZECLASS 4
 struct DimKernels {
     int D;
@@ -29,12 +31,13 @@ struct DimKernels {
     const void *nearest_pivot;   // aux_kernels.hpp nearest_pivot_kernel (bit order of the visited bitmap)
     const void *search_f64;   // M1 / M2 with float64 queries (the CLI path), search_f64.hpp
 };
-static const int DR_KIND_NW[DR_NUM_KINDS] = { 1, 1, 1, 8, 16, 8, 8, 16, 8, 12, 12, 16, 16 };
-static const bool DR_KIND_CB[DR_NUM_KINDS] = { false, false, false, true, true, true, false, false, false, false, false, false, false };   // codebook copied to LDS
-static const int DR_KIND_RB[DR_NUM_KINDS] = { 0, 0, 0, 0, 0, 0, 32, 16, 32, 24, 64, 64, 64 };                                       // rows per LDS burst
-static const bool DR_KIND_LUT[DR_NUM_KINDS] = { true, false, true, false, false, false, false, false, false, false, false, false, false };     // per-query table in LDS
-static const bool DR_KIND_PQ[DR_NUM_KINDS] = { true, false, true, true, true, true, true, true, false, true, true, true, false };
-static const bool DR_KIND_U8[DR_NUM_KINDS] = { false, false, false, false, false, false, false, false, false, false, true, true, true };    // byte rows
+static const int DR_KIND_NW[DR_NUM_KINDS] = { 1, 1, 1, 8, 16, 8, 8, 16, 8, 12, 12, 16, 16, 16, 16 };
+static const bool DR_KIND_CB[DR_NUM_KINDS] = { false, false, false, true, true, true, false, false, false, false, false, false, false, false, false };   // codebook copied to LDS
+static const int DR_KIND_RB[DR_NUM_KINDS] = { 0, 0, 0, 0, 0, 0, 32, 16, 32, 24, 64, 64, 64, 64, 64 };                                       // rows per LDS burst
+static const bool DR_KIND_LUT[DR_NUM_KINDS] = { true, false, true, false, false, false, false, false, false, false, false, false, false, false, false };     // per-query table in LDS
+static const bool DR_KIND_PQ[DR_NUM_KINDS] = { true, false, true, true, true, true, true, true, false, true, true, true, false, true, false };
+static const bool DR_KIND_U8[DR_NUM_KINDS] = { false, false, false, false, false, false, false, false, false, false, true, true, true, true, true };    // byte rows
+static const bool DR_KIND_QB[DR_NUM_KINDS] = { false, false, false, false, false, false, false, false, false, false, false, false, false, true, true };  // byte queries
 
 const DimKernels *dr_dim_kernels(int D);
 

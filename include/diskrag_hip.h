@@ -62,6 +62,7 @@ typedef struct {
 typedef struct {
     float h2d_ms, search_kernel_ms, finalize_kernel_ms, d2h_ms, total_ms;
     uint32_t grid, block, lds_bytes, waves_per_cu;
+    uint32_t variant; /* which search_kernel instantiation ran (csrc/variants.hpp) */
 } dr_timing;
 
 int dr_device_count(void);

@@ -73,8 +73,9 @@ def test_regime_probe_on_sift_scale_data():
 
 
 def test_byte_rows_are_lossless_and_only_for_integer_data():
-    """Variants 10 / 11 read a byte copy of the vectors, built only when every component is an integer in [0, 255]:
-    same bits as the float-row variant 9 and as the oracle; data that does not qualify never takes them."""
+    """Variants 10 / 11 / 13 read a byte copy of the vectors, built only when every component is an integer in [0, 255]
+    (13 / 14: the queries of the batch as well): same bits as the float-row variant 9 and as the oracle; data that does
+    not qualify never takes them."""
     from diskrag_amd import _ffi
     from diskrag_amd.synth import sift_like
     from oracle import pyoracle as orc
@@ -84,7 +85,7 @@ def test_byte_rows_are_lossless_and_only_for_integer_data():
     try:
         want = orc.search_batch(x, adj, q, medoid, orc.M1, 10, L=100, bw=8, codes=codes, codebook=cb, nthreads=8)
         blocks = {}
-        for kind in (9, 10, 11, -1):
+        for kind in (9, 10, 11, 13, -1):
             ix.debug_force_kind(kind)
             for (L, bw) in ((100, 8), (100, 0), (300, 16), (20, 8)):
                 ids, dist, cnt, st = ix.search_batch(q, 10, L=L, beam_width=bw, mode=_ffi.MODE_M1)
@@ -93,15 +94,31 @@ def test_byte_rows_are_lossless_and_only_for_integer_data():
                 assert np.array_equal(ids, w[0]) and np.array_equal(dist.view(np.uint32), w[1].astype(np.float32).view(np.uint32))
                 assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), w[3])
             blocks[kind] = (ix.timing()["block"], ix.timing()["lds_bytes"])
+            assert ix.timing()["variant"] == (kind if kind >= 0 else 13)   # integer data AND integer queries: 13
         assert blocks[9][0] == 768 and blocks[10][0] == 768 and blocks[10][1] < blocks[9][1] and blocks[11][0] == 1024
-        assert blocks[-1] == blocks[11]                         # the engine's own choice on integer data
-        # the exact traversals: float rows (8) == byte rows (12) == oracle
+        assert blocks[-1] == blocks[13] == blocks[11]
+        # byte queries (13 / 14: v_dot4_u32_u8 distances) are taken only when EVERY component of the batch is an integer
+        # in [0, 255]; one fractional, negative or too-large component and the batch runs on the float-query variants.
+        # Extreme integer queries (all 0 / all 255 against rows up to 218) stay exact as well.
+        for name, qq in (("frac", q + np.float32(0.5) * (np.arange(q.size).reshape(q.shape) == 777)),
+                         ("neg", np.where(np.arange(q.size).reshape(q.shape) == 5, np.float32(-1), q)),
+                         ("big", np.where(np.arange(q.size).reshape(q.shape) == q.size - 1, np.float32(256), q)),
+                         ("extreme", np.concatenate([np.zeros((2, 128), np.float32), np.full((2, 128), 255, np.float32), q[:28]]))):
+            qq = np.ascontiguousarray(qq, dtype=np.float32)
+            w = orc.search_batch(x, adj, qq, medoid, orc.M1, 10, L=100, bw=8, codes=codes, codebook=cb, nthreads=8)
+            for kind in (13, -1):
+                ix.debug_force_kind(kind)
+                ids, dist, cnt, st = ix.search_batch(qq, 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
+                assert ix.timing()["variant"] == (13 if name == "extreme" else 11), name
+                assert np.array_equal(ids, w[0]) and np.array_equal(dist.view(np.uint32), w[1].astype(np.float32).view(np.uint32)), name
+                assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), w[3]), name
+        # the exact traversals: float rows (8) == byte rows (12) == byte rows and queries (14) == oracle
         for (mode, omode, k, L, bw, fl, ofl) in ((2, orc.M2, 8, 0, 8, 0, orc.F_PAIRWISE), (4, orc.M4, 10, 50, 0, _ffi.F_SQDIST, orc.F_CYTHON | orc.F_PAIRWISE)):
             w = orc.search_batch(x, adj, q, medoid, omode, k, L=L, bw=bw, flags=ofl, nthreads=8)
-            for kind, blk in ((8, 512), (12, 1024), (-1, 1024)):
+            for kind, blk in ((8, 512), (12, 1024), (14, 1024), (-1, 1024)):
                 ix.debug_force_kind(kind)
                 ids, dist, cnt, st = ix.search_batch(q, k, L=L, beam_width=bw, mode=mode, flags=fl)
-                assert ix.timing()["block"] == blk
+                assert ix.timing()["block"] == blk and ix.timing()["variant"] == (kind if kind >= 0 else 14)
                 assert np.array_equal(ids, w[0]) and np.array_equal(dist.view(np.uint32), w[1].astype(np.float32).view(np.uint32))
     finally:
         ix.debug_force_kind(-1)
@@ -110,10 +127,10 @@ def test_byte_rows_are_lossless_and_only_for_integer_data():
     y = x + np.float32(0.25)
     iy, medoid, adj, cb, codes = _index(y, 32, 32)
     try:
-        for kind in (10, 11, -1):
+        for kind in (10, 11, 13, -1):
             iy.debug_force_kind(kind)
             ids, dist, cnt, st = iy.search_batch(q, 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
-            assert iy.timing()["block"] == 768 and iy.timing()["lds_bytes"] > 140000      # variant 9
+            assert iy.timing()["block"] == 768 and iy.timing()["lds_bytes"] > 140000 and iy.timing()["variant"] == 9
             w = orc.search_batch(y, adj, q, medoid, orc.M1, 10, L=100, bw=8, codes=codes, codebook=cb, nthreads=8)
             assert np.array_equal(ids, w[0]) and np.array_equal(dist.view(np.uint32), w[1].astype(np.float32).view(np.uint32))
     finally:
