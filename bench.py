@@ -162,11 +162,13 @@ def main():
                      "kernel_ms": float(np.mean(k2)), "roofline_frac": b2 / (float(np.mean(k2)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "exact_distances_per_query": float(st2["exact"].mean())}
 
-    # the same step with float32 rows (variant 9): what the kernel does on data that is not integer-valued
-    float_rows = None
-    byte_rows = bool((timing["block"] == 768 and timing["lds_bytes"] < 140000) or timing["block"] == 1024)
-    if byte_rows and not args.no_secondary:
-        ix.debug_force_kind(9)
+    # the same step on the variants that less special data gets: float32 rows (variant 9: data that is not
+    # integer-valued) and byte rows with float32 queries (variant 11: integer data, queries that are not)
+    float_rows = float_queries = None
+    byte_rows = timing["variant"] in (10, 11, 13)
+
+    def forced(kind):
+        ix.debug_force_kind(kind)
         for _ in range(2):
             ix.batch_run(args.k, L=args.L, beam_width=args.bw, mode=mode)
         ix.batch_sync()
@@ -176,9 +178,15 @@ def main():
         ix.batch_sync()
         el3 = time.perf_counter() - t3
         k3 = ix.timing()["search_kernel_ms"]
+        ran = ix.timing()["variant"]
         ix.debug_force_kind(-1)
-        float_rows = {"qps_rank0": args.nq * args.steps / el3, "kernel_ms": k3,
-                      "roofline_frac": alg_bytes / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        return {"variant": ran, "qps_rank0": args.nq * args.steps / el3, "kernel_ms": k3,
+                "roofline_frac": alg_bytes / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+
+    if byte_rows and not args.no_secondary:
+        float_rows = forced(9)
+        if timing["variant"] == 13:
+            float_queries = forced(11)
 
     total_q = args.nq * world * args.steps
     value = total_q / elapsed
@@ -194,12 +202,15 @@ def main():
                    "qps_pcie_inclusive_rank0": pcie_qps,
                    "per_query": {"expansions": float(S.mean()), "pq_distances": float(st["pq"].mean()), "pq_evaluated": float(V.mean()),
                                  "exact_distances": float(X.mean()), "algorithmic_bytes": float(bytes_q.mean())},
-                   "launch": {k_: timing[k_] for k_ in ("grid", "block", "lds_bytes", "waves_per_cu")},
+                   "launch": {k_: timing[k_] for k_ in ("variant", "grid", "block", "lds_bytes", "waves_per_cu")},
                    "finalize_kernel_ms": timing["finalize_kernel_ms"], "secondary_no_trim": secondary,
                    "row_storage": ("u8: lossless byte copy of the integer-valued vectors (every component checked; distances "
                                    "bit-identical); roofline.achieved counts the reference's 4*D bytes per scored vector, "
                                    "roofline.traffic is what HBM really moved") if byte_rows else "f32",
-                   "float32_rows": float_rows},
+                   "query_storage": ("u8: every component of the batch is an integer in [0, 255] (checked per upload), "
+                                     "distances by v_dot4_u32_u8 -- the integer sum IS the reference's float32 sum "
+                                     "(all partial sums < 2^24)") if timing["variant"] == 13 else "f32",
+                   "float32_rows": float_rows, "byte_rows_float32_queries": float_queries},
         "roofline": {"bound": "hbm", "kernel": "search_kernel<128,M1>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},

@@ -445,10 +445,34 @@ static int build_bit_order(dr_index *ix)
         std::vector<uint32_t> hl(N), hr(N);
         HIPCHK(hipMemcpyAsync(hl.data(), label.p, N * 4, hipMemcpyDeviceToHost, ix->stream));
         HIPCHK(hipStreamSynchronize(ix->stream));
-        std::vector<uint64_t> start(P + 1, 0);
-        for (uint64_t i = 0; i < N; i++) { if (hl[i] >= P) return fail(DR_E_NODEVICE, "bit order: bad label"); start[hl[i] + 1]++; }
-        for (uint64_t c = 0; c < P; c++) start[c + 1] += start[c];
-        for (uint64_t i = 0; i < N; i++) hr[i] = (uint32_t)start[hl[i]]++;      // stable: ids ascending inside a label
+        // cells that are close in space get adjacent bit ranges: the cells are grouped by the nearest of S "super" pivots
+        // (every (P/S)-th pivot), so the few cells that share a 128-byte bitmap line belong to one neighbourhood
+        static const bool flat = getenv("DR_BITORDER_FLAT") != nullptr;
+        std::vector<uint32_t> cell_order(P);
+        for (uint64_t c = 0; c < P; c++) cell_order[c] = (uint32_t)c;
+        const uint64_t S = 64;
+        if (!flat && P >= S * 8) {
+            DevBuf<uint32_t> spid, slabel;
+            DevBuf<float> spiv;
+            if (spid.reserve(S) || slabel.reserve(P) || spiv.reserve((size_t)S * D)) return DR_E_NODEVICE;
+            std::vector<uint32_t> hs(S), hsl(P);
+            for (uint64_t i = 0; i < S; i++) hs[i] = h[i * (P / S)];
+            HIPCHK(hipMemcpyAsync(spid.p, hs.data(), S * 4, hipMemcpyHostToDevice, ix->stream));
+            hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)S), dim3(256), 0, ix->stream, ix->vecp.p, spid.p, (uint32_t)S, D, spiv.p);
+            HIPCHK(hipGetLastError());
+            const float *pv2 = piv.p; const float *sv = spiv.p; uint64_t np64 = P; uint32_t s32 = (uint32_t)S; uint32_t *slab = slabel.p;
+            void *args2[] = { &pv2, &np64, &sv, &s32, &slab };
+            HIPCHK(hipLaunchKernel(ix->kern->nearest_pivot, dim3((unsigned)std::min<uint64_t>(P, (uint64_t)ix->num_cu * 16)), dim3(64), args2,
+                                   D > 256 ? (size_t)D * 4 : 0, ix->stream));
+            HIPCHK(hipMemcpyAsync(hsl.data(), slabel.p, P * 4, hipMemcpyDeviceToHost, ix->stream));
+            HIPCHK(hipStreamSynchronize(ix->stream));
+            for (uint64_t c = 0; c < P; c++) if (hsl[c] >= S) return fail(DR_E_NODEVICE, "bit order: bad super label");
+            std::stable_sort(cell_order.begin(), cell_order.end(), [&](uint32_t a, uint32_t b) { return hsl[a] < hsl[b]; });
+        }
+        std::vector<uint64_t> cnt(P, 0), start(P, 0);
+        for (uint64_t i = 0; i < N; i++) { if (hl[i] >= P) return fail(DR_E_NODEVICE, "bit order: bad label"); cnt[hl[i]]++; }
+        { uint64_t pos = 0; for (uint64_t c = 0; c < P; c++) { start[cell_order[c]] = pos; pos += cnt[cell_order[c]]; } }
+        for (uint64_t i = 0; i < N; i++) hr[i] = (uint32_t)start[hl[i]]++;      // stable: ids ascending inside a cell
         HIPCHK(hipMemcpy(ix->rank.p, hr.data(), N * 4, hipMemcpyHostToDevice));
         pid.release(); label.release(); piv.release();
         ix->rank_valid = true;

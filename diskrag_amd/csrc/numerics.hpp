@@ -37,11 +37,25 @@ DEV float sqd(float v, float q) { float d = f_sub(v, q); return f_mul(d, d); }
 
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) across the 8 lanes of an octet; every lane ends with the sum
 // (float addition is commutative, so both partners of each exchange compute identical bits).
+// The exchanges are DPP operands of the adds (no LDS permute round trips): lane^1 and lane^2 as quad permutations;
+// after those every lane of a quad holds its quad's sum, so the mirror of the 8-lane half row (lane -> 7 - lane)
+// delivers the other quad's sum. All 64 lanes must be active (every caller is wave-uniform).
+template <int CTRL> DEV unsigned dpp_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+#define DPP_QUAD_XOR1 0xB1      /* quad_perm:[1,0,3,2] */
+#define DPP_QUAD_XOR2 0x4E      /* quad_perm:[2,3,0,1] */
+#define DPP_HALF_MIRROR 0x141   /* row_half_mirror */
 DEV float octet_combine(float r)
 {
-    r = f_add(r, __shfl_xor(r, 1));
-    r = f_add(r, __shfl_xor(r, 2));
-    r = f_add(r, __shfl_xor(r, 4));
+    r = f_add(r, __uint_as_float(dpp_u32<DPP_QUAD_XOR1>(__float_as_uint(r))));
+    r = f_add(r, __uint_as_float(dpp_u32<DPP_QUAD_XOR2>(__float_as_uint(r))));
+    r = f_add(r, __uint_as_float(dpp_u32<DPP_HALF_MIRROR>(__float_as_uint(r))));
+    return r;
+}
+DEV int octet_combine_i32(int r)
+{
+    r += (int)dpp_u32<DPP_QUAD_XOR1>((unsigned)r);
+    r += (int)dpp_u32<DPP_QUAD_XOR2>((unsigned)r);
+    r += (int)dpp_u32<DPP_HALF_MIRROR>((unsigned)r);
     return r;
 }
 

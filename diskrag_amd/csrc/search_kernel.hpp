@@ -604,7 +604,7 @@ DEV void search_body(const SearchParams &p)
 #pragma unroll
             for (int w = 0; w < 4; w++) s2 = __builtin_amdgcn_udot4(qb[w], qb[w], s2, false);
             qq = (int)s2;
-            qq += __shfl_xor(qq, 1); qq += __shfl_xor(qq, 2); qq += __shfl_xor(qq, 4);
+            qq = octet_combine_i32(qq);
         }
         WSYNC();
         if constexpr (NEED_PQ && !CBLDS) {
@@ -814,9 +814,7 @@ DEV void search_body(const SearchParams &p)
                                         qx = __builtin_amdgcn_udot4(words[w4], qb[w4], qx, false);
                                         xx = __builtin_amdgcn_udot4(words[w4], words[w4], xx, false);
                                     }
-                                    int part = (int)xx - 2 * (int)qx;
-                                    part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
-                                    ev = (float)(part + qq);
+                                    ev = (float)(octet_combine_i32((int)xx - 2 * (int)qx) + qq);
                                 } else {
                                     float r = 0.0f;
 #pragma unroll
