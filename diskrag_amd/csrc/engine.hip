@@ -396,8 +396,13 @@ static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq
         bool ok = true;
         for (size_t b = 0; b < n && ok; b += 4096) {
             const size_t e = std::min(n, b + 4096);
-            int bad = 0;
-            for (size_t i = b; i < e; i++) { const float v = queries[i]; bad |= !(v >= 0.0f && v <= 255.0f && v == (float)(int)v); }
+            unsigned bad = 0;     // branch-free so that it vectorises (out-of-range and NaN are clamped before the conversion)
+            for (size_t i = b; i < e; i++) {
+                const float v = queries[i];
+                const float c = (v >= 0.0f && v <= 255.0f) ? v : -1.0f;
+                const int iv = (int)c;
+                bad |= (unsigned)(iv < 0) | (unsigned)((float)iv != v);
+            }
             ok = !bad;
         }
         ix->q_u8 = ok;
