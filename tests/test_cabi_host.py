@@ -18,6 +18,32 @@ def test_library_exports_every_header_symbol():
         assert hasattr(lib, sym), sym
 
 
+def test_ctypes_structs_match_the_header(tmp_path):
+    """The ctypes mirrors of dr_stats / dr_timing have the C layout: sizes and field offsets from a C program
+    compiled against include/diskrag_hip.h (the header is plain C: a cgo / JNI binding includes it the same way)."""
+    import shutil
+    import subprocess
+    from diskrag_amd import _ffi
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = (("dr_stats", _ffi.DrStats), ("dr_timing", _ffi.DrTiming))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "diskrag_hip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == __import__("ctypes").sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, f)]) == getattr(cls, f).offset, (cname, f)
+
+
 def test_no_device_fails_loudly():
     """No CPU fallback: without a HIP device index creation must raise, not degrade."""
     import diskrag_amd
