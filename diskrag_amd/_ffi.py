@@ -20,7 +20,7 @@ E_ARG, E_NODEVICE, E_IO, E_NOPQ, E_OVERFLOW, E_UNSUPPORTED = -1, -2, -3, -4, -5,
 
 class DrStats(C.Structure):
     _fields_ = [("steps", C.c_uint32), ("visited", C.c_uint32), ("exact", C.c_uint32), ("pq", C.c_uint32),
-                ("status", C.c_uint32), ("inserts", C.c_uint32), ("pq_evaluated", C.c_uint32), ("reserved", C.c_uint32)]
+                ("status", C.c_uint32), ("inserts", C.c_uint32), ("pq_evaluated", C.c_uint32), ("adj_prefetch_hits", C.c_uint32)]
 
 
 class DrTiming(C.Structure):
@@ -30,7 +30,7 @@ class DrTiming(C.Structure):
 
 
 STATS_DTYPE = np.dtype([("steps", "<u4"), ("visited", "<u4"), ("exact", "<u4"), ("pq", "<u4"), ("status", "<u4"),
-                        ("inserts", "<u4"), ("pq_evaluated", "<u4"), ("reserved", "<u4")])
+                        ("inserts", "<u4"), ("pq_evaluated", "<u4"), ("adj_prefetch_hits", "<u4")])
 
 # every symbol include/diskrag_hip.h declares
 EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create", "dr_index_set_pq",

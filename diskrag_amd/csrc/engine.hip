@@ -563,7 +563,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     auto lds_of = [&](int kd) -> size_t {
         const int rb = DR_KIND_RB[kd];
         const size_t pw = (DR_KIND_LUT[kd] ? (size_t)ix->m * 256 * 4 : 0) + ((DR_KIND_PQ[kd] && !DR_KIND_LUT[kd]) ? (size_t)ix->D * 4 : 0) +
-                          (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 512 +
+                          (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 512 + (DR_KIND_QB[kd] ? 528 : 0) +
                           (rb ? (size_t)rb * ix->D * (DR_KIND_U8[kd] ? 1 : 4) : (size_t)NCHR_OF_SC[sc] * 64 * 12);
         return (DR_KIND_CB[kd] ? (size_t)256 * ix->D * 4 : 0) + (size_t)DR_KIND_NW[kd] * pw;
     };

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64) void search_f64_kernel(const F64Params p)
         p.out_count[qi] = (u32)kout;
         KStats st;
         st.steps = steps; st.visited = nvisited; st.exact = nexact; st.pq = npq; st.status = status;
-        st.inserts = 0; st.pq_evaluated = npq; st.reserved = 0;
+        st.inserts = 0; st.pq_evaluated = npq; st.adj_prefetch_hits = 0;
         p.stats[qi] = st;
     }
 }

@@ -51,7 +51,7 @@
 
 enum DistKind { DIST_EXACT = 0, DIST_ADC_SQ = 2 };
 
-struct KStats { u32 steps, visited, exact, pq, status, inserts, pq_evaluated, reserved; };
+struct KStats { u32 steps, visited, exact, pq, status, inserts, pq_evaluated, adj_prefetch_hits; };
 
 struct SearchParams {
     const float *vecp;       // [N][D] chain-major
@@ -539,8 +539,12 @@ DEV void search_body(const SearchParams &p)
     // from the codebook; the per-query table is built once, straight from global memory (at D = 1536, m = 32 that is
     // the 6 KiB between three and four wavefronts per CU)
     constexpr bool QORIG_LDS = NEED_PQ && CBLDS;
+    // adjacency row of the predicted next pop prefetched into LDS: the byte-query variants only -- on variant 11 (16
+    // floats of query per lane live) the few extra live values spill in the hot loop: 1.62 -> 2.01 ms
+    constexpr bool ADJPRE = QB;
+    constexpr size_t ADJPRE_BYTES = 528;    // 64 ids + 64 bit positions + the 8-byte mask word, padded to 16
     const size_t per_wave = ((NEED_PQ && !CBLDS) ? (size_t)p.m * 256 * 4 : 0) + (QORIG_LDS ? (size_t)D * 4 : 0) + (QREG ? 0 : (size_t)D * 4) + 512 +
-                            (ROWLDS ? (size_t)RB * ROW_BYTES : MERGE_BYTES);
+                            (ADJPRE ? ADJPRE_BYTES : 0) + (ROWLDS ? (size_t)RB * ROW_BYTES : MERGE_BYTES);
     unsigned char *wbase = smem + off + (size_t)wave * per_wave;
     size_t woff = 0;
     float *lut = reinterpret_cast<float *>(wbase);
@@ -553,6 +557,8 @@ DEV void search_body(const SearchParams &p)
     woff += 256;
     float *nb_e = reinterpret_cast<float *>(wbase + woff);
     woff += 256;
+    u32 *pre_buf = reinterpret_cast<u32 *>(wbase + woff);      // [64 ids][64 positions][2 mask words]
+    if constexpr (ADJPRE) woff += ADJPRE_BYTES;
     float *rowbuf = reinterpret_cast<float *>(wbase + woff);   // [RB][D] landing area (ROWLDS)
     u64 *mk = reinterpret_cast<u64 *>(wbase + woff);           // merge scratch (shares the landing area: rows are
     u32 *mf = reinterpret_cast<u32 *>(mk + NCHR * 64);         // consumed before the decisions start)
@@ -622,6 +628,9 @@ DEV void search_body(const SearchParams &p)
 
         u32 npq_eval = 0;
         u32 steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0, ninserts = 0;
+        u32 pre_id = 0xFFFFFFFFu;   // node whose adjacency row is (being) landed in pre_buf; none at query start
+        u32 npre_hit = 0;
+        const bool pre_on = ADJPRE && has_first && p.adjr != nullptr && p.R == 64u;
         u32 nlog = 0;            // entries of this query in the slot's position log
         bool logfull = false;
         int rn = 0, cnT = 0, tn = 0;   // results; live (unexpanded, untrimmed) result entries; tie side list
@@ -675,6 +684,10 @@ DEV void search_body(const SearchParams &p)
             }
             const float cd = key_dist(ckey);
             const u32 cur = (u32)ckey;
+            // Was this node's adjacency row prefetched during the previous expansion? (static graph data: valid whatever
+            // happened to the lists since)
+            const bool pre_hit = ADJPRE && pre_on && cur == pre_id;
+            if (pre_hit) npre_hit++;
             {
                 const float W = key_dist(list_get<NCHR>(rk, rn - 1));
                 bool stop;
@@ -698,8 +711,39 @@ DEV void search_body(const SearchParams &p)
                 const u64 *auxp = has_first ? p.first + (size_t)cur * nwords + (cbase >> 6)
                                           : reinterpret_cast<const u64 *>(p.deg + (cur & ~1u));
                 const u32 sl = min(slot, p.R - 1);
-                const u32 nbid_l = idrow[sl], nbpos_l = posrow[sl];
-                const u64 aux_w = auxp[0];
+                u32 nbid_l, nbpos_l;
+                u64 aux_w;
+                if (ADJPRE && pre_hit) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    nbid_l = pre_buf[lane]; nbpos_l = pre_buf[64 + lane];
+                    aux_w = *reinterpret_cast<const u64 *>(pre_buf + 128);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // read before the next prefetch reuses the area
+                } else { nbid_l = idrow[sl]; nbpos_l = posrow[sl]; aux_w = auxp[0]; }
+                // Predict the next pop -- the best frontier entry that is left now (this expansion's neighbours may still
+                // beat it) -- and land ITS adjacency row in LDS: no VGPR destination, nobody waits for it, and when the
+                // prediction holds the next expansion starts without its first global round trip.
+                if constexpr (ADJPRE) {
+                    pre_id = 0xFFFFFFFFu;
+                    if (pre_on) {
+                        const int ia2 = frontier_first<NCHR>(rk, fl, rn);
+                        const u64 ka2 = (ia2 >= 0) ? fkey(list_get<NCHR>(rk, ia2)) : ~0ull;
+                        const u64 kb2 = (tn > 0) ? readlane64(tl.v[0], 0) : ~0ull;
+                        const u64 kn = ka2 <= kb2 ? ka2 : kb2;
+                        if (kn != ~0ull) {
+                            pre_id = (u32)kn;
+                            const u32 *gi = p.adj + (size_t)pre_id * 64 + lane, *gp = p.adjr + (size_t)pre_id * 64 + lane;
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gi,
+                                (__attribute__((address_space(3))) void *)pre_buf, 4, 0, 0);
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
+                                (__attribute__((address_space(3))) void *)(pre_buf + 64), 4, 0, 0);
+                            if (lane < 2) {
+                                const u32 *gm = reinterpret_cast<const u32 *>(p.first + (size_t)pre_id) + lane;
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gm,
+                                    (__attribute__((address_space(3))) void *)(pre_buf + 128), 4, 0, 0);
+                            }
+                        }
+                    }
+                }
                 const u32 nbid = slot < p.R ? nbid_l : 0xFFFFFFFFu;
                 const u32 nbpos = slot < p.R ? nbpos_l : 0xFFFFFFFFu;
                 const u64 aux = has_first ? aux_w : (u64)(u32)(aux_w >> ((cur & 1u) * 32));
@@ -1172,7 +1216,7 @@ DEV void search_body(const SearchParams &p)
             if (anyt && has_ties) p.tie_list[atomicAdd(p.tie_count, 1u)] = qi;
             KStats st;
             st.steps = steps; st.visited = nvisited; st.exact = nexact; st.pq = npq; st.status = status;
-            st.inserts = ninserts; st.pq_evaluated = npq_eval; st.reserved = 0;
+            st.inserts = ninserts; st.pq_evaluated = npq_eval; st.adj_prefetch_hits = npre_hit;
             p.stats[qi] = st;
         }
         PH(7);

@@ -52,7 +52,8 @@ typedef struct {
     uint32_t inserts; /* accepted result-list inserts (engine counter, not in the reference) */
     uint32_t pq_evaluated; /* ADC sums actually computed: `pq` minus those whose outcome (rerank policy True) was
                               proven from a per-query upper bound without reading the code words (engine counter) */
-    uint32_t reserved;
+    uint32_t adj_prefetch_hits; /* expansions whose adjacency row was already in LDS: the engine prefetches the row of
+                                   the predicted next node (byte-query variants 13/14; 0 elsewhere; engine counter) */
 } dr_stats;
 
 /* timing of the last dr_search_batch, or of the dr_batch_run calls since the previous dr_batch_sync /

@@ -96,7 +96,7 @@ def test_byte_rows_are_lossless_and_only_for_integer_data():
             blocks[kind] = (ix.timing()["block"], ix.timing()["lds_bytes"])
             assert ix.timing()["variant"] == (kind if kind >= 0 else 13)   # integer data AND integer queries: 13
         assert blocks[9][0] == 768 and blocks[10][0] == 768 and blocks[10][1] < blocks[9][1] and blocks[11][0] == 1024
-        assert blocks[-1] == blocks[13] == blocks[11]
+        assert blocks[-1] == blocks[13] and blocks[13][0] == blocks[11][0] and blocks[13][1] == blocks[11][1] + 16 * 528   # + adjacency landing areas
         # byte queries (13 / 14: v_dot4_u32_u8 distances) are taken only when EVERY component of the batch is an integer
         # in [0, 255]; one fractional, negative or too-large component and the batch runs on the float-query variants.
         # Extreme integer queries (all 0 / all 255 against rows up to 218) stay exact as well.

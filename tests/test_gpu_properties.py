@@ -51,6 +51,17 @@ def test_counters_are_consistent(big):
     assert (st["visited"] == st["pq"] + 1).all()                 # every visited node but the start gets one ADC
     assert (st["exact"] <= st["visited"]).all() and (st["pq_evaluated"] <= st["pq"]).all()
     assert (st["steps"] <= 1000).all() and (st["inserts"] <= st["exact"]).all()
+    # byte-row variant, R = 64, bit order on: the adjacency row of the predicted next node is prefetched into LDS
+    assert ix.timing()["variant"] == 13
+    assert (st["adj_prefetch_hits"] < st["steps"]).all() and st["adj_prefetch_hits"].sum() > 0.5 * st["steps"].sum()
+    ix.debug_force_kind(9)
+    try:
+        ids9, dist9, cnt9, st9 = ix.search_batch(q, 10, L=100, beam_width=0, mode=1)
+        assert ix.timing()["variant"] == 9 and (st9["adj_prefetch_hits"] == 0).all()
+        assert np.array_equal(ids, ids9) and np.array_equal(dist.view(np.uint32), dist9.view(np.uint32))
+        assert np.array_equal(st["steps"], st9["steps"]) and np.array_equal(st["exact"], st9["exact"])
+    finally:
+        ix.debug_force_kind(-1)
 
 
 def test_sample_matches_oracle_at_scale(big):
