@@ -3,17 +3,30 @@
 N = 1,000,000 x d = 128 L2, R = 64 slots, PQ m = 32, L_search = 100, batch = 10,000 queries, reference-faithful M1
 (SearchEngineCorrect._pq_accelerated_graph_search semantics, search_engine.py:398-506), one MI355X per rank.
 
-A "step" is one pass of the hot path over one 10k-query batch that is already resident in HBM. Multi-GPU runs are
-query-sharded replicas: every rank holds the whole index and searches its own 10k batch, there is no
-data-path collective, and the job value is the sum of the ranks' queries over the slowest rank's time (weak scaling).
+What is measured:
+  * `value`: queries per second of a stream of 10k-query batches that start in HOST memory and end as results in HOST
+    memory -- dr_search_submit / dr_search_wait (include/diskrag_hip.h): upload, search, tie-order pass and download
+    of consecutive batches overlap on separate HIP streams, three batches in flight. Distinct batches rotate
+    (--distinct-batches, default 8), so no step replays the previous step's queries.
+  * `config.qps_resident`: the same rotation with every batch already resident in HBM (dr_batch_select / dr_batch_run).
+  * a "step" is --batches-per-step (default 40) consecutive 10k-query batches, so that the timed region of the
+    driver's 20 steps lasts about a second; `ms_per_step` is per step, `config.ms_per_batch` per 10k-query batch.
 
-Prints ONE JSON line on rank 0. Synthetic data (no network): diskrag_amd/synth.py; graph, PQ codebook and codes are
-built on the device by the engine's own builder before the timed region.
+Multi-GPU (query-sharded replicas): `python bench.py --gpus N` starts N worker processes itself -- before
+any GPU call is made in this process -- one per device, each with the whole index and its own batches (weak scaling);
+they meet at file barriers in a scratch directory and rank 0 prints the one JSON line (value = all ranks' queries /
+slowest rank's time). No data-path collective, no PyTorch. The same workers also run under
+`python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE from the environment, same file barriers).
+
+Synthetic data (no network): diskrag_amd/synth.py; graph, PQ codebook and codes are built on the device by the
+engine's own builder before the timed region.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -25,221 +38,501 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy reaches
 
 
-def log(msg):
-    if int(os.environ.get("RANK", "0")) == 0:
-        print(f"[bench] {msg}", file=sys.stderr, flush=True)
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batches-per-step", dest="bps", type=int, default=40, help="10k-query batches per step")
+    ap.add_argument("--distinct-batches", dest="nb", type=int, default=8, help="distinct query batches rotated (<= 16)")
     ap.add_argument("--num-vectors", dest="n", type=int, default=1_000_000)
     ap.add_argument("--num-queries", dest="nq", type=int, default=10_000)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--R", type=int, default=64)
     ap.add_argument("--L", type=int, default=100)
     ap.add_argument("--bw", type=int, default=8, help="beam_width: 8 = the reference default of search()/the API routes (search_engine.py:530, app.py:96); 0 = None (no frontier trim)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the beam_width=None secondary measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (no trim, float rows, un-rounded data)")
     ap.add_argument("--m", type=int, default=32)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--L-build", type=int, default=100)
-    ap.add_argument("--cpu-sample", type=int, default=2000, help="queries timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--cpu-sample", type=int, default=2000, help="queries timed on the CPU oracle, all cores (rank 0, N=1 only)")
+    ap.add_argument("--cpu-sample-1t", type=int, default=150, help="queries timed on ONE CPU thread")
     ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--min-recall", type=float, default=0.95, help="the metric's recall bar: the bench fails below it")
+    ap.add_argument("--config", default="c2", choices=["c2", "c5"], help="c2: the headline (query-sharded replicas); c5: graph-sharded PQ-only search with the RCCL top-k exchange")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    backend = os.environ.get("DR_BENCH_BACKEND", "nccl")     # "gloo" lets the N>1 path run where ranks share a GPU
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+# ------------------------------------------------------------------------------------------------ ranks and barriers
+class Ranks:
+    """Rank bookkeeping + file barriers in a scratch directory shared by the ranks of ONE node (no torch, no sockets)."""
+
+    def __init__(self):
+        env = os.environ
+        if "DR_BENCH_RANK" in env:                       # started by this script's own launcher
+            self.rank, self.world = int(env["DR_BENCH_RANK"]), int(env["DR_BENCH_WORLD"])
+            self.local_rank, self.dir = self.rank, env["DR_BENCH_SYNC_DIR"]
+        elif "RANK" in env and "WORLD_SIZE" in env:       # torch.distributed.run / torchrun
+            self.rank, self.world = int(env["RANK"]), int(env["WORLD_SIZE"])
+            self.local_rank = int(env.get("LOCAL_RANK", self.rank))
+            tag = "%s_%s" % (env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "run"))
+            self.dir = os.path.join(tempfile.gettempdir(), "diskrag_bench_" + "".join(c if c.isalnum() else "_" for c in tag))
+            os.makedirs(self.dir, exist_ok=True)
         else:
-            dist.init_process_group(backend=backend)
+            self.rank, self.world, self.local_rank, self.dir = 0, 1, 0, None
+        self._n = 0
+
+    def barrier(self, timeout=1800.0):
+        if self.world == 1:
+            return
+        self._n += 1
+        Path(self.dir, "b%d.%d" % (self._n, self.rank)).write_text("x")
+        t0 = time.time()
+        while True:
+            if all(os.path.exists(os.path.join(self.dir, "b%d.%d" % (self._n, r))) for r in range(self.world)):
+                return
+            if time.time() - t0 > timeout:
+                raise RuntimeError("barrier %d timed out on rank %d" % (self._n, self.rank))
+            time.sleep(0.0005)
+
+    def put(self, name, obj):
+        if self.world == 1:
+            self._single = getattr(self, "_single", {})
+            self._single[name] = obj
+            return
+        tmp = os.path.join(self.dir, ".%s.%d.tmp" % (name, self.rank))
+        with open(tmp, "wb") as f:
+            f.write(obj if isinstance(obj, bytes) else json.dumps(obj).encode())
+        os.replace(tmp, os.path.join(self.dir, "%s.%d" % (name, self.rank)))
+
+    def get(self, name, rank, raw=False, timeout=1800.0):
+        if self.world == 1:
+            return self._single[name]
+        path = os.path.join(self.dir, "%s.%d" % (name, rank))
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout:
+                raise RuntimeError("waiting for %s timed out" % path)
+            time.sleep(0.001)
+        data = open(path, "rb").read()
+        return data if raw else json.loads(data)
+
+    def gather(self, name, obj):
+        """every rank's object, on every rank (call on all ranks)"""
+        self.put(name, obj)
+        self.barrier()
+        return [self.get(name, r) for r in range(self.world)]
+
+
+def log(rk, msg):
+    if rk.rank == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch(args):
+    """`bench.py --gpus N` without a torchrun environment: N worker processes, started BEFORE this process makes any
+    GPU call (it never does), one device each, synchronised through files. Rank 0's stdout is this process's stdout."""
+    syncdir = tempfile.mkdtemp(prefix="diskrag_bench_")
+    procs = []
+    argv = [a for a in sys.argv[1:] if a != "--worker"] + ["--worker"]
+    for r in range(args.gpus):
+        env = dict(os.environ, DR_BENCH_RANK=str(r), DR_BENCH_WORLD=str(args.gpus), DR_BENCH_SYNC_DIR=syncdir)
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    for f in os.listdir(syncdir):
+        try:
+            os.remove(os.path.join(syncdir, f))
+        except OSError:
+            pass
+    try:
+        os.rmdir(syncdir)
+    except OSError:
+        pass
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ engines
+class StubIndex:
+    """Launcher self-test double (DR_BENCH_STUB=1, tests/test_bench_launcher.py): no GPU, no search -- it only lets the
+    rank / barrier / JSON plumbing run on a CPU box. Never a fallback: the real path raises without a HIP device."""
+
+    def __init__(self, nq, k):
+        self.nq, self.k = nq, k
+
+    def results(self):
+        st = np.zeros(self.nq, dtype=[("steps", "<u4"), ("visited", "<u4"), ("exact", "<u4"), ("pq", "<u4"), ("status", "<u4"),
+                                      ("inserts", "<u4"), ("pq_evaluated", "<u4"), ("adj_prefetch_hits", "<u4")])
+        st["steps"], st["exact"] = 40, 2000
+        ids = np.tile(np.arange(self.k, dtype=np.uint32), (self.nq, 1))
+        return ids, np.zeros((self.nq, self.k), np.float32), np.full(self.nq, self.k, np.uint32), st
+
+
+def alg_bytes(st, D, R, m, k):
+    """algorithmic bytes of one launch: sum_q 4D + S*4R + V*m + X*4D + 8k, + the codebook once"""
+    S, V, X = st["steps"].astype(np.float64), st["pq_evaluated"].astype(np.float64), st["exact"].astype(np.float64)
+    per_q = 4 * D + S * 4 * R + V * m + X * 4 * D + 8 * k
+    return float(per_q.sum()) + 4 * 256 * D, per_q
+
+
+def worker(args):
+    rk = Ranks()
+    stub = os.environ.get("DR_BENCH_STUB") == "1"
+    if args.config == "c5":
+        return worker_c5(args, rk)
+    nb = max(1, min(args.nb, 16))
+    nq, k, D = args.nq, args.k, args.dim
+    launches = args.steps * args.bps
+
+    if stub:
+        time.sleep(0.05 * (1 + rk.rank))
+        rk.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.001 * launches)
+        el = time.perf_counter() - t0
+        times = rk.gather("t", el)
+        if rk.rank == 0:
+            print(json.dumps({"metric": "launcher self-test (stub engine)", "value": nq * launches * rk.world / max(times),
+                              "unit": "queries/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": max(times) / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "none", "data": "stub",
+                              "config": {"workload": "stub", "per_rank_seconds": times}}), flush=True)
+        return 0
 
     import diskrag_amd
     from diskrag_amd import HipIndex, _ffi
     from diskrag_amd.synth import recall_at_k, sift_like
 
-    if diskrag_amd.device_count() < 1:
+    ndev = diskrag_amd.device_count()
+    if ndev < 1:
         raise RuntimeError("no HIP device: the engine has no CPU fallback")
+    device = rk.local_rank % ndev
+    mode = _ffi.MODE_M1
 
     # ---------------------------------------------------------------- setup (untimed): data, graph, PQ, ground truth
     t0 = time.time()
-    x, q = sift_like(args.n, args.dim, n_queries=args.nq, n_clusters=1024, seed=2024, query_seed=9000 + rank)
-    log(f"synthetic data {x.shape} + {q.shape[0]} queries in {time.time() - t0:.1f}s")
+    x, q_all = sift_like(args.n, D, n_queries=nq * nb, n_clusters=1024, seed=2024, query_seed=9000 + rk.rank)
+    log(rk, f"synthetic data {x.shape} + {nb} distinct batches of {nq} queries in {time.time() - t0:.1f}s")
     t0 = time.time()
-    ix = HipIndex.create_empty(x, R=args.R, device=local_rank % max(1, diskrag_amd.device_count()))
+    ix = HipIndex.create_empty(x, R=args.R, device=device)
     medoid, build_s = ix.build_vamana(L_build=args.L_build, alpha=1.2, passes=2, seed=7, pad_with_zero=True)
-    log(f"vamana graph built on device in {build_s:.1f}s (upload+build {time.time() - t0:.1f}s), medoid {medoid}")
+    log(rk, f"vamana graph built on device {device} in {build_s:.1f}s (upload+build {time.time() - t0:.1f}s), medoid {medoid}")
     t0 = time.time()
+    want_cpu = rk.rank == 0 and rk.world == 1 and not args.no_cpu
     cb = ix.pq_train(args.m, n_sample=100_000, iters=8)
-    codes = ix.pq_encode(cb, want_codes=(rank == 0 and world == 1 and not args.no_cpu))
-    log(f"PQ m={args.m} trained + {args.n} vectors encoded in {time.time() - t0:.1f}s")
+    codes = ix.pq_encode(cb, want_codes=want_cpu)
+    log(rk, f"PQ m={args.m} trained + {args.n} vectors encoded in {time.time() - t0:.1f}s")
     t0 = time.time()
-    gt, _ = ix.bruteforce_topk(q, args.k)
-    log(f"brute-force ground truth in {time.time() - t0:.1f}s")
+    gt, _ = ix.bruteforce_topk(q_all, k)
+    log(rk, f"brute-force ground truth for {nq * nb} queries in {time.time() - t0:.1f}s")
 
-    mode = _ffi.MODE_M1
-    ix.batch_upload(q)
+    # the batches as a caller would hold them: page-locked host arrays (dr_host_alloc) -- and pageable copies for the
+    # secondary figure
+    qb = []
+    for b in range(nb):
+        a = _ffi.pinned_empty((nq, D), np.float32)
+        a[:] = q_all[b * nq:(b + 1) * nq]
+        qb.append(a)
 
-    def sync_all():
-        if dist is not None:
-            import torch
-            dist.barrier()
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-
-    # ---------------------------------------------------------------- warmup + timed region
-    for _ in range(args.warmup):
-        ix.batch_run(args.k, L=args.L, beam_width=args.bw, mode=mode)
-    ix.batch_sync()
-    sync_all()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        ix.batch_run(args.k, L=args.L, beam_width=args.bw, mode=mode)   # queues the step: search kernel on the engine's
-    ix.batch_sync()                                                     # stream, tie-order pass overlapping the next step;
-    sync_all()                                                          # everything is waited for here, inside the clock
-    elapsed = time.perf_counter() - t_start
-    kernel_ms = [ix.timing()["search_kernel_ms"]]   # mean launch duration over the timed steps (HIP events on the engine's stream)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    ids, dist_out, cnt, st = ix.batch_download()
-    timing = ix.timing()
-    recall = recall_at_k(ids, gt, args.k)
-    if (st["status"] != 0).any():
-        raise RuntimeError("work-area overflow during the bench")
-
-    # PCIe-inclusive rate (queries from host memory, results back to host), reported beside the headline
-    t1 = time.perf_counter()
-    ix.search_batch(q, args.k, L=args.L, beam_width=args.bw, mode=mode)
-    pcie_qps = args.nq / (time.perf_counter() - t1)
-
-    # ---------------------------------------------------------------- roofline of the dominant kernel
-    # algorithmic bytes per query: B_q = 4D + S*4R + V*m + X*4D + 8k, counters from the engine
-    S, V, X = st["steps"].astype(np.float64), st["pq_evaluated"].astype(np.float64), st["exact"].astype(np.float64)
-    bytes_q = 4 * args.dim + S * 4 * args.R + V * args.m + X * 4 * args.dim + 8 * args.k
-    alg_bytes = float(bytes_q.sum()) + 4 * 256 * args.dim       # + codebook once per batch
-    k_ms = float(np.mean(kernel_ms))
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-
-    # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950
-    # read correction applied): measured offline on this same workload, committed under profiles/
-    traffic = None
-    pmc = ROOT / "profiles" / "r01" / "pmc_traffic.json"
-    if pmc.exists() and (args.n, args.nq, args.dim, args.R, args.L, args.m) == (1_000_000, 10_000, 128, 64, 100, 32):
-        rec = json.loads(pmc.read_text()).get("beam_width_%d" % args.bw)
-        if rec:
-            traffic = rec["hbm_bytes_per_launch"]
-
-    # secondary measurement (same index, same queries): beam_width=None, the reference's no-trim mode
-    secondary = None
-    if not args.no_secondary and args.bw != 0:
-        for _ in range(2):
-            ix.batch_run(args.k, L=args.L, beam_width=0, mode=mode)
-        ix.batch_sync()
-        sync_all()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            ix.batch_run(args.k, L=args.L, beam_width=0, mode=mode)
-        ix.batch_sync()
-        k2 = [ix.timing()["search_kernel_ms"]]
-        el2 = time.perf_counter() - t2
-        ids2, _, _, st2 = ix.batch_download()
-        b2 = (4 * args.dim + st2["steps"].astype(np.float64) * 4 * args.R + st2["pq_evaluated"].astype(np.float64) * args.m +
-              st2["exact"].astype(np.float64) * 4 * args.dim + 8 * args.k).sum() + 4 * 256 * args.dim
-        secondary = {"beam_width": None, "qps_rank0": args.nq * args.steps / el2, "recall_at_10": recall_at_k(ids2, gt, args.k),
-                     "kernel_ms": float(np.mean(k2)), "roofline_frac": b2 / (float(np.mean(k2)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                     "exact_distances_per_query": float(st2["exact"].mean())}
-
-    # the same step on the variants that less special data gets: float32 rows (variant 9: data that is not
-    # integer-valued) and byte rows with float32 queries (variant 11: integer data, queries that are not)
-    float_rows = float_queries = None
-    byte_rows = timing["variant"] in (10, 11, 13)
-
-    def forced(kind):
+    def run_resident(bw, n_launch, kind=-1, batches=None):
+        """n_launch launches rotating over the resident batches; returns seconds (host clock) and mean kernel ms"""
         ix.debug_force_kind(kind)
-        for _ in range(2):
-            ix.batch_run(args.k, L=args.L, beam_width=args.bw, mode=mode)
+        nbb = len(batches) if batches is not None else nb
+        for i in range(min(4, n_launch)):
+            ix.batch_select(i % nbb); ix.batch_run(k, L=args.L, beam_width=bw, mode=mode)
         ix.batch_sync()
-        t3 = time.perf_counter()
-        for _ in range(args.steps):
-            ix.batch_run(args.k, L=args.L, beam_width=args.bw, mode=mode)
+        t1 = time.perf_counter()
+        for i in range(n_launch):
+            ix.batch_select(i % nbb)
+            ix.batch_run(k, L=args.L, beam_width=bw, mode=mode)
         ix.batch_sync()
-        el3 = time.perf_counter() - t3
-        k3 = ix.timing()["search_kernel_ms"]
-        ran = ix.timing()["variant"]
+        el = time.perf_counter() - t1
+        tm = ix.timing()
         ix.debug_force_kind(-1)
-        return {"variant": ran, "qps_rank0": args.nq * args.steps / el3, "kernel_ms": k3,
-                "roofline_frac": alg_bytes / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        return el, tm
 
-    if byte_rows and not args.no_secondary:
-        float_rows = forced(9)
-        if timing["variant"] == 13:
-            float_queries = forced(11)
+    def collect(bw, kind=-1):
+        """one launch per resident batch, results of all of them (recall, counters)"""
+        ix.debug_force_kind(kind)
+        outs = []
+        for b in range(nb):
+            ix.batch_select(b)
+            ix.batch_run(k, L=args.L, beam_width=bw, mode=mode)
+            outs.append(ix.batch_download())
+        ix.debug_force_kind(-1)
+        ids = np.concatenate([o[0] for o in outs]); st = np.concatenate([o[3] for o in outs])
+        dist = np.concatenate([o[1] for o in outs])
+        if (st["status"] != 0).any():
+            raise RuntimeError("work-area overflow during the bench")
+        return ids, dist, st
 
-    total_q = args.nq * world * args.steps
-    value = total_q / elapsed
+    for b in range(nb):
+        ix.batch_select(b)
+        ix.batch_upload(qb[b])
+    ix.batch_select(0)
+
+    # ---------------------------------------------------------------- the headline: host memory -> host memory, pipelined
+    def run_pipelined(n_launch, sources):
+        jobs, done = [], 0
+        t1 = time.perf_counter()
+        for i in range(n_launch):
+            jobs.append(ix.search_submit(sources[i % len(sources)], k, L=args.L, beam_width=args.bw, mode=mode, reuse_outputs=True))
+            if len(jobs) - done >= 3:
+                jobs[done].wait(); jobs[done] = None; done += 1
+        last = None
+        for j in range(done, len(jobs)):
+            last = jobs[j].wait()
+            if j < len(jobs) - 1:
+                jobs[j] = None
+        el = time.perf_counter() - t1
+        return el, last
+
+    run_pipelined(max(3, args.warmup * args.bps), qb)          # warm-up (also sizes every buffer of the pipeline)
+    ix.batch_sync()
+    rk.barrier()
+    elapsed, last = run_pipelined(launches, qb)
+    ix.batch_sync()                                            # everything is waited for inside the clock (it already is)
+    tm_head = ix.timing()
+    times = rk.gather("t_head", elapsed)
+    elapsed_job = max(times)
+    value = nq * launches * rk.world / elapsed_job
+
+    # ---------------------------------------------------------------- the same rotation, batches resident in HBM
+    rk.barrier()
+    el_res, tm_res = run_resident(args.bw, launches)
+    res_times = rk.gather("t_res", el_res)
+    qps_resident = nq * launches * rk.world / max(res_times)
+
+    # results of every distinct batch: recall, counters, algorithmic bytes
+    ids, dist_out, st = collect(args.bw)
+    recall = recall_at_k(ids, gt, k)
+    if recall < args.min_recall:
+        raise RuntimeError(f"recall@{k} = {recall:.4f} is below the metric's bar {args.min_recall}")
+    variant = ix.timing()["variant"]
+    a_all, per_q = alg_bytes(st, D, args.R, args.m, k)
+    alg_launch = (a_all - 4 * 256 * D) / nb + 4 * 256 * D      # per 10k-query launch
+    k_ms = float(tm_head["search_kernel_ms"])                    # mean launch duration over the timed pipelined region
+    achieved = alg_launch / (k_ms * 1e-3) / 1e9
+
+    # PCIe-inclusive rate from PAGEABLE caller memory (the library stages it), for reference
+    qb_pageable = [np.array(a) for a in qb[:min(nb, 4)]]
+    el_pg, _ = run_pipelined(max(8, launches // 8), qb_pageable)
+    qps_pageable = nq * max(8, launches // 8) / el_pg
+    # ... and one blocking dr_search_batch call, as round 1 reported it
+    t1 = time.perf_counter()
+    ix.search_batch(qb_pageable[0], k, L=args.L, beam_width=args.bw, mode=mode)
+    qps_one_call = nq / (time.perf_counter() - t1)
+
+    # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 read
+    # correction applied): collected offline on this same workload by scripts/profile_run.sh, committed under profiles/
+    traffic, traffic_src = None, None
+    for rnd in ("r02", "r01"):
+        pmc = ROOT / "profiles" / rnd / "pmc_traffic.json"
+        if traffic is None and pmc.exists() and (args.n, nq, D, args.R, args.L, args.m) == (1_000_000, 10_000, 128, 64, 100, 32):
+            rec = json.loads(pmc.read_text()).get("beam_width_%d" % args.bw)
+            if rec and (rnd == "r02" or variant == 13):
+                traffic = rec["hbm_bytes_per_launch"]
+                traffic_src = "profiles/%s/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over scripts/pmc_target.py: the same workload, not this run)" % rnd
+
+    byte_rows = variant in (11, 13)
+    secondary = float_rows = float_queries = unrounded = None
+    if not args.no_secondary and rk.world == 1:
+        n_sec = max(40, launches // 4)
+        if args.bw != 0:        # beam_width=None, the reference's no-trim mode
+            el2, tm2 = run_resident(0, n_sec)
+            ids2, _, st2 = collect(0)
+            a2, _ = alg_bytes(st2, D, args.R, args.m, k)
+            a2 = (a2 - 4 * 256 * D) / nb + 4 * 256 * D
+            secondary = {"beam_width": None, "qps_resident": nq * n_sec / el2, "recall_at_10": recall_at_k(ids2, gt, k),
+                         "kernel_ms": tm2["search_kernel_ms"], "roofline_frac": a2 / (tm2["search_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "exact_distances_per_query": float(st2["exact"].mean())}
+
+        def forced(kind):
+            el3, tm3 = run_resident(args.bw, n_sec, kind=kind)
+            return {"variant": tm3["variant"], "qps_resident": nq * n_sec / el3, "kernel_ms": tm3["search_kernel_ms"],
+                    "roofline_frac": alg_launch / (tm3["search_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+
+        if byte_rows:
+            float_rows = forced(9)          # float32 rows: what data that is not integer-valued gets
+            if variant == 13:
+                float_queries = forced(11)  # byte rows, float32 queries: integer data, queries that are not
+
     out = {
         "metric": "QPS @ recall@10>=0.95, SIFT1M-shaped d=128 L2, batch=10k",
-        "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "SIFT1M-shaped synthetic (configs[1]): N=%d d=%d L2, R=%d, L_search=%d, PQ m=%d, "
-                               "beam_width=%s, k=%d, batch=%d queries/GPU, mode=M1 reference-faithful"
-                               % (args.n, args.dim, args.R, args.L, args.m, args.bw or None, args.k, args.nq),
-                   "recall_at_10": recall, "build_seconds": build_s, "parallelism": "query-sharded replicas x%d" % world,
-                   "qps_pcie_inclusive_rank0": pcie_qps,
-                   "per_query": {"expansions": float(S.mean()), "pq_distances": float(st["pq"].mean()), "pq_evaluated": float(V.mean()),
-                                 "exact_distances": float(X.mean()), "algorithmic_bytes": float(bytes_q.mean())},
-                   "launch": {k_: timing[k_] for k_ in ("variant", "grid", "block", "lds_bytes", "waves_per_cu")},
-                   "finalize_kernel_ms": timing["finalize_kernel_ms"], "secondary_no_trim": secondary,
+        "value": value, "unit": "queries/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed_job / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": ("f32 (lossless u8 rows+queries, v_dot4: integer arithmetic that equals the reference's float32 sums bit for bit)"
+                  if variant == 13 else "f32 (lossless u8 rows)" if variant == 11 else "f32"),
+        "data": "synthetic",
+        "config": {"workload": "SIFT1M-shaped synthetic (configs[1]): N=%d d=%d L2, R=%d, L_search=%d, PQ m=%d, beam_width=%s, "
+                               "k=%d, batch=%d queries, mode=M1 reference-faithful; a step = %d consecutive batches, %d distinct "
+                               "batches per GPU rotating; value = host memory -> host memory (dr_search_submit/wait, 3 batches in flight)"
+                               % (args.n, D, args.R, args.L, args.m, args.bw or None, k, nq, args.bps, nb),
+                   "recall_at_10": recall, "build_seconds": build_s, "parallelism": "query-sharded replicas x%d" % rk.world,
+                   "ms_per_batch": elapsed_job / launches * 1e3, "timed_region_s": elapsed_job, "per_rank_seconds": times,
+                   "per_rank_qps": [nq * launches / t for t in times],
+                   "qps_resident": qps_resident, "ms_per_batch_resident": max(res_times) / launches * 1e3,
+                   "kernel_ms_resident": tm_res["search_kernel_ms"],
+                   "qps_pcie_inclusive_pageable_source": qps_pageable, "qps_one_blocking_call": qps_one_call,
+                   "per_query": {"expansions": float(st["steps"].mean()), "pq_distances": float(st["pq"].mean()),
+                                 "pq_evaluated": float(st["pq_evaluated"].mean()), "exact_distances": float(st["exact"].mean()),
+                                 "algorithmic_bytes": float(per_q.mean())},
+                   "launch": {k_: tm_head[k_] for k_ in ("variant", "grid", "block", "lds_bytes", "waves_per_cu")},
+                   "finalize_kernel_ms": tm_head["finalize_kernel_ms"], "secondary_no_trim": secondary,
                    "row_storage": ("u8: lossless byte copy of the integer-valued vectors (every component checked; distances "
                                    "bit-identical); roofline.achieved counts the reference's 4*D bytes per scored vector, "
                                    "roofline.traffic is what HBM really moved") if byte_rows else "f32",
-                   "query_storage": ("u8: every component of the batch is an integer in [0, 255] (checked per upload), "
-                                     "distances by v_dot4_u32_u8 -- the integer sum IS the reference's float32 sum "
-                                     "(all partial sums < 2^24)") if timing["variant"] == 13 else "f32",
+                   "query_storage": ("u8: every component of the batch is an integer in [0, 255] (checked per batch on the host)"
+                                     if variant == 13 else "f32"),
                    "float32_rows": float_rows, "byte_rows_float32_queries": float_queries},
-        "roofline": {"bound": "hbm", "kernel": "search_kernel<128,M1>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        "roofline": {"bound": "hbm", "kernel": "search_kernel<128,M1> variant %d" % variant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "hbm_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_launch,
+                     "note": "frac prices the reference's accounting (4*D bytes per scored vector); hbm_frac is what HBM moved; the "
+                             "kernel is bound by the chip's rate of random requests (DESIGN.md 4.1: ~55 G requests/s measured by "
+                             "tools/gather_probe.hip), not by bytes"},
     }
 
+    # ---------------------------------------------------------------- the un-rounded generator: its own data, graph, recall
+    adj = ix.get_adjacency() if want_cpu else None
+    if not args.no_secondary and rk.world == 1:
+        t0 = time.time()
+        xu, qu = sift_like(args.n, D, n_queries=nq * min(nb, 4), n_clusters=1024, seed=2024, query_seed=9000, rounded=False)
+        iu = HipIndex.create_empty(xu, R=args.R, device=device)
+        _, bsu = iu.build_vamana(L_build=args.L_build, alpha=1.2, passes=2, seed=7, pad_with_zero=True)
+        iu.pq_encode(iu.pq_train(args.m, n_sample=100_000, iters=8))
+        gtu, _ = iu.bruteforce_topk(qu, k)
+        nbu = min(nb, 4)
+        for b in range(nbu):
+            iu.batch_select(b); iu.batch_upload(qu[b * nq:(b + 1) * nq])
+        n_sec = max(40, launches // 4)
+        for i in range(4):
+            iu.batch_select(i % nbu); iu.batch_run(k, L=args.L, beam_width=args.bw, mode=mode)
+        iu.batch_sync()
+        t1 = time.perf_counter()
+        for i in range(n_sec):
+            iu.batch_select(i % nbu); iu.batch_run(k, L=args.L, beam_width=args.bw, mode=mode)
+        iu.batch_sync()
+        elu = time.perf_counter() - t1
+        tmu = iu.timing()
+        outs = []
+        for b in range(nbu):
+            iu.batch_select(b); iu.batch_run(k, L=args.L, beam_width=args.bw, mode=mode); outs.append(iu.batch_download())
+        idu = np.concatenate([o[0] for o in outs]); stu = np.concatenate([o[3] for o in outs])
+        au, _ = alg_bytes(stu, D, args.R, args.m, k)
+        au = (au - 4 * 256 * D) / nbu + 4 * 256 * D
+        unrounded = {"data": "the same mixture without rounding (float32-valued descriptors: no byte rows)", "variant": tmu["variant"],
+                     "qps_resident": nq * n_sec / elu, "recall_at_10": recall_at_k(idu, gtu, k), "kernel_ms": tmu["search_kernel_ms"],
+                     "roofline_frac": au / (tmu["search_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "build_seconds": bsu,
+                     "exact_distances_per_query": float(stu["exact"].mean()), "setup_seconds": time.time() - t0}
+        out["config"]["unrounded_data"] = unrounded
+        iu.close()
+
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1): the oracle, timed
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if want_cpu:
         from oracle import pyoracle as orc
-        adj = ix.get_adjacency()
         cores = os.cpu_count() or 1
-        ns = min(args.cpu_sample, args.nq)
+        ns = min(args.cpu_sample, nq)
+        q0 = np.array(qb[0])
         t2 = time.perf_counter()
-        oids, odist, ocnt, ost = orc.search_batch(x, adj, q[:ns], medoid, orc.M1, args.k, L=args.L, bw=args.bw,
+        oids, odist, ocnt, ost = orc.search_batch(x, adj, q0[:ns], medoid, orc.M1, k, L=args.L, bw=args.bw,
                                                   codes=codes, codebook=cb, nthreads=cores)
         cpu_s = time.perf_counter() - t2
         same = bool(np.array_equal(oids, ids[:ns]) and
                     np.array_equal(odist.astype(np.float32).view(np.uint32), dist_out[:ns].view(np.uint32)))
         out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
-                               "sample": "first %d of the %d bench queries, same index, oracle/ C restatement of M1 "
-                                         "on OpenMP threads; GPU results bit-identical on the sample: %s"
-                                         % (ns, args.nq, same)}
+                               "sample": "first %d of the bench queries, same index, oracle/ C restatement of M1 on OpenMP "
+                                         "threads; GPU results bit-identical on the sample: %s" % (ns, same)}
+        n1 = min(args.cpu_sample_1t, ns)
+        t2 = time.perf_counter()
+        orc.search_batch(x, adj, q0[:n1], medoid, orc.M1, k, L=args.L, bw=args.bw, codes=codes, codebook=cb, nthreads=1)
+        out["cpu_baseline_1t"] = {"value": n1 / (time.perf_counter() - t2), "unit": "queries/s", "cores": 1, "kind": "port",
+                                  "sample": "first %d of the bench queries, one thread" % n1}
         if not same:
             raise RuntimeError("GPU results differ from the oracle on the CPU-baseline sample")
-    if rank == 0:
+    if rk.rank == 0:
         print(json.dumps(out), flush=True)
     ix.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    rk.barrier()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ c5: graph-sharded
+def worker_c5(args, rk):
+    """BASELINE config c5 at bench scale: every rank owns ONE shard (its own vectors, sub-graph and PQ codes), every query
+    runs on every shard (the engine's PQ-only traversal, DR_MODE_PQ), the per-shard top-k lists are exchanged with one
+    RCCL all-gather per array and merged on the device (dr_sharded_search). Reports whole-job QPS and the recall of the
+    merged lists against the merged per-shard brute force."""
+    import diskrag_amd
+    from diskrag_amd import HipIndex, _ffi
+    from diskrag_amd.synth import recall_at_k, sift_like
+    ndev = diskrag_amd.device_count()
+    if ndev < 1:
+        raise RuntimeError("no HIP device: the engine has no CPU fallback")
+    device = rk.local_rank % ndev
+    nq, k, D = args.nq, args.k, args.dim
+    x, q = sift_like(args.n, D, n_queries=nq, n_clusters=1024, seed=3000 + rk.rank, query_seed=77)   # same queries on every rank
+    ix = HipIndex.create_empty(x, R=args.R, device=device)
+    medoid, build_s = ix.build_vamana(L_build=args.L_build, alpha=1.2, passes=2, seed=7, pad_with_zero=False)
+    cb = ix.pq_train(args.m, n_sample=100_000, iters=8, seed=42)      # every shard trains on its own sample
+    ix.pq_encode(cb)
+    gt_local, gt_dist = ix.bruteforce_topk(q, k)
+    # communicator: rank 0 makes the id, the others read it from the scratch directory
+    if rk.rank == 0:
+        rk.put("rccl_id", _ffi.Comm.unique_id())
+    uid = rk.get("rccl_id", 0, raw=True)
+    comm = _ffi.Comm(uid, rk.world, rk.rank, device)
+    base = rk.rank * args.n
+    # exact ground truth of the union: the same exchange on the per-shard brute-force lists
+    gts = rk.gather("gt", {"ids": (gt_local.astype(np.int64) + base).tolist(), "dist": gt_dist.tolist()}) if rk.world > 1 else None
+    if gts is None:
+        gt = gt_local
+    else:
+        from diskrag_amd.parallel import merge_topk
+        gt, _ = merge_topk([np.array(g["ids"], dtype=np.uint32) for g in gts], [np.array(g["dist"], dtype=np.float32) for g in gts], k)
+    run = lambda: _ffi.sharded_search([ix], [base], q, k, L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQ, comm=comm)
+    for _ in range(max(1, args.warmup)):
+        run()
+    rk.barrier()
+    t0 = time.perf_counter()
+    ms = np.zeros(3)
+    for _ in range(args.steps):
+        ids, dist, status, m3 = run()
+        ms += m3
+    el = time.perf_counter() - t0
+    times = rk.gather("t_c5", el)
+    if int(status.max()) != 0:
+        raise RuntimeError("work-area overflow during the bench")
+    out = {"metric": "QPS, graph-sharded PQ-only search (c5 layout at bench scale), batch=%d" % nq,
+           "value": nq * args.steps / max(times), "unit": "queries/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": max(times) / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (ADC sums over u8 codes)", "data": "synthetic",
+           "config": {"workload": "%d shards x %d points, d=%d, R=%d, PQ m=%d, DR_MODE_PQ L=%d beam_width=%s, k=%d; every query on "
+                                  "every shard; exchange = RCCL all-gather of nq*k*8 bytes per rank + device merge"
+                                  % (rk.world, args.n, D, args.R, args.m, args.L, args.bw or None, k),
+                      "recall_at_10_vs_exact": recall_at_k(ids, gt, k), "rccl_ranks": rk.world, "build_seconds": build_s,
+                      "ms_per_call": {"search": float(ms[0] / args.steps), "all_gather": float(ms[1] / args.steps),
+                                      "merge": float(ms[2] / args.steps)}}}
+    if rk.rank == 0:
+        print(json.dumps(out), flush=True)
+    comm.close()
+    ix.close()
+    rk.barrier()
+    return 0
+
+
+def main():
+    args = parse_args()
+    in_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not args.worker and not in_torchrun and args.gpus > 1:
+        return launch(args)
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -13,7 +13,10 @@ LIB_PATH = Path(_os.environ["DR_LIB"]) if _os.environ.get("DR_LIB") else PKG_DIR
 
 PAD = 0xFFFFFFFF
 MODE_M1, MODE_M2, MODE_M3, MODE_M4 = 1, 2, 3, 4
-F_USE_PQ, F_SQDIST = 1, 2
+MODE_PQ = 5      # engine mode without a reference counterpart: M1's loop on squared ADC distances only (diskrag_hip.h)
+F_USE_PQ, F_SQDIST, F_RERANK = 1, 2, 4
+MAX_RESIDENT = 16
+COMM_ID_BYTES = 128
 
 E_ARG, E_NODEVICE, E_IO, E_NOPQ, E_OVERFLOW, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 
@@ -39,7 +42,9 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_bruteforce_topk", "dr_get_node", "dr_index_close", "dr_index_create_empty", "dr_build_vamana",
            "dr_get_adjacency", "dr_pq_train", "dr_pq_encode", "dr_debug_phase_cycles", "dr_batch_sync",
            "dr_debug_force_kind", "dr_search_batch_f64",
-           "dr_index_create_codes", "dr_index_drop_vectors", "dr_pq_scan_best"]
+           "dr_index_create_codes", "dr_index_drop_vectors", "dr_pq_scan_best",
+           "dr_batch_select", "dr_search_submit", "dr_search_wait", "dr_host_alloc", "dr_host_free",
+           "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_merge_topk"]
 
 _lib = None
 
@@ -124,6 +129,30 @@ def load_library():
     L.dr_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_double)]
     L.dr_index_close.restype = None
     L.dr_index_close.argtypes = [vp]
+    L.dr_batch_select.restype = C.c_int
+    L.dr_batch_select.argtypes = [vp, C.c_uint32]
+    L.dr_search_submit.restype = C.c_int
+    L.dr_search_submit.argtypes = [vp, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                   C.c_uint32, u32p, fp, u32p, C.POINTER(DrStats), C.POINTER(C.c_uint64)]
+    L.dr_search_wait.restype = C.c_int
+    L.dr_search_wait.argtypes = [vp, C.c_uint64]
+    L.dr_host_alloc.restype = C.c_void_p
+    L.dr_host_alloc.argtypes = [C.c_uint64]
+    L.dr_host_free.restype = None
+    L.dr_host_free.argtypes = [C.c_void_p]
+    L.dr_comm_unique_id.restype = C.c_int
+    L.dr_comm_unique_id.argtypes = [C.c_void_p]
+    L.dr_comm_init.restype = C.c_int
+    L.dr_comm_init.argtypes = [C.POINTER(vp), C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.dr_comm_rank.restype = C.c_int
+    L.dr_comm_rank.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.dr_comm_destroy.restype = None
+    L.dr_comm_destroy.argtypes = [vp]
+    L.dr_sharded_search.restype = C.c_int
+    L.dr_sharded_search.argtypes = [C.POINTER(vp), u32p, C.c_uint32, vp, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p, fp]
+    L.dr_merge_topk.restype = C.c_int
+    L.dr_merge_topk.argtypes = [C.c_int, u32p, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp]
     _lib = L
     return L
 
@@ -292,6 +321,35 @@ class HipIndex:
                                                   stats.ctypes.data_as(C.POINTER(DrStats))))
         return ids, dist, cnt, stats
 
+    def batch_select(self, slot):
+        """Selects which of the MAX_RESIDENT resident batches batch_upload / batch_run refer to (slot 0 at creation)."""
+        _check(load_library().dr_batch_select(self._h, int(slot)))
+
+    def search_submit(self, queries, k, L=100, beam_width=0, mode=MODE_M1, band_policy=0, flags=0, reuse_outputs=False):
+        """Pipelined dr_search_batch: queues upload, search, tie-order pass and download and returns a PendingSearch;
+        its .wait() gives (ids, dist, count, stats). Up to 3 batches are in flight per index. With reuse_outputs the
+        result arrays come from a ring of four sets (valid until the fourth submit after this one)."""
+        q = self._queries(queries)
+        nq = q.shape[0]
+        if reuse_outputs:
+            ring = self.__dict__.setdefault("_out_ring", {})
+            key = (nq, int(k))
+            if key not in ring:
+                ring[key] = [[PendingSearch(self, None, nq, int(k)) for _ in range(4)], 0]
+            sets, pos = ring[key]
+            job = sets[pos % 4]
+            ring[key][1] = pos + 1
+            job._q = q
+        else:
+            job = PendingSearch(self, q, nq, int(k))
+        t = C.c_uint64(0)
+        _check(load_library().dr_search_submit(self._h, _p(q, C.c_float), nq, int(k), int(L), int(beam_width or 0), int(mode),
+                                               int(band_policy), int(flags), _p(job.ids, C.c_uint32), _p(job.dist, C.c_float),
+                                               _p(job.cnt, C.c_uint32), job.stats.ctypes.data_as(C.POINTER(DrStats)),
+                                               C.byref(t)))
+        job.ticket = int(t.value)
+        return job
+
     def batch_upload(self, queries):
         q = self._queries(queries)
         _check(load_library().dr_batch_upload(self._h, _p(q, C.c_float), q.shape[0]))
@@ -387,6 +445,109 @@ class HipIndex:
         nbrs = np.empty(self.R, dtype=np.uint32)
         _check(load_library().dr_get_node(self._h, int(node_id), _p(vec, C.c_float), _p(nbrs, C.c_uint32)))
         return vec, nbrs
+
+
+class PendingSearch:
+    """A batch in flight (HipIndex.search_submit). The query and output arrays are kept alive until wait()."""
+
+    def __init__(self, index, q, nq, k):
+        self._index, self._q, self.ticket = index, q, 0
+        self.ids = np.empty((nq, k), dtype=np.uint32)
+        self.dist = np.empty((nq, k), dtype=np.float32)
+        self.cnt = np.empty(nq, dtype=np.uint32)
+        self.stats = np.empty(nq, dtype=STATS_DTYPE)
+
+    def wait(self):
+        _check(load_library().dr_search_wait(self._index._h, self.ticket))
+        self._q = None
+        return self.ids, self.dist, self.cnt, self.stats
+
+
+class _PinnedBlock:
+    def __init__(self, nbytes):
+        self.ptr = load_library().dr_host_alloc(int(nbytes))
+        if not self.ptr:
+            raise MemoryError(f"dr_host_alloc({nbytes}) failed")
+
+    def __del__(self):
+        try:
+            load_library().dr_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """A numpy array over page-locked host memory (dr_host_alloc): the copy engine reads / writes it without staging."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    blk = _PinnedBlock(max(n, 1))
+    buf = (C.c_char * max(n, 1)).from_address(blk.ptr)
+    buf._block = blk      # the array keeps `buf` alive, `buf` keeps the pinned block alive
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+
+class Comm:
+    """RCCL communicator of the graph-sharded search (one process per GPU). Rank 0 calls Comm.unique_id() and hands the
+    128 bytes to the other ranks (file, pipe, ...); every rank then constructs Comm(id, nranks, rank, device)."""
+
+    def __init__(self, unique_id, nranks, rank, device=0):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        h = C.c_void_p()
+        _check(load_library().dr_comm_init(C.byref(h), buf, int(nranks), int(rank), int(device)))
+        self._h, self.rank, self.nranks = h, int(rank), int(nranks)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(load_library().dr_comm_unique_id(buf))
+        return buf.raw
+
+    def close(self):
+        if self._h:
+            load_library().dr_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sharded_search(shards, id_bases, queries, k, L=100, beam_width=8, mode=MODE_PQ, band_policy=0, flags=0, comm=None):
+    """dr_sharded_search: every index of `shards` (this rank's) searches the batch, lists are merged on the device and, with a
+    Comm, all-gathered over the ranks (RCCL) and merged again. Returns (global ids, distances, status per query, ms[3])."""
+    n = len(shards)
+    D = shards[0].D
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    if q.ndim != 2 or q.shape[1] != D:
+        raise ValueError(f"queries must be [nq, {D}], got {q.shape}")
+    nq = q.shape[0]
+    hs = (C.c_void_p * n)(*[s._h for s in shards])
+    bases = np.ascontiguousarray(id_bases, dtype=np.uint32)
+    ids = np.empty((nq, k), dtype=np.uint32)
+    dist = np.empty((nq, k), dtype=np.float32)
+    status = np.empty(nq, dtype=np.uint32)
+    ms = np.zeros(3, dtype=np.float32)
+    _check(load_library().dr_sharded_search(hs, _p(bases, C.c_uint32), n, comm._h if comm is not None else None,
+                                            _p(q, C.c_float), nq, int(k), int(L), int(beam_width or 0), int(mode),
+                                            int(band_policy), int(flags), _p(ids, C.c_uint32), _p(dist, C.c_float),
+                                            _p(status, C.c_uint32), _p(ms, C.c_float)))
+    return ids, dist, status, ms
+
+
+def merge_topk_device(ids, dist, k_out, device=0):
+    """The device merge kernel on host arrays: ids[S, nq, k] global ids (PAD = empty), dist[S, nq, k]."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    S, nq, k = ids.shape
+    out_ids = np.empty((nq, k_out), dtype=np.uint32)
+    out_dist = np.empty((nq, k_out), dtype=np.float32)
+    _check(load_library().dr_merge_topk(int(device), _p(ids, C.c_uint32), _p(dist, C.c_float), S, nq, k, int(k_out),
+                                        _p(out_ids, C.c_uint32), _p(out_dist, C.c_float)))
+    return out_ids, out_dist
 
 
 def device_count():

@@ -19,6 +19,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
 #include <map>
 #include <mutex>
 #include <string>
@@ -64,9 +65,16 @@ const DimKernels *dr_dim_kernels(int D)
     }
 }
 
+struct dr_index;
+static int quiesce_locked(dr_index *ix);
+
 template <class T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }      // error paths (HIPCHK returns) free their temporaries
     int reserve(size_t want, bool zero = false)
     {
         if (want <= n) return 0;
@@ -81,6 +89,31 @@ template <class T> struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+// One resident query batch: queries in original and chain-major order, the per-query ADC bounds of M1, and what the
+// host learnt about it at upload. DR_MAX_RESIDENT of them are addressable through dr_batch_select (bench.py rotates
+// distinct batches); the pipelined dr_search_submit path owns DR_PIPE_DEPTH more.
+struct QSlot {
+    uint32_t nq = 0;
+    DevBuf<float> q, qp, pq_ub;
+    bool pq_ub_valid = false;    // pq_ub matches these queries and the attached codebook
+    bool q_u8 = false;           // every component is an integer in [0, 255] (byte-query variants 13/14)
+    void release() { q.release(); qp.release(); pq_ub.release(); nq = 0; pq_ub_valid = false; q_u8 = false; }
+};
+#define DR_PIPE_DEPTH 3
+
+// One in-flight dr_search_submit: upload, search, tie-order pass and download are queued on four streams; the host
+// only touches it again in dr_search_wait.
+struct PipeJob {
+    bool active = false;
+    uint64_t ticket = 0;
+    int set = -1;                       // the BatchSet holding its outputs
+    uint32_t nq = 0, k = 0;
+    void *pin_in = nullptr; size_t pin_in_bytes = 0;     // staging for pageable caller memory
+    void *pin_out = nullptr; size_t pin_out_bytes = 0;
+    hipEvent_t up_done = nullptr, down_done = nullptr;
+    uint32_t *out_ids = nullptr; float *out_dist = nullptr; uint32_t *out_count = nullptr; dr_stats *stats = nullptr;
+};
+
 struct dr_index {
     int device = 0;
     uint64_t N = 0;
@@ -92,7 +125,7 @@ struct dr_index {
     // search-kernel launches are timed with a ring of event pairs and harvested at the next sync: dr_batch_run does
     // not wait for its kernel, consecutive steps queue back to back on the stream
     static constexpr int KEV = 32;
-    hipEvent_t kev[KEV][2] = {};
+    std::array<hipEvent_t, 2> kev[KEV] = {};
     int kev_pending = 0;
     double kms_sum = 0.0; uint32_t kms_n = 0;
     std::mutex mu;
@@ -110,15 +143,17 @@ struct dr_index {
     // lossless byte copy of the vectors (integer-valued data, D = 128): 0 not checked yet, 1 present, -1 data does not qualify
     DevBuf<uint8_t> vec8;
     int vec8_state = 0;
-    bool q_u8 = false;           // every component of the resident queries is an integer in [0, 255] (byte-query variants 13/14)
     bool rank_valid = false, adjr_valid = false, use_adjr = false;
     uint32_t medoid_pos = 0;
 
     // batch scratch
-    uint32_t nq = 0;             // queries currently resident
-    DevBuf<float> q, qp;
-    DevBuf<uint32_t> vis, vlog;
-    size_t vis_zeroed = 0;
+    QSlot slots[DR_MAX_RESIDENT + DR_PIPE_DEPTH];
+    QSlot *cs = &slots[0];        // the selected resident batch (dr_batch_select)
+    PipeJob jobs[DR_PIPE_DEPTH];
+    uint64_t next_ticket = 1;
+    hipStream_t up_stream = nullptr, down_stream = nullptr;
+    uint32_t last_nq = 0;         // batch size of the last launch (dr_batch_download)
+    DevBuf<uint32_t> vis, vis_epoch;   // visited words [slots][vis_words] + the per-slot query stamp (search_kernel.hpp)
     // per-step outputs are triple-buffered: the tie-order pass (finalize) of step i runs on its own stream while
     // the search kernels of steps i+1 and i+2 fill the other sets
     struct BatchSet {
@@ -129,10 +164,11 @@ struct dr_index {
         hipEvent_t search_done = nullptr, fin_start = nullptr, fin_done = nullptr;
         bool fin_pending = false;
         bool counters_zeroed = false;
+        int owner_job = -1;           // in-flight dr_search_submit whose results live here (finished before reuse)
         uint32_t ticket_base = 0;     // every launch draws exactly nq tickets from counter[0]: never reset
         void release() { counter.release(); res_n.release(); tie.release(); out_ids.release(); out_count.release();
                          res_keys.release(); log.release(); stats.release(); out_dist.release(); }
-    } sets[3];      // three sets: the tie-order pass of step i only finds room in the TAILS of the next search kernels
+    } sets[4];      // four sets (three in-flight pipelined jobs + the one being queued): the tie-order pass of step i only finds room in the TAILS of the next search kernels
                     // (its 19 VGPRs do not fit beside 3 x 168 per SIMD), so it gets two steps to finish, not one
     int parity = 0, last_set = 0;
     hipStream_t fstream = nullptr;
@@ -144,8 +180,6 @@ struct dr_index {
     DevBuf<uint32_t> f64_ids, f64_cnt, f64_vis;
     DevBuf<KStats> f64_stats;
     uint32_t fin_hint = 0;        // tie-list length to size the tie-order launches for (0: not known yet -> full grid)
-    DevBuf<float> pq_ub;
-    bool pq_ub_valid = false;     // pq_ub matches the resident queries and the attached codebook
     int adc_live = -1;            // M1 on this index: does the rerank policy A4 really consult the ADC? -1 = not measured yet
     DevBuf<u64> phase;
     uint32_t last_k = 0;
@@ -178,6 +212,9 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     ix->device = device; ix->N = N; ix->D = D; ix->R = R; ix->medoid = medoid;
     HIPCHK(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ix->fstream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ix->up_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ix->down_stream, hipStreamNonBlocking));
+    for (auto &jb : ix->jobs) { HIPCHK(hipEventCreateWithFlags(&jb.up_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&jb.down_done, hipEventDisableTiming)); }
     for (auto &e : ix->ev) HIPCHK(hipEventCreate(&e));
     for (auto &pr : ix->kev) { HIPCHK(hipEventCreate(&pr[0])); HIPCHK(hipEventCreate(&pr[1])); }
     for (auto &bs : ix->sets) { HIPCHK(hipEventCreate(&bs.search_done)); HIPCHK(hipEventCreate(&bs.fin_start)); HIPCHK(hipEventCreate(&bs.fin_done)); }
@@ -290,6 +327,7 @@ extern "C" int dr_index_set_adjacency(dr_index *ix, const uint32_t *adj)
     if (!ix || !adj) return fail(DR_E_ARG, "null argument");
     std::lock_guard<std::mutex> lk(ix->mu);
     HIPCHK(hipSetDevice(ix->device));
+    { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }     // queued searches still read the old rows
     HIPCHK(hipMemcpy(ix->adj.p, adj, (size_t)ix->N * ix->R * 4, hipMemcpyHostToDevice));
     ix->adc_live = -1;
     return build_first_masks(ix);
@@ -302,12 +340,13 @@ extern "C" int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_
     if (ix->D / m > 128) return fail(DR_E_UNSUPPORTED, "sub_dim %u > 128", ix->D / m);
     std::lock_guard<std::mutex> lk(ix->mu);
     HIPCHK(hipSetDevice(ix->device));
+    { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }     // queued searches still read the old codes
     if (ix->codes.reserve((size_t)ix->N * m)) return DR_E_NODEVICE;
     if (ix->codebook.reserve((size_t)256 * ix->D)) return DR_E_NODEVICE;
     HIPCHK(hipMemcpy(ix->codes.p, codes, (size_t)ix->N * m, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ix->codebook.p, codebook, (size_t)256 * ix->D * 4, hipMemcpyHostToDevice));
     ix->m = m; ix->sd = ix->D / m;
-    ix->pq_ub_valid = false;
+    for (auto &qs : ix->slots) qs.pq_ub_valid = false;
     ix->adc_live = -1;
     return 0;
 }
@@ -337,8 +376,7 @@ extern "C" int dr_index_drop_vectors(dr_index *ix)
     std::lock_guard<std::mutex> lk(ix->mu);
     if (ix->m == 0) return fail(DR_E_NOPQ, "dropping the vectors of an index without PQ data would leave nothing to search");
     HIPCHK(hipSetDevice(ix->device));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->fstream));
+    { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }
     ix->vecp.release();
     ix->vec8.release(); ix->vec8_state = -1;
     ix->has_vectors = false;
@@ -349,64 +387,81 @@ extern "C" void dr_index_close(dr_index *ix)
 {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) if (st) (void)hipStreamSynchronize(st);
     ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release();
-    if (ix->fstream) (void)hipStreamSynchronize(ix->fstream);
-    ix->perm.release(); ix->q.release(); ix->qp.release(); ix->vis.release(); ix->vlog.release();
+    ix->perm.release(); ix->vis.release(); ix->vis_epoch.release();
+    for (auto &qs : ix->slots) qs.release();
+    for (auto &jb : ix->jobs) {
+        if (jb.pin_in) (void)hipHostFree(jb.pin_in);
+        if (jb.pin_out) (void)hipHostFree(jb.pin_out);
+        if (jb.up_done) (void)hipEventDestroy(jb.up_done);
+        if (jb.down_done) (void)hipEventDestroy(jb.down_done);
+    }
     for (auto &bs : ix->sets) {
         bs.release();
         if (bs.search_done) (void)hipEventDestroy(bs.search_done);
         if (bs.fin_start) (void)hipEventDestroy(bs.fin_start);
         if (bs.fin_done) (void)hipEventDestroy(bs.fin_done);
     }
-    ix->pq_ub.release(); ix->phase.release(); ix->rank.release(); ix->adjr.release(); ix->fin_stat.release(); ix->vec8.release();
+    ix->phase.release(); ix->rank.release(); ix->adjr.release(); ix->fin_stat.release(); ix->vec8.release();
     ix->f64_q.release(); ix->f64_dist.release(); ix->f64_ids.release(); ix->f64_cnt.release(); ix->f64_vis.release(); ix->f64_stats.release();
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
     for (auto &pr : ix->kev) { if (pr[0]) (void)hipEventDestroy(pr[0]); if (pr[1]) (void)hipEventDestroy(pr[1]); }
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     if (ix->fstream) (void)hipStreamDestroy(ix->fstream);
+    if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
+    if (ix->down_stream) (void)hipStreamDestroy(ix->down_stream);
     delete ix;
 }
 
 // ------------------------------------------------------------------------------------------------ batches
 
+// every component an integer in [0, 255]? (byte-query variants; non-integer data leaves at the first block)
+static bool queries_are_u8(const float *queries, size_t n)
+{
+    bool ok = true;
+    for (size_t b = 0; b < n && ok; b += 4096) {
+        const size_t e = std::min(n, b + 4096);
+        unsigned bad = 0;     // branch-free so that it vectorises (out-of-range and NaN are clamped before the conversion)
+        for (size_t i = b; i < e; i++) {
+            const float v = queries[i];
+            const float c = (v >= 0.0f && v <= 255.0f) ? v : -1.0f;
+            const int iv = (int)c;
+            bad |= (unsigned)(iv < 0) | (unsigned)((float)iv != v);
+        }
+        ok = !bad;
+    }
+    return ok;
+}
+
+// queues the copy of a batch into a slot and its chain-major twin on `st`
+static int upload_slot_async(dr_index *ix, QSlot &qs, const float *src, uint32_t nq, hipStream_t st)
+{
+    if (qs.q.reserve((size_t)nq * ix->D) || qs.qp.reserve((size_t)nq * ix->D)) return DR_E_NODEVICE;
+    HIPCHK(hipMemcpyAsync(qs.q.p, src, (size_t)nq * ix->D * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(permute_queries_kernel, dim3(nq), dim3(64), 0, st, qs.q.p, nq, ix->D, ix->perm.p, qs.qp.p);
+    HIPCHK(hipGetLastError());
+    qs.nq = nq;
+    qs.pq_ub_valid = false;
+    return 0;
+}
+
 static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq, bool wait = true)
 {
     if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
     HIPCHK(hipSetDevice(ix->device));
-    if (ix->q.reserve((size_t)nq * ix->D) || ix->qp.reserve((size_t)nq * ix->D)) return DR_E_NODEVICE;
     HIPCHK(hipEventRecord(ix->ev[0], ix->stream));
-    HIPCHK(hipMemcpyAsync(ix->q.p, queries, (size_t)nq * ix->D * 4, hipMemcpyHostToDevice, ix->stream));
-    hipLaunchKernelGGL(permute_queries_kernel, dim3(nq), dim3(64), 0, ix->stream, ix->q.p, nq, ix->D, ix->perm.p,
-                       ix->qp.p);
-    HIPCHK(hipGetLastError());
+    const int rc = upload_slot_async(ix, *ix->cs, queries, nq, ix->stream);
+    if (rc) return rc;
     HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
     // dr_search_batch does not wait here: what consumes the queries is queued behind them on the same stream and the call
     // only returns after its download; the copy's duration is read at the next sync. An explicit dr_batch_upload waits,
     // so that the caller's buffer is free on return whatever kind of host memory it is.
     if (wait) HIPCHK(hipStreamSynchronize(ix->stream));
-    ix->nq = nq;
-    ix->pq_ub_valid = false;
     ix->h2d_pending = true;
-    // byte queries? (only asked when byte rows exist; non-integer data leaves at the first element)
-    ix->q_u8 = false;
-    if (ix->vec8_state == 1 || (ix->vec8_state == 0 && ix->D == 128)) {
-        const size_t n = (size_t)nq * ix->D;
-        bool ok = true;
-        for (size_t b = 0; b < n && ok; b += 4096) {
-            const size_t e = std::min(n, b + 4096);
-            unsigned bad = 0;     // branch-free so that it vectorises (out-of-range and NaN are clamped before the conversion)
-            for (size_t i = b; i < e; i++) {
-                const float v = queries[i];
-                const float c = (v >= 0.0f && v <= 255.0f) ? v : -1.0f;
-                const int iv = (int)c;
-                bad |= (unsigned)(iv < 0) | (unsigned)((float)iv != v);
-            }
-            ok = !bad;
-        }
-        ix->q_u8 = ok;
-    }
+    // byte queries? (only asked when byte rows exist)
+    ix->cs->q_u8 = (ix->vec8_state == 1 || (ix->vec8_state == 0 && ix->D == 128)) && queries_are_u8(queries, (size_t)nq * ix->D);
     return 0;
 }
 
@@ -526,40 +581,54 @@ static int sync_locked(dr_index *ix);
 // `publish` turns the sum since the last publication into timing.search_kernel_ms (mean per launch)
 static void harvest_kernel_times(dr_index *ix, bool publish)
 {
-    for (int i = 0; i < ix->kev_pending; i++) {
+    // pairs are recorded in launch order on one stream: the finished ones are a prefix of the ring
+    int done = 0;
+    while (done < ix->kev_pending && hipEventQuery(ix->kev[done][1]) == hipSuccess) {
         float a = 0;
-        if (hipEventElapsedTime(&a, ix->kev[i][0], ix->kev[i][1]) == hipSuccess) { ix->kms_sum += a; ix->kms_n++; }
+        if (hipEventElapsedTime(&a, ix->kev[done][0], ix->kev[done][1]) == hipSuccess) { ix->kms_sum += a; ix->kms_n++; }
+        done++;
     }
-    ix->kev_pending = 0;
+    (void)hipGetLastError();      // hipErrorNotReady from the query of an unfinished pair is not an error
+    if (done) {
+        std::rotate(&ix->kev[0], &ix->kev[done], &ix->kev[ix->kev_pending]);
+        ix->kev_pending -= done;
+    }
     if (publish && ix->kms_n) {
         ix->timing.search_kernel_ms = (float)(ix->kms_sum / ix->kms_n);
         ix->kms_sum = 0.0; ix->kms_n = 0;
     }
 }
 
+static int finish_job_locked(dr_index *ix, int j);
+// Per-query scratch (insert log, result keys) is sized by the batch: very large batches are processed in chunks.
+static const uint32_t DR_MAX_CHUNK = 32768;
+
 static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_t mode, uint32_t policy, uint32_t flags,
                       const BuildOverride *ov = nullptr)
 {
-    if (ov) ix->nq = ov->nq;
-    if (ix->nq == 0) return fail(DR_E_ARG, "no queries uploaded");
-    if (ix->nq > 65536 && !ov) return fail(DR_E_UNSUPPORTED, "resident batches are limited to 65536 queries (dr_search_batch chunks larger ones)");
-    if (mode < DR_MODE_M1 || mode > DR_MODE_M4) return fail(DR_E_ARG, "unknown mode %u", mode);
+    if (ov) ix->cs->nq = ov->nq;
+    if (ix->cs->nq == 0) return fail(DR_E_ARG, "no queries uploaded");
+    if (ix->cs->nq > 65536 && !ov) return fail(DR_E_UNSUPPORTED, "resident batches are limited to 65536 queries (dr_search_batch chunks larger ones)");
+    if (mode < DR_MODE_M1 || mode > DR_MODE_PQ) return fail(DR_E_ARG, "unknown mode %u", mode);
     if (k == 0) return fail(DR_E_ARG, "k must be positive");
-    const bool use_pq = (mode == DR_MODE_M1) || (mode == DR_MODE_M3 && (flags & DR_F_USE_PQ));
+    const bool pq_only = (mode == DR_MODE_M3 && (flags & DR_F_USE_PQ)) || mode == DR_MODE_PQ;   // ADC-only traversals
+    const bool rerank = (mode == DR_MODE_PQ) && (flags & DR_F_RERANK);
+    const bool use_pq = (mode == DR_MODE_M1) || pq_only;
     if (use_pq && ix->m == 0) return fail(DR_E_NOPQ, "mode %u needs PQ data (dr_index_set_pq)", mode);
-    if (!(mode == DR_MODE_M3 && use_pq)) { const int rcv = need_vectors(ix, "this search mode"); if (rcv) return rcv; }
-    // result-list capacity: M1/M4 L, M2 beam_width, M3 k (search_engine.py:468-474; vamana_graph.py:746-750, :586-590)
+    if (!pq_only || rerank) { const int rcv = need_vectors(ix, rerank ? "DR_F_RERANK" : "this search mode"); if (rcv) return rcv; }
+    // result-list capacity: M1/M4 (and the engine's PQ mode) L, M2 beam_width, M3 k (search_engine.py:468-474;
+    // vamana_graph.py:746-750, :586-590)
     const uint32_t cap = (mode == DR_MODE_M2) ? bw : (mode == DR_MODE_M3) ? k : L;
     if (cap == 0) return fail(DR_E_ARG, "result-list capacity is zero (L / beam_width / k)");
-    if (cap > 512) return fail(DR_E_UNSUPPORTED, "result-list capacity %u > 512", cap);
+    if (cap > DR_MAX_CAPACITY) return fail(DR_E_UNSUPPORTED, "result-list capacity %u > %u", cap, DR_MAX_CAPACITY);
     HIPCHK(hipSetDevice(ix->device));
 
-    const int sc = cap <= 64 ? 0 : cap <= 128 ? 1 : cap <= 256 ? 2 : 3;
+    const int sc = cap <= 64 ? 0 : cap <= 128 ? 1 : cap <= 256 ? 2 : cap <= 512 ? 3 : 4;
     // kernel variant (variants.hpp): the first available variant of the mode's preference list whose LDS footprint
     // fits. M1: byte rows with byte queries (13) > byte rows (11, 10) > float rows landed in LDS (9, 6) > codebook
     // shared in LDS (3) > per-query table (0); ADC traversal: 5 > 2; exact traversal: 14 > 12 > 8 > 1 (the builder
     // uses 1). The byte variants need integer-valued data / queries and are skipped otherwise.
-    static const int NCHR_OF_SC[4] = { 1, 2, 4, 8 };
+    static const int NCHR_OF_SC[DR_NUM_SIZECLASS] = { 1, 2, 4, 8, 16 };
     auto lds_of = [&](int kd) -> size_t {
         const int rb = DR_KIND_RB[kd];
         const size_t pw = (DR_KIND_LUT[kd] ? (size_t)ix->m * 256 * 4 : 0) + ((DR_KIND_PQ[kd] && !DR_KIND_LUT[kd]) ? (size_t)ix->D * 4 : 0) +
@@ -569,10 +638,10 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     };
     if (!ov && ix->vec8_state == 0) { const int rcb8 = build_byte_rows(ix); if (rcb8) return rcb8; }
     auto usable = [&](int kd) { return ix->kern->search[kd][sc] != nullptr && lds_of(kd) <= 160 * 1024 && (!DR_KIND_U8[kd] || ix->vec8_state == 1) &&
-                                       (!DR_KIND_QB[kd] || (ix->q_u8 && !ov)); };
-    static const int PREF_M1[] = { 13, 11, 10, 9, 6, 3, 0 }, PREF_ADC[] = { 5, 2 }, PREF_EX[] = { 14, 12, 8, 1 }, PREF_BUILD[] = { 1, 8 };
-    static const int PREF_M1_LIVE_LUT[] = { 0, 3, 13, 11, 10, 9, 6 }, PREF_M1_LIVE_CB[] = { 3, 0, 13, 11, 10, 9, 6 };
-    const bool k_m1 = (mode == DR_MODE_M1), k_adc = (mode == DR_MODE_M3 && use_pq);
+                                       (!DR_KIND_QB[kd] || (ix->cs->q_u8 && !ov)); };
+    static const int PREF_M1[] = { 13, 11, 9, 3, 0 }, PREF_ADC[] = { 5, 2 }, PREF_EX[] = { 14, 12, 8, 1 }, PREF_BUILD[] = { 1, 8 };
+    static const int PREF_M1_LIVE_LUT[] = { 0, 3, 13, 11, 9 }, PREF_M1_LIVE_CB[] = { 3, 0, 13, 11, 9 };
+    const bool k_m1 = (mode == DR_MODE_M1), k_adc = pq_only;
     // M1 has two regimes. On SIFT-scale data the rerank policy A4 is provably true for almost every expansion (Q1),
     // the ADC is skipped and the kernel is a pure row gather: vectors landed in LDS, table never built (9, 6).
     // On unit-scale data A4 is live, every new neighbour's ADC is evaluated and the table wants to be in LDS: the
@@ -580,7 +649,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // MEASURED on the first M1 batch an index state serves (its counters are read once that launch has finished, see
     // the end of this function); until then the SIFT-scale preference applies. Results never depend on the variant.
     const int *pref = k_m1 ? PREF_M1 : k_adc ? PREF_ADC : ov ? PREF_BUILD : PREF_EX;
-    const int npref = k_m1 ? 7 : k_adc ? 2 : ov ? 2 : 4;
+    const int npref = k_m1 ? 5 : k_adc ? 2 : ov ? 2 : 4;
     if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 8 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
     int kind = -1;
     for (int i = 0; i < npref && kind < 0; i++) if (usable(pref[i])) kind = pref[i];
@@ -589,7 +658,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e && !g_force_kind_set) g_force_kind = atoi(e); env_read = true; }
         const int g = g_force_kind;
         if (g >= 0 && g < DR_NUM_KINDS && usable(g)) {
-            const bool g_m1 = (g == 0 || g == 3 || g == 4 || g == 6 || g == 7 || g == 9 || g == 10 || g == 11 || g == 13), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
+            const bool g_m1 = (g == 0 || g == 3 || g == 9 || g == 11 || g == 13), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
             if ((g_m1 && k_m1) || (g_adc && k_adc) || (g_ex && !k_m1 && !k_adc)) kind = g;
         }
     }
@@ -610,29 +679,28 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
             ix->occ_cache[std::make_pair(kfn, lds)] = occ;
         }
     }
-    const uint32_t nq = ix->nq;
+    const uint32_t nq = ix->cs->nq;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nq + NW - 1) / NW, (uint64_t)occ * ix->num_cu);
     const uint32_t slots = grid * NW;
 
-    // visited set: one bitmap of N bits per wavefront slot + a log of the ids a query touched (for clearing).
     // M1 is capped at min(10L, N) expansions (search_engine.py:429); the other variants are bounded by N.
-    const uint32_t Reff = ov ? ov->RX : ix->R;
-    uint64_t max_steps = (mode == DR_MODE_M1) ? std::min<uint64_t>((uint64_t)L * 10, ix->N) : 0xFFFFFFFFull;
-    uint64_t bound = (mode == DR_MODE_M1) ? max_steps * Reff + 1 : (uint64_t)std::max<uint32_t>(cap * 10, 1000) * Reff + 1;
-    const uint32_t vis_words = (uint32_t)((ix->N + 31) / 32);
-    // the log holds every tested slot (about R per expansion); past vis_words/4 entries a streamed clear of the whole
-    // bitmap moves fewer bytes than log + per-position clears, and the kernel switches to it when the log is full
-    bound = std::min<uint64_t>(bound, std::max<uint64_t>(vis_words / 4, 4096)) + 64;
-    const uint32_t vis_limit = (uint32_t)bound;
-    if (ix->vis.reserve((size_t)slots * vis_words)) return DR_E_NODEVICE;
-    if (ix->vis_zeroed < (size_t)slots * vis_words) {
+    const bool capped = (mode == DR_MODE_M1 || mode == DR_MODE_PQ);
+    uint64_t max_steps = capped ? std::min<uint64_t>((uint64_t)L * 10, ix->N) : 0xFFFFFFFFull;
+    // visited set: per wavefront slot one word per 24 bit positions (+ an 8-bit query stamp: nothing is cleared
+    // between queries, search_kernel.hpp) and the slot's stamp counter
+    const uint32_t vis_words = (uint32_t)(((ix->N + 23) / 24 + 3) & ~3ull);
+    if ((size_t)slots * vis_words > ix->vis.n || slots > ix->vis_epoch.n) {
+        // (re)allocation: fresh words and stamps -- queued launches still use the old buffers
+        if (ix->vis.p) HIPCHK(hipStreamSynchronize(ix->stream));
+        if (ix->vis.reserve((size_t)slots * vis_words) || ix->vis_epoch.reserve(slots)) return DR_E_NODEVICE;
         HIPCHK(hipMemsetAsync(ix->vis.p, 0, ix->vis.n * 4, ix->stream));
-        ix->vis_zeroed = ix->vis.n;
+        HIPCHK(hipMemsetAsync(ix->vis_epoch.p, 0, ix->vis_epoch.n * 4, ix->stream));
     }
-    if (ix->vlog.reserve((size_t)slots * vis_limit)) return DR_E_NODEVICE;
-    const uint32_t logcap = 4096;
+    // accepted-insert log per query (tie replay): 4096 entries cover L <= 256 with room to spare, deeper lists get more
+    const uint32_t logcap = std::max<uint32_t>(4096, 16 * cap);
     const int set = ov ? 0 : ix->parity;
     dr_index::BatchSet &bs = ix->sets[set];
+    if (bs.owner_job >= 0) { const int rcj = finish_job_locked(ix, bs.owner_job); if (rcj) return rcj; }
     if (bs.fin_pending) {
         // this set's buffers may still be read by the tie-order pass of the step that used it last
         if (ov) HIPCHK(hipStreamSynchronize(ix->fstream));
@@ -650,13 +718,12 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.vecp = ix->vecp.p; p.adj = ix->adj.p; p.first = ix->first.p; p.codes = ix->codes.p; p.codebook = ix->codebook.p;
     p.adjr = (!ov && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
     p.vec8 = ix->vec8_state == 1 ? ix->vec8.p : nullptr;
-    p.queries = ix->q.p; p.queries_p = ix->qp.p;
+    p.queries = ix->cs->q.p; p.queries_p = ix->cs->qp.p;
     p.N = ix->N; p.D = ix->D; p.R = ix->R; p.m = ix->m; p.sd = ix->sd; p.medoid = ix->medoid; p.nq = nq;
     p.mode = mode; p.k = k; p.cap = cap; p.L = L; p.bw = bw; p.policy = policy; p.flags = flags;
     p.norm = (mode == DR_MODE_M2 || (mode == DR_MODE_M4 && !(flags & DR_F_SQDIST))) ? 1u : 0u;
     p.max_steps = (uint32_t)std::min<uint64_t>(max_steps, 0xFFFFFFFFull);
-    p.vis = ix->vis.p; p.vis_words = vis_words; p.vlog = ix->vlog.p; p.vis_limit = vis_limit;
-    { const char *e = getenv("DR_VIS_STREAM"); p.vis_stream_clear = (e && atoi(e) && vis_words % 4 == 0 && (size_t)slots * vis_words % 4 == 0) ? 1u : 0u; }
+    p.vis = ix->vis.p; p.vis_words = vis_words; p.vis_epoch = ix->vis_epoch.p;
     p.counter = bs.counter.p;
     p.res_keys = bs.res_keys.p; p.res_n = bs.res_n.p; p.stats = bs.stats.p;
     p.tie_list = bs.tie.p; p.tie_count = bs.counter.p + 1;
@@ -666,17 +733,20 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.pq_ub = nullptr;
     if (mode == DR_MODE_M1) {
         // per-query ADC upper bounds: a function of (queries, codebook) only, computed once per uploaded batch
-        if (!ix->pq_ub_valid) {
-            if (ix->pq_ub.reserve(nq)) return DR_E_NODEVICE;
-            hipLaunchKernelGGL(pq_bound_kernel, dim3(nq), dim3(256), (size_t)ix->D * 4 + 16, ix->stream, ix->codebook.p, ix->q.p,
-                               ix->D, ix->m, ix->sd, ix->pq_ub.p);
+        if (!ix->cs->pq_ub_valid) {
+            if (ix->cs->pq_ub.reserve(nq)) return DR_E_NODEVICE;
+            hipLaunchKernelGGL(pq_bound_kernel, dim3(nq), dim3(256), (size_t)ix->D * 4 + 16, ix->stream, ix->codebook.p, ix->cs->q.p,
+                               ix->D, ix->m, ix->sd, ix->cs->pq_ub.p);
             HIPCHK(hipGetLastError());
-            ix->pq_ub_valid = true;
+            ix->cs->pq_ub_valid = true;
         }
-        p.pq_ub = ix->pq_ub.p;
+        p.pq_ub = ix->cs->pq_ub.p;
     }
 #ifdef DR_PHASE_TIMING
     if (!ov) { if (ix->phase.reserve((size_t)nq * 8, true)) return DR_E_NODEVICE; p.phase = ix->phase.p; }
+#endif
+#ifdef DR_TRACE_VIS
+    if (!ov) { if (ix->phase.reserve((size_t)256 * 8192, true)) return DR_E_NODEVICE; p.phase = ix->phase.p; }
 #endif
     if (ov) {
         p.adj = ov->adjb; p.first = nullptr; p.deg = ov->deg; p.R = ov->RX; p.logcap = 0;
@@ -684,7 +754,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     }
 
     static const bool dbg = getenv("DR_DEBUG") != nullptr;
-    if (dbg) { fprintf(stderr, "[dr] search kind=%d sc=%d NW=%d grid=%u lds=%zu occ=%d nq=%u cap=%u slots=%u vis_words=%u vis_limit=%u\n", kind, sc, NW, grid, lds, occ, nq, cap, slots, vis_words, vis_limit); fflush(stderr); }
+    if (dbg) { fprintf(stderr, "[dr] search kind=%d sc=%d NW=%d grid=%u lds=%zu occ=%d nq=%u cap=%u slots=%u vis_words=%u\n", kind, sc, NW, grid, lds, occ, nq, cap, slots, vis_words); fflush(stderr); }
     if (!bs.counters_zeroed) { HIPCHK(hipMemsetAsync(bs.counter.p, 0, 8, ix->stream)); bs.counters_zeroed = true; bs.ticket_base = 0; }
     // Ticket counter: slot s starts on query s and every later query is a ticket; the started slots draw
     // (nq - started) successful tickets plus one failing ticket each = exactly nq per launch, so the counter is
@@ -692,6 +762,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // length (counter[1]) is zeroed on the tie-order stream after its consumer.
     p.ticket_base = bs.ticket_base;
     bs.ticket_base += nq;
+    if (!ov && ix->kev_pending == dr_index::KEV) harvest_kernel_times(ix, false);
     if (!ov && ix->kev_pending == dr_index::KEV) { HIPCHK(hipStreamSynchronize(ix->stream)); harvest_kernel_times(ix, false); }
     void *args[] = { &p };
     if (!ov) HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][0], ix->stream));
@@ -702,6 +773,15 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (ov) return 0;   // the builder consumes res_keys / res_n directly on the stream
     HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][1], ix->stream));
     ix->kev_pending++;
+    if (rerank) {
+        // DR_MODE_PQ + DR_F_RERANK: exact squared L2 of the final list's entries, k best in (distance, id) order
+        const float *vecp = ix->vecp.p; const float *qpp = ix->cs->qp.p; const u64 *rkp = bs.res_keys.p; const uint32_t *rnp = bs.res_n.p;
+        uint32_t capv = cap, kv = k, nqv = nq; uint32_t *oi = bs.out_ids.p; float *od = bs.out_dist.p; uint32_t *oc = bs.out_count.p;
+        KStats *stp = bs.stats.p;
+        void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp };
+        const size_t rlds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)cap * 8;
+        HIPCHK(hipLaunchKernel(ix->kern->rerank, dim3(std::min<uint32_t>(nq, (uint32_t)ix->num_cu * 16)), dim3(64), rargs, rlds, ix->stream));
+    }
 
     // tie replay for the queries the search kernel listed: one wavefront per query, heap in registers. It runs on
     // its own stream so that it overlaps the NEXT step's search kernel (it needs 19 VGPRs and no LDS, so its
@@ -717,7 +797,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     f.ntie_stat = ix->fin_stat.p;
     HIPCHK(hipEventRecord(bs.fin_start, ix->fstream));
     static const bool skip_fin = getenv("DR_SKIP_FINALIZE") != nullptr;   // timing experiment only: tie order is then wrong
-    if (!skip_fin)
+    if (!skip_fin && !rerank)      // (the rerank pass has already written a total (distance, id) order)
     {
         // One wavefront per tied query, 4 per workgroup, spread over the chip (packing 16 per CU slowed each replay by a
         // third). Few queries tie (29 of 10 000 on the bench data), so the grid is sized for twice the largest tie list
@@ -745,23 +825,26 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         ix->adc_live = (2 * evald > all) ? 1 : 0;
     }
     ix->last_k = k;
+    ix->last_nq = nq;
     ix->last_set = set;
-    ix->parity = (ix->parity + 1) % 3;
+    ix->parity = (ix->parity + 1) % 4;
     return 0;
 }
 
 // waits for every outstanding kernel of the handle (the overlapped tie-order pass included)
 static int sync_locked(dr_index *ix)
 {
+    HIPCHK(hipStreamSynchronize(ix->up_stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
     HIPCHK(hipStreamSynchronize(ix->fstream));
+    HIPCHK(hipStreamSynchronize(ix->down_stream));
     harvest_kernel_times(ix, true);
     if (ix->h2d_pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) ix->timing.h2d_ms = ms;
         ix->h2d_pending = false;
     }
-    if (ix->fin_stat.p && ix->nq >= 1024) {     // (small batches launch a small pass anyway: no blocking readback for them)
+    if (ix->fin_stat.p && ix->last_nq >= 1024) {     // (small batches launch a small pass anyway: no blocking readback for them)
         uint32_t mx = 0;
         HIPCHK(hipMemcpy(&mx, ix->fin_stat.p, 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemset(ix->fin_stat.p, 0, 4));
@@ -778,12 +861,12 @@ static int sync_locked(dr_index *ix)
 
 static int download_locked(dr_index *ix, uint32_t *out_ids, float *out_dist, uint32_t *out_count, dr_stats *stats)
 {
-    if (ix->nq == 0 || ix->last_k == 0) return fail(DR_E_ARG, "nothing to download");
+    if (ix->last_nq == 0 || ix->last_k == 0) return fail(DR_E_ARG, "nothing to download");
     HIPCHK(hipSetDevice(ix->device));
     int rc = sync_locked(ix);
     if (rc) return rc;
     dr_index::BatchSet &bs = ix->sets[ix->last_set];
-    const uint32_t nq = ix->nq, k = ix->last_k;
+    const uint32_t nq = ix->last_nq, k = ix->last_k;
     // results go through a pinned host slab: four asynchronous copies and one wait, then plain memcpys into the caller's
     // (pageable) arrays -- a pageable destination makes every hipMemcpyAsync a blocking staged copy of its own
     static_assert(sizeof(dr_stats) == sizeof(KStats), "stats layout");
@@ -822,6 +905,142 @@ extern "C" int dr_batch_sync(dr_index *ix)
     return sync_locked(ix);
 }
 
+// waits for everything queued on the handle (pipelined jobs included: their results reach the callers' buffers)
+static int quiesce_locked(dr_index *ix)
+{
+    for (int j = 0; j < DR_PIPE_DEPTH; j++) if (ix->jobs[j].active) { const int rc = finish_job_locked(ix, j); if (rc) return rc; }
+    for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int dr_batch_select(dr_index *ix, uint32_t slot)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    if (slot >= DR_MAX_RESIDENT) return fail(DR_E_ARG, "resident batch %u out of range (%u slots)", slot, DR_MAX_RESIDENT);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->cs = &ix->slots[slot];
+    return 0;
+}
+
+extern "C" void *dr_host_alloc(uint64_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+extern "C" void dr_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+// ---- pipelined batches: upload | search | tie order | download on four streams ------------------------------------
+static int pin_reserve(void **p, size_t *have, size_t need)
+{
+    if (*have >= need) return 0;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr; *have = 0;
+    if (hipHostMalloc(p, need, hipHostMallocDefault) != hipSuccess) return fail(DR_E_NODEVICE, "hipHostMalloc(%zu) failed", need);
+    *have = need;
+    return 0;
+}
+
+static int finish_job_locked(dr_index *ix, int j)
+{
+    PipeJob &jb = ix->jobs[j];
+    if (!jb.active) return 0;
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipEventSynchronize(jb.down_done));
+    const size_t b_ids = (size_t)jb.nq * jb.k * 4, b_cnt = (size_t)jb.nq * 4, b_st = (size_t)jb.nq * sizeof(KStats);
+    const unsigned char *hp = static_cast<const unsigned char *>(jb.pin_out);
+    memcpy(jb.out_ids, hp, b_ids);
+    memcpy(jb.out_dist, hp + b_ids, b_ids);
+    memcpy(jb.out_count, hp + 2 * b_ids, b_cnt);
+    if (jb.stats) memcpy(jb.stats, hp + 2 * b_ids + b_cnt, b_st);
+    uint32_t ties = 0;
+    memcpy(&ties, hp + 2 * b_ids + b_cnt + b_st, 4);
+    if (jb.nq >= 1024) ix->fin_hint = std::max<uint32_t>(ties, 16);
+    harvest_kernel_times(ix, false);
+    jb.active = false;
+    if (jb.set >= 0) ix->sets[jb.set].owner_job = -1;
+    return 0;
+}
+
+extern "C" int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width,
+                                uint32_t mode, uint32_t band_policy, uint32_t flags, uint32_t *out_ids, float *out_dist,
+                                uint32_t *out_count, dr_stats *stats, uint64_t *out_ticket)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    if (!out_ids || !out_dist || !out_count || !out_ticket) return fail(DR_E_ARG, "null output buffer");
+    if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
+    if (nq > DR_MAX_CHUNK) return fail(DR_E_UNSUPPORTED, "dr_search_submit takes at most %u queries per batch", DR_MAX_CHUNK);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIPCHK(hipSetDevice(ix->device));
+    const int j = (int)(ix->next_ticket % DR_PIPE_DEPTH);
+    PipeJob &jb = ix->jobs[j];
+    if (jb.active) { const int rc = finish_job_locked(ix, j); if (rc) return rc; }
+    QSlot &qs = ix->slots[DR_MAX_RESIDENT + j];
+    // pinned source (dr_host_alloc / hipHostMalloc / hipHostRegister): the copy engine reads it in place; pageable: staged
+    const float *src = queries;
+    {
+        hipPointerAttribute_t at;
+        const bool pinned = hipPointerGetAttributes(&at, queries) == hipSuccess && at.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        if (!pinned) {
+            const size_t bytes = (size_t)nq * ix->D * 4;
+            const int rc = pin_reserve(&jb.pin_in, &jb.pin_in_bytes, bytes);
+            if (rc) return rc;
+            memcpy(jb.pin_in, queries, bytes);
+            src = static_cast<const float *>(jb.pin_in);
+        }
+    }
+    const bool q_u8 = (ix->vec8_state == 1 || (ix->vec8_state == 0 && ix->D == 128)) && queries_are_u8(src, (size_t)nq * ix->D);
+    int rc = upload_slot_async(ix, qs, src, nq, ix->up_stream);
+    if (rc) return rc;
+    qs.q_u8 = q_u8;
+    if (mode == DR_MODE_M1 && ix->m) {
+        // the per-query ADC bounds travel with the upload, off the search stream
+        if (qs.pq_ub.reserve(nq)) return DR_E_NODEVICE;
+        hipLaunchKernelGGL(pq_bound_kernel, dim3(nq), dim3(256), (size_t)ix->D * 4 + 16, ix->up_stream, ix->codebook.p, qs.q.p,
+                           ix->D, ix->m, ix->sd, qs.pq_ub.p);
+        HIPCHK(hipGetLastError());
+        qs.pq_ub_valid = true;
+    }
+    HIPCHK(hipEventRecord(jb.up_done, ix->up_stream));
+    HIPCHK(hipStreamWaitEvent(ix->stream, jb.up_done, 0));
+    QSlot *const keep = ix->cs;
+    ix->cs = &qs;
+    rc = run_locked(ix, k, L, beam_width, mode, band_policy, flags);
+    ix->cs = keep;
+    if (rc) return rc;
+    const int set = ix->last_set;
+    dr_index::BatchSet &bs = ix->sets[set];
+    // download: behind the tie-order pass of this batch (which is behind its search kernel)
+    const size_t b_ids = (size_t)nq * k * 4, b_cnt = (size_t)nq * 4, b_st = (size_t)nq * sizeof(KStats);
+    rc = pin_reserve(&jb.pin_out, &jb.pin_out_bytes, 2 * b_ids + b_cnt + b_st + 4);
+    if (rc) return rc;
+    unsigned char *hp = static_cast<unsigned char *>(jb.pin_out);
+    HIPCHK(hipStreamWaitEvent(ix->down_stream, bs.fin_done, 0));
+    HIPCHK(hipMemcpyAsync(hp, bs.out_ids.p, b_ids, hipMemcpyDeviceToHost, ix->down_stream));
+    HIPCHK(hipMemcpyAsync(hp + b_ids, bs.out_dist.p, b_ids, hipMemcpyDeviceToHost, ix->down_stream));
+    HIPCHK(hipMemcpyAsync(hp + 2 * b_ids, bs.out_count.p, b_cnt, hipMemcpyDeviceToHost, ix->down_stream));
+    HIPCHK(hipMemcpyAsync(hp + 2 * b_ids + b_cnt, bs.stats.p, b_st, hipMemcpyDeviceToHost, ix->down_stream));
+    HIPCHK(hipMemcpyAsync(hp + 2 * b_ids + b_cnt + b_st, ix->fin_stat.p, 4, hipMemcpyDeviceToHost, ix->down_stream));
+    HIPCHK(hipEventRecord(jb.down_done, ix->down_stream));
+    jb.active = true; jb.ticket = ix->next_ticket++; jb.set = set; jb.nq = nq; jb.k = k;
+    jb.out_ids = out_ids; jb.out_dist = out_dist; jb.out_count = out_count; jb.stats = stats;
+    bs.owner_job = j;
+    *out_ticket = jb.ticket;
+    return 0;
+}
+
+extern "C" int dr_search_wait(dr_index *ix, uint64_t ticket)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (ticket == 0 || ticket >= ix->next_ticket) return fail(DR_E_ARG, "unknown ticket %llu", (unsigned long long)ticket);
+    for (int j = 0; j < DR_PIPE_DEPTH; j++)
+        if (ix->jobs[j].active && ix->jobs[j].ticket == ticket) return finish_job_locked(ix, j);
+    return 0;     // finished earlier (a later submit or a sync needed its slot)
+}
+
 extern "C" int dr_batch_upload(dr_index *ix, const float *queries, uint32_t nq)
 {
     if (!ix) return fail(DR_E_ARG, "null index");
@@ -852,8 +1071,6 @@ extern "C" int dr_get_timing(dr_index *ix, dr_timing *out)
     return 0;
 }
 
-// Per-query scratch (insert log, result keys) is sized by the batch: very large batches are processed in chunks.
-static const uint32_t DR_MAX_CHUNK = 32768;
 
 extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t L,
                                uint32_t beam_width, uint32_t mode, uint32_t band_policy, uint32_t flags,
@@ -966,7 +1183,7 @@ extern "C" int dr_exact_distances(dr_index *ix, const float *queries, uint32_t n
     DevBuf<uint32_t> ids; DevBuf<float> o;
     if (ids.reserve(n) || o.reserve((size_t)nq * n)) return DR_E_NODEVICE;
     HIPCHK(hipMemcpyAsync(ids.p, node_ids, (size_t)n * 4, hipMemcpyHostToDevice, ix->stream));
-    const float *vecp = ix->vecp.p; const float *qp = ix->qp.p; const uint32_t *idp = ids.p; float *op = o.p;
+    const float *vecp = ix->vecp.p; const float *qp = ix->cs->qp.p; const uint32_t *idp = ids.p; float *op = o.p;
     void *args[] = { &vecp, &qp, &nq, &idp, &n, &op };
     const unsigned gx = std::min<unsigned>((n + 7) / 8, 1024);
     HIPCHK(hipLaunchKernel(ix->kern->exact, dim3(gx, nq), dim3(64), args, (size_t)ix->D * 4, ix->stream));
@@ -987,7 +1204,7 @@ extern "C" int dr_distance_table(dr_index *ix, const float *queries, uint32_t nq
     if (o.reserve((size_t)nq * ix->m * 256)) return DR_E_NODEVICE;
     const size_t lds = (size_t)ix->D * 4 + (size_t)ix->m * 256 * 4;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&lut_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(lut_kernel, dim3(nq), dim3(64), lds, ix->stream, ix->codebook.p, ix->q.p, ix->D, ix->m, ix->sd, o.p);
+    hipLaunchKernelGGL(lut_kernel, dim3(nq), dim3(64), lds, ix->stream, ix->codebook.p, ix->cs->q.p, ix->D, ix->m, ix->sd, o.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, o.p, (size_t)nq * ix->m * 256 * 4, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
@@ -1013,7 +1230,7 @@ static int adc_common(dr_index *ix, const float *queries, uint32_t nq, const uin
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&adc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned gx = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ix->num_cu * 8);
     HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
-    hipLaunchKernelGGL(adc_kernel, dim3(gx, nq), dim3(256), lds, ix->stream, ix->codebook.p, ix->q.p, ix->codes.p,
+    hipLaunchKernelGGL(adc_kernel, dim3(gx, nq), dim3(256), lds, ix->stream, ix->codebook.p, ix->cs->q.p, ix->codes.p,
                        node_ids ? ids.p : nullptr, n, ix->D, ix->m, ix->sd, out_sq ? o1.p : nullptr, out_sqrt ? o2.p : nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
@@ -1080,7 +1297,7 @@ extern "C" int dr_pq_scan_best(dr_index *ix, const float *queries, uint32_t nq, 
     // persistent blocks: the table is built once per block; with several queries in flight the rows share the chip
     const unsigned per_q = (unsigned)std::max<uint64_t>(1, (uint64_t)occ * ix->num_cu / std::min<uint32_t>(nq, (uint32_t)occ * ix->num_cu));
     const unsigned gx = (unsigned)std::min<uint64_t>((n + 255) / 256, per_q);
-    const float *cbp = ix->codebook.p; const float *qp = ix->q.p; const uint8_t *cdp = ix->codes.p; uint64_t nn = n;
+    const float *cbp = ix->codebook.p; const float *qp = ix->cs->q.p; const uint8_t *cdp = ix->codes.p; uint64_t nn = n;
     uint32_t D = ix->D, sd = ix->sd; float *op = out_sq ? o1.p : nullptr; u64 *bp = best.p;
     void *args[] = { &cbp, &qp, &cdp, &nn, &D, &sd, &op, &bp };
     HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
@@ -1109,7 +1326,7 @@ extern "C" int dr_bruteforce_topk(dr_index *ix, const float *queries, uint32_t n
     if (rc) return rc;
     DevBuf<uint32_t> oi; DevBuf<float> od;
     if (oi.reserve((size_t)nq * k) || od.reserve((size_t)nq * k)) return DR_E_NODEVICE;
-    const float *vecp = ix->vecp.p; const float *qp = ix->qp.p; uint64_t N = ix->N; uint32_t *oip = oi.p; float *odp = od.p;
+    const float *vecp = ix->vecp.p; const float *qp = ix->cs->qp.p; uint64_t N = ix->N; uint32_t *oip = oi.p; float *odp = od.p;
     void *args[] = { &vecp, &N, &qp, &nq, &k, &oip, &odp };
     const size_t lds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 64 * 8;
     HIPCHK(hipLaunchKernel(ix->kern->bruteforce, dim3(nq), dim3(64), args, lds, ix->stream));
@@ -1183,6 +1400,7 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
     std::lock_guard<std::mutex> lk(ix->mu);
     { const int rcv = need_vectors(ix, "dr_build_vamana"); if (rcv) return rcv; }
     HIPCHK(hipSetDevice(ix->device));
+    { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }
     const uint64_t N = ix->N;
     const uint32_t D = ix->D, R = ix->R;
     const uint32_t RX = R + 64;                       // slack slots for reverse edges inside one batch
@@ -1204,11 +1422,11 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
         // acc is in chain-major positions: upload as an already-permuted query
         std::vector<float> cq(D);
         for (uint32_t e = 0; e < D; e++) cq[e] = (float)(hacc[e] / (double)N);
-        if (ix->q.reserve(D) || ix->qp.reserve(D)) return DR_E_NODEVICE;
-        HIPCHK(hipMemcpyAsync(ix->qp.p, cq.data(), D * 4, hipMemcpyHostToDevice, ix->stream));
+        if (ix->cs->q.reserve(D) || ix->cs->qp.reserve(D)) return DR_E_NODEVICE;
+        HIPCHK(hipMemcpyAsync(ix->cs->qp.p, cq.data(), D * 4, hipMemcpyHostToDevice, ix->stream));
         DevBuf<uint32_t> oi; DevBuf<float> od;
         if (oi.reserve(1) || od.reserve(1)) return DR_E_NODEVICE;
-        const float *vecp = ix->vecp.p; const float *qp = ix->qp.p; uint64_t NN = N; uint32_t one = 1; uint32_t *oip = oi.p; float *odp = od.p;
+        const float *vecp = ix->vecp.p; const float *qp = ix->cs->qp.p; uint64_t NN = N; uint32_t one = 1; uint32_t *oip = oi.p; float *odp = od.p;
         void *args[] = { &vecp, &NN, &qp, &one, &one, &oip, &odp };
         const size_t lds = (D > 256 ? (size_t)D * 4 : 0) + 64 * 8;
         HIPCHK(hipLaunchKernel(ix->kern->bruteforce, dim3(1), dim3(64), args, lds, ix->stream));
@@ -1224,7 +1442,7 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
         fwd_n.reserve(max_batch) || ovf_list.reserve(N) || ovf_count.reserve(1))
         return DR_E_NODEVICE;
     HIPCHK(hipMemsetAsync(adjb.p, 0xFF, (size_t)N * RX * 4, ix->stream));
-    if (ix->q.reserve((size_t)max_batch * D) || ix->qp.reserve((size_t)max_batch * D)) return DR_E_NODEVICE;
+    if (ix->cs->q.reserve((size_t)max_batch * D) || ix->cs->qp.reserve((size_t)max_batch * D)) return DR_E_NODEVICE;
 
     const size_t prune_lds = (D > 256 ? (size_t)D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024;
     std::vector<uint32_t> horder(N);
@@ -1244,7 +1462,7 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
             b = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(b, max_batch), N - done);
             const uint32_t *pts = order.p + done;
             // 1. queries = the batch points' own vectors (already chain-major)
-            hipLaunchKernelGGL(gather_rows_kernel, dim3(b), dim3(64), 0, ix->stream, ix->vecp.p, pts, b, D, ix->qp.p);
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(b), dim3(64), 0, ix->stream, ix->vecp.p, pts, b, D, ix->cs->qp.p);
             BuildOverride ov = { adjb.p, deg.p, RX, b };
             rc = run_locked(ix, 1, L_build, 0, DR_MODE_M4, 0, DR_F_SQDIST, &ov);
             if (rc) break;
@@ -1297,7 +1515,7 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
     (void)hipEventElapsedTime(&ms, t0, t1);
     (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     adjb.release(); deg.release(); order.release(); fwd.release(); fwd_n.release(); ovf_list.release(); ovf_count.release();
-    ix->nq = 0;
+    ix->cs->nq = 0;
     if (out_medoid) *out_medoid = ix->medoid;
     if (out_seconds) *out_seconds = ms / 1000.0f;
     return rc;
@@ -1390,6 +1608,7 @@ extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uin
     std::lock_guard<std::mutex> lk(ix->mu);
     { const int rcv = need_vectors(ix, "dr_pq_encode"); if (rcv) return rcv; }
     HIPCHK(hipSetDevice(ix->device));
+    { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }
     if (ix->codes.reserve((size_t)ix->N * m) || ix->codebook.reserve((size_t)256 * ix->D)) return DR_E_NODEVICE;
     HIPCHK(hipMemcpyAsync(ix->codebook.p, codebook, (size_t)256 * ix->D * 4, hipMemcpyHostToDevice, ix->stream));
     int rc = pq_assign(ix, nullptr, ix->N, m, ix->codebook.p, ix->codes.p);
@@ -1397,7 +1616,7 @@ extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uin
     if (out_codes) HIPCHK(hipMemcpyAsync(out_codes, ix->codes.p, (size_t)ix->N * m, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
     ix->m = m; ix->sd = ix->D / m;
-    ix->pq_ub_valid = false;
+    for (auto &qs : ix->slots) qs.pq_ub_valid = false;
     ix->adc_live = -1;
     return 0;
 }
@@ -1415,15 +1634,22 @@ extern "C" int dr_debug_force_kind(dr_index *ix, int kind, int *out_adc_live)
 extern "C" int dr_debug_phase_cycles(dr_index *ix, double *out8)
 {
     if (!ix || !out8) return fail(DR_E_ARG, "null argument");
-#ifdef DR_PHASE_TIMING
+#ifdef DR_TRACE_VIS
+    // diagnostic build: out8 is really a u32[256][16384] trace buffer (scripts/exp_vis_trace.py)
     std::lock_guard<std::mutex> lk(ix->mu);
-    if (!ix->phase.p || ix->nq == 0) return fail(DR_E_ARG, "no timed search yet");
-    std::vector<u64> h((size_t)ix->nq * 8);
+    if (!ix->phase.p) return fail(DR_E_ARG, "no traced search yet");
+    HIPCHK(hipMemcpy(out8, ix->phase.p, (size_t)256 * 8192 * 8, hipMemcpyDeviceToHost));
+    return 0;
+#elif defined(DR_PHASE_TIMING)
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (!ix->phase.p || ix->cs->nq == 0) return fail(DR_E_ARG, "no timed search yet");
+    std::vector<u64> h((size_t)ix->cs->nq * 8);
     HIPCHK(hipMemcpy(h.data(), ix->phase.p, h.size() * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out8[i] = 0;
-    for (size_t q = 0; q < ix->nq; q++) for (int i = 0; i < 8; i++) out8[i] += (double)h[q * 8 + i];
+    for (size_t q = 0; q < ix->cs->nq; q++) for (int i = 0; i < 8; i++) out8[i] += (double)h[q * 8 + i];
     return 0;
 #else
     return fail(DR_E_UNSUPPORTED, "library was not built with -DDR_PHASE_TIMING");
 #endif
 }
+#include "comm.inc"

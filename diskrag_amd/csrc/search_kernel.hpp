@@ -2,6 +2,7 @@
 //
 // Reference control flow restated (file:line into Jolara-ai/diskrag):
 //   M1 search_engine.py:398-506, M2 pydiskann/vamana_graph.py:719-760, M3 :535-605, M4 :607-640.
+//   (mode 5 = DR_MODE_PQ, no reference counterpart: M1's loop with the squared ADC as the only distance.)
 // All four are the same loop -- pop the closest frontier node, score its unvisited neighbours in stored
 // order, insert the accepted ones into a bounded result list and the frontier, optionally trim the frontier --
 // and differ in distance function, result-list capacity, stop rule and trim rule (SearchParams).
@@ -44,7 +45,6 @@
 #define PH_END(qi) do {} while (0)
 #endif
 
-#define DR_ST_VIS_OVERFLOW 1u   // (retired: a full position log now switches the query to a whole-bitmap clear)
 #define DR_ST_CAND_OVERFLOW 2u
 #define DR_ST_LOG_OVERFLOW 4u
 #define DR_ST_INTERNAL 8u      // a loop guard fired (never expected; bounds every loop so a bug cannot hang the GPU)
@@ -70,11 +70,9 @@ struct SearchParams {
     u32 mode, k, cap, L, bw, policy, flags;
     u32 norm;                // 1: traversal metric is sqrt(squared L2) (M2, M4: np.linalg.norm)
     u32 max_steps;           // M1: min(10L, N); others: 0xFFFFFFFF
-    u32 *vis;                // [slots][vis_words] visited bitmaps (all zero between queries)
-    u32 vis_words;
-    u32 *vlog;               // [slots][vis_limit] bit positions set in the bitmap by the running query
-    u32 vis_limit;
-    u32 vis_stream_clear;    // 1: clear the whole slot bitmap with wide stores after a query (small N) instead of per id
+    u32 *vis;                // [slots][vis_words] visited sets: words of 24 position bits + an 8-bit query stamp (see below)
+    u32 vis_words;           // ceil(N / 24), rounded up to a multiple of 4
+    u32 *vis_epoch;          // [slots] stamp of the last query each slot served (persists across launches)
     u32 *counter;            // [2]: query ticket counter (monotonic: a launch draws exactly nq tickets), tie-list length
     u32 ticket_base;         // value of the ticket counter when this launch starts
     u64 *res_keys;           // [nq][cap] ascending (dist bits << 32 | ~id)
@@ -532,6 +530,10 @@ DEV void search_body(const SearchParams &p)
     if constexpr (NEED_PQ && CBLDS && !ROWLDS) off += (size_t)256 * D * 4;
     constexpr size_t MERGE_BYTES = (size_t)NCHR * 64 * 12;   // merge scratch: NCHR*64 keys (u64) + states (u32)
     constexpr size_t ROW_BYTES = U8 ? (size_t)D : (size_t)D * 4;   // a landed row: bytes (lossless, see below) or floats
+    // buckets of the visited-set grouping table ({word, lane} entries in the idle landing area / merge scratch)
+    constexpr size_t VSCR = (RB > 0) ? (size_t)RB * ROW_BYTES : MERGE_BYTES;
+    constexpr int VT = VSCR >= 8192 ? 1024 : VSCR >= 4096 ? 512 : VSCR >= 2048 ? 256 : VSCR >= 1024 ? 128 : 64;
+    static_assert((size_t)VT * 8 <= VSCR, "grouping table must fit the scratch area");
     static_assert(!U8 || (ROWLDS && D == 128), "byte rows: the 12-wave landing variant at D = 128");
     static_assert(!QB || U8, "byte queries go with byte rows");
     static_assert(!ROWLDS || (size_t)RB * ROW_BYTES >= MERGE_BYTES, "the row landing area doubles as merge scratch");
@@ -579,8 +581,12 @@ DEV void search_body(const SearchParams &p)
     // the trip count is bounded by nq whatever the counter holds.
     const u32 slot_id = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * NW + wave));
     const u32 nslots = gridDim.x * NW;
+    // Visited set of the running query: one word per 24 bit positions, the top byte holding the STAMP of the query that
+    // wrote it. A word whose stamp is not the running query's is an empty word, so nothing is ever cleared between
+    // queries (the clears and the log they needed were a quarter of the kernel's memory requests); the stamp counts
+    // 1..255 per slot and the slot's words are wiped once per 255 queries.
     u32 *vbm = p.vis + (size_t)slot_id * p.vis_words;
-    u32 *vlog = p.vlog + (size_t)slot_id * p.vis_limit;
+    u32 vstamp = (u32)__builtin_amdgcn_readfirstlane((int)p.vis_epoch[slot_id]);
     const int cap = (int)p.cap;
     const u32 nwords = (p.R + 63) / 64;
 
@@ -631,8 +637,18 @@ DEV void search_body(const SearchParams &p)
         u32 pre_id = 0xFFFFFFFFu;   // node whose adjacency row is (being) landed in pre_buf; none at query start
         u32 npre_hit = 0;
         const bool pre_on = ADJPRE && has_first && p.adjr != nullptr && p.R == 64u;
-        u32 nlog = 0;            // entries of this query in the slot's position log
-        bool logfull = false;
+#ifdef DR_TRACE_VIS
+        u32 trn = 0;
+#endif
+        // next stamp; after 255 queries the slot's words are wiped and the count restarts
+        if (vstamp >= 255u) {
+            uint4 *vb4 = reinterpret_cast<uint4 *>(vbm);
+            for (u32 i = lane; i < p.vis_words / 4; i += 64) vb4[i] = make_uint4(0, 0, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            vstamp = 0u;
+        }
+        vstamp++;
+        const u32 vtag = vstamp << 24;
         int rn = 0, cnT = 0, tn = 0;   // results; live (unexpanded, untrimmed) result entries; tie side list
         u32 junk = 0;   // evicted frontier entries that are worse than every result (only their count matters)
         RegList<NCHR> rk;
@@ -646,8 +662,11 @@ DEV void search_body(const SearchParams &p)
         // ---- start node (search_engine.py:416-426)
         {
             const u32 start = p.medoid;
-            if (lane == 0) { const u32 sp = p.adjr ? p.medoid_pos : start; atomicOr(&vbm[sp >> 5], 1u << (sp & 31)); if (!p.vis_stream_clear) vlog[0] = sp; }
-            nlog = 1;
+            if (lane == 0) {
+                const u32 sp = p.adjr ? p.medoid_pos : start;
+                const u32 sw = __umulhi(sp, 0xAAAAAAABu) >> 4;            // sp / 24
+                vbm[sw] = vtag | (1u << (sp - sw * 24u));                // first word of this query: whatever was there is stale
+            }
             nvisited = 1;
             float d0;
             if constexpr (KIND == DIST_ADC_SQ) {
@@ -752,23 +771,74 @@ DEV void search_body(const SearchParams &p)
                 else active = slot < min((u32)aux, p.R) && nbid != 0xFFFFFFFFu;
                 PH(2);
                 // visited test-and-set: one atomic round trip; duplicates inside a row were removed by `first`
+#ifdef DR_TRACE_VIS
+                // diagnostic build: the bit positions tested by the first queries, one 0xFFFFFFFF marker per expansion
+                if (p.phase && qi < 256u) {
+                    u32 *tr = reinterpret_cast<u32 *>(p.phase) + (size_t)qi * 16384;
+                    const u64 am = __ballot(active);
+                    const u32 na = (u32)__popcll(am);
+                    if (trn + na + 1 < 16384u) {
+                        if (lane == 0) tr[1 + trn] = 0xFFFFFFFFu;
+                        if (active) tr[2 + trn + __popcll(am & lanemask_lt())] = nbpos;
+                        trn += na + 1;
+                        if (lane == 0) tr[0] = trn;
+                    }
+                }
+#endif
                 bool isnew = false;
-                if (active) {
-                    const u32 bit = 1u << (nbpos & 31);
-                    isnew = (atomicOr(&vbm[nbpos >> 5], bit) & bit) == 0u;
+                // ---- visited test-and-set WITHOUT atomics and without clears.
+                // The slot's set is private to this wavefront, so the test is a plain load (sc1: served by the L2, never by
+                // a stale L1 line) and the set a plain store; a word stamped by an earlier query reads as empty. What an
+                // atomic gave for free -- several lanes of one instruction hitting the same word -- is done in LDS: lanes
+                // are grouped by word (hash table of {word, lane} entries in the idle landing / merge scratch: a lane
+                // that reads back its own word has found its group's leader; groups that lost their bucket to another
+                // word retry with the next hash, then one at a time), the group's bits are OR-ed into the leader's LDS
+                // word, and only leaders store. (Memory-side atomics and the per-query clears measured slower: the
+                // kernel is bound by the chip's RATE of random requests, ~55 G/s, and this form issues the fewest.)
+                const u32 vw = __umulhi(nbpos, 0xAAAAAAABu) >> 4;        // nbpos / 24
+                const u32 vbit = 1u << (nbpos - vw * 24u);
+                u32 vraw = 0u;
+                if (active) vraw = __hip_atomic_load(&vbm[vw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                {
+                    u32 vldr = (u32)lane;
+                    u32 *vacc = reinterpret_cast<u32 *>(nb_e);         // idle until the distances are written
+                    u64 *vtab = reinterpret_cast<u64 *>(mk);           // idle until the rows land / the merge
+                    vacc[lane] = 0u;
+                    bool vpend = active;
+                    u64 pendm = __ballot(vpend);
+                    const u32 hsh = vw * 0x9E3779B1u;
+#pragma unroll 1
+                    for (int vr = 0; vr < 2 && pendm != 0ull; vr++) {
+                        const u32 hb = (hsh >> (vr ? 8 : 20)) & (u32)(VT - 1);
+                        if (vpend) vtab[hb] = ((u64)vw << 32) | (u32)lane;
+                        WSYNC();
+                        const u64 ent = vtab[hb];
+                        WSYNC();
+                        if (vpend && (u32)(ent >> 32) == vw) { vldr = (u32)ent; vpend = false; atomicOr(&vacc[vldr], vbit); }
+                        pendm = __ballot(vpend);
+                    }
+#pragma unroll 1
+                    while (pendm != 0ull) {      // leftovers (two hash collisions in a row): one group per trip
+                        const int f = __ffsll((long long)pendm) - 1;
+                        const u32 wf = readlane32(vw, f);
+                        if (vpend && vw == wf) { vldr = (u32)f; vpend = false; atomicOr(&vacc[f], vbit); }
+                        pendm = __ballot(vpend);
+                    }
+                    WSYNC();
+                    const u32 gbits = vacc[lane];
+                    WSYNC();
+                    const u32 vold = ((vraw >> 24) == vstamp) ? (vraw & 0x00FFFFFFu) : 0u;
+                    isnew = active && (vold & vbit) == 0u;
+                    // (store -> later load of the same word: both are served by the L2 in this wave's issue order, and
+                    // every expansion that stored has since waited for row loads issued after its stores)
+                    if (active && vldr == (u32)lane && (gbits & ~vold) != 0u) vbm[vw] = vtag | vold | gbits;
                 }
                 const u64 newmask = __ballot(isnew);
                 const int nnew = __popcll(newmask);
                 if (nnew == 0) continue;
                 // the positions set by this query are logged for the end-of-query clear; a log that fills up switches
                 // the query to a whole-bitmap clear: nothing can overflow
-                if (nlog + (u32)nnew > p.vis_limit) logfull = true;
-                if (isnew) {
-                    const int rnk = __popcll(newmask & lanemask_lt());
-                    nb_id[rnk] = nbid;
-                    if (!logfull && !p.vis_stream_clear) vlog[nlog + rnk] = nbpos;
-                }
-                if (!logfull) nlog += (u32)nnew;
+                if (isnew) nb_id[__popcll(newmask & lanemask_lt())] = nbid;
                 nvisited += nnew;
                 WSYNC();
                 PH(3);
@@ -986,7 +1056,7 @@ DEV void search_body(const SearchParams &p)
                         int lb_lo = 0, lb_hi = rn, ut_lo = 0, ut_hi = rn, ux_lo = 0, ux_hi = rn;
                         const u64 key_ut = ((u64)tbits << 32) | 0xFFFFFFFFull, key_ux = ((u64)xbits << 32) | 0xFFFFFFFFull;
                         if (iscand) {
-                            constexpr int ITER = (NCHR == 1) ? 7 : (NCHR == 2) ? 8 : (NCHR == 4) ? 9 : 10;
+                            constexpr int ITER = (NCHR == 1) ? 7 : (NCHR == 2) ? 8 : (NCHR == 4) ? 9 : (NCHR == 8) ? 10 : 11;
 #pragma unroll
                             for (int it = 0; it < ITER; it++) {
                                 const int m1 = (lb_lo + lb_hi) >> 1, m2 = (ut_lo + ut_hi) >> 1;
@@ -1098,7 +1168,7 @@ DEV void search_body(const SearchParams &p)
             }
             PH(6);
             // ---- frontier trim
-            if (kmode == 1u || kmode == 2u) {
+            if (kmode == 1u || kmode == 2u || kmode == 5u) {
                 // candidates = heapq.nsmallest(beam_width, candidates) (search_engine.py:477-479)
                 if (p.bw != 0u && (u32)(cnT + tn) + junk > p.bw) {
                     u32 excess = (u32)(cnT + tn) + junk - p.bw;
@@ -1160,28 +1230,6 @@ DEV void search_body(const SearchParams &p)
             }
         }
 
-        // ---- clear the visited bits this query set (the bitmap is all zero between queries)
-        if (p.vis_stream_clear || logfull) {
-            // small N (or a full log): the whole slot bitmap is a few hundred 1-KiB wave stores, cheaper than one 64-byte
-            // read-modify-write per visited id
-            if ((p.vis_words & 3u) == 0u) {
-                uint4 *vb4 = reinterpret_cast<uint4 *>(vbm);
-                for (u32 i = lane; i < p.vis_words / 4; i += 64) vb4[i] = make_uint4(0, 0, 0, 0);
-            } else {
-                for (u32 i = lane; i < p.vis_words; i += 64) vbm[i] = 0u;
-            }
-        } else
-        // (four log reads in flight per trip; the stores bypass L1 like the atomics that will follow them)
-        for (u32 i0 = 0; i0 < nlog; i0 += 256) {
-            const u32 ia = i0 + lane, ib = ia + 64, ic = ia + 128, id_ = ia + 192;
-            const u32 va = (ia < nlog) ? vlog[ia] : 0xFFFFFFFFu, vb = (ib < nlog) ? vlog[ib] : 0xFFFFFFFFu;
-            const u32 vc = (ic < nlog) ? vlog[ic] : 0xFFFFFFFFu, vd = (id_ < nlog) ? vlog[id_] : 0xFFFFFFFFu;
-            if (va != 0xFFFFFFFFu) __hip_atomic_store(&vbm[va >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (vb != 0xFFFFFFFFu) __hip_atomic_store(&vbm[vb >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (vc != 0xFFFFFFFFu) __hip_atomic_store(&vbm[vc >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (vd != 0xFFFFFFFFu) __hip_atomic_store(&vbm[vd >> 5], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-
         // ---- write results
 #pragma unroll
         for (int c = 0; c < NCHR; c++) {
@@ -1227,6 +1275,7 @@ DEV void search_body(const SearchParams &p)
             qi = (u32)__builtin_amdgcn_readfirstlane((int)t) - p.ticket_base + nslots;
         }
     }
+    if (lane == 0) p.vis_epoch[slot_id] = vstamp;
 }
 
 template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false>

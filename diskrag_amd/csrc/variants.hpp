@@ -8,20 +8,21 @@
 //   1 exact traversal (M2, M4, M3 without PQ, builder), 1 wave per workgroup
 //   2 ADC-only traversal (M3 with PQ), per-query table
 //   3 M1, codebook shared in LDS, 8 waves per workgroup      (D <= 128 only, else nullptr)
-//   4 M1, codebook shared in LDS, 16 waves per workgroup     (D <= 128 only)
+//   4 (retired)
 //   5 ADC-only traversal, codebook shared in LDS, 8 waves    (D <= 128 only)
-//   6 M1, vectors landed in LDS by global_load_lds (32 rows/burst), codebook in global, 8 waves  (D = 128)
-//   7 same, 16 rows/burst, 16 waves                                                            (D = 128)
+//   6, 7 (retired: superseded by 9)
 //   8 exact traversal, vectors landed in LDS, 8 waves                                          (D = 128)
 //   9 M1, vectors landed in LDS, 24 rows/burst, 12 waves                                       (D = 128)
-//  10 M1, BYTE vectors landed in LDS (lossless copy of integer-valued data), 64 rows/burst, 12 waves (D = 128)
-//  11 same, 16 waves (128 VGPRs: a few spilled dwords, 7 % faster than 12 waves once the row bytes are quartered)
+//  10 (retired: the 12-wave form of 11)
+//  11 M1, BYTE vectors landed in LDS (lossless copy of integer-valued data), 64 rows/burst, 16 waves (D = 128;
+//     128 VGPRs: a few spilled dwords, 7 % faster than 12 waves once the row bytes are quartered)
 //  12 exact traversal (M2, M4, M3 without PQ) on BYTE vectors, 64 rows/burst, 16 waves          (D = 128)
 //  13 = 11 with BYTE queries as well (every component of the batch an integer in [0, 255]): v_dot4_u32_u8 distances
 //  14 = 12 with byte queries
-// sizeclass: result capacity <= 64 / 128 / 256 / 512
+// sizeclass: result capacity <= 64 / 128 / 256 / 512 / 1024 (the last one: one-wavefront-per-workgroup variants 0, 1, 2 only)
 #define DR_NUM_KINDS 15
-#define DR_NUM_SIZECLASS 4
+#define DR_NUM_SIZECLASS 5
+#define DR_MAX_CAPACITY 1024u
 struct DimKernels {
     int D;
     const void *search[DR_NUM_KINDS][DR_NUM_SIZECLASS];
@@ -30,6 +31,7 @@ struct DimKernels {
     const void *prune;
     const void *nearest_pivot;   // aux_kernels.hpp nearest_pivot_kernel (bit order of the visited bitmap)
     const void *search_f64;   // M1 / M2 with float64 queries (the CLI path), search_f64.hpp
+    const void *rerank;       // aux_kernels.hpp rerank_kernel (DR_MODE_PQ + DR_F_RERANK)
 };
 static const int DR_KIND_NW[DR_NUM_KINDS] = { 1, 1, 1, 8, 16, 8, 8, 16, 8, 12, 12, 16, 16, 16, 16 };
 static const bool DR_KIND_CB[DR_NUM_KINDS] = { false, false, false, true, true, true, false, false, false, false, false, false, false, false, false };   // codebook copied to LDS

@@ -1,5 +1,8 @@
-"""Multi-GPU host logic. One process per GPU; `torch.distributed` (backend "nccl" = RCCL on ROCm,
-"gloo" in the CPU tests) is used only for control-plane collectives -- the search itself never leaves a GPU.
+"""Multi-GPU host logic: how queries and id ranges are cut, and the canonical merge -- the host
+statement of what the device does (dr_sharded_search: device merge kernel + RCCL all-gather, include/diskrag_hip.h;
+bench.py: query-sharded replicas with file barriers). Nothing on the GPU path imports torch; the `torch.distributed`
+helpers below (`allgather_merge_topk`, `gather_rows`, `max_over_ranks`) exist for the 2-rank gloo test on CPU, which
+checks the sharding and merge logic across processes without a GPU.
 
 Two layouts:
   * query-sharded replicas (configs c2-c4): every rank holds the whole index, takes a contiguous slice of the

@@ -1,21 +1,31 @@
 """Graph-sharded search: the id space is cut into disjoint ranges, every range has its own
 Vamana sub-graph and PQ codes on one GPU, every query runs on every shard, and the per-shard top-k lists are merged
-in canonical (distance, id) order. Across processes the lists travel in ONE all-gather of nq*k*8 bytes per rank
-(`parallel.allgather_merge_topk`; RCCL over xGMI when the group's backend is "nccl"); shards that live in the same
-process are merged locally first, so 1 process x 8 shards and 8 processes x 1 shard give the same answer.
+in canonical (distance, id) order.
 
-The reference has no sharded search; its PQ-only traversal is `beam_search_with_pq` (pydiskann/vamana_graph.py:535-605,
-mode M3 here) and that is what each shard runs by default. Parity anchor: the merged result equals the merge of the
-per-shard oracle runs (tests/test_gpu_sharded.py), and across ranks the gloo test in tests/test_parallel_gloo.py.
+The GPU path is the C ABI's dr_sharded_search (include/diskrag_hip.h): lists of the shards of one process are merged by a
+device kernel, lists of different processes (one per GPU) travel in ONE RCCL all-gather per array over xGMI, issued on
+the device-resident results, and are merged on the device again -- no host staging, no PyTorch. `comm` is an
+`_ffi.Comm` (RCCL communicator; None for a single process). 1 process x 8 shards and 8 processes x 1 shard give the
+same answer.
+
+A host-logic twin (per-shard `search_batch` calls merged with numpy, optionally exchanged through a torch.distributed
+group that the caller passes in) is kept for objects that are not device indexes: it is what the 2-rank gloo test on
+CPU exercises. torch is imported only when such a group is given.
+
+The reference has no sharded search. Its PQ-only traversal is `beam_search_with_pq` (pydiskann/vamana_graph.py:535-605,
+mode M3): a k-sized heap and a trim that pops the BEST candidates (quirk Q9) -- recall 0.00002-0.014 at c3 scale. The
+engine's DR_MODE_PQ (M1's loop on ADC distances, diskrag_hip.h) is the flagged, intentional divergence for this path;
+both are served. Parity anchor: the merged result equals the merge of the per-shard oracle runs
+(tests/test_gpu_sharded.py, tests/test_gpu_round2.py).
 """
 import numpy as np
 
 from . import _ffi
-from .parallel import PAD, allgather_merge_topk, merge_topk
+from .parallel import PAD, merge_topk
 
 
 class GraphShard:
-    """One shard: a HipIndex over the vectors with global ids [base, base + index.N)."""
+    """One shard: an index over the vectors with global ids [base, base + index.N)."""
 
     def __init__(self, index, base):
         self.index = index
@@ -29,34 +39,40 @@ def globalize(local_ids, base):
 
 
 class ShardedSearch:
-    def __init__(self, shards, group=None, collective_device=None):
+    def __init__(self, shards, comm=None, group=None, collective_device=None):
         """`shards`: the GraphShard objects this process owns (one per GPU in the 8-process layout).
-        `group`: a torch.distributed process group, or None with torch.distributed uninitialised for one process."""
+        `comm`: `_ffi.Comm` spanning the processes (device indexes). `group`: a torch.distributed process group for the
+        host-logic twin (CPU test only)."""
         self.shards = list(shards)
+        self.comm = comm
         self.group = group
         self.collective_device = collective_device
 
-    def _distributed(self):
-        try:
-            import torch.distributed as dist
-        except ImportError:
-            return False
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+    def _on_device(self):
+        return all(isinstance(sh.index, _ffi.HipIndex) for sh in self.shards)
 
     def search_batch(self, queries, k, L=100, beam_width=8, mode=_ffi.MODE_M3, band_policy=0, flags=_ffi.F_USE_PQ):
         """Every local shard searches all queries; returns (global ids [nq,k] PAD-padded, distances [nq,k] NaN-padded,
-        per-shard stats list). Raises if any shard reports a non-zero status (nothing is dropped silently)."""
+        info). Raises if any shard reports a non-zero status (nothing is dropped silently)."""
+        if self._on_device():
+            ids, dist, status, ms = _ffi.sharded_search([sh.index for sh in self.shards], [sh.base for sh in self.shards],
+                                                        queries, k, L=L, beam_width=beam_width, mode=mode,
+                                                        band_policy=band_policy, flags=flags, comm=self.comm)
+            if int(status.max(initial=0)) != 0:
+                raise _ffi.DiskragHipError(-5, f"sharded search: status {int(status.max())}")
+            return ids, dist, {"status": status, "ms": {"search": float(ms[0]), "all_gather": float(ms[1]), "merge": float(ms[2])}}
         ids_l, dist_l, stats_l = [], [], []
         for sh in self.shards:
             ids, dist, cnt, st = sh.index.search_batch(queries, k, L=L, beam_width=beam_width, mode=mode,
                                                        band_policy=band_policy, flags=flags)
             if int(st["status"].max(initial=0)) != 0:
-                raise _ffi.DiskragHipError(-1, f"shard at base {sh.base}: search status {int(st['status'].max())}")
+                raise _ffi.DiskragHipError(-5, f"shard at base {sh.base}: search status {int(st['status'].max())}")
             ids_l.append(globalize(ids, sh.base))
             dist_l.append(dist)
             stats_l.append(st)
         ids, dist = merge_topk(ids_l, dist_l, k)
-        if self._distributed():
+        if self.group is not None:
+            from .parallel import allgather_merge_topk
             # ids are already global: shard_base 0 in the exchange
             ids, dist = allgather_merge_topk(ids, dist, 0, k, group=self.group, device=self.collective_device)
         return ids, dist, stats_l

@@ -7,7 +7,7 @@ import numpy as np
 
 
 def sift_like(n, d=128, n_queries=10000, n_clusters=1024, seed=2024, latent=32, within=1.0, noise=0.2,
-              query_seed=None):
+              query_seed=None, rounded=True):
     """Returns (vectors f32[n,d], queries f32[n_queries,d]); queries come from the same mixture, disjoint stream.
 
     x = round(affine(B z + noise)), z ~ mixture of n_clusters Gaussians in a `latent`-dimensional space, B a fixed
@@ -28,7 +28,8 @@ def sift_like(n, d=128, n_queries=10000, n_clusters=1024, seed=2024, latent=32, 
             a = r.randint(0, n_clusters, size=e - s)
             z = cent[a] + within * r.randn(e - s, latent).astype(np.float32)
             p = z @ B + noise * r.randn(e - s, d).astype(np.float32)
-            out[s:e] = np.clip(np.rint((p + 4.0) * (218.0 / 8.0)), 0, 218)
+            v = (p + 4.0) * (218.0 / 8.0)
+            out[s:e] = np.clip(np.rint(v), 0, 218) if rounded else v       # rounded=False: SURVEY 8d's "un-rounded variant"
         return out
 
     x = draw(n, rs)

@@ -26,10 +26,20 @@ extern "C" {
 #define DR_MODE_M2 2u /* beam_search_from_disk                              pydiskann/vamana_graph.py:719-760 */
 #define DR_MODE_M3 3u /* beam_search_with_pq                                pydiskann/vamana_graph.py:535-605 */
 #define DR_MODE_M4 4u /* greedy_search / greedy_search_cython               vamana_graph.py:607-640, cython_utils.pyx:72-122 */
+/* Engine mode with NO reference counterpart (intentional divergence): the loop of
+ * _pq_accelerated_graph_search (search_engine.py:398-506: L-sized result list, stop rule :438, step cap :429, frontier
+ * trim by heapq.nsmallest :477-479) with the squared ADC (fast_pq.py:320-328) as the ONLY distance -- what the
+ * reference's PQ-only traversal beam_search_with_pq (DR_MODE_M3 + DR_F_USE_PQ) would be without its k-sized heap and
+ * without the trim that pops the BEST candidates (vamana_graph.py:586-593). Serves PQ-only shards (config c5) and,
+ * with DR_F_RERANK, config c3's "PQ traversal + full-precision rerank of the L list" (SURVEY.md 8d). Restated in
+ * oracle/ as mode 5; the reference-faithful M3 stays as it is. */
+#define DR_MODE_PQ 5u
 
 /* flags */
 #define DR_F_USE_PQ 1u /* M3: use_pq=True (ADC-only traversal, vamana_graph.py:318-320) */
 #define DR_F_SQDIST 2u /* M4: Cython twin metric, squared L2 (cython_utils.pyx:18-24) instead of the L2 norm */
+#define DR_F_RERANK 4u /* DR_MODE_PQ: score the final result list with exact squared L2 (A1, search_engine.py:374-379) and
+                          return the k best in (distance, id) order; needs the stored vectors */
 
 /* error codes */
 #define DR_OK 0
@@ -99,6 +109,35 @@ int dr_index_drop_vectors(dr_index *ix);
 
 int dr_index_set_adjacency(dr_index *ix, const uint32_t *adj);
 
+/* ---- graph-sharded search (BASELINE config c5; no reference counterpart) -----------------
+ * The id space is cut into disjoint ranges; every range is an index of its own (its own Vamana sub-graph, PQ codes)
+ * on one GPU; every query runs on every shard; the per-shard top-k lists (shard-local ids + the shard's base) are
+ * merged in canonical (distance ascending, id ascending) order. Across processes the lists travel in ONE RCCL
+ * all-gather of nq*k*(4+4) bytes per rank (over xGMI inside a node), issued on the engine's stream on the
+ * device-resident result arrays, and are merged by a device kernel -- no host staging, no PyTorch.
+ *
+ * dr_comm_unique_id: rank 0 creates the 128-byte RCCL id and hands it to the other ranks by whatever side channel the
+ * host has (a file, a pipe, MPI); dr_comm_init is collective over the nranks processes (one process per GPU);
+ * librccl.so is loaded on first use, the rest of the library does not depend on it.
+ * dr_sharded_search: runs (mode, flags) on each of this rank's `nshards` indexes (all on `comm`'s device; without a
+ * comm: on the first shard's device, one process), merges them on the device, all-gathers and merges across ranks;
+ * every rank receives the full result. id_base[s] is added to shard s's local ids. Output as dr_search_batch
+ * (DR_PAD / NaN padded); out_status[nq] (may be NULL) receives the OR of the shards' dr_stats.status per query. */
+typedef struct dr_comm dr_comm;
+#define DR_COMM_ID_BYTES 128
+int dr_comm_unique_id(void *out_id /*[DR_COMM_ID_BYTES]*/);
+int dr_comm_init(dr_comm **out, const void *unique_id, int nranks, int rank, int device);
+int dr_comm_rank(const dr_comm *c, int *out_rank, int *out_nranks);
+void dr_comm_destroy(dr_comm *c);
+int dr_sharded_search(dr_index *const *shards, const uint32_t *id_base, uint32_t nshards, dr_comm *comm,
+                      const float *queries, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width, uint32_t mode,
+                      uint32_t band_policy, uint32_t flags, uint32_t *out_ids, float *out_dist, uint32_t *out_status,
+                      float *out_ms /*[3] search, all-gather, merge (may be NULL)*/);
+/* The merge kernel alone, on host arrays (test seam): ids[S][nq][k] GLOBAL ids (DR_PAD = empty), dist[S][nq][k];
+ * empty and NaN entries sort last and come out as DR_PAD / NaN. */
+int dr_merge_topk(int device, const uint32_t *ids, const float *dist, uint32_t S, uint32_t nq, uint32_t k,
+                  uint32_t k_out, uint32_t *out_ids, float *out_dist);
+
 /* Searches a batch. queries[nq][D] float32 on the host. Outputs (host): out_ids[nq][k] (DR_PAD padded),
  * out_dist[nq][k] (NaN padded; M1: squared L2, M2/M4: L2 norm, M3: sqrt of the traversal metric, Q7),
  * out_count[nq] (results may be shorter than k), stats[nq] (may be NULL).
@@ -134,6 +173,27 @@ int dr_batch_run(dr_index *ix, uint32_t k, uint32_t L, uint32_t beam_width, uint
 int dr_batch_sync(dr_index *ix);
 int dr_batch_download(dr_index *ix, uint32_t *out_ids, float *out_dist, uint32_t *out_count, dr_stats *stats);
 int dr_get_timing(dr_index *ix, dr_timing *out);
+
+/* Several batches can be resident at once (bench.py rotates distinct 10k-query batches): dr_batch_select picks the
+ * batch that dr_batch_upload / dr_batch_run (and the kernel-level entry points below, which use it as scratch) refer
+ * to. Slot 0 is selected when the handle is created. */
+#define DR_MAX_RESIDENT 16u
+int dr_batch_select(dr_index *ix, uint32_t slot);
+
+/* Asynchronous, pipelined form of dr_search_batch (same arguments and results): dr_search_submit queues the upload
+ * of the batch, its search, the tie-order pass and the download on separate HIP streams and returns a ticket;
+ * dr_search_wait blocks until that batch's results are in the caller's output buffers. Up to 3 batches are in flight
+ * per handle (a fourth submit first finishes the oldest), so the copies of batch i+1 / i-1 overlap the search kernel of
+ * batch i and the throughput of a stream of host-resident batches approaches the HBM-resident rate. nq <= 32768 per
+ * submit. The query buffer may be reused as soon as dr_search_submit returns when it is pageable memory (it is staged);
+ * memory from dr_host_alloc (pinned: the copy engine reads it directly, no staging copy) must stay untouched until the
+ * ticket has been waited for. The output buffers belong to the library until then. */
+int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width,
+                     uint32_t mode, uint32_t band_policy, uint32_t flags, uint32_t *out_ids, float *out_dist,
+                     uint32_t *out_count, dr_stats *stats, uint64_t *out_ticket);
+int dr_search_wait(dr_index *ix, uint64_t ticket);
+void *dr_host_alloc(uint64_t bytes); /* page-locked host memory (NULL on failure) */
+void dr_host_free(void *p);
 
 /* Kernel-level entry points (B5 seams: reader.get_node + np.sum, pq_model.compute_distance_table,
  * pq_model.asymmetric_distance; diskann_persist.py:219, fast_pq.py:294-333). They run the same device

@@ -14,6 +14,10 @@
  *   M3 in-memory beam search       pydiskann/vamana_graph.py:535-605 (+ distance dispatch :301-329)
  *   M4 in-memory greedy search     pydiskann/vamana_graph.py:607-640; Cython twin cython_utils.pyx:72-122
  *   heapq                          CPython Lib/heapq.py (tie order of the returned lists depends on it, Q11)
+ *   mode 5 (ORC_PQ)                NOT in the reference: M1's loop with the squared ADC as the only distance (the
+ *                                  engine's flagged PQ-only traversal, an intentional divergence from quirk Q9); it is
+ *                                  the checker for DR_MODE_PQ and is pinned only through the pieces it shares with
+ *                                  M1 (loop, heaps) and M3-with-PQ (ADC distance), both golden-pinned
  *
  * Parity pinning: every function here is checked in tests/test_oracle_golden.py against golden vectors that
  * tests/golden/gen_golden.py produced by running the reference itself (imported from /root/reference in the
@@ -34,9 +38,11 @@
 #define ORC_M2 2u
 #define ORC_M3 3u
 #define ORC_M4 4u
+#define ORC_PQ 5u         /* engine mode DR_MODE_PQ (no reference counterpart): M1's loop on squared ADC distances only */
 #define ORC_F_USE_PQ 1u   /* M3: use_pq=True */
 #define ORC_F_CYTHON 2u   /* M4: greedy_search_cython twin (squared L2 via l2_distance_fast_cython) */
 #define ORC_F_QUERY_F64 4u
+#define ORC_F_RERANK 16u  /* ORC_PQ: exact squared L2 (A1) of the final list, (distance, id) order */
 #define ORC_F_PAIRWISE 8u  /* squared-L2 modes: use the numpy pairwise order (what the device computes) instead of the
                              sequential Cython loop, whose -ffast-math order is unpinned anyway */
 
@@ -99,7 +105,7 @@ int orc_search_batch(const float *vectors, const uint32_t *adj, const uint8_t *c
 {
     orc_index ix = { N, D, R, m, medoid, vectors, adj, codes, codebook };
     int rc_all = 0;
-    if (mode < ORC_M1 || mode > ORC_M4) return -1;
+    if (mode < ORC_M1 || mode > ORC_PQ) return -1;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
 #endif

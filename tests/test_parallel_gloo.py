@@ -54,7 +54,7 @@ def _worker(rank, world, port, ret):
                 return li, ld, np.full(len(queries), k, dtype=np.uint32), st
 
         quarters = [parallel.shard_slice(n, 2 * world, 2 * rank + j) for j in range(2)]
-        eng = ShardedSearch([GraphShard(OracleShard(g.vectors[sl]), sl.start) for sl in quarters])
+        eng = ShardedSearch([GraphShard(OracleShard(g.vectors[sl]), sl.start) for sl in quarters], group=dist.group.WORLD)
         sids, sdist, _ = eng.search_batch(g.queries, k)
         ret[rank] = (all_ids, mids, mdist, slow, sids, sdist)
     finally:
