@@ -625,22 +625,26 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
 
     const int sc = cap <= 64 ? 0 : cap <= 128 ? 1 : cap <= 256 ? 2 : cap <= 512 ? 3 : 4;
     // kernel variant (variants.hpp): the first available variant of the mode's preference list whose LDS footprint
-    // fits. M1: byte rows with byte queries (13) > byte rows (11, 10) > float rows landed in LDS (9, 6) > codebook
+    // fits. M1: byte rows with byte queries (13) > byte rows (11) > float rows landed in LDS (9) > codebook
     // shared in LDS (3) > per-query table (0); ADC traversal: 5 > 2; exact traversal: 14 > 12 > 8 > 1 (the builder
     // uses 1). The byte variants need integer-valued data / queries and are skipped otherwise.
     static const int NCHR_OF_SC[DR_NUM_SIZECLASS] = { 1, 2, 4, 8, 16 };
     auto lds_of = [&](int kd) -> size_t {
         const int rb = DR_KIND_RB[kd];
-        const size_t pw = (DR_KIND_LUT[kd] ? (size_t)ix->m * 256 * 4 : 0) + ((DR_KIND_PQ[kd] && !DR_KIND_LUT[kd]) ? (size_t)ix->D * 4 : 0) +
-                          (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 512 + (DR_KIND_QB[kd] ? 528 : 0) +
+        const bool qorig_lds = DR_KIND_PQ[kd] && !DR_KIND_LUT[kd] && !rb;          // search_kernel.hpp QORIG_LDS
+        const size_t bloom = (rb || DR_KIND_CB[kd] || ix->D <= 256) ? 512 : 0;      // search_kernel.hpp VB_BITS / 8
+        const size_t pw = (DR_KIND_LUT[kd] ? (size_t)ix->m * 256 * 4 : 0) + (qorig_lds ? (size_t)ix->D * 4 : 0) +
+                          (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 512 + bloom + (DR_KIND_QB[kd] ? 528 : 0) +
                           (rb ? (size_t)rb * ix->D * (DR_KIND_U8[kd] ? 1 : 4) : (size_t)NCHR_OF_SC[sc] * 64 * 12);
+        if (DR_KIND_MW[kd])      // one copy of everything but the merge scratch, + the ADC hand-off array and control words
+            return pw - (size_t)NCHR_OF_SC[sc] * 64 * 12 + 320 + (size_t)DR_KIND_NW[kd] * NCHR_OF_SC[sc] * 64 * 12;
         return (DR_KIND_CB[kd] ? (size_t)256 * ix->D * 4 : 0) + (size_t)DR_KIND_NW[kd] * pw;
     };
     if (!ov && ix->vec8_state == 0) { const int rcb8 = build_byte_rows(ix); if (rcb8) return rcb8; }
     auto usable = [&](int kd) { return ix->kern->search[kd][sc] != nullptr && lds_of(kd) <= 160 * 1024 && (!DR_KIND_U8[kd] || ix->vec8_state == 1) &&
                                        (!DR_KIND_QB[kd] || (ix->cs->q_u8 && !ov)); };
-    static const int PREF_M1[] = { 13, 11, 9, 3, 0 }, PREF_ADC[] = { 5, 2 }, PREF_EX[] = { 14, 12, 8, 1 }, PREF_BUILD[] = { 1, 8 };
-    static const int PREF_M1_LIVE_LUT[] = { 0, 3, 13, 11, 9 }, PREF_M1_LIVE_CB[] = { 3, 0, 13, 11, 9 };
+    static const int PREF_M1[] = { 13, 11, 9, 3, 15, 0 }, PREF_ADC[] = { 5, 16, 2 }, PREF_EX[] = { 14, 12, 8, 1 }, PREF_BUILD[] = { 1, 8 };
+    static const int PREF_M1_LIVE_LUT[] = { 15, 0, 3, 13, 11, 9 }, PREF_M1_LIVE_CB[] = { 3, 15, 0, 13, 11, 9 };
     const bool k_m1 = (mode == DR_MODE_M1), k_adc = pq_only;
     // M1 has two regimes. On SIFT-scale data the rerank policy A4 is provably true for almost every expansion (Q1),
     // the ADC is skipped and the kernel is a pure row gather: vectors landed in LDS, table never built (9, 6).
@@ -649,7 +653,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // MEASURED on the first M1 batch an index state serves (its counters are read once that launch has finished, see
     // the end of this function); until then the SIFT-scale preference applies. Results never depend on the variant.
     const int *pref = k_m1 ? PREF_M1 : k_adc ? PREF_ADC : ov ? PREF_BUILD : PREF_EX;
-    const int npref = k_m1 ? 5 : k_adc ? 2 : ov ? 2 : 4;
+    const int npref = k_m1 ? 6 : k_adc ? 3 : ov ? 2 : 4;
     if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 8 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
     int kind = -1;
     for (int i = 0; i < npref && kind < 0; i++) if (usable(pref[i])) kind = pref[i];
@@ -658,7 +662,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e && !g_force_kind_set) g_force_kind = atoi(e); env_read = true; }
         const int g = g_force_kind;
         if (g >= 0 && g < DR_NUM_KINDS && usable(g)) {
-            const bool g_m1 = (g == 0 || g == 3 || g == 9 || g == 11 || g == 13), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
+            const bool g_m1 = (g == 0 || g == 3 || g == 9 || g == 11 || g == 13 || g == 15), g_adc = (g == 2 || g == 5 || g == 16), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
             if ((g_m1 && k_m1) || (g_adc && k_adc) || (g_ex && !k_m1 && !k_adc)) kind = g;
         }
     }
@@ -680,8 +684,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         }
     }
     const uint32_t nq = ix->cs->nq;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nq + NW - 1) / NW, (uint64_t)occ * ix->num_cu);
-    const uint32_t slots = grid * NW;
+    const bool mwq = DR_KIND_MW[kind];      // the workgroup's wavefronts serve ONE query
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(mwq ? (uint64_t)nq : ((uint64_t)nq + NW - 1) / NW, (uint64_t)occ * ix->num_cu);
+    const uint32_t slots = mwq ? grid : grid * NW;
 
     // M1 is capped at min(10L, N) expansions (search_engine.py:429); the other variants are bounded by N.
     const bool capped = (mode == DR_MODE_M1 || mode == DR_MODE_PQ);

@@ -2,7 +2,7 @@
 # rocprofv3 evidence for the bench kernel (run on the GPU box through gpurun). Output: gpurun_out/prof/
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 for bw in 8 0; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_bw$bw -- python3 scripts/pmc_target.py $bw > $OUT/pmc_fetch_bw$bw.out 2> $OUT/pmc_fetch_bw$bw.err
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_bw$bw -- python3 scripts/pmc_target.py $bw > $OUT/pmc_write_bw$bw.out 2> $OUT/pmc_write_bw$bw.err
@@ -28,7 +28,10 @@ for bw in (8, 0):
 json.dump(out, open('gpurun_out/prof/pmc_traffic.json', 'w'), indent=1)
 print(json.dumps({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if 'bytes' in kk}) for k, v in out.items()}, indent=1))
 PY
-# the bench line quotes roofline.traffic from profiles/r01/pmc_traffic.json: refresh it first, then run the bench
-cp $OUT/pmc_traffic.json profiles/r01/pmc_traffic.json
-python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+# the bench line quotes roofline.traffic from profiles/r02/pmc_traffic.json: refresh it first, then run the bench
+mkdir -p profiles/r02; cp $OUT/pmc_traffic.json profiles/r02/pmc_traffic.json
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
+cp $OUT/bench.json profiles/r02/bench.json; cp $OUT/bench_under_rocprof.json profiles/r02/bench_under_rocprof.json
+cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) profiles/r02/kernel_stats.csv
+mkdir -p gpurun_out/r02; cp profiles/r02/* gpurun_out/r02/

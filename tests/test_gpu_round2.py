@@ -218,3 +218,45 @@ def test_pq_encode_reproduces_the_reference_codes(name):
         da = ((g.codebook[j, codes[i, j]].astype(np.float64) - sub) ** 2).sum()
         db = ((g.codebook[j, g.codes[i, j]].astype(np.float64) - sub) ** 2).sum()
         assert da <= db * (1 + 1e-6) + 1e-12, (i, j, da, db)     # ours is at least as near: the reference's pick was a rounding tie
+
+
+@pytest.mark.parametrize("name", ["unit1536_R16_m32", "unit1536_R16_m64"])
+def test_multi_wave_queries_match_the_single_wave_kernels_and_the_oracle(name):
+    """D = 1536: variants 15 / 16 (four wavefronts share one query and one table) against variants 0 / 2 and the oracle,
+    both band policies, several capacities, a batch larger than the grid."""
+    from diskrag_amd import _ffi
+    from oracle import pyoracle as orc
+    g = load_golden(name)
+    ix = get_index(name)
+    q = np.concatenate([g.queries] * 40)[:2500]           # more queries than workgroup slots (4 x 256 CUs)
+    try:
+        for (L, bw, pol, k) in ((100, 8, 0, 10), (100, 0, 1, 10), (20, 8, 0, 5), (300, 16, 1, 10), (600, 0, 0, 10)):
+            w = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.M1, k, L=L, bw=bw, policy=pol, codes=g.codes,
+                                 codebook=g.codebook, nthreads=8)
+            for kind in (15, 0):
+                if kind == 15 and L > 512:
+                    continue
+                ix.debug_force_kind(kind)
+                ids, dist, cnt, st = ix.search_batch(q, k, L=L, beam_width=bw, mode=_ffi.MODE_M1, band_policy=pol)
+                assert ix.timing()["variant"] == kind
+                assert int(st["status"].max()) == 0
+                n = len(g.queries)
+                for rep in range(0, len(q) - n + 1, n * 13):
+                    sl = slice(rep, rep + n)
+                    assert np.array_equal(ids[sl], w[0]), (kind, L, bw, pol)
+                    assert np.array_equal(bits(dist[sl]), bits(w[1].astype(np.float32)))
+                    assert np.array_equal(_stats4(st[sl]), w[3])
+        for (mode, omode, fl, ofl, L, bw, k) in ((_ffi.MODE_PQ, orc.PQ, 0, 0, 100, 8, 10), (_ffi.MODE_M3, orc.M3, _ffi.F_USE_PQ, orc.F_USE_PQ, 10, 8, 10),
+                                                 (_ffi.MODE_PQ, orc.PQ, 0, 0, 64, 0, 20)):
+            gi = get_index(name, mem=(mode == _ffi.MODE_M3))
+            adj = g.mem_adj if mode == _ffi.MODE_M3 else g.adj
+            w = orc.search_batch(g.vectors, adj, g.queries, g.medoid, omode, k, L=L, bw=bw, flags=ofl, codes=g.codes, codebook=g.codebook)
+            for kind in (16, 2):
+                gi.debug_force_kind(kind)
+                ids, dist, cnt, st = gi.search_batch(g.queries, k, L=L, beam_width=bw, mode=mode, flags=fl)
+                assert gi.timing()["variant"] == kind
+                assert np.array_equal(ids, w[0]) and np.array_equal(cnt, w[2]) and np.array_equal(_stats4(st), w[3])
+                valid = w[0] != 0xFFFFFFFF
+                assert np.array_equal(bits(dist)[valid], bits(w[1].astype(np.float32))[valid])
+    finally:
+        ix.debug_force_kind(-1)
