@@ -44,7 +44,8 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_debug_force_kind", "dr_search_batch_f64",
            "dr_index_create_codes", "dr_index_drop_vectors", "dr_pq_scan_best",
            "dr_batch_select", "dr_search_submit", "dr_search_wait", "dr_host_alloc", "dr_host_free",
-           "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_merge_topk"]
+           "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_merge_topk",
+           "dr_debug_prune", "dr_pq_train_ex", "dr_index_create_codes_empty", "dr_pq_encode_rows", "dr_build_vamana_pq"]
 
 _lib = None
 
@@ -118,6 +119,14 @@ def load_library():
     L.dr_get_adjacency.argtypes = [vp, u32p]
     L.dr_pq_train.restype = C.c_int
     L.dr_pq_train.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, fp]
+    L.dr_index_create_codes_empty.restype = C.c_int
+    L.dr_index_create_codes_empty.argtypes = [C.POINTER(vp), C.c_uint64, C.c_uint32, C.c_uint32, fp, C.c_uint32, C.c_int]
+    L.dr_pq_encode_rows.restype = C.c_int
+    L.dr_pq_encode_rows.argtypes = [vp, fp, C.c_uint64, C.c_uint64]
+    L.dr_build_vamana_pq.restype = C.c_int
+    L.dr_build_vamana_pq.argtypes = [vp, C.c_uint32, C.c_float, C.c_uint32, C.c_uint64, C.c_uint32, u32p, fp]
+    L.dr_pq_train_ex.restype = C.c_int
+    L.dr_pq_train_ex.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, fp, C.POINTER(C.c_double)]
     L.dr_pq_encode.restype = C.c_int
     L.dr_pq_encode.argtypes = [vp, fp, C.c_uint32, u8p]
     L.dr_search_batch_f64.restype = C.c_int
@@ -151,6 +160,8 @@ def load_library():
     L.dr_sharded_search.restype = C.c_int
     L.dr_sharded_search.argtypes = [C.POINTER(vp), u32p, C.c_uint32, vp, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p, fp]
+    L.dr_debug_prune.restype = C.c_int
+    L.dr_debug_prune.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_float, C.c_uint32, u32p, u32p]
     L.dr_merge_topk.restype = C.c_int
     L.dr_merge_topk.argtypes = [C.c_int, u32p, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp]
     _lib = L
@@ -224,6 +235,33 @@ class HipIndex:
         ix.m = m
         return ix
 
+    @classmethod
+    def create_codes_empty(cls, N, D, R, codebook, device=0):
+        """A PQ-only shard to be filled by encode_rows() and built by build_vamana_pq() (config c5: vectors never stored)."""
+        cb = np.ascontiguousarray(codebook, dtype=np.float32)
+        m = cb.shape[0]
+        if cb.shape != (m, 256, D // m):
+            raise ValueError(f"codebook shape {cb.shape} does not match D={D}")
+        h = C.c_void_p()
+        _check(load_library().dr_index_create_codes_empty(C.byref(h), int(N), int(D), int(R), _p(cb, C.c_float), m, int(device)))
+        ix = cls(h, N, D, R, 0)
+        ix.m = m
+        return ix
+
+    def encode_rows(self, vectors, row0):
+        v = np.ascontiguousarray(vectors, dtype=np.float32)
+        if v.ndim != 2 or v.shape[1] != self.D:
+            raise ValueError(f"vectors must be [rows, {self.D}]")
+        _check(load_library().dr_pq_encode_rows(self._h, _p(v, C.c_float), int(row0), v.shape[0]))
+
+    def build_vamana_pq(self, L_build=64, alpha=1.2, passes=2, seed=1, max_batch=0):
+        med = C.c_uint32(0)
+        secs = C.c_float(0)
+        _check(load_library().dr_build_vamana_pq(self._h, int(L_build), float(alpha), int(passes), int(seed), int(max_batch),
+                                                 C.byref(med), C.byref(secs)))
+        self.medoid = int(med.value)
+        return self.medoid, float(secs.value)
+
     def drop_vectors(self):
         """Frees the stored vectors: the index becomes a PQ-only shard (M3 with F_USE_PQ only)."""
         _check(load_library().dr_index_drop_vectors(self._h))
@@ -246,6 +284,14 @@ class HipIndex:
         cb = np.empty((m, 256, self.D // m), dtype=np.float32)
         _check(load_library().dr_pq_train(self._h, int(m), int(n_sample), int(iters), int(seed), _p(cb, C.c_float)))
         return cb
+
+    def pq_train_ex(self, m, n_sample=100000, max_iter=300, n_init=3, tol=1e-4, seed=42):
+        """k-means++ seeding, n_init restarts, sklearn's stopping rule (DiskANNPQ.fit): (codebook, inertia on the sample)."""
+        cb = np.empty((m, 256, self.D // m), dtype=np.float32)
+        inertia = C.c_double(0)
+        _check(load_library().dr_pq_train_ex(self._h, int(m), int(n_sample), int(max_iter), int(n_init), float(tol), int(seed),
+                                             _p(cb, C.c_float), C.byref(inertia)))
+        return cb, float(inertia.value)
 
     def pq_encode(self, codebook, want_codes=False):
         cb = np.ascontiguousarray(codebook, dtype=np.float32)
@@ -428,6 +474,15 @@ class HipIndex:
         _check(load_library().dr_bruteforce_topk(self._h, _p(q, C.c_float), q.shape[0], int(k), _p(ids, C.c_uint32),
                                                  _p(dist, C.c_float)))
         return ids, dist
+
+    def debug_prune(self, point, candidates, alpha, R):
+        """The builder's robust prune of one point over an explicit candidate list: picked ids in pick order."""
+        c = np.ascontiguousarray(candidates, dtype=np.uint32)
+        sel = np.empty(int(R), dtype=np.uint32)
+        cnt = C.c_uint32(0)
+        _check(load_library().dr_debug_prune(self._h, int(point), _p(c, C.c_uint32), c.size, float(alpha), int(R),
+                                             _p(sel, C.c_uint32), C.byref(cnt)))
+        return sel[:int(cnt.value)]
 
     def debug_force_kind(self, kind):
         """Pins the search-kernel variant (-1: engine's choice); returns the handle's A4 regime (1 live, 0 not, -1 unknown)."""

@@ -21,7 +21,10 @@
 #include <algorithm>
 #include <array>
 #include <map>
+#include <atomic>
+#include <cmath>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -29,6 +32,7 @@
 #include "engine_kernels.hpp"
 #include "search_f64.hpp"
 #include "build_kernels.hpp"
+#include "build_pq_kernels.hpp"
 #include "variants.hpp"
 
 static thread_local std::string g_err;
@@ -136,6 +140,7 @@ struct dr_index {
     DevBuf<u64> first;
     DevBuf<uint8_t> codes;
     DevBuf<float> codebook;
+    DevBuf<float> sdc;            // centroid-pair table [m][256][256] (PQ-only builder), built on first use
     DevBuf<uint32_t> perm;
     std::vector<uint32_t> h_perm;
     // bit order of the visited bitmaps (build_bit_order): rank[id] = bit position, adjr = rank of every adjacency slot
@@ -388,7 +393,7 @@ extern "C" void dr_index_close(dr_index *ix)
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) if (st) (void)hipStreamSynchronize(st);
-    ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release();
+    ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release(); ix->sdc.release();
     ix->perm.release(); ix->vis.release(); ix->vis_epoch.release();
     for (auto &qs : ix->slots) qs.release();
     for (auto &jb : ix->jobs) {
@@ -571,7 +576,8 @@ static int build_byte_rows(dr_index *ix)
 
 // Builder override: search over the under-construction rows (RX slots, degree array instead of first-masks),
 // queries already resident in ix->q / ix->qp, no outputs besides res_keys / res_n.
-struct BuildOverride { const uint32_t *adjb; const uint32_t *deg; uint32_t RX; uint32_t nq; };
+struct BuildOverride { const uint32_t *adjb; const uint32_t *deg; uint32_t RX; uint32_t nq;
+                       const float *sdc = nullptr; const uint32_t *pts = nullptr; };   // sdc/pts: PQ-only builder (codes are the queries)
 
 static int g_force_kind = -1;   // test/diagnostic hook: DR_FORCE_KIND environment variable / dr_debug_force_kind
 static bool g_force_kind_set = false;
@@ -611,7 +617,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (ix->cs->nq > 65536 && !ov) return fail(DR_E_UNSUPPORTED, "resident batches are limited to 65536 queries (dr_search_batch chunks larger ones)");
     if (mode < DR_MODE_M1 || mode > DR_MODE_PQ) return fail(DR_E_ARG, "unknown mode %u", mode);
     if (k == 0) return fail(DR_E_ARG, "k must be positive");
-    const bool pq_only = (mode == DR_MODE_M3 && (flags & DR_F_USE_PQ)) || mode == DR_MODE_PQ;   // ADC-only traversals
+    const bool pq_only = (mode == DR_MODE_M3 && (flags & DR_F_USE_PQ)) || mode == DR_MODE_PQ || (ov && ov->sdc);   // ADC-only traversals
     const bool rerank = (mode == DR_MODE_PQ) && (flags & DR_F_RERANK);
     const bool use_pq = (mode == DR_MODE_M1) || pq_only;
     if (use_pq && ix->m == 0) return fail(DR_E_NOPQ, "mode %u needs PQ data (dr_index_set_pq)", mode);
@@ -636,15 +642,13 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         const size_t pw = (DR_KIND_LUT[kd] ? (size_t)ix->m * 256 * 4 : 0) + (qorig_lds ? (size_t)ix->D * 4 : 0) +
                           (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 512 + bloom + (DR_KIND_QB[kd] ? 528 : 0) +
                           (rb ? (size_t)rb * ix->D * (DR_KIND_U8[kd] ? 1 : 4) : (size_t)NCHR_OF_SC[sc] * 64 * 12);
-        if (DR_KIND_MW[kd])      // one copy of everything but the merge scratch, + the ADC hand-off array and control words
-            return pw - (size_t)NCHR_OF_SC[sc] * 64 * 12 + 320 + (size_t)DR_KIND_NW[kd] * NCHR_OF_SC[sc] * 64 * 12;
         return (DR_KIND_CB[kd] ? (size_t)256 * ix->D * 4 : 0) + (size_t)DR_KIND_NW[kd] * pw;
     };
     if (!ov && ix->vec8_state == 0) { const int rcb8 = build_byte_rows(ix); if (rcb8) return rcb8; }
     auto usable = [&](int kd) { return ix->kern->search[kd][sc] != nullptr && lds_of(kd) <= 160 * 1024 && (!DR_KIND_U8[kd] || ix->vec8_state == 1) &&
                                        (!DR_KIND_QB[kd] || (ix->cs->q_u8 && !ov)); };
-    static const int PREF_M1[] = { 13, 11, 9, 3, 15, 0 }, PREF_ADC[] = { 5, 16, 2 }, PREF_EX[] = { 14, 12, 8, 1 }, PREF_BUILD[] = { 1, 8 };
-    static const int PREF_M1_LIVE_LUT[] = { 15, 0, 3, 13, 11, 9 }, PREF_M1_LIVE_CB[] = { 3, 15, 0, 13, 11, 9 };
+    static const int PREF_M1[] = { 13, 11, 9, 3, 0 }, PREF_ADC[] = { 5, 2 }, PREF_EX[] = { 14, 12, 8, 1 }, PREF_BUILD[] = { 1, 8 };
+    static const int PREF_M1_LIVE_LUT[] = { 0, 3, 13, 11, 9 }, PREF_M1_LIVE_CB[] = { 3, 0, 13, 11, 9 };
     const bool k_m1 = (mode == DR_MODE_M1), k_adc = pq_only;
     // M1 has two regimes. On SIFT-scale data the rerank policy A4 is provably true for almost every expansion (Q1),
     // the ADC is skipped and the kernel is a pure row gather: vectors landed in LDS, table never built (9, 6).
@@ -652,8 +656,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // per-query table (0) when 8 of them fit a CU, else the shared codebook (3). Which regime an index is in is
     // MEASURED on the first M1 batch an index state serves (its counters are read once that launch has finished, see
     // the end of this function); until then the SIFT-scale preference applies. Results never depend on the variant.
-    const int *pref = k_m1 ? PREF_M1 : k_adc ? PREF_ADC : ov ? PREF_BUILD : PREF_EX;
-    const int npref = k_m1 ? 6 : k_adc ? 3 : ov ? 2 : 4;
+    static const int PREF_BUILD_PQ[] = { 2 };
+    const int *pref = k_m1 ? PREF_M1 : (ov && ov->sdc) ? PREF_BUILD_PQ : k_adc ? PREF_ADC : ov ? PREF_BUILD : PREF_EX;
+    const int npref = k_m1 ? 5 : (ov && ov->sdc) ? 1 : k_adc ? 2 : ov ? 2 : 4;
     if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 8 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
     int kind = -1;
     for (int i = 0; i < npref && kind < 0; i++) if (usable(pref[i])) kind = pref[i];
@@ -662,7 +667,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e && !g_force_kind_set) g_force_kind = atoi(e); env_read = true; }
         const int g = g_force_kind;
         if (g >= 0 && g < DR_NUM_KINDS && usable(g)) {
-            const bool g_m1 = (g == 0 || g == 3 || g == 9 || g == 11 || g == 13 || g == 15), g_adc = (g == 2 || g == 5 || g == 16), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
+            const bool g_m1 = (g == 0 || g == 3 || g == 9 || g == 11 || g == 13), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
             if ((g_m1 && k_m1) || (g_adc && k_adc) || (g_ex && !k_m1 && !k_adc)) kind = g;
         }
     }
@@ -684,9 +689,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         }
     }
     const uint32_t nq = ix->cs->nq;
-    const bool mwq = DR_KIND_MW[kind];      // the workgroup's wavefronts serve ONE query
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(mwq ? (uint64_t)nq : ((uint64_t)nq + NW - 1) / NW, (uint64_t)occ * ix->num_cu);
-    const uint32_t slots = mwq ? grid : grid * NW;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nq + NW - 1) / NW, (uint64_t)occ * ix->num_cu);
+    const uint32_t slots = grid * NW;
 
     // M1 is capped at min(10L, N) expansions (search_engine.py:429); the other variants are bounded by N.
     const bool capped = (mode == DR_MODE_M1 || mode == DR_MODE_PQ);
@@ -754,6 +758,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (!ov) { if (ix->phase.reserve((size_t)256 * 8192, true)) return DR_E_NODEVICE; p.phase = ix->phase.p; }
 #endif
     if (ov) {
+        p.sdc = ov->sdc; p.build_pts = ov->pts;
         p.adj = ov->adjb; p.first = nullptr; p.deg = ov->deg; p.R = ov->RX; p.logcap = 0;
         p.tie_list = nullptr; p.out_ids = nullptr; p.out_dist = nullptr; p.out_count = nullptr;
     }
@@ -1395,15 +1400,16 @@ static uint64_t splitmix64(uint64_t &x)
     return z ^ (z >> 31);
 }
 
-extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint32_t passes, uint64_t seed,
-                               uint32_t pad_with_zero, uint32_t max_batch, uint32_t *out_medoid, float *out_seconds)
+static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint32_t passes, uint64_t seed,
+                               uint32_t pad_with_zero, uint32_t max_batch, uint32_t *out_medoid, float *out_seconds, bool pq)
 {
     if (!ix) return fail(DR_E_ARG, "null index");
     if (L_build == 0 || L_build > 256) return fail(DR_E_ARG, "L_build must be in 1..256");
     if (ix->R > 128) return fail(DR_E_UNSUPPORTED, "builder supports R <= 128");
     if (passes == 0) passes = 2;
-    std::lock_guard<std::mutex> lk(ix->mu);
-    { const int rcv = need_vectors(ix, "dr_build_vamana"); if (rcv) return rcv; }
+    std::unique_lock<std::mutex> lk(ix->mu);
+    if (!pq) { const int rcv = need_vectors(ix, "dr_build_vamana"); if (rcv) return rcv; }
+    if (pq && ix->m == 0) return fail(DR_E_NOPQ, "dr_build_vamana_pq needs the code words (dr_index_create_codes_empty + dr_pq_encode_rows)");
     HIPCHK(hipSetDevice(ix->device));
     { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }
     const uint64_t N = ix->N;
@@ -1415,7 +1421,7 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
     HIPCHK(hipEventRecord(t0, ix->stream));
 
     // ---- medoid: stored vector nearest to the centroid (the reference samples, cython_utils.pyx:210-263)
-    {
+    if (!pq) {
         DevBuf<double> acc;
         if (acc.reserve(D, true)) return DR_E_NODEVICE;
         hipLaunchKernelGGL(column_sum_kernel, dim3(1024), dim3(128), 0, ix->stream, ix->vecp.p, N, D, acc.p);
@@ -1440,16 +1446,48 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
         HIPCHK(hipStreamSynchronize(ix->stream));
         oi.release(); od.release();
         ix->medoid = med;
+    } else {
+        // PQ-only: the mean of the decoded vectors follows from the per-sub-quantiser histogram of the code words; the
+        // medoid is the code word nearest to it (flat ADC scan)
+        DevBuf<uint32_t> hist;
+        if (hist.reserve((size_t)ix->m * 256, true)) return DR_E_NODEVICE;
+        hipLaunchKernelGGL(code_histogram_kernel, dim3(4096), dim3(256), 0, ix->stream, ix->codes.p, N, ix->m, hist.p);
+        HIPCHK(hipGetLastError());
+        std::vector<uint32_t> hh((size_t)ix->m * 256);
+        std::vector<float> hcb((size_t)256 * D), mean(D, 0.0f);
+        HIPCHK(hipMemcpyAsync(hh.data(), hist.p, hh.size() * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipMemcpyAsync(hcb.data(), ix->codebook.p, hcb.size() * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        for (uint32_t jq = 0; jq < ix->m; jq++)
+            for (uint32_t t = 0; t < ix->sd; t++) {
+                double a = 0;
+                for (uint32_t c = 0; c < 256; c++) a += (double)hh[jq * 256 + c] * hcb[((size_t)jq * 256 + c) * ix->sd + t];
+                mean[jq * ix->sd + t] = (float)(a / (double)N);
+            }
+        // flat scan for the nearest code word (pq_scan_kernel through the regular entry point's machinery)
+        ix->mu.unlock();
+        uint32_t best = 0; float bsq = 0, kms = 0;
+        const int rcs = dr_pq_scan_best(ix, mean.data(), 1, nullptr, &best, &bsq, &kms);
+        ix->mu.lock();
+        if (rcs) return rcs;
+        ix->medoid = best;
     }
-
     DevBuf<uint32_t> adjb, deg, order, fwd, fwd_n, ovf_list, ovf_count;
     if (adjb.reserve((size_t)N * RX) || deg.reserve(N + 2, true) || order.reserve(N) || fwd.reserve((size_t)max_batch * R) ||
         fwd_n.reserve(max_batch) || ovf_list.reserve(N) || ovf_count.reserve(1))
         return DR_E_NODEVICE;
     HIPCHK(hipMemsetAsync(adjb.p, 0xFF, (size_t)N * RX * 4, ix->stream));
-    if (ix->cs->q.reserve((size_t)max_batch * D) || ix->cs->qp.reserve((size_t)max_batch * D)) return DR_E_NODEVICE;
+    if (!pq && (ix->cs->q.reserve((size_t)max_batch * D) || ix->cs->qp.reserve((size_t)max_batch * D))) return DR_E_NODEVICE;
+    if (pq && !ix->sdc.p) {
+        // centroid-pair table S[m][256][256] (8 MB at m = 32): every distance of the PQ-only builder is a sum of its entries
+        if (ix->sdc.reserve((size_t)ix->m * 65536)) return DR_E_NODEVICE;
+        hipLaunchKernelGGL(sdc_table_kernel, dim3(ix->m * 256), dim3(256), 0, ix->stream, ix->codebook.p, ix->m, ix->sd, ix->sdc.p);
+        HIPCHK(hipGetLastError());
+    }
 
-    const size_t prune_lds = (D > 256 ? (size_t)D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024;
+    const size_t prune_lds = pq ? (size_t)ix->m * 1024 + (size_t)DR_PRUNE_MAXC * 24 + 1024
+                                : (D > 256 ? (size_t)D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024;
+    if (pq) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&prune_pq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
     std::vector<uint32_t> horder(N);
     uint64_t rng = seed ? seed : 1;
     int rc = 0;
@@ -1466,9 +1504,10 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
             uint32_t b = (pass == 0) ? std::min<uint64_t>(bsz, std::max<uint64_t>(1, done / 16 + 1)) : max_batch;
             b = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(b, max_batch), N - done);
             const uint32_t *pts = order.p + done;
-            // 1. queries = the batch points' own vectors (already chain-major)
-            hipLaunchKernelGGL(gather_rows_kernel, dim3(b), dim3(64), 0, ix->stream, ix->vecp.p, pts, b, D, ix->cs->qp.p);
+            // 1. queries = the batch points' own vectors (already chain-major); PQ-only: their code words
+            if (!pq) hipLaunchKernelGGL(gather_rows_kernel, dim3(b), dim3(64), 0, ix->stream, ix->vecp.p, pts, b, D, ix->cs->qp.p);
             BuildOverride ov = { adjb.p, deg.p, RX, b };
+            if (pq) { ov.sdc = ix->sdc.p; ov.pts = pts; }
             rc = run_locked(ix, 1, L_build, 0, DR_MODE_M4, 0, DR_F_SQDIST, &ov);
             if (rc) break;
             // 2. prune -> forward rows
@@ -1476,7 +1515,14 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
             pp.vecp = ix->vecp.p; pp.adjb = adjb.p; pp.deg = deg.p; pp.RX = RX; pp.R = R; pp.alpha = a;
             pp.points = pts; pp.npoints = b; pp.res_keys = ix->sets[0].res_keys.p; pp.res_n = ix->sets[0].res_n.p; pp.cap = L_build;
             pp.fwd = fwd.p; pp.fwd_n = fwd_n.p;
-            {
+            PrunePQParams pq_pp;
+            pq_pp.codes = ix->codes.p; pq_pp.sdc = ix->sdc.p; pq_pp.m = ix->m; pq_pp.adjb = adjb.p; pq_pp.deg = deg.p; pq_pp.RX = RX; pq_pp.R = R;
+            pq_pp.alpha = a; pq_pp.points = pts; pq_pp.npoints = b; pq_pp.res_keys = pp.res_keys; pq_pp.res_n = pp.res_n; pq_pp.cap = L_build;
+            pq_pp.fwd = fwd.p; pq_pp.fwd_n = fwd_n.p;
+            if (pq) {
+                hipLaunchKernelGGL(prune_pq_kernel, dim3(std::min<unsigned>(b, (unsigned)ix->num_cu * 4)), dim3(64), prune_lds, ix->stream, pq_pp);
+                HIPCHK(hipGetLastError());
+            } else {
                 void *args[] = { &pp };
                 const unsigned g = std::min<unsigned>(b, (unsigned)ix->num_cu * 16);
                 HIPCHK(hipLaunchKernel(ix->kern->prune, dim3(g), dim3(64), args, prune_lds, ix->stream));
@@ -1498,9 +1544,16 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
                 PruneParams po = pp;
                 po.points = ovf_list.p; po.npoints = novf; po.res_keys = nullptr; po.res_n = nullptr; po.cap = 0;
                 po.fwd = nullptr; po.fwd_n = nullptr;
+                if (pq) {
+                    PrunePQParams qo = pq_pp;
+                    qo.points = ovf_list.p; qo.npoints = novf; qo.res_keys = nullptr; qo.res_n = nullptr; qo.cap = 0; qo.fwd = nullptr; qo.fwd_n = nullptr;
+                    hipLaunchKernelGGL(prune_pq_kernel, dim3(std::min<unsigned>(novf, (unsigned)ix->num_cu * 4)), dim3(64), prune_lds, ix->stream, qo);
+                    HIPCHK(hipGetLastError());
+                } else {
                 void *args[] = { &po };
                 const unsigned g = std::min<unsigned>(novf, (unsigned)ix->num_cu * 16);
                 HIPCHK(hipLaunchKernel(ix->kern->prune, dim3(g), dim3(64), args, prune_lds, ix->stream));
+                }
             }
             done += b;
             if (bsz < max_batch) bsz *= 2;
@@ -1526,6 +1579,94 @@ extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint
     return rc;
 }
 
+extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint32_t passes, uint64_t seed,
+                               uint32_t pad_with_zero, uint32_t max_batch, uint32_t *out_medoid, float *out_seconds)
+{
+    return build_vamana_common(ix, L_build, alpha, passes, seed, pad_with_zero, max_batch, out_medoid, out_seconds, false);
+}
+
+// ---- PQ-only shards built on the device (BASELINE config c5): code words streamed in, graph built from code words ------
+extern "C" int dr_index_create_codes_empty(dr_index **out, uint64_t N, uint32_t D, uint32_t R, const float *codebook, uint32_t m, int device)
+{
+    if (!out || !codebook) return fail(DR_E_ARG, "null argument");
+    if (m == 0 || D % m || D / m > 128) return fail(DR_E_ARG, "bad n_subvectors %u for D=%u", m, D);
+    dr_index *ix = new dr_index();
+    int rc = index_alloc_common(ix, N, D, R, 0, device, false);
+    if (!rc && (ix->codes.reserve((size_t)N * m, true) || ix->codebook.reserve((size_t)256 * D))) rc = DR_E_NODEVICE;
+    if (!rc && hipMemcpy(ix->codebook.p, codebook, (size_t)256 * D * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail(DR_E_NODEVICE, "codebook upload failed");
+    if (!rc && hipMemset(ix->adj.p, 0xFF, (size_t)N * R * 4) != hipSuccess) rc = fail(DR_E_NODEVICE, "memset failed");
+    if (!rc && hipMemset(ix->first.p, 0, (size_t)N * ((R + 63) / 64) * 8) != hipSuccess) rc = fail(DR_E_NODEVICE, "memset failed");
+    if (rc) { dr_index_close(ix); return rc; }
+    ix->m = m; ix->sd = D / m;
+    *out = ix;
+    return 0;
+}
+
+extern "C" int dr_pq_encode_rows(dr_index *ix, const float *vectors, uint64_t row0, uint64_t rows)
+{
+    if (!ix || !vectors) return fail(DR_E_ARG, "null argument");
+    if (ix->m == 0) return fail(DR_E_NOPQ, "no codebook attached");
+    if (rows == 0 || row0 + rows > ix->N) return fail(DR_E_ARG, "rows [%llu, %llu) outside the index", (unsigned long long)row0, (unsigned long long)(row0 + rows));
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIPCHK(hipSetDevice(ix->device));
+    const uint32_t D = ix->D, m = ix->m, sd = ix->sd;
+    const uint64_t chunk = std::max<uint64_t>(1, (1ull << 30) / (D * 4));
+    DevBuf<float> tmp;
+    if (tmp.reserve((size_t)std::min(chunk, rows) * D)) return DR_E_NODEVICE;
+    const size_t lds = (size_t)256 * sd * 4;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_assign_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (uint64_t r0 = 0; r0 < rows; r0 += chunk) {
+        const uint64_t n = std::min(chunk, rows - r0);
+        HIPCHK(hipMemcpyAsync(tmp.p, vectors + (size_t)r0 * D, (size_t)n * D * 4, hipMemcpyHostToDevice, ix->stream));
+        const unsigned gx = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ix->num_cu * 4);
+        hipLaunchKernelGGL(pq_assign_rows_kernel, dim3(gx, m), dim3(256), lds, ix->stream, tmp.p, n, D, m, sd, ix->codebook.p,
+                           ix->codes.p + (size_t)(row0 + r0) * m);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ix->stream));
+    }
+    ix->adc_live = -1;
+    return 0;
+}
+
+extern "C" int dr_build_vamana_pq(dr_index *ix, uint32_t L_build, float alpha, uint32_t passes, uint64_t seed, uint32_t max_batch,
+                                  uint32_t *out_medoid, float *out_seconds)
+{
+    return build_vamana_common(ix, L_build, alpha, passes, seed, 0, max_batch, out_medoid, out_seconds, true);
+}
+
+// Test seam for the builder: the robust prune of ONE point over an explicit candidate list, run by the
+// same prune_kernel the builder launches. The tests compare it with the CPU restatement of the reference's
+// robust_prune_fast_cython (cython_utils.pyx:435-492) without that function's stale vector reads.
+extern "C" int dr_debug_prune(dr_index *ix, uint32_t point, const uint32_t *candidates, uint32_t n, float alpha, uint32_t R,
+                              uint32_t *out_selected, uint32_t *out_count)
+{
+    if (!ix || !candidates || !out_selected || !out_count) return fail(DR_E_ARG, "null argument");
+    if (point >= ix->N || n == 0 || n > DR_PRUNE_MAXC || R == 0 || R > 192) return fail(DR_E_ARG, "bad prune arguments (n <= %d, R <= 192)", DR_PRUNE_MAXC);
+    for (uint32_t i = 0; i < n; i++) if (candidates[i] >= ix->N) return fail(DR_E_ARG, "candidate id %u out of range", candidates[i]);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    { const int rcv = need_vectors(ix, "dr_debug_prune"); if (rcv) return rcv; }
+    HIPCHK(hipSetDevice(ix->device));
+    // the candidates travel as a one-query "search result" (the kernel recomputes their distances); the row itself is empty
+    DevBuf<u64> keys; DevBuf<uint32_t> resn, adjb, deg, pts, fwd, fwdn;
+    if (keys.reserve(n) || resn.reserve(1) || adjb.reserve((size_t)ix->N * R) || deg.reserve(ix->N + 2, true) || pts.reserve(1) ||
+        fwd.reserve(R) || fwdn.reserve(1)) return DR_E_NODEVICE;
+    std::vector<u64> hk(n);
+    for (uint32_t i = 0; i < n; i++) hk[i] = (u64)(uint32_t)(~candidates[i]);
+    HIPCHK(hipMemcpyAsync(keys.p, hk.data(), (size_t)n * 8, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(hipMemcpyAsync(resn.p, &n, 4, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(hipMemcpyAsync(pts.p, &point, 4, hipMemcpyHostToDevice, ix->stream));
+    PruneParams pp;
+    pp.vecp = ix->vecp.p; pp.adjb = adjb.p; pp.deg = deg.p; pp.RX = R; pp.R = R; pp.alpha = alpha;
+    pp.points = pts.p; pp.npoints = 1; pp.res_keys = keys.p; pp.res_n = resn.p; pp.cap = n; pp.fwd = fwd.p; pp.fwd_n = fwdn.p;
+    void *args[] = { &pp };
+    const size_t prune_lds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024;
+    HIPCHK(hipLaunchKernel(ix->kern->prune, dim3(1), dim3(64), args, prune_lds, ix->stream));
+    HIPCHK(hipMemcpyAsync(out_selected, fwd.p, (size_t)R * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipMemcpyAsync(out_count, fwdn.p, 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ PQ build
 
 static int pq_assign(dr_index *ix, const uint32_t *d_ids, uint64_t n, uint32_t m, const float *d_codebook, uint8_t *d_out)
@@ -1540,7 +1681,53 @@ static int pq_assign(dr_index *ix, const uint32_t *d_ids, uint64_t n, uint32_t m
     return 0;
 }
 
-extern "C" int dr_pq_train(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t iters, uint64_t seed, float *out_codebook)
+// runs fn(j) for j in [0, n) on up to `hardware_concurrency` host threads
+template <class F> static void parallel_for(uint32_t n, F fn)
+{
+    const uint32_t nt = std::max(1u, std::min<uint32_t>(n, std::thread::hardware_concurrency()));
+    if (nt <= 1) { for (uint32_t j = 0; j < n; j++) fn(j); return; }
+    std::vector<std::thread> th;
+    std::atomic<uint32_t> next{0};
+    for (uint32_t t = 0; t < nt; t++) th.emplace_back([&] { for (uint32_t j = next.fetch_add(1); j < n; j = next.fetch_add(1)) fn(j); });
+    for (auto &t : th) t.join();
+}
+
+// Greedy k-means++ seeding of one sub-quantiser (Arthur & Vassilvitskii 2007 with sklearn's 2 + log k local trials per
+// step: sklearn.cluster._kmeans._kmeans_plusplus is what DiskANNPQ.fit reaches through init='k-means++', fast_pq.py:231-238).
+static void kmeanspp_init(const float *x, uint32_t ns, uint32_t D, uint32_t off, uint32_t sd, uint64_t seed, float *cb /*[256][sd]*/)
+{
+    uint64_t rng = seed;
+    auto unif = [&]() { return (double)(splitmix64(rng) >> 11) * (1.0 / 9007199254740992.0); };
+    const uint32_t K = 256, trials = 2 + (uint32_t)std::log((double)K);
+    std::vector<double> d2(ns), cand_d2((size_t)trials * ns);
+    auto dist2 = [&](uint32_t i, const float *c) { double s2 = 0; const float *xi = x + (size_t)i * D + off; for (uint32_t t = 0; t < sd; t++) { const double d = (double)xi[t] - c[t]; s2 += d * d; } return s2; };
+    const uint32_t first = (uint32_t)(unif() * ns) % ns;
+    memcpy(cb, x + (size_t)first * D + off, sd * 4);
+    double pot = 0;
+    for (uint32_t i = 0; i < ns; i++) { d2[i] = dist2(i, cb); pot += d2[i]; }
+    std::vector<uint32_t> cand(trials);
+    for (uint32_t c = 1; c < K; c++) {
+        // candidates with probability proportional to the squared distance to the nearest chosen centre
+        std::vector<double> r(trials);
+        for (auto &v : r) v = unif() * pot;
+        std::sort(r.begin(), r.end());
+        { double acc = 0; uint32_t ti = 0; for (uint32_t i = 0; i < ns && ti < trials; i++) { acc += d2[i]; while (ti < trials && r[ti] < acc) cand[ti++] = i; } while (ti < trials) cand[ti++] = ns - 1; }
+        double best_pot = -1; uint32_t best_t = 0;
+        for (uint32_t t = 0; t < trials; t++) {
+            const float *cc = x + (size_t)cand[t] * D + off;
+            double np = 0;
+            double *cd = &cand_d2[(size_t)t * ns];
+            for (uint32_t i = 0; i < ns; i++) { const double dn = std::min(d2[i], dist2(i, cc)); cd[i] = dn; np += dn; }
+            if (best_pot < 0 || np < best_pot) { best_pot = np; best_t = t; }
+        }
+        memcpy(cb + (size_t)c * sd, x + (size_t)cand[best_t] * D + off, sd * 4);
+        memcpy(d2.data(), &cand_d2[(size_t)best_t * ns], (size_t)ns * 8);
+        pot = best_pot;
+    }
+}
+
+extern "C" int dr_pq_train_ex(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t max_iter, uint32_t n_init, float tol, uint64_t seed,
+                              float *out_codebook, double *out_inertia)
 {
     if (!ix || !out_codebook) return fail(DR_E_ARG, "null argument");
     if (m == 0 || ix->D % m || ix->D / m > 128) return fail(DR_E_ARG, "bad n_subvectors %u for D=%u", m, ix->D);
@@ -1550,7 +1737,8 @@ extern "C" int dr_pq_train(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t
     HIPCHK(hipSetDevice(ix->device));
     const uint32_t D = ix->D, sd = D / m;
     const uint32_t ns = (uint32_t)std::min<uint64_t>(n_sample ? n_sample : 100000, ix->N);
-    if (iters == 0) iters = 10;
+    if (max_iter == 0) max_iter = 10;
+    if (n_init == 0) n_init = 1;
     // sample without replacement (partial Fisher-Yates over ids)
     std::vector<uint32_t> ids(ns);
     {
@@ -1571,39 +1759,89 @@ extern "C" int dr_pq_train(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t
     std::vector<float> x((size_t)ns * D);
     HIPCHK(hipMemcpyAsync(x.data(), d_x.p, (size_t)ns * D * 4, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
-    // init: 256 distinct sample rows per sub-quantiser
-    std::vector<float> cb((size_t)m * 256 * sd);
-    for (uint32_t jq = 0; jq < m; jq++)
-        for (uint32_t c = 0; c < 256; c++) {
-            const uint32_t r = (uint32_t)(((uint64_t)c * ns) / 256 + jq) % ns;
-            memcpy(&cb[((size_t)jq * 256 + c) * sd], &x[(size_t)r * D + jq * sd], sd * 4);
+
+    // sklearn's stopping rule: total squared centre shift <= tol * mean per-feature variance (KMeans tol, default 1e-4)
+    std::vector<double> tol_j(m, 0.0);
+    parallel_for(m, [&](uint32_t jq) {
+        double vsum = 0;
+        for (uint32_t t = 0; t < sd; t++) {
+            double s1 = 0, s2 = 0;
+            for (uint32_t i = 0; i < ns; i++) { const double v = x[(size_t)i * D + jq * sd + t]; s1 += v; s2 += v * v; }
+            const double mu = s1 / ns;
+            vsum += s2 / ns - mu * mu;
         }
+        tol_j[jq] = (double)tol * vsum / sd;
+    });
+
+    std::vector<float> cb((size_t)m * 256 * sd), best_cb((size_t)m * 256 * sd);
+    std::vector<double> best_inertia(m, -1.0), inertia(m), shift(m);
     std::vector<uint8_t> assign((size_t)ns * m);
-    std::vector<double> sums((size_t)256 * sd);
-    std::vector<uint32_t> cnt(256);
-    for (uint32_t it = 0; it < iters; it++) {
+    auto assign_step = [&]() -> int {
         HIPCHK(hipMemcpyAsync(d_cb.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice, ix->stream));
-        int rc = pq_assign(ix, d_ids.p, ns, m, d_cb.p, d_assign.p);
+        const int rc = pq_assign(ix, d_ids.p, ns, m, d_cb.p, d_assign.p);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(assign.data(), d_assign.p, assign.size(), hipMemcpyDeviceToHost, ix->stream));
         HIPCHK(hipStreamSynchronize(ix->stream));
-        for (uint32_t jq = 0; jq < m; jq++) {
-            std::fill(sums.begin(), sums.end(), 0.0);
-            std::fill(cnt.begin(), cnt.end(), 0u);
-            for (uint32_t i = 0; i < ns; i++) {
-                const uint32_t c = assign[(size_t)i * m + jq];
-                cnt[c]++;
-                const float *xi = &x[(size_t)i * D + jq * sd];
-                for (uint32_t t = 0; t < sd; t++) sums[(size_t)c * sd + t] += xi[t];
-            }
-            for (uint32_t c = 0; c < 256; c++)
-                if (cnt[c])
-                    for (uint32_t t = 0; t < sd; t++) cb[((size_t)jq * 256 + c) * sd + t] = (float)(sums[(size_t)c * sd + t] / cnt[c]);
+        return 0;
+    };
+    for (uint32_t r = 0; r < n_init; r++) {
+        parallel_for(m, [&](uint32_t jq) {
+            kmeanspp_init(x.data(), ns, D, jq * sd, sd, (seed ? seed : 42) * 0x9E3779B97F4A7C15ull + ((uint64_t)r << 32) + jq + 1,
+                          &cb[(size_t)jq * 256 * sd]);
+        });
+        for (uint32_t it = 0; it < max_iter; it++) {
+            const int rc = assign_step();
+            if (rc) return rc;
+            parallel_for(m, [&](uint32_t jq) {
+                std::vector<double> sums((size_t)256 * sd, 0.0);
+                std::vector<uint32_t> cnt(256, 0u);
+                for (uint32_t i = 0; i < ns; i++) {
+                    const uint32_t c = assign[(size_t)i * m + jq];
+                    cnt[c]++;
+                    const float *xi = &x[(size_t)i * D + jq * sd];
+                    for (uint32_t t = 0; t < sd; t++) sums[(size_t)c * sd + t] += xi[t];
+                }
+                double sh = 0;
+                for (uint32_t c = 0; c < 256; c++)
+                    if (cnt[c])
+                        for (uint32_t t = 0; t < sd; t++) {
+                            float &dst = cb[((size_t)jq * 256 + c) * sd + t];
+                            const float nv = (float)(sums[(size_t)c * sd + t] / cnt[c]);
+                            sh += ((double)nv - dst) * ((double)nv - dst);
+                            dst = nv;
+                        }
+                shift[jq] = sh;
+            });
+            bool done = true;
+            for (uint32_t jq = 0; jq < m; jq++) done = done && shift[jq] <= tol_j[jq];
+            if (done) break;
         }
+        // labels and inertia of the final centres
+        const int rc = assign_step();
+        if (rc) return rc;
+        parallel_for(m, [&](uint32_t jq) {
+            double in = 0;
+            for (uint32_t i = 0; i < ns; i++) {
+                const float *c = &cb[((size_t)jq * 256 + assign[(size_t)i * m + jq]) * sd];
+                const float *xi = &x[(size_t)i * D + jq * sd];
+                for (uint32_t t = 0; t < sd; t++) { const double d = (double)xi[t] - c[t]; in += d * d; }
+            }
+            inertia[jq] = in;
+        });
+        for (uint32_t jq = 0; jq < m; jq++)
+            if (best_inertia[jq] < 0 || inertia[jq] < best_inertia[jq]) {
+                best_inertia[jq] = inertia[jq];
+                memcpy(&best_cb[(size_t)jq * 256 * sd], &cb[(size_t)jq * 256 * sd], (size_t)256 * sd * 4);
+            }
     }
-    memcpy(out_codebook, cb.data(), cb.size() * 4);
-    d_ids.release(); d_x.release(); d_cb.release(); d_assign.release();
+    memcpy(out_codebook, best_cb.data(), best_cb.size() * 4);
+    if (out_inertia) { double tot = 0; for (double v : best_inertia) tot += v; *out_inertia = tot; }
     return 0;
+}
+
+extern "C" int dr_pq_train(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t iters, uint64_t seed, float *out_codebook)
+{
+    return dr_pq_train_ex(ix, m, n_sample, iters ? iters : 10, 1, 1e-4f, seed, out_codebook, nullptr);
 }
 
 extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uint8_t *out_codes)

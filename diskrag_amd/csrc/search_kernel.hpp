@@ -87,6 +87,10 @@ struct SearchParams {
     u32 *out_count;          // [nq]
     u64 *phase;              // [nq][8] cycle sums (DR_PHASE_TIMING builds only)
     const float *pq_ub;      // [nq] precomputed sqrt-ADC upper bounds (pq_bound_kernel) or nullptr
+    // builder over a PQ-only shard (no stored vectors): query qi IS the stored point build_pts[qi], known by its code
+    // word only, and its table T[j][c] = |C_j[c] - C_j[code_j]|^2 is m rows of the centroid-pair table sdc[m][256][256]
+    const float *sdc;
+    const u32 *build_pts;
 };
 
 DEV u32 lane_id() { return threadIdx.x & 63; }
@@ -500,18 +504,9 @@ DEV u32 a4_threshold_bits(float pq, float thr, bool &ok) {
     return cb;
 }
 
-// NWQ    wavefronts per QUERY (1, or NW: the whole workgroup serves one query). The per-query table T[m][256] costs
-//        32-64 KiB of LDS at the product's dimension (D = 1536), i.e. four single-wave queries per CU and a memory system
-//        that idles through each one's dependent chain. With NWQ = 4 the four wavefronts of a workgroup share ONE table
-//        and one query: they run the same control flow on identical list registers (everything below is deterministic),
-//        wavefront 0 alone touches the visited set, the log and the outputs, and the heavy parts are split -- table
-//        build by sub-quantiser, ADC sums by neighbour, stored vectors by row pass -- with a workgroup barrier at each
-//        hand-off. Four workgroups per CU = 16 wavefronts streaming rows instead of 4.
-template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false, int NWQ = 1>
+template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false>
 DEV void search_body(const SearchParams &p)
 {
-    constexpr bool MW = NWQ > 1;
-    static_assert(!MW || (NWQ == NW && !CBLDS && RB == 0 && !U8 && !QB), "multi-wave queries: per-query table variants only");
     constexpr bool QREG = (D <= 256);
     constexpr bool SPLIT = QREG && split_form_ok<D>();
     constexpr bool ROWLDS = RB > 0;
@@ -542,8 +537,7 @@ DEV void search_body(const SearchParams &p)
     // buckets of the visited-set grouping table ({word, lane} entries in the idle landing area / merge scratch)
     constexpr size_t VSCR = (RB > 0) ? (size_t)RB * ROW_BYTES : MERGE_BYTES;
     constexpr int VT = VSCR >= 8192 ? 1024 : VSCR >= 4096 ? 512 : VSCR >= 2048 ? 256 : VSCR >= 1024 ? 128 : 64;
-    static_assert((size_t)VT * 8 + (MW ? 256 : 0) <= VSCR, "grouping table must fit the scratch area");
-    static_assert(!MW || !SPLIT, "multi-wave queries use the streaming row form (large D)");
+    static_assert((size_t)VT * 8 <= VSCR, "grouping table must fit the scratch area");
     static_assert(!U8 || (ROWLDS && D == 128), "byte rows: the 12-wave landing variant at D = 128");
     static_assert(!QB || U8, "byte queries go with byte rows");
     static_assert(!ROWLDS || (size_t)RB * ROW_BYTES >= MERGE_BYTES, "the row landing area doubles as merge scratch");
@@ -560,12 +554,9 @@ DEV void search_body(const SearchParams &p)
     // floats of query per lane live) the few extra live values spill in the hot loop: 1.62 -> 2.01 ms
     constexpr bool ADJPRE = QB;
     constexpr size_t ADJPRE_BYTES = 528;    // 64 ids + 64 bit positions + the 8-byte mask word, padded to 16
-    // (multi-wave queries: everything up to the filter is ONE copy shared by the workgroup, followed by the shared ADC
-    // hand-off array and control words; only the merge scratch is per wavefront)
-    const size_t shared_part = ((NEED_PQ && !CBLDS) ? (size_t)p.m * 256 * 4 : 0) + (QORIG_LDS ? (size_t)D * 4 : 0) + (QREG ? 0 : (size_t)D * 4) + 512 +
-                               (size_t)VB_BITS / 8 + (ADJPRE ? ADJPRE_BYTES : 0);
-    const size_t per_wave = shared_part + (ROWLDS ? (size_t)RB * ROW_BYTES : MERGE_BYTES);
-    unsigned char *wbase = MW ? smem : smem + off + (size_t)wave * per_wave;
+    const size_t per_wave = ((NEED_PQ && !CBLDS) ? (size_t)p.m * 256 * 4 : 0) + (QORIG_LDS ? (size_t)D * 4 : 0) + (QREG ? 0 : (size_t)D * 4) + 512 +
+                            (size_t)VB_BITS / 8 + (ADJPRE ? ADJPRE_BYTES : 0) + (ROWLDS ? (size_t)RB * ROW_BYTES : MERGE_BYTES);
+    unsigned char *wbase = smem + off + (size_t)wave * per_wave;
     size_t woff = 0;
     float *lut = reinterpret_cast<float *>(wbase);
     if constexpr (NEED_PQ && !CBLDS) woff += (size_t)p.m * 256 * 4;
@@ -581,13 +572,9 @@ DEV void search_body(const SearchParams &p)
     woff += (size_t)VB_BITS / 8;
     u32 *pre_buf = reinterpret_cast<u32 *>(wbase + woff);      // [64 ids][64 positions][2 mask words]
     if constexpr (ADJPRE) woff += ADJPRE_BYTES;
-    float *sh_pq = reinterpret_cast<float *>(wbase + woff);    // [64] ADC sums handed between the wavefronts of a query (MW)
-    u32 *sh_ctl = reinterpret_cast<u32 *>(wbase + woff + 256); // [16] new-neighbour mask, next query ticket (MW)
-    if constexpr (MW) woff += 256 + 64 + (size_t)wave * MERGE_BYTES;
     float *rowbuf = reinterpret_cast<float *>(wbase + woff);   // [RB][D] landing area (ROWLDS)
     u64 *mk = reinterpret_cast<u64 *>(wbase + woff);           // merge scratch (shares the landing area: rows are
     u32 *mf = reinterpret_cast<u32 *>(mk + NCHR * 64);         // consumed before the decisions start)
-    const bool w0 = !MW || wave == 0;      // the wavefront that owns a query's side effects
 
     if constexpr (NEED_PQ && CBLDS && !ROWLDS) {
         const float4 *src = reinterpret_cast<const float4 *>(p.codebook);
@@ -603,8 +590,8 @@ DEV void search_body(const SearchParams &p)
     // kernel time against the static s, s + slots, ... schedule). The loop is a counted loop on a scalar with the
     // ticket as a second scalar condition: the exit is an s_cbranch_scc (checked in the ISA of every variant) and
     // the trip count is bounded by nq whatever the counter holds.
-    const u32 slot_id = (u32)__builtin_amdgcn_readfirstlane((int)(MW ? blockIdx.x : blockIdx.x * NW + wave));
-    const u32 nslots = MW ? gridDim.x : gridDim.x * NW;
+    const u32 slot_id = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * NW + wave));
+    const u32 nslots = gridDim.x * NW;
     // Visited set of the running query: one word per 24 bit positions, the top byte holding the STAMP of the query that
     // wrote it. A word whose stamp is not the running query's is an empty word, so nothing is ever cleared between
     // queries (the clears and the log they needed were a quarter of the kernel's memory requests); the stamp counts
@@ -621,17 +608,16 @@ DEV void search_body(const SearchParams &p)
         // ---- per-query setup
         QueryRegs<D> qreg;
         const float *qorig = QORIG_LDS ? qorig_lds : p.queries + (size_t)qi * D;
-        {
+        if (!(KIND == DIST_ADC_SQ && p.sdc != nullptr)) {      // (the PQ-only builder has no query vectors)
             const float *qg = p.queries + (size_t)qi * D;
             const float *qpg = p.queries_p + (size_t)qi * D;
-            if constexpr (MW) __syncthreads();      // the previous query's readers of the shared areas are done
-            for (int i = MW ? (int)threadIdx.x : lane; i < D; i += 64 * NWQ) {
+            for (int i = lane; i < D; i += 64) {
                 if constexpr (QORIG_LDS) qorig_lds[i] = qg[i];
                 if constexpr (!QREG) qperm[i] = qpg[i];
             }
-            if constexpr (VB_BITS > 0) { if (w0) for (int i = lane; i < VB_BITS / 32; i += 64) blm[i] = 0u; }
             if constexpr (QREG) load_query_regs<0, D, D>(qpg, j, qreg);
         }
+        if constexpr (VB_BITS > 0) { for (int i = lane; i < VB_BITS / 32; i += 64) blm[i] = 0u; }
         // Byte queries (the engine selects this variant only when EVERY component of EVERY query of the batch is an
         // integer in [0, 255], like the rows): the same 16 chain steps of lane j packed into four words, and sum q^2.
         u32 qb[4] = { 0u, 0u, 0u, 0u };
@@ -647,16 +633,17 @@ DEV void search_body(const SearchParams &p)
         }
         WSYNC();
         if constexpr (NEED_PQ && !CBLDS) {
-            if constexpr (MW) {
-                // each wavefront builds the rows of its share of the sub-quantisers
-                const u32 j0 = (p.m * (u32)wave) / NWQ, j1 = (p.m * (u32)(wave + 1)) / NWQ;
-                if (j1 > j0) build_lut_wave(lut + (size_t)j0 * 256, p.codebook + (size_t)j0 * 256 * p.sd, p.queries + (size_t)qi * D + j0 * p.sd, j1 - j0, p.sd);
+            if (KIND == DIST_ADC_SQ && p.sdc != nullptr) {
+                const u8 *mycodes = p.codes + (size_t)p.build_pts[qi] * p.m;
+                for (u32 jq = 0; jq < p.m; jq++) {
+                    const float4 *src = reinterpret_cast<const float4 *>(p.sdc + ((size_t)jq * 256 + mycodes[jq]) * 256);
+                    reinterpret_cast<float4 *>(lut + (size_t)jq * 256)[lane] = src[lane];
+                }
             } else {
                 build_lut_wave(lut, p.codebook, p.queries + (size_t)qi * D, p.m, p.sd);
             }
             WSYNC();
         }
-        if constexpr (MW) __syncthreads();
         // Upper bound of sqrt(ADC) over ALL code words for this query: sum_j max_c T[j][c] accumulated in the same
         // j order as A3 (float addition and sqrt are monotone, so the bound holds in float arithmetic too). When
         // it is below 0.8 * (a lower bound of the worst result distance during an expansion), the rerank policy A4
@@ -677,13 +664,12 @@ DEV void search_body(const SearchParams &p)
         // next stamp; after 255 queries the slot's words are wiped and the count restarts
         if (vstamp >= 255u) {
             uint4 *vb4 = reinterpret_cast<uint4 *>(vbm);
-            if (w0) for (u32 i = lane; i < p.vis_words / 4; i += 64) vb4[i] = make_uint4(0, 0, 0, 0);
+            for (u32 i = lane; i < p.vis_words / 4; i += 64) vb4[i] = make_uint4(0, 0, 0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             vstamp = 0u;
         }
         vstamp++;
         const u32 vtag = vstamp << 24;
-        u32 mwpar = 0;                 // multi-wave queries: which set of control words the next hand-off uses
         int rn = 0, cnT = 0, tn = 0;   // results; live (unexpanded, untrimmed) result entries; tie side list
         u32 junk = 0;   // evicted frontier entries that are worse than every result (only their count matters)
         RegList<NCHR> rk;
@@ -697,7 +683,7 @@ DEV void search_body(const SearchParams &p)
         // ---- start node (search_engine.py:416-426)
         {
             const u32 start = p.medoid;
-            if (lane == 0 && w0) {
+            if (lane == 0) {
                 const u32 sp = p.adjr ? p.medoid_pos : start;
                 const u32 sw = __umulhi(sp, 0xAAAAAAABu) >> 4;            // sp / 24
                 vbm[sw] = vtag | (1u << (sp - sw * 24u));                // first word of this query: whatever was there is stale
@@ -718,7 +704,7 @@ DEV void search_body(const SearchParams &p)
             u64 dr; u32 df; bool dd;
             rn = list_insert_f<NCHR>(rk, fl, 0, cap, ((u64)db << 32) | (u32)(~start), dr, df, dd);
             cnT = 1;
-            if (lane == 0 && w0 && p.logcap > 0) qlog[0] = ((u64)db << 32) | start;
+            if (lane == 0 && p.logcap > 0) qlog[0] = ((u64)db << 32) | start;
             ninserts = 1;
         }
         PH(0);
@@ -836,18 +822,15 @@ DEV void search_body(const SearchParams &p)
                 u32 vraw = 0u;
                 const u32 hsh = vw * 0x9E3779B1u;
                 const u32 bh = hsh >> 20;                                // filter bit of this word
-                const bool vact = active && w0;      // (multi-wave queries: wavefront 0 owns the visited set)
-                bool vneed = vact;
-                if constexpr (VB_BITS > 0) vneed = vact && ((blm[bh >> 5] >> (bh & 31)) & 1u) != 0u;
+                bool vneed = active;
+                if constexpr (VB_BITS > 0) vneed = active && ((blm[bh >> 5] >> (bh & 31)) & 1u) != 0u;
                 if (vneed) vraw = __hip_atomic_load(&vbm[vw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 {
                     u32 vldr = (u32)lane;
+                    u32 *vacc = reinterpret_cast<u32 *>(nb_e);         // idle until the distances are written
                     u64 *vtab = reinterpret_cast<u64 *>(mk);           // idle until the rows land / the merge
-                    // (idle until the distances are written; multi-wave queries: the other wavefronts may still be
-                    // reading the previous expansion's distances there, so wavefront 0 uses its own scratch)
-                    u32 *vacc = MW ? reinterpret_cast<u32 *>(vtab + VT) : reinterpret_cast<u32 *>(nb_e);
                     vacc[lane] = 0u;
-                    bool vpend = vact;
+                    bool vpend = active;
                     u64 pendm = __ballot(vpend);
 #pragma unroll 1
                     for (int vr = 0; vr < 2 && pendm != 0ull; vr++) {
@@ -870,27 +853,18 @@ DEV void search_body(const SearchParams &p)
                     const u32 gbits = vacc[lane];
                     WSYNC();
                     const u32 vold = ((vraw >> 24) == vstamp) ? (vraw & 0x00FFFFFFu) : 0u;
-                    isnew = vact && (vold & vbit) == 0u;
+                    isnew = active && (vold & vbit) == 0u;
                     // (store -> later load of the same word: both are served by the L2 in this wave's issue order, and
                     // every expansion that stored has since waited for row loads issued after its stores)
-                    if (vact && vldr == (u32)lane && (gbits & ~vold) != 0u) {
+                    if (active && vldr == (u32)lane && (gbits & ~vold) != 0u) {
                         vbm[vw] = vtag | vold | gbits;
                         if constexpr (VB_BITS > 0) atomicOr(&blm[bh >> 5], 1u << (bh & 31));
                     }
                 }
-                u64 newmask = __ballot(isnew);
-                if (isnew) nb_id[__popcll(newmask & lanemask_lt())] = nbid;
-                if constexpr (MW) {
-                    // hand the outcome to the other wavefronts of the query (two sets of control words: a wavefront is at
-                    // most one barrier behind)
-                    u32 *ctl = sh_ctl + (mwpar & 1u) * 2u;
-                    if (w0 && lane == 0) { ctl[0] = (u32)newmask; ctl[1] = (u32)(newmask >> 32); }
-                    __syncthreads();
-                    newmask = (u64)ctl[0] | ((u64)ctl[1] << 32);
-                    mwpar++;
-                }
+                const u64 newmask = __ballot(isnew);
                 const int nnew = __popcll(newmask);
                 if (nnew == 0) continue;
+                if (isnew) nb_id[__popcll(newmask & lanemask_lt())] = nbid;
                 nvisited += nnew;
                 WSYNC();
                 PH(3);
@@ -915,21 +889,14 @@ DEV void search_body(const SearchParams &p)
                 // either). The rows to score are compacted in stored order.
                 uint4 cw0 = make_uint4(0, 0, 0, 0), cw1 = cw0, cw2 = cw0, cw3 = cw0;
                 const u8 *mycode = p.codes + (size_t)myid * p.m;
-                // (multi-wave queries: neighbour i's sum is computed by wavefront i mod NWQ and handed over through LDS)
-                const bool adc_mine = lane < nnew && (!MW || (lane % NWQ) == wave);
-                if constexpr (NEED_PQ) { if (need_adc && adc_mine) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m); }
+                if constexpr (NEED_PQ) { if (need_adc && lane < nnew) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m); }
                 float adc_s = 0.0f;
                 u32 xbits = 0u;               // bits of the A4 threshold; 0 when A4 is proven true
                 int nrow = nnew, myrow = lane;
                 bool rowlane = lane < nnew;
                 if constexpr (FILTER) {
                     if (need_adc) {
-                        if (adc_mine) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
-                        if constexpr (MW) {
-                            if (adc_mine) sh_pq[lane] = adc_s;
-                            __syncthreads();
-                            adc_s = sh_pq[lane < nnew ? lane : 0];
-                        }
+                        if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
                         pq_d = f_sqrt(adc_s);   // asymmetric_distance = sqrt (fast_pq.py:330-333)
                         bool ok = true;
                         xbits = a4_threshold_bits(pq_d, p.policy == 0u ? 1.2f : 0.8f, ok);
@@ -1056,27 +1023,21 @@ DEV void search_body(const SearchParams &p)
                             }
                         }
                     } else {
-                        // (multi-wave queries: the row passes are dealt round-robin to the wavefronts)
-                        for (int r0 = MW ? wave : 0; r0 * 8 < nrow; r0 += NWQ) {
+                        for (int r0 = 0; r0 * 8 < nrow; r0++) {
                             const int idx = min(r0 * 8 + oct, nrow - 1);
                             float ev = pw_row_stream<0, D, D, QREG>(p.vecp + (size_t)nb_id[idx] * D, &qreg, qperm, j);
                             if (knorm) ev = f_sqrt(ev);
                             if (j == 0 && r0 * 8 + oct < nrow) nb_e[r0 * 8 + oct] = ev;
                         }
                     }
-                    if constexpr (MW) __syncthreads(); else WSYNC();
+                    WSYNC();
                     e = rowlane ? nb_e[myrow] : __builtin_inff();
                     if constexpr (FILTER) {
                         npq += nnew;            // the reference counts one PQ distance per new neighbour
                         if (need_adc) npq_eval += nnew;
                     }
                 } else {
-                    if (adc_mine) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
-                    if constexpr (MW) {
-                        if (adc_mine) sh_pq[lane] = adc_s;
-                        __syncthreads();
-                        adc_s = sh_pq[lane < nnew ? lane : 0];
-                    }
+                    if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
                     e = adc_s;
                     npq += nnew; npq_eval += nnew;
                     PH(4);
@@ -1172,7 +1133,7 @@ DEV void search_body(const SearchParams &p)
                         // accepted-insert log, in stored order (finalize replays the reference's heap from it)
                         {
                             const u32 o = ninserts + (u32)__popcll(accmask & lanemask_lt());
-                            if (isacc && w0 && o < p.logcap) qlog[o] = ((u64)ebits << 32) | myid;
+                            if (isacc && o < p.logcap) qlog[o] = ((u64)ebits << 32) | myid;
                             if (ninserts + (u32)na > p.logcap && p.logcap > 0) status |= DR_ST_LOG_OVERFLOW;
                             ninserts += (u32)na;
                         }
@@ -1299,7 +1260,7 @@ DEV void search_body(const SearchParams &p)
 #pragma unroll
         for (int c = 0; c < NCHR; c++) {
             const int i = c * 64 + lane;
-            if (i < rn && w0) p.res_keys[(size_t)qi * cap + i] = rk.v[c];
+            if (i < rn) p.res_keys[(size_t)qi * cap + i] = rk.v[c];
         }
         const int kout = min((int)p.k, rn);
         bool t = false;
@@ -1311,19 +1272,19 @@ DEV void search_body(const SearchParams &p)
             float a = key_dist(rk.v[c]), b = key_dist(nextk);
             if (kmode == 3u) { a = f_sqrt(a); b = f_sqrt(b); }
             if (i < kout && i + 1 < rn && a == b) t = true;
-            if (has_out && w0) {
+            if (has_out) {
                 if (i < (int)p.k) {
                     p.out_ids[(size_t)qi * p.k + i] = (i < kout) ? ~(u32)rk.v[c] : 0xFFFFFFFFu;
                     p.out_dist[(size_t)qi * p.k + i] = (i < kout) ? a : __uint_as_float(0x7FC00000u);
                 }
             }
         }
-        if (has_out && w0) for (int i = NCHR * 64 + lane; i < (int)p.k; i += 64) {
+        if (has_out) for (int i = NCHR * 64 + lane; i < (int)p.k; i += 64) {
             p.out_ids[(size_t)qi * p.k + i] = 0xFFFFFFFFu;
             p.out_dist[(size_t)qi * p.k + i] = __uint_as_float(0x7FC00000u);
         }
         const bool anyt = __ballot(t) != 0ull;
-        if (lane == 0 && w0) {
+        if (lane == 0) {
             p.res_n[qi] = (u32)rn;
             if (p.out_count) p.out_count[qi] = (u32)kout;
             if (anyt && has_ties) p.tie_list[atomicAdd(p.tie_count, 1u)] = qi;
@@ -1336,28 +1297,15 @@ DEV void search_body(const SearchParams &p)
         PH_END(qi);
         {
             u32 t = 0;
-            if (lane == 0 && w0) t = atomicAdd(p.counter, 1u);
-            t = (u32)__builtin_amdgcn_readfirstlane((int)t);
-            if constexpr (MW) {
-                if (w0 && lane == 0) sh_ctl[8] = t;
-                __syncthreads();
-                t = (u32)__builtin_amdgcn_readfirstlane((int)sh_ctl[8]);
-            }
-            qi = t - p.ticket_base + nslots;
+            if (lane == 0) t = atomicAdd(p.counter, 1u);
+            qi = (u32)__builtin_amdgcn_readfirstlane((int)t) - p.ticket_base + nslots;
         }
     }
-    if (lane == 0 && w0) p.vis_epoch[slot_id] = vstamp;
+    if (lane == 0) p.vis_epoch[slot_id] = vstamp;
 }
 
 template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const SearchParams p)
 {
     search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB, U8, QB>(p);
-}
-
-// one query per workgroup of NWQ wavefronts (see NWQ above); four workgroups per CU
-template <int D, bool FILTER, int KIND, int NCHR, int NWQ>
-__global__ __launch_bounds__(64 * NWQ, 4) void search_kernel_mw(const SearchParams p)
-{
-    search_body<D, FILTER, KIND, NCHR, NWQ, false, 0, false, false, NWQ>(p);
 }

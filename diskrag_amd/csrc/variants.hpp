@@ -19,11 +19,8 @@
 //  12 exact traversal (M2, M4, M3 without PQ) on BYTE vectors, 64 rows/burst, 16 waves          (D = 128)
 //  13 = 11 with BYTE queries as well (every component of the batch an integer in [0, 255]): v_dot4_u32_u8 distances
 //  14 = 12 with byte queries
-//  15 M1, per-query table SHARED by the 4 wavefronts of a workgroup that serve ONE query (search_kernel_mw; D >= 768:
-//     the table is 32-64 KiB there, four single-wave queries per CU otherwise)
-//  16 ADC-only traversal (M3 with PQ, DR_MODE_PQ), same form
 // sizeclass: result capacity <= 64 / 128 / 256 / 512 / 1024 (the last one: one-wavefront-per-workgroup variants 0, 1, 2 only)
-#define DR_NUM_KINDS 17
+#define DR_NUM_KINDS 15
 #define DR_NUM_SIZECLASS 5
 #define DR_MAX_CAPACITY 1024u
 struct DimKernels {
@@ -36,14 +33,13 @@ struct DimKernels {
     const void *search_f64;   // M1 / M2 with float64 queries (the CLI path), search_f64.hpp
     const void *rerank;       // aux_kernels.hpp rerank_kernel (DR_MODE_PQ + DR_F_RERANK)
 };
-static const int DR_KIND_NW[DR_NUM_KINDS] = { 1, 1, 1, 8, 16, 8, 8, 16, 8, 12, 12, 16, 16, 16, 16, 4, 4 };
-static const bool DR_KIND_MW[DR_NUM_KINDS] = { false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, true, true };   // one query per workgroup
-static const bool DR_KIND_CB[DR_NUM_KINDS] = { false, false, false, true, true, true, false, false, false, false, false, false, false, false, false, false, false };   // codebook copied to LDS
-static const int DR_KIND_RB[DR_NUM_KINDS] = { 0, 0, 0, 0, 0, 0, 32, 16, 32, 24, 64, 64, 64, 64, 64, 0, 0 };                                       // rows per LDS burst
-static const bool DR_KIND_LUT[DR_NUM_KINDS] = { true, false, true, false, false, false, false, false, false, false, false, false, false, false, false, true, true };     // per-query table in LDS
-static const bool DR_KIND_PQ[DR_NUM_KINDS] = { true, false, true, true, true, true, true, true, false, true, true, true, false, true, false, true, true };
-static const bool DR_KIND_U8[DR_NUM_KINDS] = { false, false, false, false, false, false, false, false, false, false, true, true, true, true, true, false, false };    // byte rows
-static const bool DR_KIND_QB[DR_NUM_KINDS] = { false, false, false, false, false, false, false, false, false, false, false, false, false, true, true, false, false };  // byte queries
+static const int DR_KIND_NW[DR_NUM_KINDS] = { 1, 1, 1, 8, 16, 8, 8, 16, 8, 12, 12, 16, 16, 16, 16 };
+static const bool DR_KIND_CB[DR_NUM_KINDS] = { false, false, false, true, true, true, false, false, false, false, false, false, false, false, false };   // codebook copied to LDS
+static const int DR_KIND_RB[DR_NUM_KINDS] = { 0, 0, 0, 0, 0, 0, 32, 16, 32, 24, 64, 64, 64, 64, 64 };                                       // rows per LDS burst
+static const bool DR_KIND_LUT[DR_NUM_KINDS] = { true, false, true, false, false, false, false, false, false, false, false, false, false, false, false };     // per-query table in LDS
+static const bool DR_KIND_PQ[DR_NUM_KINDS] = { true, false, true, true, true, true, true, true, false, true, true, true, false, true, false };
+static const bool DR_KIND_U8[DR_NUM_KINDS] = { false, false, false, false, false, false, false, false, false, false, true, true, true, true, true };    // byte rows
+static const bool DR_KIND_QB[DR_NUM_KINDS] = { false, false, false, false, false, false, false, false, false, false, false, false, false, true, true };  // byte queries
 
 const DimKernels *dr_dim_kernels(int D);
 

@@ -32,14 +32,19 @@ SUPPORTED_DIMENSIONS = {128, 256, 768, 960, 1536}
 RAW_CODEBOOK_NAME = "pq_codebook.f32"   # [m][256][D/m] float32 little-endian, written by export_codebook()
 
 
-def export_codebook(pq_model_pkl, out_path=None):
-    """Converts the reference's pq_model.pkl (a pickle holding sklearn KMeans objects, T3,
-    diskann_persist.py:33-105) into the raw float file the GPU box can read without sklearn."""
-    pq_model_pkl = Path(pq_model_pkl)
-    with open(pq_model_pkl, "rb") as f:
+def read_codebook(pq_model_pkl):
+    """The codebook [m][256][D/m] held by the reference's pq_model.pkl (a pickle of sklearn KMeans objects, T3,
+    diskann_persist.py:33-105). Needs sklearn to unpickle; nothing is written."""
+    with open(Path(pq_model_pkl), "rb") as f:
         data = pickle.load(f)
     kms = data["kmeans_list"] if isinstance(data, dict) else data.kmeans_list
-    cb = np.stack([np.asarray(km.cluster_centers_, dtype=np.float32) for km in kms])
+    return np.stack([np.asarray(km.cluster_centers_, dtype=np.float32) for km in kms])
+
+
+def export_codebook(pq_model_pkl, out_path=None):
+    """Converts pq_model.pkl into the raw float file a box without sklearn can read (explicit, offline step)."""
+    pq_model_pkl = Path(pq_model_pkl)
+    cb = read_codebook(pq_model_pkl)
     out_path = Path(out_path) if out_path else pq_model_pkl.with_name(RAW_CODEBOOK_NAME)
     cb.tofile(out_path)
     return cb
@@ -71,10 +76,11 @@ class SearchEngineCorrect:
         self.n_subvectors = 0
         self.sub_dim = 0
         self.num_centroids = 0
+        self._pq_codes_host = None
         if self.use_pq:
             self._load_pq(index_dir)
         self._text_lookup = text_lookup
-        self._meta_table = None
+        self._meta_rows = None            # vector_index -> (text, metadata), built on first use
         self._meta_path = cdir / "metadata.parquet"
         self.search_stats = {"total_searches": 0, "total_exact_computations": 0, "total_pq_computations": 0,
                              "total_search_time": 0.0}
@@ -88,18 +94,33 @@ class SearchEngineCorrect:
             logger.warning("PQ 文件不完整，切換到暴力搜索模式")
             self.use_pq = False
             return
+        # Only a model that cannot be READ downgrades the engine (the reference's behaviour for its pickle); file-system
+        # and device errors surface. Nothing is written while loading: the raw codebook file is an offline export.
         try:
             m = int(self.meta["n_subvectors"])
-            codes = np.fromfile(codes_path, dtype=np.uint8).reshape(int(self.meta["N"]), m)   # T2
+            ncent = int(self.meta.get("pq_centroids", self.meta.get("n_centroids", 256)))
+            if ncent != 256:
+                raise ValueError(f"PQ codebook with {ncent} centroids (the engine serves 256: uint8 codes)")
+            codes = np.fromfile(codes_path, dtype=np.uint8)
+            if codes.size != int(self.meta["N"]) * m:
+                raise ValueError(f"pq_codes.bin holds {codes.size} bytes, expected N*m = {int(self.meta['N']) * m}")
+            codes = codes.reshape(int(self.meta["N"]), m)                                       # T2
             if raw_path.exists():
-                cb = np.fromfile(raw_path, dtype=np.float32).reshape(m, 256, self.dimension // m)
+                cb = np.fromfile(raw_path, dtype=np.float32)
+                if cb.size != m * 256 * (self.dimension // m):
+                    raise ValueError(f"{raw_path.name} holds {cb.size} floats, expected {m * 256 * (self.dimension // m)}")
+                cb = cb.reshape(m, 256, self.dimension // m)
             else:
-                cb = export_codebook(pkl_path, raw_path)        # needs sklearn; raises on a box without it
-            self.index.set_pq(cb, codes)
-            self.n_subvectors, self.sub_dim, self.num_centroids = m, self.dimension // m, 256
-        except Exception as e:  # noqa: BLE001 - mirrors the reference's blanket downgrade
+                cb = read_codebook(pkl_path)                 # needs sklearn; raises on a box without it
+                if cb.shape != (m, 256, self.dimension // m):
+                    raise ValueError(f"pq_model.pkl codebook shape {cb.shape}")
+        except (ValueError, KeyError, ImportError, ModuleNotFoundError, pickle.UnpicklingError, AttributeError, EOFError) as e:
             logger.warning("PQ 模型載入失敗: %s，切換到暴力搜索模式", e)
             self.use_pq = False
+            return
+        self.index.set_pq(cb, codes)
+        self._pq_codes_host = codes
+        self.n_subvectors, self.sub_dim, self.num_centroids = m, self.dimension // m, 256
 
     def close(self):
         self.index.close()
@@ -198,23 +219,103 @@ class SearchEngineCorrect:
 
     # ------------------------------------------------------------------ text join
     def _get_text_by_index(self, idx: int):
+        """CollectionManager.get_text_by_index (preprocessing/collection.py:445-510): text and metadata of one vector.
+        The reference re-reads metadata.parquet and filters it for every hit (Q17); here the file is read once into a
+        vector_index -> row dict. Same shaping: a JSON-string metadata is parsed (fallback {"text", "id"}), a struct
+        becomes a dict, and a nested "metadata" JSON string is merged in without overriding top-level keys."""
         if self._text_lookup is not None:
             return self._text_lookup(int(idx))
-        if self._meta_table is None:
-            if not self._meta_path.exists():
-                return None
-            import pyarrow.parquet as pq   # read once (the reference re-reads per hit, Q17)
-            self._meta_table = pq.read_table(self._meta_path).to_pylist()
-        for row in self._meta_table:
-            if row.get("vector_index") == idx:
-                md = row.get("metadata")
-                if isinstance(md, str):
-                    try:
-                        md = json.loads(md)
-                    except json.JSONDecodeError:
-                        md = {"id": idx, "text": row.get("text")}
-                return row.get("text"), md if md is not None else row
-        return None
+        if self._meta_rows is None:
+            rows = {}
+            if self._meta_path.exists():
+                import pyarrow.parquet as pq
+                for row in pq.read_table(self._meta_path).to_pylist():
+                    vi = row.get("vector_index")
+                    if vi is not None and int(vi) not in rows:          # the reference takes the first matching row
+                        rows[int(vi)] = row
+            self._meta_rows = rows
+        row = self._meta_rows.get(int(idx))
+        if row is None:
+            return None
+        text, raw = row.get("text"), row.get("metadata")
+        if isinstance(raw, str):
+            try:
+                md = json.loads(raw)
+            except json.JSONDecodeError:
+                md = {"text": text, "id": int(idx)}
+        elif isinstance(raw, dict):
+            md = dict(raw)
+        else:
+            md = {"text": text, "id": int(idx)}
+        if isinstance(md, dict) and isinstance(md.get("metadata"), str):
+            try:
+                for key, value in json.loads(md["metadata"]).items():
+                    if key not in md:
+                        md[key] = value
+            except (json.JSONDecodeError, AttributeError):
+                pass
+        return text, md
+
+    # ------------------------------------------------------------------ B5: the per-kernel seams (SURVEY.md 8b)
+    def _compute_exact_distance(self, query_vector: np.ndarray, node_id: int):
+        """search_engine.py:374-379: squared L2 of one stored vector, numpy's summation order (float32 queries)."""
+        self._bump(1, 0, 0.0, n=0)
+        return self.index.exact_distances(np.asarray(query_vector, dtype=np.float32)[None, :], [int(node_id)])[0, 0]
+
+    def _build_pq_lut_fixed(self, query_vector: np.ndarray) -> np.ndarray:
+        """search_engine.py:281-318 -> DiskANNPQ.compute_distance_table (fast_pq.py:294-318): T[m][256] float32."""
+        if not self.use_pq:
+            raise ValueError("PQ 模型缺少 kmeans_list，無法進行距離計算")
+        return self.index.distance_table(np.asarray(query_vector, dtype=np.float32)[None, :])[0]
+
+    _build_pq_lut = _build_pq_lut_fixed            # search_engine.py:262-279 (same table)
+
+    def _get_pq_distance(self, lut: np.ndarray, pq_code: np.ndarray):
+        """search_engine.py:365-372 -> asymmetric_distance (fast_pq.py:320-333): sqrt of the float32 sum of T[j, code_j]
+        taken in sub-quantiser order. Pure host arithmetic on the caller's arrays (diagnostics only; the search kernels
+        compute the same sum on the device from their own table)."""
+        s = np.float32(0.0)
+        for j, c in enumerate(np.asarray(pq_code).reshape(-1)):
+            s = np.float32(s + np.float32(lut[j, int(c)]))
+        return np.sqrt(s)
+
+    def _run_diagnostic_check(self) -> bool:
+        """search_engine.py:142-254: exact and PQ distances of a few stored vectors must be computable and correlated."""
+        try:
+            n = int(self.meta["N"])
+            idx = np.random.choice(n, min(10, n), replace=False)
+            q, _ = self.index.get_node(int(idx[0]))
+            exact = [float(self._compute_exact_distance(q, int(i))) for i in idx[:5]]
+            if not exact:
+                return False
+            if not self.use_pq:
+                return True
+            lut = self._build_pq_lut_fixed(q)
+            if lut.shape != (self.n_subvectors, 256) or np.allclose(lut, 0):
+                return False
+            pqd = [float(self._get_pq_distance(lut, self._pq_codes_host[int(i)])) for i in idx[:5]]
+            if len(exact) > 2 and np.std(exact) > 0 and np.std(pqd) > 0 and np.corrcoef(exact, pqd)[0, 1] < 0.5:
+                logger.error("距離相關性過低")
+                return False
+            return True
+        except Exception as e:  # noqa: BLE001 - the reference reports any failure as a failed diagnosis
+            logger.error("診斷過程中發生錯誤: %s", e)
+            return False
+
+    def _debug_search_step_by_step(self, query_vector: np.ndarray, k: int = 5) -> Dict:
+        """search_engine.py:319-362: the medoid's distance and exact / PQ distances of its first neighbours."""
+        medoid_exact = self._compute_exact_distance(query_vector, self.medoid_idx)
+        try:
+            lut = self._build_pq_lut_fixed(query_vector)
+        except Exception as e:  # noqa: BLE001
+            return {"error": str(e)}
+        _, nbrs = self.index.get_node(self.medoid_idx)
+        info = []
+        for nb in [int(v) for v in nbrs if int(v) < len(self._pq_codes_host)][:5]:
+            e = self._compute_exact_distance(query_vector, nb)
+            p = self._get_pq_distance(lut, self._pq_codes_host[nb])
+            info.append({"id": nb, "exact_dist": e, "pq_dist": p, "ratio": p / e if e > 0 else float("inf")})
+        return {"medoid_idx": self.medoid_idx, "medoid_exact_dist": medoid_exact, "neighbor_info": info}
 
     # ------------------------------------------------------------------ B4
     def _run(self, query_vector, k, L_search, beam_width, use_pq_search):
@@ -254,6 +355,31 @@ class SearchEngineCorrect:
                            "total_time": time.time() - t_all},
                 "stats": {"search_type": kind, "nodes_visited": st.get("nodes_visited", 0), "k": k,
                           "L_search": L_search}}
+
+    def search_with_debug(self, query: str, k: int = 5, beam_width: int = 8, embedding_fn: Optional[Callable] = None,
+                          L_search: Optional[int] = None, use_pq_search: bool = True, debug_mode: bool = False
+                          ) -> Dict[str, Any]:
+        """search_engine.py:616-660: with debug_mode the diagnosis, the step-by-step view and both searches side by side;
+        otherwise search()."""
+        if embedding_fn is None:
+            raise ValueError("必須提供 embedding_fn 來產生查詢向量")
+        if L_search is None:
+            L_search = max(k * 2, 20)
+        if not debug_mode:
+            return self.search(query, k, beam_width, embedding_fn, L_search, use_pq_search)
+        query_vector = np.asarray(embedding_fn(query))
+        diagnostic_result = self._run_diagnostic_check()
+        debug_info = self._debug_search_step_by_step(query_vector, k)
+        exact_results, _ = self._exact_graph_search(query_vector, k, L_search)
+        pq_results = []
+        if use_pq_search:
+            try:
+                pq_results, _ = self._pq_accelerated_graph_search(query_vector, k, L_search, beam_width)
+            except Exception as e:  # noqa: BLE001 - as the reference: a failing PQ search is reported, not raised
+                logger.error("PQ 搜索失敗: %s", e)
+                pq_results = []
+        return {"debug_info": debug_info, "exact_results": exact_results,
+                "pq_results": pq_results if use_pq_search else [], "diagnostic_passed": diagnostic_result}
 
     def faq_search(self, query: str, k: int = 5, beam_width: int = 8, embedding_fn: Optional[Callable] = None,
                    L_search: Optional[int] = None, use_pq_search: bool = True) -> Dict[str, Any]:

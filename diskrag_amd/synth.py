@@ -100,3 +100,44 @@ def recall_at_k(ids, gt, k=10):
     for a, b in zip(ids[:, :k], gt[:, :k]):
         hit += len(set(a.tolist()) & set(b.tolist()))
     return hit / (k * len(ids))
+
+
+class UnitMixtureStream:
+    """The unit_mixture family as a row-addressable stream: rows [start, start + rows) are a pure function of
+    (seed, row block), so a dataset far larger than host memory (config c5: 1.25e8 x 1536 per shard) can be generated,
+    encoded and forgotten chunk by chunk, and any chunk can be regenerated later. One Philox stream per 32768-row block."""
+
+    BLOCK = 1 << 15
+
+    def __init__(self, d=1536, n_clusters=4096, seed=7, latent=64, within=1.0, noise=0.05, threads=32):
+        self.d, self.n_clusters, self.within, self.noise, self.threads = d, n_clusters, within, noise, threads
+        self.root = np.random.SeedSequence(seed)
+        g0 = np.random.Generator(np.random.Philox(self.root.spawn(1)[0]))
+        self.B = (g0.standard_normal((latent, d), dtype=np.float32) / np.float32(np.sqrt(latent)))
+        self.cent = g0.standard_normal((n_clusters, latent), dtype=np.float32)
+        self.latent = latent
+
+    def _block(self, stream, b, rows):
+        # always the whole block (then cut): a row's value must not depend on how the caller chunks the stream
+        r = np.random.Generator(np.random.Philox(np.random.SeedSequence([self.root.entropy, stream, b])))
+        idx = r.integers(0, self.n_clusters, size=self.BLOCK)
+        z = self.cent[idx] + np.float32(self.within) * r.standard_normal((self.BLOCK, self.latent), dtype=np.float32)
+        p = z @ self.B
+        p += np.float32(self.noise) * r.standard_normal((self.BLOCK, self.d), dtype=np.float32)
+        p /= np.linalg.norm(p, axis=1, keepdims=True)
+        return p[:rows]
+
+    def draw(self, start, rows, stream=0):
+        """rows [start, start + rows) of stream `stream` (0 = data, 1 = queries); start must be a multiple of BLOCK."""
+        from concurrent.futures import ThreadPoolExecutor
+        assert start % self.BLOCK == 0
+        out = np.empty((rows, self.d), dtype=np.float32)
+        blocks = list(range(0, rows, self.BLOCK))
+
+        def fill(o):
+            n = min(self.BLOCK, rows - o)
+            out[o:o + n] = self._block(stream, (start + o) // self.BLOCK, n)
+
+        with ThreadPoolExecutor(max_workers=self.threads) as ex:
+            list(ex.map(fill, blocks))
+        return out

@@ -230,13 +230,44 @@ int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint32_t passes
                     uint32_t pad_with_zero, uint32_t max_batch, uint32_t *out_medoid, float *out_seconds);
 int dr_get_adjacency(dr_index *ix, uint32_t *out /*[N][R]*/);
 
-/* PQ build on the device. dr_pq_train: m independent Lloyd k-means with 256 centroids on a
- * sample of the stored vectors (DiskANNPQ.fit, pq/fast_pq.py:197-243; sklearn's k-means++ / n_init restarts are
- * not reproduced: codebooks are not bit-comparable, golden fixtures ship reference codebooks instead).
+/* PQ-only shards built on the device (BASELINE config c5: 1e9 x 1536 -- the vectors are never stored).
+ * dr_index_create_codes_empty allocates adjacency + code words for N points and attaches the codebook;
+ * dr_pq_encode_rows encodes a streamed chunk of vectors (host, row-major) into rows [row0, row0 + rows) of the code table
+ * and forgets the vectors (DiskANNPQ.encode, pq/fast_pq.py:245-267); dr_build_vamana_pq then builds the Vamana graph from
+ * the code words alone: the batched builder of dr_build_vamana with every distance replaced by the symmetric PQ
+ * distance d(a, b) = sum_j |C_j[code_a[j]] - C_j[code_b[j]]|^2 (the reference has it as pq_distance_fast_cython,
+ * pydiskann/cython_utils.pyx:26-51; entries in the table's summation order, the sum in the ADC's), read from a
+ * centroid-pair table [m][256][256]. The reference never builds from codes (vamana_graph.py:405 "always exact distances
+ * at build time"): this is the engine's own construction, held to graph quality (recall of DR_MODE_PQ searches against
+ * the brute-force ADC ranking), not to parity. Rows are DR_PAD padded. */
+int dr_index_create_codes_empty(dr_index **out, uint64_t N, uint32_t D, uint32_t R, const float *codebook /*[m][256][D/m]*/,
+                                uint32_t m, int device);
+int dr_pq_encode_rows(dr_index *ix, const float *vectors /*[rows][D]*/, uint64_t row0, uint64_t rows);
+int dr_build_vamana_pq(dr_index *ix, uint32_t L_build, float alpha, uint32_t passes, uint64_t seed, uint32_t max_batch,
+                       uint32_t *out_medoid, float *out_seconds);
+
+/* Test seam for the builder: the robust prune of ONE point over an explicit candidate list (n <= 448), run by the kernel
+ * the builder launches; out_selected[R] receives the picked ids in pick order (DR_PAD padded). It is the textbook form
+ * of robust_prune_fast_cython (pydiskann/cython_utils.pyx:435-492): candidates sorted by (distance, id), greedy picks,
+ * every later candidate c with alpha * d(p*, c) <= d(p, c) dropped. The reference's loop additionally reads vector
+ * slots its own erase() calls left behind (oracle/pybuild.py documents and reproduces that); the device builder does
+ * not -- an intentional divergence. */
+int dr_debug_prune(dr_index *ix, uint32_t point, const uint32_t *candidates, uint32_t n, float alpha, uint32_t R,
+                   uint32_t *out_selected /*[R]*/, uint32_t *out_count);
+
+/* PQ build on the device. dr_pq_train_ex: m independent k-means with 256 centroids on a sample of the
+ * stored vectors, as DiskANNPQ.fit runs sklearn's KMeans (pq/fast_pq.py:188-243): greedy k-means++ seeding, n_init
+ * restarts keeping the lowest inertia per sub-quantiser, Lloyd iterations (assignment on the device, centroid update on
+ * host threads) until the total squared centre shift is <= tol * mean feature variance or max_iter is reached.
+ * out_inertia (may be NULL) receives the summed quantisation error on the sample. Codebooks are not bit-comparable with
+ * sklearn's (different random streams): the golden fixtures ship reference codebooks, and the trainer is held to the
+ * reference's quantisation error (tests/test_gpu_round2.py). dr_pq_train = one restart, `iters` iterations, tol 1e-4.
  * dr_pq_encode: nearest-centroid codes for all N vectors (DiskANNPQ.encode, fast_pq.py:245-267), attached to
  * the index like dr_index_set_pq; out_codes may be NULL. */
 int dr_pq_train(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t iters, uint64_t seed,
                 float *out_codebook /*[m][256][D/m]*/);
+int dr_pq_train_ex(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t max_iter, uint32_t n_init, float tol, uint64_t seed,
+                   float *out_codebook /*[m][256][D/m]*/, double *out_inertia);
 int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uint8_t *out_codes /*[N][m] or NULL*/);
 
 /* Diagnostic builds only (-DDR_PHASE_TIMING): shader-clock sums per phase of the last search, summed over queries:

@@ -1,0 +1,94 @@
+"""Operating points of the other BASELINE shapes on one MI355X (GPU box): where does recall@10 reach 0.95, and at what QPS?
+Sweeps the reference-faithful M1 (L, beam_width, band policy) and the engine's PQ traversal + exact rerank of the L list
+(DR_MODE_PQ | DR_F_RERANK: SURVEY.md 8d's definition of c3) on a c3- / c4-shaped index built on the device.
+Usage: python scripts/operating_points.py c3 10000000 [nq] [quick]   -> JSON lines in gpurun_out/op_<shape>_<N>.jsonl
+(one line per run, written as it goes: a run that dies keeps what it measured)."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from diskrag_amd import HipIndex, _ffi                      # noqa: E402
+from diskrag_amd.synth import unit_mixture, unit_mixture_parallel, recall_at_k     # noqa: E402
+
+shape, n = sys.argv[1], int(sys.argv[2])
+nq = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
+spec = sys.argv[4] if len(sys.argv) > 4 else "full"
+quick = spec == "quick"
+D, m, ncl, latent = {"c3": (1536, 32, 4096, 64), "c4": (96, 16, 4096, 32)}[shape]
+R = 64
+path = f"gpurun_out/op_{shape}_{n}{'' if spec in ('full', 'quick') else '_' + spec}.jsonl"
+out = open(path, "w")
+
+
+def emit(rec):
+    out.write(json.dumps(rec) + "\n"); out.flush()
+    print(json.dumps(rec), flush=True)
+
+
+t0 = time.perf_counter()
+gen = unit_mixture_parallel if n * D >= (1 << 32) else unit_mixture
+x, q = gen(n, D, n_queries=nq, n_clusters=ncl, seed=11, latent=latent)
+gen_s = time.perf_counter() - t0
+t0 = time.perf_counter()
+ix = HipIndex.create_empty(x, R=R)
+up_s = time.perf_counter() - t0
+med, bsec = ix.build_vamana(L_build=100, alpha=1.2, passes=2, seed=7)
+t0 = time.perf_counter()
+cb = ix.pq_train(m, n_sample=100000, iters=5)
+ix.pq_encode(cb)
+pq_s = time.perf_counter() - t0
+t0 = time.perf_counter()
+gt, _ = ix.bruteforce_topk(q, 10)
+emit({"setup": {"shape": shape, "N": n, "D": D, "R": R, "m": m, "nq": nq, "generate_s": gen_s, "upload_s": up_s, "build_s": bsec,
+                "pq_s": pq_s, "ground_truth_s": time.perf_counter() - t0}})
+del x
+ix.batch_upload(q)
+
+
+def run(tag, **kw):
+    try:
+        ix.batch_run(10, **kw); ix.batch_sync()
+        reps = 2
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ix.batch_run(10, **kw)
+        ix.batch_sync()
+        dt = (time.perf_counter() - t1) / reps
+        ids, dist, cnt, st = ix.batch_download()
+        t = ix.timing()
+        alg = float((4.0 * D + st["steps"] * 4.0 * R + st["pq_evaluated"] * float(m) + st["exact"] * 4.0 * D + 80).sum())
+        emit({"run": tag, "args": {k: int(v) for k, v in kw.items()}, "qps": nq / dt, "recall_at_10": recall_at_k(ids, gt, 10),
+              "kernel_ms": t["search_kernel_ms"], "variant": t["variant"], "waves_per_cu": t["waves_per_cu"],
+              "steps": float(st["steps"].mean()), "exact": float(st["exact"].mean()), "pq_evaluated": float(st["pq_evaluated"].mean()),
+              "status_max": int(st["status"].max()), "alg_bytes_per_query": alg / nq,
+              "alg_frac_of_8TBps": alg / (t["search_kernel_ms"] * 1e-3) / 8e12})
+    except Exception as e:          # a capacity or LDS limit: record it and go on
+        emit({"run": tag, "error": str(e)})
+
+
+if spec == "extra":
+    # second pass: pin the first operating points at recall >= 0.95 between the grid points of the full sweep, and the
+    # exact beam search (M2, beam_search_from_disk) with wider beams
+    for bwx in (96, 128, 192, 256):
+        run(f"M2_bw{bwx}", L=100, beam_width=bwx, mode=_ffi.MODE_M2)
+    for L in ((500, 600) if shape == "c4" else (250, 300)):
+        run(f"M1_L{L}_bwNone_policy0", L=L, beam_width=0, mode=_ffi.MODE_M1, band_policy=0)
+        run(f"M1_L{L}_bw8_policy0", L=L, beam_width=8, mode=_ffi.MODE_M1, band_policy=0)
+    for L in ((300, 350) if shape == "c4" else (250, 300, 350)):
+        run(f"PQ_rerank_L{L}_bwNone", L=L, beam_width=0, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)
+    ix.close()
+    sys.exit(0)
+Ls = (100, 200, 400) if quick else (100, 200, 400, 800)
+for L in Ls:
+    for bw in (8, 0):
+        for pol in (0, 1):
+            run(f"M1_L{L}_bw{bw or 'None'}_policy{pol}", L=L, beam_width=bw, mode=_ffi.MODE_M1, band_policy=pol)
+for L in Ls:
+    for bw in (8, 0):
+        run(f"PQ_rerank_L{L}_bw{bw or 'None'}", L=L, beam_width=bw, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)
+run("M2_bw8", L=100, beam_width=8, mode=_ffi.MODE_M2)
+run("M2_bw64", L=100, beam_width=64, mode=_ffi.MODE_M2)
+ix.close()

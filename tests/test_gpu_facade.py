@@ -175,3 +175,71 @@ def test_concurrent_searches_on_one_handle():
     for t in threads:
         t.join(timeout=120)
     assert not errors, errors[:3]
+
+
+def test_b5_seams_diagnostics_and_search_with_debug(tmp_path):
+    """The per-kernel seams as METHODS (_compute_exact_distance, _build_pq_lut_fixed, _get_pq_distance)
+    against the reference's golden K1 bits, the metadata join from metadata.parquet (one read, nested metadata merged as
+    CollectionManager.get_text_by_index does), and search_with_debug (search_engine.py:616-660)."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from diskrag_amd.search_engine import SearchEngineCorrect
+    g = load_golden("sift128_R64_m32")
+    cdir = write_collection(tmp_path, "c", g)
+    n = len(g.vectors)
+    rows = {"vector_index": list(range(n)), "text": [f"t{i}" for i in range(n)],
+            "metadata": [json.dumps({"type": "faq", "qa_id": f"qa{i // 4}", "metadata": json.dumps({"source": "s%d" % i, "type": "x"})})
+                         if i % 5 else "not json" for i in range(n)]}
+    pq.write_table(pa.table(rows), cdir / "metadata.parquet")
+    eng = SearchEngineCorrect("c", base_dir=tmp_path)
+    try:
+        nodes = g.z["k1_nodes"]
+        for qi in range(2):
+            q = g.queries[qi]
+            lut = eng._build_pq_lut_fixed(q)
+            assert np.array_equal(lut.view(np.uint32), g.z["k1_lut"][qi].view(np.uint32))
+            for t, node in enumerate(nodes[:6]):
+                e = eng._compute_exact_distance(q, int(node))
+                assert np.float32(e).view(np.uint32) == g.z["k1_exact"][qi, t].view(np.uint32)
+                p = eng._get_pq_distance(lut, g.codes[int(node)])
+                assert np.float32(p).view(np.uint32) == g.z["k1_adc"][qi, t].view(np.uint32)
+        text, md = eng._get_text_by_index(7)
+        assert text == "t7" and md["qa_id"] == "qa1" and md["type"] == "faq" and md["source"] == "s7"   # nested merged, top level kept
+        text, md = eng._get_text_by_index(10)
+        assert md == {"text": "t10", "id": 10}                                                          # unparsable metadata
+        assert eng._get_text_by_index(n + 5) is None
+        assert eng._run_diagnostic_check() is True
+        emb = lambda s: g.queries[3]          # noqa: E731
+        dbg = eng.search_with_debug("x", k=5, embedding_fn=emb, debug_mode=True)
+        assert dbg["diagnostic_passed"] is True and len(dbg["exact_results"]) == 5 and len(dbg["pq_results"]) == 5
+        assert dbg["debug_info"]["medoid_idx"] == g.medoid and len(dbg["debug_info"]["neighbor_info"]) == 5
+        plain = eng.search_with_debug("x", k=5, embedding_fn=emb)
+        assert [r["text"] for r in plain["results"]] == [r["text"] for r in eng.search("x", k=5, embedding_fn=emb)["results"]]
+        res = eng.faq_search("x", k=3, embedding_fn=emb)
+        assert all(r["metadata"]["type"] == "faq" for r in res["results"])
+    finally:
+        eng.close()
+
+
+def test_pq_load_surfaces_io_errors_and_never_writes(tmp_path):
+    """loading must not write into the index directory, and only an unreadable model downgrades to exact mode."""
+    import os
+    from diskrag_amd.search_engine import SearchEngineCorrect
+    g = load_golden("randn128_R16_m32")
+    cdir = write_collection(tmp_path, "c", g)
+    before = sorted(os.listdir(cdir / "index"))
+    eng = SearchEngineCorrect("c", base_dir=tmp_path)
+    assert eng.use_pq and sorted(os.listdir(cdir / "index")) == before
+    eng.close()
+    # a truncated code file is a model-format error: exact mode, as the reference does for a model it cannot load
+    (cdir / "index" / "pq_codes.bin").write_bytes(b"\x00" * 10)
+    eng = SearchEngineCorrect("c", base_dir=tmp_path)
+    assert not eng.use_pq
+    eng.close()
+    meta = json.loads((cdir / "index" / "meta.json").read_text())
+    meta["pq_centroids"] = 128
+    (cdir / "index" / "meta.json").write_text(json.dumps(meta))
+    g.codes.tofile(cdir / "index" / "pq_codes.bin")
+    eng = SearchEngineCorrect("c", base_dir=tmp_path)
+    assert not eng.use_pq                    # 128 centroids: refused explicitly, not reshaped wrongly
+    eng.close()
