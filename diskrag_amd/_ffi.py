@@ -45,7 +45,8 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_index_create_codes", "dr_index_drop_vectors", "dr_pq_scan_best",
            "dr_batch_select", "dr_search_submit", "dr_search_wait", "dr_host_alloc", "dr_host_free",
            "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_merge_topk",
-           "dr_debug_prune", "dr_pq_train_ex", "dr_index_create_codes_empty", "dr_pq_encode_rows", "dr_build_vamana_pq"]
+           "dr_debug_prune", "dr_pq_train_ex", "dr_index_create_codes_empty", "dr_pq_encode_rows", "dr_build_vamana_pq",
+           "dr_scalar_kernels"]
 
 _lib = None
 
@@ -125,6 +126,8 @@ def load_library():
     L.dr_pq_encode_rows.argtypes = [vp, fp, C.c_uint64, C.c_uint64]
     L.dr_build_vamana_pq.restype = C.c_int
     L.dr_build_vamana_pq.argtypes = [vp, C.c_uint32, C.c_float, C.c_uint32, C.c_uint64, C.c_uint32, u32p, fp]
+    L.dr_scalar_kernels.restype = C.c_int
+    L.dr_scalar_kernels.argtypes = [C.c_int, fp, fp, C.c_uint32, C.c_uint32, fp, fp]
     L.dr_pq_train_ex.restype = C.c_int
     L.dr_pq_train_ex.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_uint64, fp, C.POINTER(C.c_double)]
     L.dr_pq_encode.restype = C.c_int
@@ -603,6 +606,19 @@ def merge_topk_device(ids, dist, k_out, device=0):
     _check(load_library().dr_merge_topk(int(device), _p(ids, C.c_uint32), _p(dist, C.c_float), S, nq, k, int(k_out),
                                         _p(out_ids, C.c_uint32), _p(out_dist, C.c_float)))
     return out_ids, out_dist
+
+
+def scalar_kernels(x, y, device=0):
+    """C8 on the device: (squared L2, cosine distance) of the row pairs x[i], y[i]."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    if x.shape != y.shape or x.ndim != 2:
+        raise ValueError("x and y must be [n, D] arrays of one shape")
+    l2 = np.empty(x.shape[0], dtype=np.float32)
+    cs = np.empty(x.shape[0], dtype=np.float32)
+    _check(load_library().dr_scalar_kernels(int(device), _p(x, C.c_float), _p(y, C.c_float), x.shape[0], x.shape[1],
+                                            _p(l2, C.c_float), _p(cs, C.c_float)))
+    return l2, cs
 
 
 def device_count():

@@ -49,6 +49,8 @@ __global__ void code_histogram_kernel(const u8 *__restrict__ codes, u64 n, u32 m
         atomicAdd(&hist[(i % m) * 256 + codes[i]], 1u);
 }
 
+#define DR_PRUNE_PQ_MAXC 320    // candidates whose code words are cached in LDS (L_build + row slots of the c5 shapes)
+
 struct PrunePQParams {
     const u8 *codes; const float *sdc; u32 m;
     u32 *adjb; u32 *deg; u32 RX, R; float alpha;
@@ -68,19 +70,56 @@ __global__ __launch_bounds__(64) void prune_pq_kernel(const PrunePQParams p)
     u32 *raw = reinterpret_cast<u32 *>(keyB + DR_PRUNE_MAXC);
     u32 *keep = raw + DR_PRUNE_MAXC;
     u32 *outsel = keep + DR_PRUNE_MAXC;                                               // [256]
+    u32 *cslot2 = outsel + 256;                                                       // [MAXC] second slot array of the compaction
+    u8 *ccode = reinterpret_cast<u8 *>(cslot2 + DR_PRUNE_MAXC);                       // [DR_PRUNE_PQ_MAXC][m] candidates' code words
     const int lane = lane_id();
-    auto stage_rows = [&](u32 node) {
-        const u8 *cd = p.codes + (size_t)node * p.m;
+    // (code words are read as whole 16-byte pieces, and every loop over their bytes is unrolled: the m row loads / table
+    // reads that depend on a piece are issued together, and no register array is indexed dynamically)
+    const bool wide = (p.m & 15u) == 0 && p.m <= 64;
+    auto stage_rows = [&](const u8 *cd) {       // cd: a code word (global memory, or the LDS copy of a candidate's)
         WSYNC();
-        for (u32 jq = 0; jq < p.m; jq++)
-            reinterpret_cast<float4 *>(rows + (size_t)jq * 256)[lane] =
-                reinterpret_cast<const float4 *>(p.sdc + ((size_t)jq * 256 + cd[jq]) * 256)[lane];
+        if (wide) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (i * 16 < (int)p.m) {
+                    const uint4 w = reinterpret_cast<const uint4 *>(cd)[i];
+                    const u32 words[4] = { w.x, w.y, w.z, w.w };
+                    float4 r[16];
+#pragma unroll
+                    for (int t = 0; t < 16; t++) {
+                        const u32 c = (words[t >> 2] >> (8 * (t & 3))) & 255u;
+                        r[t] = reinterpret_cast<const float4 *>(p.sdc + ((size_t)(i * 16 + t) * 256 + c) * 256)[lane];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 16; t++) reinterpret_cast<float4 *>(rows + (size_t)(i * 16 + t) * 256)[lane] = r[t];
+                }
+            }
+        } else {
+            for (u32 jq = 0; jq < p.m; jq++)
+                reinterpret_cast<float4 *>(rows + (size_t)jq * 256)[lane] =
+                    reinterpret_cast<const float4 *>(p.sdc + ((size_t)jq * 256 + cd[jq]) * 256)[lane];
+        }
         WSYNC();
     };
-    auto dist_to = [&](u32 node) {      // sum_j rows[j][code_node[j]], A3's order
-        const u8 *cd = p.codes + (size_t)node * p.m;
+    // sum_j rows[j][code[j]], A3's order; `cd` points at a code word (LDS copy of a candidate's, or global)
+    auto dist_code = [&](const u8 *cd) {
         float s2 = 0.0f;
-        for (u32 jq = 0; jq < p.m; jq++) s2 = f_add(s2, rows[jq * 256 + cd[jq]]);
+        if (wide) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (i * 16 < (int)p.m) {
+                    const uint4 w = reinterpret_cast<const uint4 *>(cd)[i];
+                    const u32 words[4] = { w.x, w.y, w.z, w.w };
+                    float tv[16];
+#pragma unroll
+                    for (int t = 0; t < 16; t++) tv[t] = rows[(i * 16 + t) * 256 + ((words[t >> 2] >> (8 * (t & 3))) & 255u)];
+#pragma unroll
+                    for (int t = 0; t < 16; t++) s2 = f_add(s2, tv[t]);
+                }
+            }
+        } else {
+            for (u32 jq = 0; jq < p.m; jq++) s2 = f_add(s2, rows[jq * 256 + cd[jq]]);
+        }
         return s2;
     };
     for (u32 pi = blockIdx.x; pi < p.npoints; pi += gridDim.x) {
@@ -111,9 +150,9 @@ __global__ __launch_bounds__(64) void prune_pq_kernel(const PrunePQParams p)
                 nraw += __popcll(mm);
             }
         }
-        if (nraw > DR_PRUNE_MAXC) nraw = DR_PRUNE_MAXC;
-        stage_rows(pt);
-        for (int i = lane; i < nraw; i += 64) keyA[i] = ((u64)__float_as_uint(dist_to(raw[i])) << 32) | raw[i];
+        if (nraw > DR_PRUNE_PQ_MAXC) nraw = DR_PRUNE_PQ_MAXC;
+        stage_rows(p.codes + (size_t)pt * p.m);
+        for (int i = lane; i < nraw; i += 64) keyA[i] = ((u64)__float_as_uint(dist_code(p.codes + (size_t)raw[i] * p.m)) << 32) | raw[i];
         WSYNC();
         for (int base = 0; base < nraw; base += 64) {
             const int i = base + lane;
@@ -134,17 +173,28 @@ __global__ __launch_bounds__(64) void prune_pq_kernel(const PrunePQParams p)
             na += __popcll(mm);
         }
         WSYNC();
+        // the surviving candidates' code words are cached in LDS once (slot = sorted position); the slot travels with the
+        // key through the compactions, so the pick loop reads no code word from memory
+        u32 *slotA = raw, *slotB = cslot2;
+        for (int i = lane; i < na; i += 64) {
+            const u8 *g = p.codes + (size_t)(u32)keyA[i] * p.m;
+            if (wide) { for (u32 w4 = 0; w4 < p.m / 16; w4++) reinterpret_cast<uint4 *>(ccode + (size_t)i * p.m)[w4] = reinterpret_cast<const uint4 *>(g)[w4]; }
+            else { for (u32 jq = 0; jq < p.m; jq++) ccode[(size_t)i * p.m + jq] = g[jq]; }
+            slotA[i] = (u32)i;
+        }
+        WSYNC();
         u64 *cur = keyA, *nxt = keyB;
+        u32 *scur = slotA, *snxt = slotB;
         int nsel = 0;
         while (na > 0 && nsel < (int)p.R) {
             const u32 star = (u32)cur[0];
             if (lane == 0) outsel[nsel] = star;
             nsel++;
             if (na == 1 || nsel >= (int)p.R) break;
-            stage_rows(star);
+            stage_rows(ccode + (size_t)scur[0] * p.m);
             for (int i = 1 + lane; i < na; i += 64) {
                 const u64 kc = cur[i];
-                keep[i] = (f_mul(p.alpha, dist_to((u32)kc)) <= key_dist(kc)) ? 0u : 1u;     // pruned when alpha * d(p*, c) <= d(p, c)
+                keep[i] = (f_mul(p.alpha, dist_code(ccode + (size_t)scur[i] * p.m)) <= key_dist(kc)) ? 0u : 1u;   // pruned when alpha * d(p*, c) <= d(p, c)
             }
             WSYNC();
             int nn = 0;
@@ -152,11 +202,12 @@ __global__ __launch_bounds__(64) void prune_pq_kernel(const PrunePQParams p)
                 const int i = base + lane;
                 const bool ok = (i < na) && keep[i] != 0u;
                 const u64 mm = __ballot(ok);
-                if (ok) nxt[nn + __popcll(mm & lanemask_lt())] = cur[i];
+                if (ok) { const int o = nn + __popcll(mm & lanemask_lt()); nxt[o] = cur[i]; snxt[o] = scur[i]; }
                 nn += __popcll(mm);
             }
             WSYNC();
             u64 *t = cur; cur = nxt; nxt = t;
+            u32 *ts = scur; scur = snxt; snxt = ts;
             na = nn;
         }
         WSYNC();
@@ -165,6 +216,29 @@ __global__ __launch_bounds__(64) void prune_pq_kernel(const PrunePQParams p)
         if (lane == 0) {
             p.deg[pt] = (u32)nsel;
             if (p.fwd_n) p.fwd_n[pi] = (u32)nsel;
+        }
+    }
+}
+
+// ---- C8 scalar kernels (pydiskann/cython_utils.pyx:18-24 l2_distance_fast_cython, :53-70 cosine_similarity_cython) -------
+// Row pairs x[i], y[i]: squared L2, and the cosine DISTANCE 1 - dot / (|x| |y|) (0.0 when either norm is 0). One wavefront
+// per pair; the reference accumulates in float32 in index order but is compiled -ffast-math (order unpinned, its own
+// test allows rtol 1e-5): here the lanes' partial sums are combined by a butterfly.
+__global__ __launch_bounds__(64) void scalar_pairs_kernel(const float *__restrict__ x, const float *__restrict__ y, u32 n, u32 D,
+                                                          float *__restrict__ out_l2, float *__restrict__ out_cos)
+{
+    const u32 lane = threadIdx.x;
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        float l2 = 0.0f, dot = 0.0f, nx = 0.0f, ny = 0.0f;
+        for (u32 t = lane; t < D; t += 64) {
+            const float a = x[(size_t)i * D + t], b = y[(size_t)i * D + t];
+            l2 += (a - b) * (a - b); dot += a * b; nx += a * a; ny += b * b;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { l2 += __shfl_xor(l2, o); dot += __shfl_xor(dot, o); nx += __shfl_xor(nx, o); ny += __shfl_xor(ny, o); }
+        if (lane == 0) {
+            if (out_l2) out_l2[i] = l2;
+            if (out_cos) out_cos[i] = (nx == 0.0f || ny == 0.0f) ? 0.0f : (float)(1.0 - (double)dot / (sqrt((double)nx) * sqrt((double)ny)));
         }
     }
 }

@@ -1485,7 +1485,10 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
         HIPCHK(hipGetLastError());
     }
 
-    const size_t prune_lds = pq ? (size_t)ix->m * 1024 + (size_t)DR_PRUNE_MAXC * 24 + 1024
+    // DR_PQ_BUILD_SLACK (diagnosis): how far a row of the PQ-only builder may exceed R before it is re-pruned (default: a quarter of the slack slots: 4x fewer re-prunes at 2 points of recall, profiles/r02/scale_c5_small_4M.json)
+    static const char *slack_env = getenv("DR_PQ_BUILD_SLACK");
+    const uint32_t pq_slack = slack_env ? std::min<uint32_t>((uint32_t)atoi(slack_env), RX - R - 1) : (RX - R) / 4;
+    const size_t prune_lds = pq ? (size_t)ix->m * 1024 + (size_t)DR_PRUNE_MAXC * 28 + 1024 + (size_t)DR_PRUNE_PQ_MAXC * ix->m
                                 : (D > 256 ? (size_t)D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024;
     if (pq) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&prune_pq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
     std::vector<uint32_t> horder(N);
@@ -1531,8 +1534,9 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
             HIPCHK(hipMemsetAsync(ovf_count.p, 0, 4, ix->stream));
             {
                 const uint64_t threads = (uint64_t)b * R;
+                // (PQ-only builder: rows run half-way into their slack before they are re-pruned, see reverse_edges_kernel)
                 hipLaunchKernelGGL(reverse_edges_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ix->stream,
-                                   adjb.p, deg.p, RX, R, pts, b, fwd.p, fwd_n.p, ovf_list.p, ovf_count.p, (uint32_t)N);
+                                   adjb.p, deg.p, RX, R, pts, b, fwd.p, fwd_n.p, ovf_list.p, ovf_count.p, (uint32_t)N, pq ? R + pq_slack : R);
                 HIPCHK(hipGetLastError());
             }
             uint32_t novf = 0;
@@ -1557,6 +1561,22 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
             }
             done += b;
             if (bsz < max_batch) bsz *= 2;
+        }
+    }
+    if (!rc && pq) {
+        // what is still over R after the last batch is pruned now
+        HIPCHK(hipMemsetAsync(ovf_count.p, 0, 4, ix->stream));
+        hipLaunchKernelGGL(collect_over_kernel, dim3(4096), dim3(256), 0, ix->stream, deg.p, N, R, ovf_list.p, ovf_count.p);
+        HIPCHK(hipGetLastError());
+        uint32_t novf = 0;
+        HIPCHK(hipMemcpyAsync(&novf, ovf_count.p, 4, hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        if (novf) {
+            PrunePQParams qo;
+            qo.codes = ix->codes.p; qo.sdc = ix->sdc.p; qo.m = ix->m; qo.adjb = adjb.p; qo.deg = deg.p; qo.RX = RX; qo.R = R; qo.alpha = alpha;
+            qo.points = ovf_list.p; qo.npoints = novf; qo.res_keys = nullptr; qo.res_n = nullptr; qo.cap = 0; qo.fwd = nullptr; qo.fwd_n = nullptr;
+            hipLaunchKernelGGL(prune_pq_kernel, dim3(std::min<unsigned>(novf, (unsigned)ix->num_cu * 4)), dim3(64), prune_lds, ix->stream, qo);
+            HIPCHK(hipGetLastError());
         }
     }
     if (!rc) {
@@ -1861,6 +1881,25 @@ extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uin
     ix->m = m; ix->sd = ix->D / m;
     for (auto &qs : ix->slots) qs.pq_ub_valid = false;
     ix->adc_live = -1;
+    return 0;
+}
+
+// C8: the reference's scalar distance kernels on row pairs (no index needed).
+extern "C" int dr_scalar_kernels(int device, const float *x, const float *y, uint32_t n, uint32_t D, float *out_l2, float *out_cos)
+{
+    if (!x || !y || n == 0 || D == 0 || (!out_l2 && !out_cos)) return fail(DR_E_ARG, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DR_E_NODEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(DR_E_ARG, "device %d out of range (%d devices)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    DevBuf<float> dx, dy, o1, o2;
+    if (dx.reserve((size_t)n * D) || dy.reserve((size_t)n * D) || o1.reserve(n) || o2.reserve(n)) return DR_E_NODEVICE;
+    HIPCHK(hipMemcpy(dx.p, x, (size_t)n * D * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dy.p, y, (size_t)n * D * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(scalar_pairs_kernel, dim3(std::min<uint32_t>(n, 65535)), dim3(64), 0, nullptr, dx.p, dy.p, n, D, o1.p, o2.p);
+    HIPCHK(hipGetLastError());
+    if (out_l2) HIPCHK(hipMemcpy(out_l2, o1.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (out_cos) HIPCHK(hipMemcpy(out_cos, o2.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

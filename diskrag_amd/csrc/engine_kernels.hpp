@@ -314,11 +314,13 @@ __global__ void gather_rows_kernel(const float *__restrict__ src, const u32 *__r
 }
 
 // Adds p to the row of each of its selected neighbours (cython_utils.pyx:338-348). Rows have RX >= R slots;
-// the thread that takes slot R reports the row for re-pruning (:350-356).
+// the thread that takes slot `trigger` reports the row for re-pruning: trigger = R is the reference's rule (a row is
+// pruned as soon as it exceeds R, :350-356); the PQ-only builder lets rows run into their slack first (R + slack/2:
+// one re-prune per ~slack/2 reverse edges instead of one per edge) and prunes what is still over R at the end.
 __global__ void reverse_edges_kernel(u32 *__restrict__ adjb, u32 *__restrict__ deg, u32 RX, u32 R,
                                      const u32 *__restrict__ points, u32 npoints, const u32 *__restrict__ fwd,
                                      const u32 *__restrict__ fwd_n, u32 *__restrict__ ovf_list,
-                                     u32 *__restrict__ ovf_count, u32 ovf_cap)
+                                     u32 *__restrict__ ovf_count, u32 ovf_cap, u32 trigger)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 pi = t / R, s = t % R;
@@ -332,10 +334,17 @@ __global__ void reverse_edges_kernel(u32 *__restrict__ adjb, u32 *__restrict__ d
         if (__hip_atomic_load(&row[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pt) return;
     const u32 slot = atomicAdd(&deg[n], 1u);
     if (slot < RX) __hip_atomic_store(&row[slot], pt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (slot == R) {
+    if (slot == trigger) {
         const u32 k = atomicAdd(ovf_count, 1u);
         if (k < ovf_cap) ovf_list[k] = n;
     }
+}
+
+// rows whose degree exceeds R (final prune of the slack-tolerant builder)
+__global__ void collect_over_kernel(const u32 *__restrict__ deg, u64 N, u32 R, u32 *__restrict__ list, u32 *__restrict__ count)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x)
+        if (deg[i] > R) list[atomicAdd(count, 1u)] = (u32)i;
 }
 
 // Final rows: the first min(deg, R) ids, then `padval` (0 reproduces the reference writer, diskann_persist.py:23).

@@ -634,10 +634,29 @@ DEV void search_body(const SearchParams &p)
         WSYNC();
         if constexpr (NEED_PQ && !CBLDS) {
             if (KIND == DIST_ADC_SQ && p.sdc != nullptr) {
+                // the point's code word in whole 16-byte pieces, then the table rows of a piece, sixteen loads in flight
+                // (every loop over the bytes is unrolled: no register array is indexed dynamically)
                 const u8 *mycodes = p.codes + (size_t)p.build_pts[qi] * p.m;
-                for (u32 jq = 0; jq < p.m; jq++) {
-                    const float4 *src = reinterpret_cast<const float4 *>(p.sdc + ((size_t)jq * 256 + mycodes[jq]) * 256);
-                    reinterpret_cast<float4 *>(lut + (size_t)jq * 256)[lane] = src[lane];
+                if ((p.m & 15u) == 0 && p.m <= 64) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (i * 16 < (int)p.m) {
+                            const uint4 w = reinterpret_cast<const uint4 *>(mycodes)[i];
+                            const u32 words[4] = { w.x, w.y, w.z, w.w };
+                            float4 r[16];
+#pragma unroll
+                            for (int t = 0; t < 16; t++) {
+                                const u32 c = (words[t >> 2] >> (8 * (t & 3))) & 255u;
+                                r[t] = reinterpret_cast<const float4 *>(p.sdc + ((size_t)(i * 16 + t) * 256 + c) * 256)[lane];
+                            }
+#pragma unroll
+                            for (int t = 0; t < 16; t++) reinterpret_cast<float4 *>(lut + (size_t)(i * 16 + t) * 256)[lane] = r[t];
+                        }
+                    }
+                } else {
+                    for (u32 jq = 0; jq < p.m; jq++)
+                        reinterpret_cast<float4 *>(lut + (size_t)jq * 256)[lane] =
+                            reinterpret_cast<const float4 *>(p.sdc + ((size_t)jq * 256 + mycodes[jq]) * 256)[lane];
                 }
             } else {
                 build_lut_wave(lut, p.codebook, p.queries + (size_t)qi * D, p.m, p.sd);

@@ -214,6 +214,13 @@ int dr_pq_scan_best(dr_index *ix, const float *queries, uint32_t nq, float *out_
 int dr_bruteforce_topk(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t *out_ids,
                        float *out_dist);
 
+/* C8: the reference's scalar distance kernels on n row pairs x[i], y[i] of dimension D: squared L2
+ * (l2_distance_fast_cython, pydiskann/cython_utils.pyx:18-24) and cosine distance 1 - cos (cosine_similarity_cython,
+ * :53-70; 0.0 when either norm is 0). The reference compiles them -ffast-math (summation order unpinned) and tests them
+ * at rtol 1e-5 (test_pydiskann_cython.sh:50-54): the same tolerance holds here. Either output may be NULL. The metric
+ * 'cosine' exists only in the reference's in-memory M3 (vamana_graph.py:294-299); the disk paths are L2-only. */
+int dr_scalar_kernels(int device, const float *x, const float *y, uint32_t n, uint32_t D, float *out_l2, float *out_cos);
+
 /* Reads node i back from HBM in the reference's (vector, neighbours) form -- MMapNodeReader.get_node. */
 int dr_get_node(dr_index *ix, uint64_t node_id, float *out_vec /*[D]*/, uint32_t *out_nbrs /*[R]*/);
 

@@ -30,7 +30,7 @@ def save():
 t0 = time.perf_counter()
 sample = gen.draw(0, 262144)
 tmp = HipIndex.create_empty(sample, R=R)
-cb, inertia = tmp.pq_train_ex(m, n_sample=100000, max_iter=25, n_init=1, seed=5)
+cb, inertia = tmp.pq_train_ex(m, n_sample=50000, max_iter=15, n_init=1, seed=5)
 tmp.close()
 out["codebook_s"] = time.perf_counter() - t0
 del sample

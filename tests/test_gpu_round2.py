@@ -311,3 +311,18 @@ def test_pq_only_builder_makes_a_searchable_shard():
         assert np.array_equal(ids, w[0]) and np.array_equal(bits(dist), bits(w[1].astype(np.float32)))
     finally:
         sh.close()
+
+@pytest.mark.parametrize("d", [7, 64, 96, 128, 130, 960, 1536])
+def test_scalar_kernels_on_the_device(d):
+    """C8: l2_distance_fast_cython / cosine_similarity_cython on the device against the reference's own outputs
+    (tests/golden/k_scalar.npz), at the reference's tolerance (test_pydiskann_cython.sh:50-54: rtol 1e-5, atol 1e-6)."""
+    from diskrag_amd import _ffi
+    from tests.conftest import GOLDEN
+    z = np.load(GOLDEN / "k_scalar.npz")
+    a, b = z[f"a{d}"], z[f"b{d}"]
+    l2, cs = _ffi.scalar_kernels(a, b)
+    np.testing.assert_allclose(l2, z[f"l2_{d}"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(cs, z[f"cos_{d}"], rtol=1e-5, atol=1e-6)
+    zero = np.zeros_like(a[:2])
+    _, c0 = _ffi.scalar_kernels(zero, b[:2])
+    assert (c0 == 0.0).all()                      # either norm zero -> 0.0 (cython_utils.pyx:66-67)
