@@ -172,10 +172,11 @@ class StubIndex:
         return ids, np.zeros((self.nq, self.k), np.float32), np.full(self.nq, self.k, np.uint32), st
 
 
-def alg_bytes(st, D, R, m, k):
-    """algorithmic bytes of one launch: sum_q 4D + S*4R + V*m + X*4D + 8k, + the codebook once"""
+def alg_bytes(st, D, R, m, k, row_bytes=None):
+    """algorithmic bytes of one launch: sum_q 4D + S*4R + V*m + X*row_bytes + 8k, + the codebook once.
+    row_bytes = 4D is the reference's accounting (a float32 vector per exact distance); the byte-row kernels read D."""
     S, V, X = st["steps"].astype(np.float64), st["pq_evaluated"].astype(np.float64), st["exact"].astype(np.float64)
-    per_q = 4 * D + S * 4 * R + V * m + X * 4 * D + 8 * k
+    per_q = 4 * D + S * 4 * R + V * m + X * (4 * D if row_bytes is None else row_bytes) + 8 * k
     return float(per_q.sum()) + 4 * 256 * D, per_q
 
 
@@ -316,7 +317,7 @@ def worker(args):
     a_all, per_q = alg_bytes(st, D, args.R, args.m, k)
     alg_launch = (a_all - 4 * 256 * D) / nb + 4 * 256 * D      # per 10k-query launch
     k_ms = float(tm_head["search_kernel_ms"])                    # mean launch duration over the timed pipelined region
-    achieved = alg_launch / (k_ms * 1e-3) / 1e9
+    achieved_ref = alg_launch / (k_ms * 1e-3) / 1e9
 
     # PCIe-inclusive rate from PAGEABLE caller memory (the library stages it), for reference
     qb_pageable = [np.array(a) for a in qb[:min(nb, 4)]]
@@ -343,13 +344,17 @@ def worker(args):
                 traffic_src = "profiles/%s/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over scripts/pmc_target.py: the same workload, not this run)" % rnd
 
     byte_rows = variant in (11, 13)
+    # the kernel's own necessary bytes: a scored vector is D bytes for the byte-row variants, 4D for float rows
+    a_k, _ = alg_bytes(st, D, args.R, args.m, k, row_bytes=D if byte_rows else 4 * D)
+    alg_kernel = (a_k - 4 * 256 * D) / nb + 4 * 256 * D
+    achieved = alg_kernel / (k_ms * 1e-3) / 1e9
     secondary = float_rows = float_queries = unrounded = None
     if not args.no_secondary and rk.world == 1:
         n_sec = max(40, launches // 4)
         if args.bw != 0:        # beam_width=None, the reference's no-trim mode
             el2, tm2 = run_resident(0, n_sec)
             ids2, _, st2 = collect(0)
-            a2, _ = alg_bytes(st2, D, args.R, args.m, k)
+            a2, _ = alg_bytes(st2, D, args.R, args.m, k, row_bytes=D if byte_rows else 4 * D)
             a2 = (a2 - 4 * 256 * D) / nb + 4 * 256 * D
             secondary = {"beam_width": None, "qps_resident": nq * n_sec / el2, "recall_at_10": recall_at_k(ids2, gt, k),
                          "kernel_ms": tm2["search_kernel_ms"], "roofline_frac": a2 / (tm2["search_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -358,7 +363,7 @@ def worker(args):
         def forced(kind):
             el3, tm3 = run_resident(args.bw, n_sec, kind=kind)
             return {"variant": tm3["variant"], "qps_resident": nq * n_sec / el3, "kernel_ms": tm3["search_kernel_ms"],
-                    "roofline_frac": alg_launch / (tm3["search_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                    "roofline_frac": (alg_launch if tm3["variant"] not in (11, 13) else alg_kernel) / (tm3["search_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
         if byte_rows:
             float_rows = forced(9)          # float32 rows: what data that is not integer-valued gets
@@ -388,7 +393,7 @@ def worker(args):
                    "launch": {k_: tm_head[k_] for k_ in ("variant", "grid", "block", "lds_bytes", "waves_per_cu")},
                    "finalize_kernel_ms": tm_head["finalize_kernel_ms"], "secondary_no_trim": secondary,
                    "row_storage": ("u8: lossless byte copy of the integer-valued vectors (every component checked; distances "
-                                   "bit-identical); roofline.achieved counts the reference's 4*D bytes per scored vector, "
+                                   "bit-identical); roofline.achieved counts D bytes per scored vector, roofline.reference_accounting 4*D, "
                                    "roofline.traffic is what HBM really moved") if byte_rows else "f32",
                    "query_storage": ("u8: every component of the batch is an integer in [0, 255] (checked per batch on the host)"
                                      if variant == 13 else "f32"),
@@ -396,10 +401,15 @@ def worker(args):
         "roofline": {"bound": "hbm", "kernel": "search_kernel<128,M1> variant %d" % variant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "hbm_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_launch,
-                     "note": "frac prices the reference's accounting (4*D bytes per scored vector); hbm_frac is what HBM moved; the "
-                             "kernel is bound by the chip's rate of random requests (DESIGN.md 4.1: ~55 G requests/s measured by "
-                             "tools/gather_probe.hip), not by bytes"},
+                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_kernel,
+                     "row_bytes": D if byte_rows else 4 * D,
+                     "reference_accounting": {"algorithmic_bytes_per_launch": alg_launch, "achieved": achieved_ref,
+                                              "frac": achieved_ref / HBM_PEAK_GBPS,
+                                              "note": "SURVEY 8d's figure with 4*D bytes per scored vector, i.e. what a float-row "
+                                                      "kernel would have to move for the same work; can exceed 1 on byte rows"},
+                     "note": "frac = the kernel's own algorithmic bytes (D bytes per scored vector on byte rows) / kernel time / peak; "
+                             "hbm_frac is what the PMC counters say HBM moved; the kernel is bound by the chip's rate of random "
+                             "requests (DESIGN.md 4.1: ~55 G requests/s measured by tools/gather_probe.hip), not by bytes"},
     }
 
     # ---------------------------------------------------------------- the un-rounded generator: its own data, graph, recall
