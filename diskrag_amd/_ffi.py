@@ -46,7 +46,7 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_batch_select", "dr_search_submit", "dr_search_wait", "dr_host_alloc", "dr_host_free",
            "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_merge_topk",
            "dr_debug_prune", "dr_pq_train_ex", "dr_index_create_codes_empty", "dr_pq_encode_rows", "dr_build_vamana_pq",
-           "dr_scalar_kernels"]
+           "dr_scalar_kernels", "dr_index_inline_codes"]
 
 _lib = None
 
@@ -135,6 +135,8 @@ def load_library():
     L.dr_search_batch_f64.restype = C.c_int
     L.dr_search_batch_f64.argtypes = [vp, C.POINTER(C.c_double)] + [C.c_uint32] * 7 + [u32p, C.POINTER(C.c_double), u32p,
                                                                                       C.POINTER(DrStats)]
+    L.dr_index_inline_codes.restype = C.c_int
+    L.dr_index_inline_codes.argtypes = [vp, C.c_int]
     L.dr_debug_force_kind.restype = C.c_int
     L.dr_debug_force_kind.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
     L.dr_debug_phase_cycles.restype = C.c_int
@@ -486,6 +488,11 @@ class HipIndex:
         _check(load_library().dr_debug_prune(self._h, int(point), _p(c, C.c_uint32), c.size, float(alpha), int(R),
                                              _p(sel, C.c_uint32), C.byref(cnt)))
         return sel[:int(cnt.value)]
+
+    def inline_codes(self, enable=True):
+        """Keeps the code words of every node's neighbours beside its adjacency row (N*R*m bytes of HBM): one coalesced
+        read per expansion for the ADC of the rerank-policy-live M1 and of the PQ-only traversals. Results unchanged."""
+        _check(load_library().dr_index_inline_codes(self._h, 1 if enable else 0))
 
     def debug_force_kind(self, kind):
         """Pins the search-kernel variant (-1: engine's choice); returns the handle's A4 regime (1 live, 0 not, -1 unknown)."""

@@ -139,6 +139,8 @@ struct dr_index {
     DevBuf<uint32_t> adj;
     DevBuf<u64> first;
     DevBuf<uint8_t> codes;
+    DevBuf<uint8_t> nbcodes;      // [N][R][m] inline neighbour codes (dr_index_inline_codes), rebuilt before the next search when stale
+    bool inline_codes = false, nbcodes_valid = false;
     DevBuf<float> codebook;
     DevBuf<float> sdc;            // centroid-pair table [m][256][256] (PQ-only builder), built on first use
     DevBuf<uint32_t> perm;
@@ -243,6 +245,7 @@ static int need_vectors(const dr_index *ix, const char *what)
 static int build_first_masks(dr_index *ix)
 {
     ix->adjr_valid = false;       // the adjacency changed: its bit-position twin is rebuilt before the next search
+    ix->nbcodes_valid = false;
     DevBuf<uint32_t> bad;
     if (bad.reserve(1, true)) return DR_E_NODEVICE;
     const uint64_t rows_per_block = 4;
@@ -334,7 +337,7 @@ extern "C" int dr_index_set_adjacency(dr_index *ix, const uint32_t *adj)
     HIPCHK(hipSetDevice(ix->device));
     { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }     // queued searches still read the old rows
     HIPCHK(hipMemcpy(ix->adj.p, adj, (size_t)ix->N * ix->R * 4, hipMemcpyHostToDevice));
-    ix->adc_live = -1;
+    ix->adc_live = -1; ix->nbcodes_valid = false;
     return build_first_masks(ix);
 }
 
@@ -352,7 +355,7 @@ extern "C" int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_
     HIPCHK(hipMemcpy(ix->codebook.p, codebook, (size_t)256 * ix->D * 4, hipMemcpyHostToDevice));
     ix->m = m; ix->sd = ix->D / m;
     for (auto &qs : ix->slots) qs.pq_ub_valid = false;
-    ix->adc_live = -1;
+    ix->adc_live = -1; ix->nbcodes_valid = false;
     return 0;
 }
 
@@ -483,6 +486,19 @@ static uint32_t next_pow2(uint64_t v)
 // from the vectors or adjacency rows). So bits are numbered by a coarse clustering instead (nearest of P pivot
 // vectors, ids sorted by label), and every adjacency slot carries its neighbour's bit position in a second array
 // read with the row (+4R bytes per expansion). Any bijection is correct; results never depend on it.
+// Inline neighbour codes: see inline_codes_kernel (engine_kernels.hpp). N*R*m bytes; rebuilt when codes or adjacency change.
+static int build_inline_codes(dr_index *ix)
+{
+    if (!ix->codes.p || ix->m == 0 || (ix->m & 3u)) return fail(DR_E_UNSUPPORTED, "inline neighbour codes need PQ codes with n_subvectors %% 4 == 0");
+    if (ix->nbcodes.reserve((size_t)ix->N * ix->R * ix->m)) return DR_E_NODEVICE;
+    const uint64_t total = (uint64_t)ix->N * ix->R * (ix->m / 4);
+    const unsigned gx = (unsigned)std::min<uint64_t>((total + 255) / 256, (uint64_t)ix->num_cu * 64);
+    hipLaunchKernelGGL(inline_codes_kernel, dim3(gx), dim3(256), 0, ix->stream, ix->adj.p, ix->codes.p, ix->N, ix->R, ix->m, ix->nbcodes.p);
+    HIPCHK(hipGetLastError());
+    ix->nbcodes_valid = true;
+    return 0;
+}
+
 static int build_bit_order(dr_index *ix)
 {
     static const bool off = getenv("DR_NO_BITORDER") != nullptr;
@@ -639,8 +655,10 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         const int rb = DR_KIND_RB[kd];
         const bool qorig_lds = DR_KIND_PQ[kd] && !DR_KIND_LUT[kd] && !rb;          // search_kernel.hpp QORIG_LDS
         const size_t bloom = (rb || DR_KIND_CB[kd] || ix->D <= 256) ? 512 : 0;      // search_kernel.hpp VB_BITS / 8
+        const bool adc_only = (kd == 2 || kd == 5);                  // no exact distances: no chain-major query copy in LDS
+        const bool adjpre = DR_KIND_QB[kd];                          // search_kernel.hpp ADJPRE
         const size_t pw = (DR_KIND_LUT[kd] ? (size_t)ix->m * 256 * 4 : 0) + (qorig_lds ? (size_t)ix->D * 4 : 0) +
-                          (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 512 + bloom + (DR_KIND_QB[kd] ? 528 : 0) +
+                          ((ix->D > 256 && !adc_only) ? (size_t)ix->D * 4 : 0) + 512 + bloom + (adjpre ? 528 : 0) +
                           (rb ? (size_t)rb * ix->D * (DR_KIND_U8[kd] ? 1 : 4) : (size_t)NCHR_OF_SC[sc] * 64 * 12);
         return (DR_KIND_CB[kd] ? (size_t)256 * ix->D * 4 : 0) + (size_t)DR_KIND_NW[kd] * pw;
     };
@@ -724,8 +742,10 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     SearchParams p;
     memset(&p, 0, sizeof p);
     if (!ov && !ix->adjr_valid) { const int rcb = build_bit_order(ix); if (rcb) return rcb; }
+    if (!ov && ix->inline_codes && !ix->nbcodes_valid && ix->codes.p && (mode == DR_MODE_M1 || pq_only)) { const int rci = build_inline_codes(ix); if (rci) return rci; }
     p.vecp = ix->vecp.p; p.adj = ix->adj.p; p.first = ix->first.p; p.codes = ix->codes.p; p.codebook = ix->codebook.p;
     p.adjr = (!ov && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
+    p.nbcodes = (!ov && ix->inline_codes && ix->nbcodes_valid) ? ix->nbcodes.p : nullptr;
     p.vec8 = ix->vec8_state == 1 ? ix->vec8.p : nullptr;
     p.queries = ix->cs->q.p; p.queries_p = ix->cs->qp.p;
     p.N = ix->N; p.D = ix->D; p.R = ix->R; p.m = ix->m; p.sd = ix->sd; p.medoid = ix->medoid; p.nq = nq;
@@ -1644,7 +1664,7 @@ extern "C" int dr_pq_encode_rows(dr_index *ix, const float *vectors, uint64_t ro
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ix->stream));
     }
-    ix->adc_live = -1;
+    ix->adc_live = -1; ix->nbcodes_valid = false;
     return 0;
 }
 
@@ -1880,7 +1900,7 @@ extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uin
     HIPCHK(hipStreamSynchronize(ix->stream));
     ix->m = m; ix->sd = ix->D / m;
     for (auto &qs : ix->slots) qs.pq_ub_valid = false;
-    ix->adc_live = -1;
+    ix->adc_live = -1; ix->nbcodes_valid = false;
     return 0;
 }
 
@@ -1900,6 +1920,19 @@ extern "C" int dr_scalar_kernels(int device, const float *x, const float *y, uin
     HIPCHK(hipGetLastError());
     if (out_l2) HIPCHK(hipMemcpy(out_l2, o1.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (out_cos) HIPCHK(hipMemcpy(out_cos, o2.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Inline neighbour codes on / off (off by default: N*R*m bytes of HBM). The block is (re)built on the device before the
+// next search that evaluates ADC sums; results never depend on it.
+extern "C" int dr_index_inline_codes(dr_index *ix, int enable)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIPCHK(hipSetDevice(ix->device));
+    { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }
+    ix->inline_codes = enable != 0;
+    if (!ix->inline_codes) { ix->nbcodes.release(); ix->nbcodes_valid = false; }
     return 0;
 }
 

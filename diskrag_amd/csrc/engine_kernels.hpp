@@ -458,3 +458,22 @@ __global__ void pack_u8_kernel(const float *__restrict__ vecp, u64 N, u32 D, con
         out[row * D + (e & 7u) * S + (e >> 3)] = (u8)(u32)r;
     }
 }
+
+// Inline neighbour codes (dr_index_inline_codes): nbcodes[i][s][0..m) = codes[adj[i][s]][0..m) -- the code words of a
+// node's neighbours stored beside its adjacency row, so that an expansion reads them as ONE contiguous block of R*m
+// bytes (fully coalesced, issued together with the row) instead of R scattered m-byte gathers behind the visited test.
+// Slots that hold no real id (DR_PAD, ids >= N) get zeros; they are never scored.
+__global__ void inline_codes_kernel(const u32 *__restrict__ adj, const u8 *__restrict__ codes, u64 N, u32 R, u32 m,
+                                    u8 *__restrict__ nbcodes)
+{
+    const u32 wpr = m / 4;                                    // 4-byte words per code word (m % 4 == 0)
+    const u64 total = N * R * wpr;
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
+        const u64 slot = t / wpr;
+        const u32 w = (u32)(t - slot * wpr);
+        const u32 id = adj[slot];
+        u32 v = 0u;
+        if ((u64)id < N) v = reinterpret_cast<const u32 *>(codes + (size_t)id * m)[w];
+        reinterpret_cast<u32 *>(nbcodes)[t] = v;
+    }
+}

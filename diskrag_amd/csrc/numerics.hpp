@@ -202,6 +202,116 @@ template <int D> constexpr bool split_form_ok()
 }
 template <> constexpr bool split_form_ok<256>() { return true; }
 
+// ---- chunked form for large D: a software pipeline over sub-trees ("chunks") of the pairwise tree ----------
+// A 6-KiB row (D = 1536) scored by pw_row_stream leaves the order of loads and arithmetic to the compiler, which keeps
+// 4-13 KiB per wavefront in flight and drains to zero at every pass boundary: with 4 wavefronts per CU (the per-query
+// table fills the LDS) that is ~0.5 of the HBM rate. Here the row is cut at a level of the SAME tree (a chunk = a
+// whole sub-tree, so the arithmetic and its order are unchanged), a chunk's loads go to their own registers, and the
+// caller keeps NBUF - 1 chunks in flight ahead of the one being reduced, across row passes (search_kernel.hpp).
+template <int D> struct ChunkCfg {
+    static constexpr int leaf() { int n = D; while (n > 128) n = n / 2 - ((n / 2) % 8); return n; }
+    static constexpr int LS = leaf();                       // leaf size (every leaf equal for the dimensions below)
+    static constexpr int S = LS / 8, G = S / 4, REM = S % 4;
+#ifndef DR_CHUNK_LPC
+#define DR_CHUNK_LPC 2
+#endif
+#ifndef DR_CHUNK_NBUF
+#define DR_CHUNK_NBUF 4
+#endif
+    static constexpr int LPC = DR_CHUNK_LPC;                // leaves per chunk
+    static constexpr int CH = LS * LPC;                     // elements per chunk (D = 1536, 768: 192; 960: 240)
+    static constexpr int NC = D / CH;                       // chunks per row
+    static constexpr int NBUF = DR_CHUNK_NBUF;              // ring depth (NC % NBUF == 0: buffer index is static)
+    static constexpr bool ok = (D > 256) && (D % CH == 0) && (NC % NBUF == 0) && ((NC & (NC - 1)) == 0);
+};
+template <int D> struct ChunkRegs {
+    float4 g[ChunkCfg<D>::LPC * ChunkCfg<D>::G];
+    float r[ChunkCfg<D>::LPC * ChunkCfg<D>::REM + 1];
+};
+
+template <int COFF, int OFF, int N, int D> DEV void chunk_load(const float *__restrict__ row, int j, ChunkRegs<D> &cr)
+{
+    if constexpr (N <= 128) {
+        static_assert(N == ChunkCfg<D>::LS, "equal leaves");
+        constexpr int G = ChunkCfg<D>::G, REM = ChunkCfg<D>::REM, LI = (OFF - COFF) / N;
+#pragma unroll
+        for (int g = 0; g < G; g++) cr.g[LI * G + g] = *reinterpret_cast<const float4 *>(row + OFF + g * 32 + j * 4);
+#pragma unroll
+        for (int u = 0; u < REM; u++) cr.r[LI * REM + u] = row[OFF + G * 32 + j * REM + u];
+    } else {
+        constexpr int N2 = (N / 2) - ((N / 2) % 8);
+        chunk_load<COFF, OFF, N2, D>(row, j, cr);
+        chunk_load<COFF, OFF + N2, N - N2, D>(row, j, cr);
+    }
+}
+// the sub-tree's sum, bit for bit what pw_row_stream<OFF, N> returns (query chain-major in LDS)
+template <int COFF, int OFF, int N, int D> DEV float chunk_reduce(const ChunkRegs<D> &cr, const float *qlds, int j)
+{
+    if constexpr (N <= 128) {
+        constexpr int G = ChunkCfg<D>::G, REM = ChunkCfg<D>::REM, LI = (OFF - COFF) / N;
+        float r = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const float4 v = cr.g[LI * G + g];
+            const float4 qq = *reinterpret_cast<const float4 *>(qlds + OFF + g * 32 + j * 4);
+            const float s0 = sqd(v.x, qq.x), s1 = sqd(v.y, qq.y), s2 = sqd(v.z, qq.z), s3 = sqd(v.w, qq.w);
+            r = (g == 0) ? s0 : f_add(r, s0);
+            r = f_add(r, s1);
+            r = f_add(r, s2);
+            r = f_add(r, s3);
+        }
+#pragma unroll
+        for (int u = 0; u < REM; u++) {
+            const float s = sqd(cr.r[LI * REM + u], qlds[OFF + G * 32 + j * REM + u]);
+            r = (G == 0 && u == 0) ? s : f_add(r, s);
+        }
+        return octet_combine(r);
+    } else {
+        constexpr int N2 = (N / 2) - ((N / 2) % 8);
+        const float a = chunk_reduce<COFF, OFF, N2, D>(cr, qlds, j);
+        const float b = chunk_reduce<COFF, OFF + N2, N - N2, D>(cr, qlds, j);
+        return f_add(a, b);
+    }
+}
+// the levels of the tree above the chunks: c[0..NC) are the chunk sums in row order
+template <int LO, int N> DEV float chunk_tree(const float *c)
+{
+    if constexpr (N == 1) return c[LO];
+    else return f_add(chunk_tree<LO, N / 2>(c), chunk_tree<LO + N / 2, N / 2>(c));
+}
+
+// One row pass of the pipeline: chunk C of the row `rp` is reduced while chunks C+1 .. C+NBUF-1 are in flight -- the
+// last of them issued here, from this row or (HAS_NEXT) from the next pass's row `rnext`. HAS_NEXT is a template
+// parameter, not a branch: behind a branch the compiler's wait counters must assume the loads were not issued and the
+// pipeline drains at every pass boundary.
+template <int D, int C, bool HAS_NEXT>
+DEV void chunk_pass(const float *__restrict__ rp, const float *__restrict__ rnext, int j,
+                    ChunkRegs<D> (&buf)[ChunkCfg<D>::NBUF], const float *qlds, float (&cres)[ChunkCfg<D>::NC])
+{
+    constexpr int CH = ChunkCfg<D>::CH, NC = ChunkCfg<D>::NC, NBUF = ChunkCfg<D>::NBUF;
+    if constexpr (C < NC) {
+        constexpr int CN = C + NBUF - 1;
+        if constexpr (CN < NC) chunk_load<CN * CH, CN * CH, CH, D>(rp, j, buf[CN % NBUF]);
+        else if constexpr (HAS_NEXT) chunk_load<(CN - NC) * CH, (CN - NC) * CH, CH, D>(rnext, j, buf[CN % NBUF]);
+        // (scheduling barriers: a pass is one basic block, and without them the machine scheduler sinks the loads next
+        // to their uses -- fewer live registers, no pipeline)
+        __builtin_amdgcn_sched_barrier(0);
+        cres[C] = chunk_reduce<C * CH, C * CH, CH, D>(buf[C % NBUF], qlds, j);
+        __builtin_amdgcn_sched_barrier(0);
+        chunk_pass<D, C + 1, HAS_NEXT>(rp, rnext, j, buf, qlds, cres);
+    }
+}
+// the pipeline's prologue: chunks 0 .. NBUF-2 of the first row
+template <int D, int C> DEV void chunk_prologue(const float *__restrict__ rp, int j, ChunkRegs<D> (&buf)[ChunkCfg<D>::NBUF])
+{
+    constexpr int CH = ChunkCfg<D>::CH, NBUF = ChunkCfg<D>::NBUF;
+    if constexpr (C < NBUF - 1) {
+        chunk_load<C * CH, C * CH, CH, D>(rp, j, buf[C]);
+        __builtin_amdgcn_sched_barrier(0);
+        chunk_prologue<D, C + 1>(rp, j, buf);
+    }
+}
+
 // Same run with the centroid already in registers and a compile-time length (numpy order for n <= 128).
 template <int N>
 DEV float pw_run_regs(const float (&c)[N], const float *q)

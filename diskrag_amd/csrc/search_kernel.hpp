@@ -61,6 +61,7 @@ struct SearchParams {
     const u64 *first;        // [N][ceil(R/64)] bit s: slot s is a real id and its first occurrence in the row
     const u32 *deg;          // build mode (first == nullptr): rows hold deg[i] distinct ids, the rest is DR_PAD
     const u8 *codes;         // [N][m]
+    const u8 *nbcodes;       // [N][R][m] code words of every adjacency slot's neighbour, or nullptr (dr_index_inline_codes)
     const float *codebook;   // [m][256][sd]
     const float *queries;    // [nq][D] original element order
     const float *queries_p;  // [nq][D] chain-major
@@ -513,6 +514,7 @@ DEV void search_body(const SearchParams &p)
     static_assert(!ROWLDS || (CBLDS && SPLIT && (64 % (D / 4)) == 0), "row landing needs whole rows per instruction");
     constexpr int NP = !SPLIT ? 1 : (NW >= 16 ? 1 : (NW >= 8 ? 2 : 4));   // row passes in flight
     constexpr bool NEED_PQ = FILTER || KIND == DIST_ADC_SQ;
+    constexpr bool SPEC_CODES = NEED_PQ && !ROWLDS;   // code words fetched beside the visited test (see there)
     // the rerank-policy kernels only ever serve M1 (squared distances, trim rule of search_engine.py:477-479): folding the
     // mode at compile time drops the other variants' branches and their scalar registers from the hot loop
     const u32 kmode = FILTER ? 1u : p.mode;
@@ -552,9 +554,13 @@ DEV void search_body(const SearchParams &p)
     constexpr int VB_BITS = (ROWLDS || CBLDS || D <= 256) ? 4096 : 0;
     // adjacency row of the predicted next pop prefetched into LDS: the byte-query variants only -- on variant 11 (16
     // floats of query per lane live) the few extra live values spill in the hot loop: 1.62 -> 2.01 ms
+    // (measured on the rerank-policy-live M1 at D = 96 and on the ADC-only traversals as well, round 2: 58 % hits and
+    // 3-6 % SLOWER -- those kernels are bound by the number of memory requests, not by the length of the chain)
     constexpr bool ADJPRE = QB;
+    // the chain-major query copy in LDS (large D) is only read by exact distances
+    constexpr bool QPERM_LDS = !QREG && KIND != DIST_ADC_SQ;
     constexpr size_t ADJPRE_BYTES = 528;    // 64 ids + 64 bit positions + the 8-byte mask word, padded to 16
-    const size_t per_wave = ((NEED_PQ && !CBLDS) ? (size_t)p.m * 256 * 4 : 0) + (QORIG_LDS ? (size_t)D * 4 : 0) + (QREG ? 0 : (size_t)D * 4) + 512 +
+    const size_t per_wave = ((NEED_PQ && !CBLDS) ? (size_t)p.m * 256 * 4 : 0) + (QORIG_LDS ? (size_t)D * 4 : 0) + (QPERM_LDS ? (size_t)D * 4 : 0) + 512 +
                             (size_t)VB_BITS / 8 + (ADJPRE ? ADJPRE_BYTES : 0) + (ROWLDS ? (size_t)RB * ROW_BYTES : MERGE_BYTES);
     unsigned char *wbase = smem + off + (size_t)wave * per_wave;
     size_t woff = 0;
@@ -563,7 +569,7 @@ DEV void search_body(const SearchParams &p)
     float *qorig_lds = reinterpret_cast<float *>(wbase + woff);
     if constexpr (QORIG_LDS) woff += (size_t)D * 4;
     float *qperm = reinterpret_cast<float *>(wbase + woff);
-    if constexpr (!QREG) woff += (size_t)D * 4;
+    if constexpr (QPERM_LDS) woff += (size_t)D * 4;
     u32 *nb_id = reinterpret_cast<u32 *>(wbase + woff);
     woff += 256;
     float *nb_e = reinterpret_cast<float *>(wbase + woff);
@@ -613,7 +619,7 @@ DEV void search_body(const SearchParams &p)
             const float *qpg = p.queries_p + (size_t)qi * D;
             for (int i = lane; i < D; i += 64) {
                 if constexpr (QORIG_LDS) qorig_lds[i] = qg[i];
-                if constexpr (!QREG) qperm[i] = qpg[i];
+                if constexpr (QPERM_LDS) qperm[i] = qpg[i];
             }
             if constexpr (QREG) load_query_regs<0, D, D>(qpg, j, qreg);
         }
@@ -844,6 +850,27 @@ DEV void search_body(const SearchParams &p)
                 bool vneed = active;
                 if constexpr (VB_BITS > 0) vneed = active && ((blm[bh >> 5] >> (bh & 31)) & 1u) != 0u;
                 if (vneed) vraw = __hip_atomic_load(&vbm[vw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // Code words of the row's neighbours fetched BESIDE the visited test instead of after it (one dependent
+                // round trip less per expansion) whenever their ADC may be needed: always for the ADC traversals; for M1
+                // unless the bound that lets the expansion skip the ADC already holds with every active lane counted as
+                // new (a superset of the final need_adc below, so the registers are loaded whenever they are used). The
+                // few code words of neighbours that turn out to be visited are wasted requests (~15 %).
+                uint4 cw0 = make_uint4(0, 0, 0, 0), cw1 = cw0, cw2 = cw0, cw3 = cw0;
+                // (inline neighbour codes: the slot's code word sits in the block beside the adjacency row -- one coalesced
+                // read of R*m bytes per expansion instead of a scattered m-byte gather per neighbour)
+                const u8 *mycode = p.nbcodes ? p.nbcodes + ((size_t)cur * p.R + min(slot, p.R - 1)) * p.m : p.codes + (size_t)nbid * p.m;
+                if constexpr (SPEC_CODES) {
+                    bool spec = true;
+                    if constexpr (FILTER) {
+                        const int nact = __popcll(__ballot(active));
+                        if (rn + nact <= (int)p.L) spec = false;
+                        else if (rn == cap && cap - 1 - nact >= 0) {
+                            const float Wlow = key_dist(list_get<NCHR>(rk, cap - 1 - nact));
+                            if (pq_ub < f_mul(Wlow, 0.8f)) spec = false;
+                        }
+                    }
+                    if (spec && active) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m);
+                }
                 {
                     u32 vldr = (u32)lane;
                     u32 *vacc = reinterpret_cast<u32 *>(nb_e);         // idle until the distances are written
@@ -883,12 +910,12 @@ DEV void search_body(const SearchParams &p)
                 const u64 newmask = __ballot(isnew);
                 const int nnew = __popcll(newmask);
                 if (nnew == 0) continue;
-                if (isnew) nb_id[__popcll(newmask & lanemask_lt())] = nbid;
                 nvisited += nnew;
-                WSYNC();
                 PH(3);
 
-                const u32 myid = nb_id[lane < nnew ? lane : 0];
+                // Every lane stays on its own neighbour (stored order = lane order; the decisions below only need that
+                // order); only the rows to fetch are compacted, once, after the ADC has said which are needed.
+                const u32 myid = nbid;
                 float pq_d = 0.0f, e = 0.0f;
                 // Is the ADC value of this expansion's neighbours needed at all? (A4 is provably True for all of
                 // them when the list cannot fill up during the expansion, or when pq_ub clears the threshold for
@@ -906,32 +933,30 @@ DEV void search_body(const SearchParams &p)
                 // iff W > x), and while the list is full W only shrinks during the expansion, so a neighbour with
                 // x >= W now can never pass: its stored vector is not fetched at all (the reference would not score it
                 // either). The rows to score are compacted in stored order.
-                uint4 cw0 = make_uint4(0, 0, 0, 0), cw1 = cw0, cw2 = cw0, cw3 = cw0;
-                const u8 *mycode = p.codes + (size_t)myid * p.m;
-                if constexpr (NEED_PQ) { if (need_adc && lane < nnew) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m); }
+                if constexpr (NEED_PQ && !SPEC_CODES) { if (need_adc && isnew) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m); }
                 float adc_s = 0.0f;
                 u32 xbits = 0u;               // bits of the A4 threshold; 0 when A4 is proven true
-                int nrow = nnew, myrow = lane;
-                bool rowlane = lane < nnew;
+                bool rowlane = isnew;
                 if constexpr (FILTER) {
                     if (need_adc) {
-                        if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
+                        if (isnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
                         pq_d = f_sqrt(adc_s);   // asymmetric_distance = sqrt (fast_pq.py:330-333)
                         bool ok = true;
                         xbits = a4_threshold_bits(pq_d, p.policy == 0u ? 1.2f : 0.8f, ok);
-                        if (__ballot(lane < nnew && !ok) != 0ull) status |= DR_ST_INTERNAL;
+                        if (__ballot(isnew && !ok) != 0ull) status |= DR_ST_INTERNAL;
                         if (rn == cap) {
                             const u32 W0b = (u32)(list_get<NCHR>(rk, rn - 1) >> 32);
-                            rowlane = lane < nnew && xbits < W0b;
-                            const u64 nm = __ballot(rowlane);
-                            nrow = __popcll(nm);
-                            myrow = __popcll(nm & lanemask_lt());
-                            WSYNC();            // every lane holds its id in a register: the id array can be rewritten
-                            if (rowlane) nb_id[myrow] = myid;
-                            WSYNC();
+                            rowlane = isnew && xbits < W0b;
                         }
                         PH(4);
                     }
+                }
+                const u64 rowmask = __ballot(rowlane);
+                const int nrow = __popcll(rowmask);
+                const int myrow = __popcll(rowmask & lanemask_lt());
+                if constexpr (KIND != DIST_ADC_SQ) {
+                    if (rowlane) nb_id[myrow] = myid;
+                    WSYNC();
                 }
                 if constexpr (KIND != DIST_ADC_SQ) {
                     if constexpr (ROWLDS && U8) {
@@ -1041,6 +1066,31 @@ DEV void search_body(const SearchParams &p)
                                 }
                             }
                         }
+                    } else if constexpr (ChunkCfg<D>::ok && !QREG) {
+                        // large rows (D = 768, 960, 1536): the software pipeline of numerics.hpp -- NBUF - 1 chunks of the
+                        // running row (or of the next pass's row) in flight behind the chunk being reduced
+                        ChunkRegs<D> cbuf[ChunkCfg<D>::NBUF];
+                        const int npass = (nrow + 7) >> 3;
+                        if (npass > 0) {
+                            const float *rp = p.vecp + (size_t)nb_id[min(oct, nrow - 1)] * D;
+                            chunk_prologue<D, 0>(rp, j, cbuf);
+                            float cres[ChunkCfg<D>::NC];
+                            // one loop, two bodies (a pass with / without a next pass to prefetch for): the loop header
+                            // is only reached with the same NBUF - 1 chunks in flight, so the wait counts stay exact
+#pragma unroll 1
+                            for (int r0 = 0; r0 < npass; r0++) {
+                                if (r0 + 1 < npass) {
+                                    const float *rnext = p.vecp + (size_t)nb_id[min((r0 + 1) * 8 + oct, nrow - 1)] * D;
+                                    chunk_pass<D, 0, true>(rp, rnext, j, cbuf, qperm, cres);
+                                    rp = rnext;
+                                } else {
+                                    chunk_pass<D, 0, false>(rp, rp, j, cbuf, qperm, cres);
+                                }
+                                float ev = chunk_tree<0, ChunkCfg<D>::NC>(cres);
+                                if (knorm) ev = f_sqrt(ev);
+                                if (j == 0 && r0 * 8 + oct < nrow) nb_e[r0 * 8 + oct] = ev;
+                            }
+                        }
                     } else {
                         for (int r0 = 0; r0 * 8 < nrow; r0++) {
                             const int idx = min(r0 * 8 + oct, nrow - 1);
@@ -1056,7 +1106,8 @@ DEV void search_body(const SearchParams &p)
                         if (need_adc) npq_eval += nnew;
                     }
                 } else {
-                    if (lane < nnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
+                    if constexpr (!SPEC_CODES) { if (isnew) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m); }
+                    if (isnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
                     e = adc_s;
                     npq += nnew; npq_eval += nnew;
                     PH(4);
@@ -1085,7 +1136,7 @@ DEV void search_body(const SearchParams &p)
                     const bool full0 = (rn == cap);
                     const u32 W0b = (u32)(list_get<NCHR>(rk, rn - 1) >> 32);
                     // lanes that can still be scored (superset of those that can be accepted)
-                    const u64 cm = __ballot(lane < nnew && (!full0 || (count_pass ? xbits : ebits) < W0b));
+                    const u64 cm = __ballot(isnew && (!full0 || (count_pass ? xbits : ebits) < W0b));
                     const u64 mykey = ((u64)ebits << 32) | (u32)(~myid);
                     int na = 0;
                     u64 accmask = 0ull;
@@ -1324,7 +1375,7 @@ DEV void search_body(const SearchParams &p)
 }
 
 template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 1) void search_kernel(const SearchParams p)
+__global__ __launch_bounds__(64 * NW, (NW == 1 && D <= 256) ? 2 : 1) void search_kernel(const SearchParams p)
 {
     search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB, U8, QB>(p);
 }

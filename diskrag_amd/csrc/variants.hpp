@@ -19,6 +19,8 @@
 //  12 exact traversal (M2, M4, M3 without PQ) on BYTE vectors, 64 rows/burst, 16 waves          (D = 128)
 //  13 = 11 with BYTE queries as well (every component of the batch an integer in [0, 255]): v_dot4_u32_u8 distances
 //  14 = 12 with byte queries
+// (tried in round 2 and removed: 16-wave forms of 3 and 5 for D <= 96 -- twice the queries in flight, 30 % slower than the
+//  per-query table at the c4 shape: that kernel is bound by its number of memory requests, not by latency)
 // sizeclass: result capacity <= 64 / 128 / 256 / 512 / 1024 (the last one: one-wavefront-per-workgroup variants 0, 1, 2 only)
 #define DR_NUM_KINDS 15
 #define DR_NUM_SIZECLASS 5

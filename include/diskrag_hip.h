@@ -277,6 +277,14 @@ int dr_pq_train_ex(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t max_ite
                    float *out_codebook /*[m][256][D/m]*/, double *out_inertia);
 int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uint8_t *out_codes /*[N][m] or NULL*/);
 
+/* Inline neighbour codes (off by default; enable != 0 turns them on): the PQ code words of every node's neighbours are
+ * kept beside its adjacency row ([N][R][m] bytes of HBM, built on the device before the next search that evaluates ADC
+ * sums and rebuilt whenever codes or adjacency change), so that an expansion of the rerank-policy-live M1
+ * (search_engine.py:447-456: one ADC per new neighbour) or of a PQ-only traversal reads them as one coalesced block
+ * instead of R scattered gathers behind the visited test -- the layout DiskANN uses for its on-disk nodes, here for the
+ * HBM request rate. Results never depend on it. Needs n_subvectors % 4 == 0. */
+int dr_index_inline_codes(dr_index *ix, int enable);
+
 /* Diagnostic builds only (-DDR_PHASE_TIMING): shader-clock sums per phase of the last search, summed over queries:
  * 0 setup+table, 1 pop/stop, 2 adjacency, 3 visited set, 4 ADC, 5 exact distances, 6 decisions/inserts, 7 output. */
 int dr_debug_phase_cycles(dr_index *ix, double *out8);

@@ -20,7 +20,10 @@ med, bsec = ix.build_vamana(L_build=100 if shape != "c5s" else 64, alpha=1.2, pa
 cb = ix.pq_train(m, n_sample=100000, iters=5)
 ix.pq_encode(cb)
 gt, _ = ix.bruteforce_topk(q, 10)
-print(f"# {shape} N={n} D={D} m={m} R={R} build {bsec:.1f}s", flush=True)
+import os
+if os.environ.get("DR_INLINE") == "1":
+    ix.inline_codes(True)
+print(f"# {shape} N={n} D={D} m={m} R={R} build {bsec:.1f}s inline_codes={os.environ.get('DR_INLINE', '0')}", flush=True)
 
 
 def run(tag, kind=-1, **kw):

@@ -47,6 +47,20 @@ def test_live_policy_every_variant_matches_oracle(D, m, kinds):
                     ran.add(kind)
         assert ix.debug_force_kind(-1) == 1                      # measured: the policy is live on this data
         assert ran == set(kinds)                                 # every pinned variant really ran
+        # inline neighbour codes (the code words of a row's neighbours read as one block): same bits, every variant
+        ix.inline_codes(True)
+        for kind in (-1,) + tuple(kinds):
+            ix.debug_force_kind(kind)
+            for (L, bw, pol) in cases[:4]:
+                ids, dist, cnt, st = ix.search_batch(q, 10, L=L, beam_width=bw, mode=_ffi.MODE_M1, band_policy=pol)
+                w_ids, w_dist, w_cnt, w_st = want[(L, bw, pol)]
+                assert int(st["status"].max()) == 0
+                assert np.array_equal(ids, w_ids), ("inline", kind, L, bw, pol)
+                valid = w_ids != 0xFFFFFFFF
+                assert np.array_equal(dist[valid].view(np.uint32), w_dist[valid].astype(np.float32).view(np.uint32))
+                assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), w_st), kind
+        ix.inline_codes(False)
+        ix.debug_force_kind(-1)
         # the policy is live: a good share of the visited neighbours was NOT exact-scored, and the ADC was evaluated
         ids, dist, cnt, st = ix.search_batch(q, 10, L=100, beam_width=0, mode=_ffi.MODE_M1, band_policy=1)
         assert st["exact"].sum() < 0.8 * st["visited"].sum() and st["pq_evaluated"].sum() > 0.5 * st["pq"].sum()

@@ -76,13 +76,20 @@ def test_pq_mode_matches_its_oracle_restatement(name):
     try:
         for (L, bw, k) in ((100, 8, 10), (40, 0, 10), (10, 3, 10), (200, 16, 25), (64, 8, 64)):
             w = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, codes=g.codes, codebook=g.codebook)
-            for eng in (ix, shard):
+            for eng, inline in ((ix, False), (shard, False), (shard, True)):
+                eng.inline_codes(inline)      # (True: the neighbours' code words read as one block beside the adjacency row)
                 ids, dist, cnt, st = eng.search_batch(g.queries, k, L=L, beam_width=bw, mode=_ffi.MODE_PQ)
                 assert int(st["status"].max()) == 0
-                assert np.array_equal(ids, w[0]), (name, L, bw)
+                assert np.array_equal(ids, w[0]), (name, L, bw, inline)
                 valid = w[0] != 0xFFFFFFFF
                 assert np.array_equal(bits(dist)[valid], bits(w[1].astype(np.float32))[valid])
                 assert np.array_equal(cnt, w[2]) and np.array_equal(_stats4(st), w[3])
+                if inline:      # the reference-faithful PQ traversal reads the same block
+                    w3 = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.M3, min(k, 10), L=min(k, 10), bw=8, flags=orc.F_USE_PQ,
+                                          codes=g.codes, codebook=g.codebook)
+                    i3, d3, c3, s3 = eng.search_batch(g.queries, min(k, 10), L=min(k, 10), beam_width=8, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
+                    assert np.array_equal(i3, w3[0]) and np.array_equal(c3, w3[2]) and np.array_equal(_stats4(s3), w3[3])
+            shard.inline_codes(False)
             wr = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, flags=orc.F_RERANK, codes=g.codes,
                                   codebook=g.codebook)
             ids, dist, cnt, st = ix.search_batch(g.queries, k, L=L, beam_width=bw, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)
