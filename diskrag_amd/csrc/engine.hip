@@ -142,6 +142,8 @@ struct dr_index {
     DevBuf<uint8_t> nbcodes;      // [N][R][m] inline neighbour codes (dr_index_inline_codes), rebuilt before the next search when stale
     bool inline_codes = false, nbcodes_valid = false;
     DevBuf<float> codebook;
+    DevBuf<float> codebook_p;     // chain-major copy of the codebook (sub_dim % 8 == 0, >= 16): built before the next search that builds per-query tables
+    bool codebook_p_valid = false;
     DevBuf<float> sdc;            // centroid-pair table [m][256][256] (PQ-only builder), built on first use
     DevBuf<uint32_t> perm;
     std::vector<uint32_t> h_perm;
@@ -355,6 +357,7 @@ extern "C" int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_
     HIPCHK(hipMemcpy(ix->codebook.p, codebook, (size_t)256 * ix->D * 4, hipMemcpyHostToDevice));
     ix->m = m; ix->sd = ix->D / m;
     for (auto &qs : ix->slots) qs.pq_ub_valid = false;
+    ix->codebook_p_valid = false;
     ix->adc_live = -1; ix->nbcodes_valid = false;
     return 0;
 }
@@ -396,7 +399,7 @@ extern "C" void dr_index_close(dr_index *ix)
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) if (st) (void)hipStreamSynchronize(st);
-    ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release(); ix->sdc.release();
+    ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release(); ix->codebook_p.release(); ix->nbcodes.release(); ix->sdc.release();
     ix->perm.release(); ix->vis.release(); ix->vis_epoch.release();
     for (auto &qs : ix->slots) qs.release();
     for (auto &jb : ix->jobs) {
@@ -499,14 +502,14 @@ static int build_inline_codes(dr_index *ix)
     return 0;
 }
 
-static int build_bit_order(dr_index *ix)
+// rank[id] = the node's place in the locality order (a function of the vectors only). Leaves rank_valid false when the
+// index is too small or holds no vectors.
+static int build_rank(dr_index *ix)
 {
     static const bool off = getenv("DR_NO_BITORDER") != nullptr;
-    ix->use_adjr = false;
-    ix->adjr_valid = true;
     if (off || ix->N < 32768 || !ix->has_vectors) return 0;
     const uint64_t N = ix->N;
-    const uint32_t D = ix->D, R = ix->R;
+    const uint32_t D = ix->D;
     if (!ix->rank_valid) {
         uint64_t P = (uint64_t)(1.5e13 / ((double)N * D * 3.0));
         P = std::min<uint64_t>(std::min<uint64_t>(P, 4096), N / 64) & ~7ull;
@@ -558,6 +561,17 @@ static int build_bit_order(dr_index *ix)
         pid.release(); label.release(); piv.release();
         ix->rank_valid = true;
     }
+    return 0;
+}
+
+static int build_bit_order(dr_index *ix)
+{
+    ix->use_adjr = false;
+    ix->adjr_valid = true;
+    { const int rcr = build_rank(ix); if (rcr) return rcr; }
+    if (!ix->rank_valid) return 0;
+    const uint64_t N = ix->N;
+    const uint32_t R = ix->R;
     if (ix->adjr.reserve((size_t)N * R)) return DR_E_NODEVICE;
     hipLaunchKernelGGL(map_adjacency_kernel, dim3((unsigned)std::min<uint64_t>((N * R + 255) / 256, 65535)), dim3(256), 0, ix->stream,
                        ix->adj.p, N * R, N, ix->rank.p, ix->adjr.p);
@@ -746,6 +760,17 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.vecp = ix->vecp.p; p.adj = ix->adj.p; p.first = ix->first.p; p.codes = ix->codes.p; p.codebook = ix->codebook.p;
     p.adjr = (!ov && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
     p.nbcodes = (!ov && ix->inline_codes && ix->nbcodes_valid) ? ix->nbcodes.p : nullptr;
+    p.codebook_p = nullptr;
+    if (DR_KIND_LUT[kind] && !(ov && ov->sdc) && (ix->sd == 16 || ix->sd == 24 || ix->sd == 32 || ix->sd == 48)) {      // build_lut_wave's octet cases
+        if (!ix->codebook_p_valid) {
+            if (ix->codebook_p.reserve((size_t)256 * ix->D)) return DR_E_NODEVICE;
+            const uint64_t total = (uint64_t)256 * ix->D;
+            hipLaunchKernelGGL(codebook_perm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ix->stream, ix->codebook.p, ix->codebook_p.p, total, ix->sd);
+            HIPCHK(hipGetLastError());
+            ix->codebook_p_valid = true;
+        }
+        p.codebook_p = ix->codebook_p.p;
+    }
     p.vec8 = ix->vec8_state == 1 ? ix->vec8.p : nullptr;
     p.queries = ix->cs->q.p; p.queries_p = ix->cs->qp.p;
     p.N = ix->N; p.D = ix->D; p.R = ix->R; p.m = ix->m; p.sd = ix->sd; p.medoid = ix->medoid; p.nq = nq;
@@ -1601,8 +1626,15 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
     }
     if (!rc) {
         const uint64_t total = N * R;
-        hipLaunchKernelGGL(compact_adj_kernel, dim3((unsigned)std::min<uint64_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, ix->stream, adjb.p,
-                           deg.p, N, RX, R, pad_with_zero ? 0u : 0xFFFFFFFFu, ix->adj.p);
+        if (R <= 128) {     // rows in a canonical order: a device-built graph is reproducible bit for bit (engine_kernels.hpp)
+            const int rcr = build_rank(ix);      // (locality order of the visited bits: neighbours that share a bitmap line sit in adjacent lanes)
+            if (rcr) return rcr;
+            hipLaunchKernelGGL(compact_adj_sorted_kernel, dim3((unsigned)std::min<uint64_t>((N + 3) / 4, (uint64_t)ix->num_cu * 32)), dim3(256), 0, ix->stream, adjb.p,
+                               deg.p, N, RX, R, pad_with_zero ? 0u : 0xFFFFFFFFu, ix->rank_valid ? ix->rank.p : nullptr, ix->adj.p);
+        }
+        else
+            hipLaunchKernelGGL(compact_adj_kernel, dim3((unsigned)std::min<uint64_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, ix->stream, adjb.p,
+                               deg.p, N, RX, R, pad_with_zero ? 0u : 0xFFFFFFFFu, ix->adj.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(ix->stream));
         rc = build_first_masks(ix);
@@ -1900,6 +1932,7 @@ extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uin
     HIPCHK(hipStreamSynchronize(ix->stream));
     ix->m = m; ix->sd = ix->D / m;
     for (auto &qs : ix->slots) qs.pq_ub_valid = false;
+    ix->codebook_p_valid = false;
     ix->adc_live = -1; ix->nbcodes_valid = false;
     return 0;
 }

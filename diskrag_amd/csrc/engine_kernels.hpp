@@ -359,6 +359,37 @@ __global__ void compact_adj_kernel(const u32 *__restrict__ adjb, const u32 *__re
     }
 }
 
+// The same with every row's neighbours in a canonical order -- ascending place in the locality order of the visited bits
+// (rank[id], a function of the vectors only: neighbours that share a bitmap line end up in adjacent lanes), or ascending
+// id when there is no such order (small or PQ-only indexes); R <= 128, one wavefront per row, rank by counting. The
+// batched builder appends reverse edges with atomics, so the ORDER inside a row depends on arrival order while the SET
+// does not (two builds of one dataset: identical sorted rows, different raw rows -- and M1 / M3 walk a row in stored
+// order). A canonical order makes device-built graphs reproducible bit for bit; the reference's own order is a Python
+// set's iteration order (diskann_persist.py:17-24), i.e. arbitrary as well.
+__global__ __launch_bounds__(256) void compact_adj_sorted_kernel(const u32 *__restrict__ adjb, const u32 *__restrict__ deg, u64 N, u32 RX, u32 R,
+                                                                   u32 padval, const u32 *__restrict__ rank, u32 *__restrict__ adj)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);
+    for (u64 row = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < N; row += nwaves) {
+        const u32 d = min(deg[row], R);
+        const u32 x0 = lane < d ? adjb[row * RX + lane] : 0xFFFFFFFFu;
+        const u32 x1 = lane + 64u < d ? adjb[row * RX + 64u + lane] : 0xFFFFFFFFu;
+        // sort key (distinct inside a row: ids are, and rank is a bijection)
+        const u32 k0 = (rank && lane < d && (u64)x0 < N) ? rank[x0] : x0;
+        const u32 k1 = (rank && lane + 64u < d && (u64)x1 < N) ? rank[x1] : x1;
+        u32 r0 = 0u, r1 = 0u;
+        for (u32 t = 0; t < d; t++) {
+            const u32 v = t < 64u ? (u32)__builtin_amdgcn_readlane((int)k0, (int)t) : (u32)__builtin_amdgcn_readlane((int)k1, (int)(t - 64u));
+            r0 += v < k0 ? 1u : 0u;
+            r1 += v < k1 ? 1u : 0u;
+        }
+        if (lane < d) adj[row * R + r0] = x0;
+        if (lane + 64u < d) adj[row * R + r1] = x1;
+        for (u32 s = d + lane; s < R; s += 64u) adj[row * R + s] = padval;
+    }
+}
+
 __global__ void column_sum_kernel(const float *__restrict__ vecp, u64 N, u32 D, double *__restrict__ acc)
 {
     // one block per chunk of rows; thread e sums dimension e (+blockDim strides)
@@ -475,5 +506,19 @@ __global__ void inline_codes_kernel(const u32 *__restrict__ adj, const u8 *__res
         u32 v = 0u;
         if ((u64)id < N) v = reinterpret_cast<const u32 *>(codes + (size_t)id * m)[w];
         reinterpret_cast<u32 *>(nbcodes)[t] = v;
+    }
+}
+
+// Chain-major copy of the codebook for build_lut_octet (search_kernel.hpp): within every entry of sd floats (one leaf of
+// the pairwise tree: sd <= 128, sd % 8 == 0) element 8t + j moves to g*32 + j*4 + u for t = 4g + u < 4G, and to
+// G*32 + j*REM + (t - 4G) for the remaining REM = (sd/8) % 4 steps -- pw_build_perm_rec's layout for a leaf.
+__global__ void codebook_perm_kernel(const float *__restrict__ cb, float *__restrict__ cbp, u64 total, u32 sd)
+{
+    const u32 S = sd / 8, G = S / 4, rem = S % 4;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u64 e = i / sd;
+        const u32 k = (u32)(i - e * sd), t = k / 8, j = k % 8, g = t / 4, u = t % 4;
+        const u32 pos = (g < G) ? g * 32 + j * 4 + u : G * 32 + j * rem + (t - 4 * G);
+        cbp[e * sd + pos] = cb[i];
     }
 }

@@ -63,6 +63,7 @@ struct SearchParams {
     const u8 *codes;         // [N][m]
     const u8 *nbcodes;       // [N][R][m] code words of every adjacency slot's neighbour, or nullptr (dr_index_inline_codes)
     const float *codebook;   // [m][256][sd]
+    const float *codebook_p; // the same with every entry stored chain-major (sub_dim % 8 == 0, >= 16), or nullptr: build_lut_octet
     const float *queries;    // [nq][D] original element order
     const float *queries_p;  // [nq][D] chain-major
     u64 N;
@@ -321,10 +322,109 @@ DEV void build_lut_sd(float *lut, const float *__restrict__ codebook, const floa
     }
 }
 
+// A2 for sub_dim >= 16 (the large dimensions: D = 1536 / m = 32 has 48 floats per centroid, 1.5 MB of codebook per
+// query). The lane-per-entry form above reads its centroids with a 4*SD-byte stride between lanes (every load instruction
+// touches 64 cache lines) and exposes one memory round trip per trip of 64 entries: 128 dependent trips, 580 k cycles per
+// query -- a quarter of the c3 kernel and 40 % of the PQ-only traversal. Here an OCTET scores one entry the way exact
+// distances are scored (lane j owns accumulator chain j, octet_combine), from a copy of the codebook whose entries are
+// stored chain-major (codebook_perm_kernel: position g*32 + j*4 + u of an entry = its element 8*(4g+u) + j, then the
+// remaining steps j*REM + r), so that a wave instruction reads 8 consecutive entries as one contiguous run, and UP
+// passes (8*UP entries) are in flight at once. Same arithmetic in the same order: the same bits.
+// q: the query in its original element order (global memory); the lane's S values of the NEXT sub-quantiser are fetched
+// while this one is computed.
+template <int SD> struct LutBuf {
+    static constexpr int S = SD / 8, G = S / 4, REM = S % 4;
+    static constexpr int UP = SD >= 32 ? 8 : 16;          // passes per batch: 8*UP entries, UP*(G + (REM > 0)) loads
+    float4 g4[UP][G > 0 ? G : 1];
+    float rr[UP][REM > 0 ? REM : 1];
+};
+template <int SD> DEV void lut_issue(LutBuf<SD> &b, const float *__restrict__ base, u32 e0, int j, int oct)
+{
+    constexpr int G = LutBuf<SD>::G, REM = LutBuf<SD>::REM, UP = LutBuf<SD>::UP;
+#pragma unroll
+    for (int u = 0; u < UP; u++) {
+        const float *ent = base + (size_t)(e0 + u * 8 + oct) * SD;
+#pragma unroll
+        for (int g = 0; g < G; g++) b.g4[u][g] = *reinterpret_cast<const float4 *>(ent + g * 32 + j * 4);
+#pragma unroll
+        for (int r = 0; r < REM; r++) b.rr[u][r] = ent[G * 32 + j * REM + r];
+    }
+}
+template <int SD> DEV void lut_reduce(const LutBuf<SD> &b, const float (&qv)[SD / 8], float *lut_row, u32 e0, int j, int oct)
+{
+    constexpr int G = LutBuf<SD>::G, REM = LutBuf<SD>::REM, UP = LutBuf<SD>::UP;
+#pragma unroll
+    for (int u = 0; u < UP; u++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const float4 v = b.g4[u][g];
+            const float s0 = sqd(v.x, qv[g * 4 + 0]), s1 = sqd(v.y, qv[g * 4 + 1]);
+            const float s2 = sqd(v.z, qv[g * 4 + 2]), s3 = sqd(v.w, qv[g * 4 + 3]);
+            acc = (g == 0) ? s0 : f_add(acc, s0);
+            acc = f_add(acc, s1);
+            acc = f_add(acc, s2);
+            acc = f_add(acc, s3);
+        }
+#pragma unroll
+        for (int r = 0; r < REM; r++) {
+            const float sv = sqd(b.rr[u][r], qv[G * 4 + r]);
+            acc = (G == 0 && r == 0) ? sv : f_add(acc, sv);
+        }
+        acc = octet_combine(acc);
+        if (j == 0) lut_row[e0 + u * 8 + oct] = acc;
+    }
+}
+// Two batches alternate: while one is reduced the other's loads are in flight (also across sub-quantisers; the batch
+// issued after the last one re-reads the last sub-quantiser's first entries instead of branching, so that the compiler's
+// wait counts stay exact).
+template <int SD>
+DEV void build_lut_octet(float *lut, const float *__restrict__ cbp, const float *__restrict__ q, u32 m)
+{
+    constexpr int S = SD / 8, UP = LutBuf<SD>::UP, NE = 256 / (8 * UP);
+    static_assert(SD % 8 == 0 && SD >= 16 && SD <= 128 && NE >= 2 && NE % 2 == 0, "octet form");
+    const int lane = lane_id(), j = lane & 7, oct = lane >> 3;
+    LutBuf<SD> A, B;
+    float qn[S];
+#pragma unroll
+    for (int t = 0; t < S; t++) qn[t] = q[8 * t + j];
+    lut_issue<SD>(A, cbp, 0, j, oct);
+#pragma unroll 1
+    for (u32 jq = 0; jq < m; jq++) {
+        float qv[S];
+#pragma unroll
+        for (int t = 0; t < S; t++) qv[t] = qn[t];
+        const u32 jn = min(jq + 1, m - 1);
+#pragma unroll
+        for (int t = 0; t < S; t++) qn[t] = q[jn * SD + 8 * t + j];
+        const float *base = cbp + (size_t)jq * 256 * SD;
+        const float *base_n = cbp + (size_t)jn * 256 * SD;
+        float *row = lut + jq * 256;
+#pragma unroll
+        for (int ne = 0; ne < NE; ne += 2) {
+            lut_issue<SD>(B, base, (u32)(ne + 1) * 8 * UP, j, oct);
+            lut_reduce<SD>(A, qv, row, (u32)ne * 8 * UP, j, oct);
+            if (ne + 2 < NE) lut_issue<SD>(A, base, (u32)(ne + 2) * 8 * UP, j, oct);
+            else lut_issue<SD>(A, base_n, 0, j, oct);
+            lut_reduce<SD>(B, qv, row, (u32)(ne + 1) * 8 * UP, j, oct);
+        }
+    }
+}
+
 // A2: whole table for one query, entries spread over the wave. q in original order (LDS).
-DEV void build_lut_wave(float *lut, const float *__restrict__ codebook, const float *q, u32 m, u32 sd)
+DEV void build_lut_wave(float *lut, const float *__restrict__ codebook, const float *q, u32 m, u32 sd,
+                        const float *__restrict__ codebook_p = nullptr)
 {
     const u32 total = m * 256;
+    if (codebook_p != nullptr) {      // chain-major copy of the codebook (global memory) and q in global memory: octet form
+        switch (sd) {
+        case 16: build_lut_octet<16>(lut, codebook_p, q, m); return;
+        case 24: build_lut_octet<24>(lut, codebook_p, q, m); return;
+        case 32: build_lut_octet<32>(lut, codebook_p, q, m); return;
+        case 48: build_lut_octet<48>(lut, codebook_p, q, m); return;
+        default: break;     // (wider centroids keep the lane-per-entry form: their double buffers would set the kernel's register count)
+        }
+    }
     switch (sd) {
     case 2: build_lut_sd<2>(lut, codebook, q, total); return;
     case 3: build_lut_sd<3>(lut, codebook, q, total); return;
@@ -665,7 +765,7 @@ DEV void search_body(const SearchParams &p)
                             reinterpret_cast<const float4 *>(p.sdc + ((size_t)jq * 256 + mycodes[jq]) * 256)[lane];
                 }
             } else {
-                build_lut_wave(lut, p.codebook, p.queries + (size_t)qi * D, p.m, p.sd);
+                build_lut_wave(lut, p.codebook, p.queries + (size_t)qi * D, p.m, p.sd, p.codebook_p);
             }
             WSYNC();
         }

@@ -31,7 +31,11 @@ if sys.argv[1] == "run":
     np.savez(f"/tmp/m3_{tag}.npz", **out)
     if tag == "a":
         np.savez("/tmp/m3_index.npz", adj=ix.get_adjacency(), codes=codes, cb=cb, med=med)
-    print("run", tag, "in-process reps equal:", bool((out["ids0"] == out["ids1"]).all()))
+    import hashlib
+    h = lambda a: hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()[:12]
+    adj_now = ix.get_adjacency()
+    print("run", tag, "in-process reps equal:", bool((out["ids0"] == out["ids1"]).all()), "| sha1 adjacency", h(adj_now), "sorted rows", h(np.sort(adj_now, axis=1)),
+          "codebook", h(cb), "codes", h(codes), "medoid", med)
 else:
     from oracle import pyoracle as orc
     a, b = np.load("/tmp/m3_a.npz"), np.load("/tmp/m3_b.npz")
