@@ -1266,19 +1266,31 @@ DEV void search_body(const SearchParams &p)
                                 }
                             }
                         }
+                        // (the candidate masks are built as two 32-bit halves -- candidates in lanes 0..31, then 32..63 -- so
+                        // that every update is one select and one OR instead of two of each on a 64-bit register pair)
                         u64 Mt = 0ull, Mx = 0ull, lessm = 0ull, oldm[NCHR];
 #pragma unroll
                         for (int ch = 0; ch < NCHR; ch++) oldm[ch] = 0ull;
-                        for (u64 mm = cm; mm != 0ull; mm &= mm - 1ull) {
-                            const int f = __ffsll((long long)mm) - 1;
-                            const u32 ef = readlane32(ebits, f);
-                            const u64 kf = readlane64(mykey, f);
-                            const u64 bit = 1ull << f;
-                            Mt |= (f < lane && ef <= tbits) ? bit : 0ull;
-                            if (count_pass) Mx |= (f < lane && ef <= xbits) ? bit : 0ull;
-                            lessm |= (kf < mykey) ? bit : 0ull;
 #pragma unroll
-                            for (int ch = 0; ch < NCHR; ch++) oldm[ch] |= (kf < rk.v[ch]) ? bit : 0ull;
+                        for (int half = 0; half < 2; half++) {
+                            u32 mt = 0u, mx = 0u, ls = 0u, om[NCHR];
+#pragma unroll
+                            for (int ch = 0; ch < NCHR; ch++) om[ch] = 0u;
+                            for (u32 mm = (u32)(cm >> (32 * half)); mm != 0u; mm &= mm - 1u) {
+                                const int fl = __ffs((int)mm) - 1;
+                                const int f = fl + 32 * half;
+                                const u32 ef = readlane32(ebits, f);
+                                const u64 kf = readlane64(mykey, f);
+                                const u32 bit = 1u << fl;
+                                mt |= (f < lane && ef <= tbits) ? bit : 0u;
+                                if (count_pass) mx |= (f < lane && ef <= xbits) ? bit : 0u;
+                                ls |= (kf < mykey) ? bit : 0u;
+#pragma unroll
+                                for (int ch = 0; ch < NCHR; ch++) om[ch] |= (kf < rk.v[ch]) ? bit : 0u;
+                            }
+                            Mt |= (u64)mt << (32 * half); Mx |= (u64)mx << (32 * half); lessm |= (u64)ls << (32 * half);
+#pragma unroll
+                            for (int ch = 0; ch < NCHR; ch++) oldm[ch] |= (u64)om[ch] << (32 * half);
                         }
                         // a lane can be accepted only if its own exact distance beats the current worst (when full)
                         const bool canacc = iscand && (!full0 || tbits < W0b);
