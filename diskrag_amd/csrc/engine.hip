@@ -28,6 +28,8 @@
 #include <string>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>      // device radix sort (the builder's reverse-edge pass)
+
 #include "../../include/diskrag_hip.h"
 #include "engine_kernels.hpp"
 #include "search_f64.hpp"
@@ -1523,6 +1525,17 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
         return DR_E_NODEVICE;
     HIPCHK(hipMemsetAsync(adjb.p, 0xFF, (size_t)N * RX * 4, ix->stream));
     if (!pq && (ix->cs->q.reserve((size_t)max_batch * D) || ix->cs->qp.reserve((size_t)max_batch * D))) return DR_E_NODEVICE;
+    // reverse-edge pass: sorted pairs (deterministic; DR_BUILD_ATOMIC_REV=1 selects the atomic append it replaced, for A/B)
+    static const bool rev_atomic = getenv("DR_BUILD_ATOMIC_REV") != nullptr;
+    DevBuf<u64> rkeys_a, rkeys_b;
+    DevBuf<unsigned char> rtemp;
+    if (!rev_atomic) {
+        const size_t np = (size_t)max_batch * R;
+        if (rkeys_a.reserve(np) || rkeys_b.reserve(np)) return DR_E_NODEVICE;
+        size_t tb = 0;
+        HIPCHK(rocprim::radix_sort_keys(nullptr, tb, rkeys_a.p, rkeys_b.p, (unsigned int)np, 0u, 64u, ix->stream));
+        if (rtemp.reserve(tb + 16)) return DR_E_NODEVICE;
+    }
     if (pq && !ix->sdc.p) {
         // centroid-pair table S[m][256][256] (8 MB at m = 32): every distance of the PQ-only builder is a sum of its entries
         if (ix->sdc.reserve((size_t)ix->m * 65536)) return DR_E_NODEVICE;
@@ -1580,9 +1593,20 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
             {
                 const uint64_t threads = (uint64_t)b * R;
                 // (PQ-only builder: rows run half-way into their slack before they are re-pruned, see reverse_edges_kernel)
-                hipLaunchKernelGGL(reverse_edges_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ix->stream,
-                                   adjb.p, deg.p, RX, R, pts, b, fwd.p, fwd_n.p, ovf_list.p, ovf_count.p, (uint32_t)N, pq ? R + pq_slack : R);
-                HIPCHK(hipGetLastError());
+                if (rev_atomic) {
+                    hipLaunchKernelGGL(reverse_edges_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ix->stream,
+                                       adjb.p, deg.p, RX, R, pts, b, fwd.p, fwd_n.p, ovf_list.p, ovf_count.p, (uint32_t)N, pq ? R + pq_slack : R);
+                    HIPCHK(hipGetLastError());
+                } else {
+                    // sorted (target, source) pairs, one thread per target's run: deterministic (engine_kernels.hpp)
+                    hipLaunchKernelGGL(rev_pairs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ix->stream, pts, b, R, fwd.p, fwd_n.p, rkeys_a.p);
+                    HIPCHK(hipGetLastError());
+                    size_t tb = rtemp.n;
+                    HIPCHK(rocprim::radix_sort_keys((void *)rtemp.p, tb, rkeys_a.p, rkeys_b.p, (unsigned int)threads, 0u, 64u, ix->stream));
+                    hipLaunchKernelGGL(rev_apply_sorted_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ix->stream, rkeys_b.p, (uint32_t)threads,
+                                       adjb.p, deg.p, RX, ovf_list.p, ovf_count.p, (uint32_t)N, pq ? R + pq_slack : R);
+                    HIPCHK(hipGetLastError());
+                }
             }
             uint32_t novf = 0;
             HIPCHK(hipMemcpyAsync(&novf, ovf_count.p, 4, hipMemcpyDeviceToHost, ix->stream));

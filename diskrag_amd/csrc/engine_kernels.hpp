@@ -340,6 +340,53 @@ __global__ void reverse_edges_kernel(u32 *__restrict__ adjb, u32 *__restrict__ d
     }
 }
 
+// The deterministic form of the reverse-edge pass (the builder's default): the batch's (target, source) pairs are sorted
+// (rocprim radix sort on target << 32 | source) and the thread that finds the head of a target's run appends the whole run
+// in ascending source order. Which edges a full slack row keeps (the smallest sources) and the order inside every row no
+// longer depend on the arrival order of atomics: two builds of one dataset are identical bit for bit.
+__global__ void rev_pairs_kernel(const u32 *__restrict__ points, u32 npoints, u32 R, const u32 *__restrict__ fwd,
+                                 const u32 *__restrict__ fwd_n, u64 *__restrict__ keys)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npoints * R) return;
+    const u32 pi = t / R, s = t % R;
+    u64 key = ~0ull;
+    if (s < fwd_n[pi]) {
+        const u32 pt = points[pi], n = fwd[(size_t)pi * R + s];
+        if (n != 0xFFFFFFFFu && n != pt) key = ((u64)n << 32) | pt;
+    }
+    keys[t] = key;
+}
+__global__ void rev_apply_sorted_kernel(const u64 *__restrict__ keys, u32 total, u32 *__restrict__ adjb, u32 *__restrict__ deg, u32 RX,
+                                        u32 *__restrict__ ovf_list, u32 *__restrict__ ovf_count, u32 ovf_cap, u32 trigger)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const u64 k0 = keys[i];
+    if (k0 == ~0ull) return;
+    const u32 n = (u32)(k0 >> 32);
+    if (i > 0 && (u32)(keys[i - 1] >> 32) == n) return;         // not the head of its target's run
+    u32 *row = adjb + (size_t)n * RX;
+    const u32 d0 = deg[n];                                       // this thread is the only writer of row n in this launch
+    const u32 have = min(d0, RX);
+    u32 d = d0;
+    for (u32 j = i; j < total; j++) {
+        const u64 k = keys[j];
+        if ((u32)(k >> 32) != n) break;
+        const u32 pt = (u32)k;
+        bool dup = false;
+        for (u32 e = 0; e < have; e++) dup = dup || row[e] == pt;   // (sources of one batch are distinct: only the old entries)
+        if (dup) continue;
+        if (d < RX) row[d] = pt;
+        d++;
+    }
+    deg[n] = d;
+    if (d0 <= trigger && d > trigger) {          // the row passed the re-prune threshold in this batch (slot == trigger)
+        const u32 q = atomicAdd(ovf_count, 1u);
+        if (q < ovf_cap) ovf_list[q] = n;
+    }
+}
+
 // rows whose degree exceeds R (final prune of the slack-tolerant builder)
 __global__ void collect_over_kernel(const u32 *__restrict__ deg, u64 N, u32 R, u32 *__restrict__ list, u32 *__restrict__ count)
 {

@@ -1487,6 +1487,9 @@ DEV void search_body(const SearchParams &p)
 }
 
 template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false>
+// (minimum wavefronts per SIMD: 2 for the one-wavefront workgroups at D <= 256, which are register-limited -- forcing 3 on
+// the exact traversals (168 VGPRs, 25 spilled) measured 0...+5 % slower at the c4 shape; the large dimensions hold a
+// 32-KiB table or the row pipeline's buffers: 1)
 __global__ __launch_bounds__(64 * NW, (NW == 1 && D <= 256) ? 2 : 1) void search_kernel(const SearchParams p)
 {
     search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB, U8, QB>(p);
