@@ -763,7 +763,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.adjr = (!ov && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
     p.nbcodes = (!ov && ix->inline_codes && ix->nbcodes_valid) ? ix->nbcodes.p : nullptr;
     p.codebook_p = nullptr;
-    if (DR_KIND_LUT[kind] && !(ov && ov->sdc) && (ix->sd == 16 || ix->sd == 24 || ix->sd == 32 || ix->sd == 48)) {      // build_lut_wave's octet cases
+    if (DR_KIND_LUT[kind] && !(ov && ov->sdc) && ix->D > 256 && (ix->sd == 16 || ix->sd == 24 || ix->sd == 32 || ix->sd == 48)) {      // build_lut_wave's octet cases
         if (!ix->codebook_p_valid) {
             if (ix->codebook_p.reserve((size_t)256 * ix->D)) return DR_E_NODEVICE;
             const uint64_t total = (uint64_t)256 * ix->D;

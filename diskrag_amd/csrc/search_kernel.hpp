@@ -412,11 +412,14 @@ DEV void build_lut_octet(float *lut, const float *__restrict__ cbp, const float 
 }
 
 // A2: whole table for one query, entries spread over the wave. q in original order (LDS).
+// OCTET: instantiate the octet forms (their double buffers cost up to 96 VGPRs: only where sub_dim >= 16 is a real
+// configuration and 512 registers are available, D > 256 -- inlined into the D = 96 kernels they made the register allocator spill 215 dwords)
+template <bool OCTET = false>
 DEV void build_lut_wave(float *lut, const float *__restrict__ codebook, const float *q, u32 m, u32 sd,
                         const float *__restrict__ codebook_p = nullptr)
 {
     const u32 total = m * 256;
-    if (codebook_p != nullptr) {      // chain-major copy of the codebook (global memory) and q in global memory: octet form
+    if constexpr (OCTET) if (codebook_p != nullptr) {      // chain-major copy of the codebook (global memory) and q in global memory: octet form
         switch (sd) {
         case 16: build_lut_octet<16>(lut, codebook_p, q, m); return;
         case 24: build_lut_octet<24>(lut, codebook_p, q, m); return;
@@ -612,7 +615,7 @@ DEV void search_body(const SearchParams &p)
     constexpr bool SPLIT = QREG && split_form_ok<D>();
     constexpr bool ROWLDS = RB > 0;
     static_assert(!ROWLDS || (CBLDS && SPLIT && (64 % (D / 4)) == 0), "row landing needs whole rows per instruction");
-    constexpr int NP = !SPLIT ? 1 : (NW >= 16 ? 1 : (NW >= 8 ? 2 : 4));   // row passes in flight
+    constexpr int NP = !SPLIT ? 1 : (NW >= 16 ? 1 : ((NW >= 8 || D >= 256) ? 2 : 4));   // row passes in flight (D = 256: 32 VGPRs per pass)
     constexpr bool NEED_PQ = FILTER || KIND == DIST_ADC_SQ;
     constexpr bool SPEC_CODES = NEED_PQ && !ROWLDS;   // code words fetched beside the visited test (see there)
     // the rerank-policy kernels only ever serve M1 (squared distances, trim rule of search_engine.py:477-479): folding the
@@ -765,7 +768,7 @@ DEV void search_body(const SearchParams &p)
                             reinterpret_cast<const float4 *>(p.sdc + ((size_t)jq * 256 + mycodes[jq]) * 256)[lane];
                 }
             } else {
-                build_lut_wave(lut, p.codebook, p.queries + (size_t)qi * D, p.m, p.sd, p.codebook_p);
+                build_lut_wave<(D > 256)>(lut, p.codebook, p.queries + (size_t)qi * D, p.m, p.sd, p.codebook_p);
             }
             WSYNC();
         }
@@ -1013,9 +1016,18 @@ DEV void search_body(const SearchParams &p)
                 nvisited += nnew;
                 PH(3);
 
-                // Every lane stays on its own neighbour (stored order = lane order; the decisions below only need that
-                // order); only the rows to fetch are compacted, once, after the ADC has said which are needed.
-                const u32 myid = nbid;
+                // PQ kernels: every lane stays on its own neighbour (stored order = lane order; the decisions below only
+                // need that order) and only the rows to fetch are compacted, once, after the ADC has said which are
+                // needed. Exact traversals: every new neighbour is fetched, so the new ids are compacted right here and
+                // lanes 0 .. nnew-1 take them (the sparse form costs those kernels 18-25 VGPRs, i.e. a wavefront per
+                // SIMD at D = 96).
+                u32 myid = nbid;
+                if constexpr (!NEED_PQ) {
+                    if (isnew) nb_id[__popcll(newmask & lanemask_lt())] = nbid;
+                    WSYNC();
+                    myid = nb_id[lane < nnew ? lane : 0];
+                    isnew = lane < nnew;
+                }
                 float pq_d = 0.0f, e = 0.0f;
                 // Is the ADC value of this expansion's neighbours needed at all? (A4 is provably True for all of
                 // them when the list cannot fill up during the expansion, or when pq_ub clears the threshold for
@@ -1051,12 +1063,15 @@ DEV void search_body(const SearchParams &p)
                         PH(4);
                     }
                 }
-                const u64 rowmask = __ballot(rowlane);
-                const int nrow = __popcll(rowmask);
-                const int myrow = __popcll(rowmask & lanemask_lt());
-                if constexpr (KIND != DIST_ADC_SQ) {
-                    if (rowlane) nb_id[myrow] = myid;
-                    WSYNC();
+                int nrow = nnew, myrow = lane;
+                if constexpr (NEED_PQ) {
+                    const u64 rowmask = __ballot(rowlane);
+                    nrow = __popcll(rowmask);
+                    myrow = __popcll(rowmask & lanemask_lt());
+                    if constexpr (KIND != DIST_ADC_SQ) {
+                        if (rowlane) nb_id[myrow] = myid;
+                        WSYNC();
+                    }
                 }
                 if constexpr (KIND != DIST_ADC_SQ) {
                     if constexpr (ROWLDS && U8) {
