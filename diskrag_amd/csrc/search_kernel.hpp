@@ -15,9 +15,10 @@
 //   LDS    PQ data for ADC: either the whole codebook shared by all wavefronts of the workgroup (D <= 128:
 //          4*256*D bytes <= 128 KiB; table entries T[j][c] are recomputed per neighbour in the reference's order,
 //          which lets 8-16 queries share a CU instead of the 4 that per-query tables allow), or the per-query
-//          table T[m][256] (larger D); the query in original order; a 64-entry staging area per expansion
-//   HBM    exact visited set: one bitmap per wavefront slot, tested-and-set with a single atomicOr per
-//          neighbour (one memory round trip), cleared after the query from a log of the touched ids;
+//          table T[m][256] (larger D); the landing area of the row variants (the stored vectors of an expansion arrive
+//          by global_load_lds); a 64-entry staging area per expansion; the word filter of the visited set
+//   HBM    exact visited set: per wavefront slot one word per 24 bit positions + an 8-bit stamp of the query that wrote
+//          it (plain load / plain store, lanes that share a word combined in LDS, never cleared between queries);
 //          accepted-insert log per query (tie replay in finalize)
 //
 // Sequential semantics kept exactly: the neighbours of one expansion are scored in parallel (distances do not
