@@ -30,7 +30,11 @@ import tempfile
 import time
 from pathlib import Path
 
-import numpy as np
+# (the host BLAS of this image is built for 64 threads: on a 256-thread box it warns and, with many Python threads,
+# corrupts its buffer table at exit -- cap it before numpy loads it; the bench's host work is not BLAS-bound)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "64")
+
+import numpy as np  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))

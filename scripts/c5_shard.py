@@ -4,10 +4,13 @@ are never stored (1.25e8 x 1536 x 4 B = 768 GB); the Vamana graph is built from 
 (dr_build_vamana_pq) and searched with the engine's PQ-only traversal (DR_MODE_PQ) and the reference's (M3 with PQ).
 Usage: python scripts/c5_shard.py [N] [chunk_rows] [n_gt_queries]  -> gpurun_out/scale_c5_shard.json"""
 import json
+import os
 import sys
 import time
 
-import numpy as np
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "64")     # the image's BLAS is built for 64 threads; 96 generator threads call into it
+
+import numpy as np  # noqa: E402
 
 sys.path.insert(0, ".")
 from diskrag_amd import HipIndex, _ffi                       # noqa: E402
