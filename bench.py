@@ -64,16 +64,31 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--min-recall", type=float, default=0.95, help="the metric's recall bar: the bench fails below it")
     ap.add_argument("--config", default="c2", choices=["c2", "c5"], help="c2: the headline (query-sharded replicas); c5: graph-sharded PQ-only search with the RCCL top-k exchange")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank its own batches of --num-queries; strong (SURVEY.md 8e): ONE stream of "
+                         "--num-queries batches, every batch cut into contiguous slices of nq/N queries, one per rank")
+    ap.add_argument("--blocking-calls", type=int, default=24, help="blocking dr_search_batch calls timed for config.qps_blocking_call (median)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
 
 # ------------------------------------------------------------------------------------------------ ranks and barriers
 class Ranks:
-    """Rank bookkeeping + file barriers in a scratch directory shared by the ranks of ONE node (no torch, no sockets)."""
+    """Rank bookkeeping + file barriers in a scratch directory shared by the ranks of ONE node (no torch, no sockets).
+
+    The directory is fresh for every job. The script's own launcher makes it (mkdtemp) and hands it over in the environment.
+    Under torchrun nothing in the environment is unique per job (MASTER_PORT 29500 and run id 'none' by default), so the
+    ranks agree on a fresh directory through a handshake in a base directory named from port + run id: every rank r
+    publishes a random nonce (`join.r`), rank 0 creates the directory (mkdtemp) and answers each nonce it sees with
+    `assign.r` = (nonce, directory), rank r accepts only an answer that carries ITS nonce and confirms with `here.r` inside
+    the new directory. Files a crashed earlier job left behind carry other nonces and are ignored, so a barrier can
+    never be satisfied, nor a time or an RCCL id read, from another run's files. Every file is written atomically
+    (os.replace). A rank that fails drops an `abort` file, which ends the waits of the others at once."""
 
     def __init__(self):
         env = os.environ
+        self._n = 0
+        self._base = None
         if "DR_BENCH_RANK" in env:                       # started by this script's own launcher
             self.rank, self.world = int(env["DR_BENCH_RANK"]), int(env["DR_BENCH_WORLD"])
             self.local_rank, self.dir = self.rank, env["DR_BENCH_SYNC_DIR"]
@@ -81,21 +96,78 @@ class Ranks:
             self.rank, self.world = int(env["RANK"]), int(env["WORLD_SIZE"])
             self.local_rank = int(env.get("LOCAL_RANK", self.rank))
             tag = "%s_%s" % (env.get("MASTER_PORT", "0"), env.get("TORCHELASTIC_RUN_ID", "run"))
-            self.dir = os.path.join(tempfile.gettempdir(), "diskrag_bench_" + "".join(c if c.isalnum() else "_" for c in tag))
-            os.makedirs(self.dir, exist_ok=True)
+            self._base = os.path.join(tempfile.gettempdir(), "diskrag_bench_" + "".join(c if c.isalnum() else "_" for c in tag))
+            os.makedirs(self._base, exist_ok=True)
+            self.dir = self._handshake() if self.world > 1 else None
         else:
             self.rank, self.world, self.local_rank, self.dir = 0, 1, 0, None
-        self._n = 0
+
+    @staticmethod
+    def _write(path, data):
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, path)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path, "rb") as f:
+                return f.read()
+        except OSError:
+            return None
+
+    def _handshake(self, timeout=1800.0):
+        B, t0 = self._base, time.time()
+        if self.rank == 0:
+            fresh = tempfile.mkdtemp(prefix="job_", dir=B)
+            seen = {}
+            while True:
+                missing = [r for r in range(1, self.world) if not os.path.exists(os.path.join(fresh, "here.%d" % r))]
+                if not missing:
+                    return fresh
+                for r in missing:
+                    nonce = self._read(os.path.join(B, "join.%d" % r))
+                    if nonce and seen.get(r) != nonce:
+                        self._write(os.path.join(B, "assign.%d" % r), nonce + b"\n" + fresh.encode())
+                        seen[r] = nonce
+                if time.time() - t0 > timeout:
+                    raise RuntimeError("rank 0: ranks %s never joined" % missing)
+                time.sleep(0.002)
+        nonce = os.urandom(16).hex().encode()
+        self._write(os.path.join(B, "join.%d" % self.rank), nonce)
+        while True:
+            a = self._read(os.path.join(B, "assign.%d" % self.rank))
+            if a and a.split(b"\n", 1)[0] == nonce:
+                fresh = a.split(b"\n", 1)[1].decode()
+                self._write(os.path.join(fresh, "here.%d" % self.rank), b"x")
+                return fresh
+            if time.time() - t0 > timeout:
+                raise RuntimeError("rank %d: no directory assigned by rank 0" % self.rank)
+            time.sleep(0.002)
+
+    def _check_abort(self):
+        if self.dir and os.path.exists(os.path.join(self.dir, "abort")):
+            raise RuntimeError("rank %d: another rank aborted: %s" % (self.rank, (self._read(os.path.join(self.dir, "abort")) or b"").decode()))
+
+    def abort(self, why):
+        """called by a failing rank: the others stop waiting for it"""
+        if self.world > 1 and self.dir:
+            try:
+                self._write(os.path.join(self.dir, "abort"), ("rank %d: %s" % (self.rank, why)).encode())
+            except OSError:
+                pass
 
     def barrier(self, timeout=1800.0):
         if self.world == 1:
             return
         self._n += 1
-        Path(self.dir, "b%d.%d" % (self._n, self.rank)).write_text("x")
+        self._write(os.path.join(self.dir, "b%d.%d" % (self._n, self.rank)), b"x")
         t0 = time.time()
         while True:
             if all(os.path.exists(os.path.join(self.dir, "b%d.%d" % (self._n, r))) for r in range(self.world)):
                 return
+            self._check_abort()
             if time.time() - t0 > timeout:
                 raise RuntimeError("barrier %d timed out on rank %d" % (self._n, self.rank))
             time.sleep(0.0005)
@@ -105,10 +177,7 @@ class Ranks:
             self._single = getattr(self, "_single", {})
             self._single[name] = obj
             return
-        tmp = os.path.join(self.dir, ".%s.%d.tmp" % (name, self.rank))
-        with open(tmp, "wb") as f:
-            f.write(obj if isinstance(obj, bytes) else json.dumps(obj).encode())
-        os.replace(tmp, os.path.join(self.dir, "%s.%d" % (name, self.rank)))
+        self._write(os.path.join(self.dir, "%s.%d" % (name, self.rank)), obj if isinstance(obj, bytes) else json.dumps(obj).encode())
 
     def get(self, name, rank, raw=False, timeout=1800.0):
         if self.world == 1:
@@ -116,6 +185,7 @@ class Ranks:
         path = os.path.join(self.dir, "%s.%d" % (name, rank))
         t0 = time.time()
         while not os.path.exists(path):
+            self._check_abort()
             if time.time() - t0 > timeout:
                 raise RuntimeError("waiting for %s timed out" % path)
             time.sleep(0.001)
@@ -127,6 +197,36 @@ class Ranks:
         self.put(name, obj)
         self.barrier()
         return [self.get(name, r) for r in range(self.world)]
+
+    def finish(self):
+        """last call of a rank: after it nobody reads the directory any more; under torchrun rank 0 removes it (the
+        script's own launcher removes the one it made)."""
+        if self.world == 1 or not self.dir:
+            return
+        self.barrier()
+        if self._base is None:
+            return
+        self._write(os.path.join(self.dir, "bye.%d" % self.rank), b"x")
+        if self.rank != 0:
+            try:
+                os.remove(os.path.join(self._base, "join.%d" % self.rank))
+            except OSError:
+                pass
+            return
+        t0 = time.time()
+        while not all(os.path.exists(os.path.join(self.dir, "bye.%d" % r)) for r in range(self.world)) and time.time() - t0 < 60:
+            time.sleep(0.002)
+        import shutil
+        shutil.rmtree(self.dir, ignore_errors=True)
+        for r in range(1, self.world):
+            try:
+                os.remove(os.path.join(self._base, "assign.%d" % r))
+            except OSError:
+                pass
+        try:
+            os.rmdir(self._base)
+        except OSError:
+            pass
 
 
 def log(rk, msg):
@@ -145,9 +245,19 @@ def launch(args):
         env = dict(os.environ, DR_BENCH_RANK=str(r), DR_BENCH_WORLD=str(args.gpus), DR_BENCH_SYNC_DIR=syncdir)
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = p.wait() or rc
+    # watch every child: the first failure ends the job (the others would sit in a barrier until its timeout)
+    rc, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for o in live:
+                    o.terminate()
+        time.sleep(0.02)
     for f in os.listdir(syncdir):
         try:
             os.remove(os.path.join(syncdir, f))
@@ -184,28 +294,68 @@ def alg_bytes(st, D, R, m, k, row_bytes=None):
     return float(per_q.sum()) + 4 * 256 * D, per_q
 
 
+def isolated_pq_scan(device, n_codes=64_000_000, m=32, D=128, nq=4):
+    """north_star's "PQ-scan kernel >= 40 % of the HBM-read roofline": the isolated ADC kernel (pq_scan_kernel: table in LDS,
+    code words streamed, strict sequential float sum) over a table of random code words far larger than L2 + Infinity
+    Cache (2 GB); algorithmic bytes = N*m per query, duration from HIP events around the launch."""
+    from diskrag_amd import HipIndex
+    rs = np.random.default_rng(5)
+    codes = rs.integers(0, 256, size=(n_codes, m), dtype=np.uint8)
+    cb = rs.standard_normal((m, 256, D // m), dtype=np.float32)
+    q = rs.standard_normal((nq, D), dtype=np.float32)
+    sc = HipIndex.create_codes(np.zeros((n_codes, 1), dtype=np.uint32), 0, D, cb, codes, device=device)
+    del codes
+    ms = sorted(sc.pq_scan_best(q)[2] for _ in range(5))
+    sc.close()
+    gbps = nq * n_codes * m / (ms[2] * 1e-3) / 1e9
+    return {"kernel": "pq_scan_kernel<2>", "code_bytes_per_launch": nq * n_codes * m, "kernel_ms_median": ms[2], "GBps": gbps,
+            "frac": gbps / HBM_PEAK_GBPS, "queries_per_launch": nq}
+
+
 def worker(args):
     rk = Ranks()
+    try:
+        rc = worker_c5(args, rk) if args.config == "c5" else worker_c2(args, rk)
+    except BaseException as e:          # the other ranks stop waiting for this one
+        rk.abort("%s: %s" % (type(e).__name__, e))
+        raise
+    rk.finish()
+    return rc
+
+
+def slice_of(nq, world, rank):
+    """strong scaling: rank r owns the contiguous slice [lo, hi) of every nq-query batch"""
+    return (nq * rank) // world, (nq * (rank + 1)) // world
+
+
+def worker_c2(args, rk):
     stub = os.environ.get("DR_BENCH_STUB") == "1"
-    if args.config == "c5":
-        return worker_c5(args, rk)
+    strong = args.scaling == "strong"
+    lo, hi = slice_of(args.nq, rk.world, rk.rank) if strong else (0, args.nq)
     nb = max(1, min(args.nb, 16))
-    nq, k, D = args.nq, args.k, args.dim
+    nq_job, k, D = args.nq, args.k, args.dim     # queries per batch of the whole job
+    nq = hi - lo                                 # ... and of this rank (strong scaling: its slice)
+    if nq < 1:
+        raise RuntimeError("strong scaling: rank %d has an empty slice (%d queries over %d ranks)" % (rk.rank, nq_job, rk.world))
     launches = args.steps * args.bps
 
     if stub:
+        if os.environ.get("DR_BENCH_STUB_FAIL_RANK") == str(rk.rank):
+            raise RuntimeError("stub failure requested on rank %d" % rk.rank)
         time.sleep(0.05 * (1 + rk.rank))
         rk.barrier()
         t0 = time.perf_counter()
         time.sleep(0.001 * launches)
         el = time.perf_counter() - t0
         times = rk.gather("t", el)
+        slices = rk.gather("slice", [lo, hi])
         if rk.rank == 0:
-            print(json.dumps({"metric": "launcher self-test (stub engine)", "value": nq * launches * rk.world / max(times),
+            total_q = nq_job * launches * (1 if strong else rk.world)
+            print(json.dumps({"metric": "launcher self-test (stub engine)", "value": total_q / max(times),
                               "unit": "queries/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": max(times) / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                              "ms_per_step": max(times) / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
                               "vs_baseline": None, "dtype": "none", "data": "stub",
-                              "config": {"workload": "stub", "per_rank_seconds": times}}), flush=True)
+                              "config": {"workload": "stub", "per_rank_seconds": times, "per_rank_slice": slices}}), flush=True)
         return 0
 
     import diskrag_amd
@@ -220,7 +370,12 @@ def worker(args):
 
     # ---------------------------------------------------------------- setup (untimed): data, graph, PQ, ground truth
     t0 = time.time()
-    x, q_all = sift_like(args.n, D, n_queries=nq * nb, n_clusters=1024, seed=2024, query_seed=9000 + rk.rank)
+    if strong:      # the job's batches are the same on every rank; this rank keeps its slice of each
+        x, q_job = sift_like(args.n, D, n_queries=nq_job * nb, n_clusters=1024, seed=2024, query_seed=9000)
+        q_all = np.ascontiguousarray(q_job.reshape(nb, nq_job, D)[:, lo:hi].reshape(nb * nq, D))
+        del q_job
+    else:
+        x, q_all = sift_like(args.n, D, n_queries=nq * nb, n_clusters=1024, seed=2024, query_seed=9000 + rk.rank)
     log(rk, f"synthetic data {x.shape} + {nb} distinct batches of {nq} queries in {time.time() - t0:.1f}s")
     t0 = time.time()
     ix = HipIndex.create_empty(x, R=args.R, device=device)
@@ -304,17 +459,32 @@ def worker(args):
     tm_head = ix.timing()
     times = rk.gather("t_head", elapsed)
     elapsed_job = max(times)
-    value = nq * launches * rk.world / elapsed_job
+    slices = rk.gather("slice", [lo, hi])
+    if strong and rk.rank == 0:      # the slices tile every batch exactly once
+        edges = sorted(slices)
+        if edges[0][0] != 0 or edges[-1][1] != nq_job or any(a[1] != b[0] for a, b in zip(edges, edges[1:])):
+            raise RuntimeError("strong scaling: slices %s do not tile [0, %d)" % (edges, nq_job))
+    total_q = launches * (nq_job if strong else nq * rk.world)      # queries the whole job answered in the timed region
+    value = total_q / elapsed_job
 
     # ---------------------------------------------------------------- the same rotation, batches resident in HBM
     rk.barrier()
     el_res, tm_res = run_resident(args.bw, launches)
     res_times = rk.gather("t_res", el_res)
-    qps_resident = nq * launches * rk.world / max(res_times)
+    qps_resident = total_q / max(res_times)
 
     # results of every distinct batch: recall, counters, algorithmic bytes
     ids, dist_out, st = collect(args.bw)
-    recall = recall_at_k(ids, gt, k)
+    # the pipelined path (what `value` times) must have produced the same answers as the resident path the recall is
+    # computed from: its last waited batch against the same batch of collect()
+    lb = (launches - 1) % nb
+    if not (np.array_equal(last[0], ids[lb * nq:(lb + 1) * nq]) and
+            np.array_equal(last[1].view(np.uint32), dist_out[lb * nq:(lb + 1) * nq].view(np.uint32)) and
+            np.array_equal(last[3]["status"], st["status"][lb * nq:(lb + 1) * nq])):
+        raise RuntimeError("the pipelined path (dr_search_submit/wait) and the resident path disagree on batch %d" % lb)
+    recall_local = recall_at_k(ids, gt, k)
+    recalls = rk.gather("recall", [recall_local, nq])
+    recall = sum(r * n for r, n in recalls) / sum(n for _, n in recalls) if strong else recall_local
     if recall < args.min_recall:
         raise RuntimeError(f"recall@{k} = {recall:.4f} is below the metric's bar {args.min_recall}")
     variant = ix.timing()["variant"]
@@ -327,11 +497,17 @@ def worker(args):
     qb_pageable = [np.array(a) for a in qb[:min(nb, 4)]]
     el_pg, _ = run_pipelined(max(8, launches // 8), qb_pageable)
     qps_pageable = nq * max(8, launches // 8) / el_pg
-    # ... and one blocking dr_search_batch call, as round 1 reported it
+    # ... and SURVEY.md 8d's literal metric: nq / wall time of ONE blocking dr_search_batch call (upload, search, tie order,
+    # download, nothing overlapped), median over --blocking-calls calls rotating the distinct batches (pageable sources)
     ix.batch_select(15)             # (a blocking call uploads into the selected resident batch: keep it off the bench's)
-    t1 = time.perf_counter()
-    ix.search_batch(qb_pageable[0], k, L=args.L, beam_width=args.bw, mode=mode)
-    qps_one_call = nq / (time.perf_counter() - t1)
+    call_s = []
+    for i in range(max(3, args.blocking_calls) + 2):
+        src = qb_pageable[i % len(qb_pageable)]
+        t1 = time.perf_counter()
+        ix.search_batch(src, k, L=args.L, beam_width=args.bw, mode=mode)
+        call_s.append(time.perf_counter() - t1)
+    call_s = sorted(call_s[2:])     # (the first two calls size the slot's buffers)
+    qps_one_call = nq / call_s[len(call_s) // 2]
     if nb == 16:
         ix.batch_upload(qb[15])
     ix.batch_select(0)
@@ -339,13 +515,15 @@ def worker(args):
     # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 read
     # correction applied): collected offline on this same workload by scripts/profile_run.sh, committed under profiles/
     traffic, traffic_src = None, None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         pmc = ROOT / "profiles" / rnd / "pmc_traffic.json"
         if traffic is None and pmc.exists() and (args.n, nq, D, args.R, args.L, args.m) == (1_000_000, 10_000, 128, 64, 100, 32):
             rec = json.loads(pmc.read_text()).get("beam_width_%d" % args.bw)
-            if rec and (rnd == "r02" or variant == 13):
+            if rec and (rnd != "r01" or variant == 13):
                 traffic = rec["hbm_bytes_per_launch"]
-                traffic_src = "profiles/%s/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over scripts/pmc_target.py: the same workload, not this run)" % rnd
+                traffic_src = ("profiles/%s/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over scripts/pmc_target.py "
+                               "-- the same workload and build, collected by scripts/profile_run.sh in ANOTHER run on another box of the pool (a PMC pass "
+                               "cannot share a process with the timed region); hbm_frac divides it by THIS run's kernel time") % rnd
 
     byte_rows = variant in (11, 13)
     # the kernel's own necessary bytes: a scored vector is D bytes for the byte-row variants, 4D for float rows
@@ -374,23 +552,46 @@ def worker(args):
             if variant == 13:
                 float_queries = forced(11)  # byte rows, float32 queries: integer data, queries that are not
 
+    # What one GPU does with the per-GPU slice of a strong-scaling job ("1250 at G = 8 no longer fills the
+    # chip -- report that knee"): the same pipelined stream with every batch cut to nq/G queries, on this one GPU.
+    small_batch = pq_scan = None
+    if not args.no_secondary and rk.world == 1:
+        small_batch = {}
+        for g in (2, 4, 8):
+            n_g = nq // g
+            if n_g < 1:
+                continue
+            srcs = [a[:n_g] for a in qb]
+            run_pipelined(12, srcs)
+            el_g, _ = run_pipelined(max(40, launches // 2), srcs)
+            ix.batch_sync()
+            small_batch["%d_queries_per_batch" % n_g] = {"qps": n_g * max(40, launches // 2) / el_g, "as_gpus_of_a_strong_scaling_job": g,
+                                                      "kernel_ms": ix.timing()["search_kernel_ms"]}
+        pq_scan = isolated_pq_scan(device)
+
     out = {
         "metric": "QPS @ recall@10>=0.95, SIFT1M-shaped d=128 L2, batch=10k",
         "value": value, "unit": "queries/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed_job / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": elapsed_job / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": ("f32 (lossless u8 rows+queries, v_dot4: integer arithmetic that equals the reference's float32 sums bit for bit)"
                   if variant == 13 else "f32 (lossless u8 rows)" if variant == 11 else "f32"),
         "data": "synthetic",
         "config": {"workload": "SIFT1M-shaped synthetic (configs[1]): N=%d d=%d L2, R=%d, L_search=%d, PQ m=%d, beam_width=%s, "
                                "k=%d, batch=%d queries, mode=M1 reference-faithful; a step = %d consecutive batches, %d distinct "
                                "batches per GPU rotating; value = host memory -> host memory (dr_search_submit/wait, 3 batches in flight)"
-                               % (args.n, D, args.R, args.L, args.m, args.bw or None, k, nq, args.bps, nb),
-                   "recall_at_10": recall, "build_seconds": build_s, "parallelism": "query-sharded replicas x%d" % rk.world,
+                               % (args.n, D, args.R, args.L, args.m, args.bw or None, k, nq_job, args.bps, nb)
+                               + ("; STRONG scaling: every batch is cut into %d contiguous slices, one per GPU (slice of rank 0: %d queries)" % (rk.world, nq) if strong else ""),
+                   "recall_at_10": recall, "build_seconds": build_s,
+                   "parallelism": ("query-sharded replicas x%d, one batch split over the ranks" if strong else "query-sharded replicas x%d") % rk.world,
+                   "per_rank_slice": slices if strong else None,
                    "ms_per_batch": elapsed_job / launches * 1e3, "timed_region_s": elapsed_job, "per_rank_seconds": times,
-                   "per_rank_qps": [nq * launches / t for t in times],
+                   "per_rank_qps": [(sl[1] - sl[0]) * launches / t for sl, t in zip(slices, times)],
                    "qps_resident": qps_resident, "ms_per_batch_resident": max(res_times) / launches * 1e3,
                    "kernel_ms_resident": tm_res["search_kernel_ms"],
-                   "qps_pcie_inclusive_pageable_source": qps_pageable, "qps_one_blocking_call": qps_one_call,
+                   "qps_pcie_inclusive_pageable_source": qps_pageable,
+                   "qps_blocking_call": {"median": qps_one_call, "calls": len(call_s), "best": nq / call_s[0], "worst": nq / call_s[-1],
+                                         "note": "SURVEY.md 8d's literal metric: nq / wall time of one blocking dr_search_batch call "
+                                                 "(pageable source; upload + search + tie order + download, nothing overlapped)"},
                    "per_query": {"expansions": float(st["steps"].mean()), "pq_distances": float(st["pq"].mean()),
                                  "pq_evaluated": float(st["pq_evaluated"].mean()), "exact_distances": float(st["exact"].mean()),
                                  "algorithmic_bytes": float(per_q.mean())},
@@ -401,7 +602,8 @@ def worker(args):
                                    "roofline.traffic is what HBM really moved") if byte_rows else "f32",
                    "query_storage": ("u8: every component of the batch is an integer in [0, 255] (checked per batch on the host)"
                                      if variant == 13 else "f32"),
-                   "float32_rows": float_rows, "byte_rows_float32_queries": float_queries},
+                   "float32_rows": float_rows, "byte_rows_float32_queries": float_queries,
+                   "small_batches_on_one_gpu": small_batch, "pq_scan": pq_scan},
         "roofline": {"bound": "hbm", "kernel": "search_kernel<128,M1> variant %d" % variant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "hbm_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
@@ -476,7 +678,6 @@ def worker(args):
     if rk.rank == 0:
         print(json.dumps(out), flush=True)
     ix.close()
-    rk.barrier()
     return 0
 
 
@@ -540,7 +741,6 @@ def worker_c5(args, rk):
         print(json.dumps(out), flush=True)
     comm.close()
     ix.close()
-    rk.barrier()
     return 0
 
 

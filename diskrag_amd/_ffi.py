@@ -13,6 +13,7 @@ LIB_PATH = Path(_os.environ["DR_LIB"]) if _os.environ.get("DR_LIB") else PKG_DIR
 
 PAD = 0xFFFFFFFF
 MODE_M1, MODE_M2, MODE_M3, MODE_M4 = 1, 2, 3, 4
+PIPE_DEPTH = 3          # DR_PIPE_DEPTH (csrc/engine.hip): batches in flight per handle
 MODE_PQ = 5      # engine mode without a reference counterpart: M1's loop on squared ADC distances only (diskrag_hip.h)
 F_USE_PQ, F_SQDIST, F_RERANK = 1, 2, 4
 MAX_RESIDENT = 16
@@ -29,7 +30,7 @@ class DrStats(C.Structure):
 class DrTiming(C.Structure):
     _fields_ = [("h2d_ms", C.c_float), ("search_kernel_ms", C.c_float), ("finalize_kernel_ms", C.c_float),
                 ("d2h_ms", C.c_float), ("total_ms", C.c_float), ("grid", C.c_uint32), ("block", C.c_uint32),
-                ("lds_bytes", C.c_uint32), ("waves_per_cu", C.c_uint32), ("variant", C.c_uint32)]
+                ("lds_bytes", C.c_uint32), ("waves_per_cu", C.c_uint32), ("variant", C.c_uint32), ("lut_kernel_ms", C.c_float)]
 
 
 STATS_DTYPE = np.dtype([("steps", "<u4"), ("visited", "<u4"), ("exact", "<u4"), ("pq", "<u4"), ("status", "<u4"),
@@ -323,8 +324,9 @@ class HipIndex:
 
     def close(self):
         if self._h:
-            load_library().dr_index_close(self._h)
+            load_library().dr_index_close(self._h)       # drains every stream; unfinished jobs are dropped, not delivered
             self._h = None
+            self.__dict__.pop("_inflight", None)
 
     def __del__(self):
         try:
@@ -399,6 +401,14 @@ class HipIndex:
                                                _p(job.cnt, C.c_uint32), job.stats.ctypes.data_as(C.POINTER(DrStats)),
                                                C.byref(t)))
         job.ticket = int(t.value)
+        # The library writes into the job's arrays when the batch is FINISHED -- in wait(), or earlier, when a later submit
+        # reuses its pipeline slot or a build / set_pq quiesces the handle. A caller that drops the job without wait()
+        # (an exception between submit and wait) must not free them under the library: the index keeps every submitted
+        # job until the library can no longer touch it (its slot has been reused: ticket <= newest - PIPE_DEPTH).
+        live = self.__dict__.setdefault("_inflight", {})
+        live[job.ticket] = job
+        for tk in [tk for tk in live if tk + PIPE_DEPTH <= job.ticket]:
+            del live[tk]
         return job
 
     def batch_upload(self, queries):
@@ -525,6 +535,7 @@ class PendingSearch:
     def wait(self):
         _check(load_library().dr_search_wait(self._index._h, self.ticket))
         self._q = None
+        self._index.__dict__.get("_inflight", {}).pop(self.ticket, None)
         return self.ids, self.dist, self.cnt, self.stats
 
 

@@ -101,9 +101,10 @@ template <class T> struct DevBuf {
 struct QSlot {
     uint32_t nq = 0;
     DevBuf<float> q, qp, pq_ub;
+    DevBuf<float> lut;           // [nq][m][256] per-query tables of the batch (lut_build_kernel), rebuilt by every search that uses them
     bool pq_ub_valid = false;    // pq_ub matches these queries and the attached codebook
     bool q_u8 = false;           // every component is an integer in [0, 255] (byte-query variants 13/14)
-    void release() { q.release(); qp.release(); pq_ub.release(); nq = 0; pq_ub_valid = false; q_u8 = false; }
+    void release() { q.release(); qp.release(); pq_ub.release(); lut.release(); nq = 0; pq_ub_valid = false; q_u8 = false; }
 };
 #define DR_PIPE_DEPTH 3
 
@@ -131,9 +132,10 @@ struct dr_index {
     // search-kernel launches are timed with a ring of event pairs and harvested at the next sync: dr_batch_run does
     // not wait for its kernel, consecutive steps queue back to back on the stream
     static constexpr int KEV = 32;
-    std::array<hipEvent_t, 2> kev[KEV] = {};
+    std::array<hipEvent_t, 3> kev[KEV] = {};     // [0] search kernel start (= end of its table build), [1] its end, [2] table build start
+    bool kev_lut[KEV] = {};
     int kev_pending = 0;
-    double kms_sum = 0.0; uint32_t kms_n = 0;
+    double kms_sum = 0.0, lms_sum = 0.0; uint32_t kms_n = 0;
     std::mutex mu;
 
     DevBuf<float> vecp;
@@ -144,8 +146,6 @@ struct dr_index {
     DevBuf<uint8_t> nbcodes;      // [N][R][m] inline neighbour codes (dr_index_inline_codes), rebuilt before the next search when stale
     bool inline_codes = false, nbcodes_valid = false;
     DevBuf<float> codebook;
-    DevBuf<float> codebook_p;     // chain-major copy of the codebook (sub_dim % 8 == 0, >= 16): built before the next search that builds per-query tables
-    bool codebook_p_valid = false;
     DevBuf<float> sdc;            // centroid-pair table [m][256][256] (PQ-only builder), built on first use
     DevBuf<uint32_t> perm;
     std::vector<uint32_t> h_perm;
@@ -227,7 +227,7 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     HIPCHK(hipStreamCreateWithFlags(&ix->down_stream, hipStreamNonBlocking));
     for (auto &jb : ix->jobs) { HIPCHK(hipEventCreateWithFlags(&jb.up_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&jb.down_done, hipEventDisableTiming)); }
     for (auto &e : ix->ev) HIPCHK(hipEventCreate(&e));
-    for (auto &pr : ix->kev) { HIPCHK(hipEventCreate(&pr[0])); HIPCHK(hipEventCreate(&pr[1])); }
+    for (auto &pr : ix->kev) { HIPCHK(hipEventCreate(&pr[0])); HIPCHK(hipEventCreate(&pr[1])); HIPCHK(hipEventCreate(&pr[2])); }
     for (auto &bs : ix->sets) { HIPCHK(hipEventCreate(&bs.search_done)); HIPCHK(hipEventCreate(&bs.fin_start)); HIPCHK(hipEventCreate(&bs.fin_done)); }
     ix->h_perm.resize(D);
     pw_build_perm_rec(0, D, ix->h_perm.data());
@@ -359,7 +359,6 @@ extern "C" int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_
     HIPCHK(hipMemcpy(ix->codebook.p, codebook, (size_t)256 * ix->D * 4, hipMemcpyHostToDevice));
     ix->m = m; ix->sd = ix->D / m;
     for (auto &qs : ix->slots) qs.pq_ub_valid = false;
-    ix->codebook_p_valid = false;
     ix->adc_live = -1; ix->nbcodes_valid = false;
     return 0;
 }
@@ -401,7 +400,7 @@ extern "C" void dr_index_close(dr_index *ix)
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) if (st) (void)hipStreamSynchronize(st);
-    ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release(); ix->codebook_p.release(); ix->nbcodes.release(); ix->sdc.release();
+    ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release(); ix->nbcodes.release(); ix->sdc.release();
     ix->perm.release(); ix->vis.release(); ix->vis_epoch.release();
     for (auto &qs : ix->slots) qs.release();
     for (auto &jb : ix->jobs) {
@@ -420,7 +419,7 @@ extern "C" void dr_index_close(dr_index *ix)
     ix->f64_q.release(); ix->f64_dist.release(); ix->f64_ids.release(); ix->f64_cnt.release(); ix->f64_vis.release(); ix->f64_stats.release();
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
-    for (auto &pr : ix->kev) { if (pr[0]) (void)hipEventDestroy(pr[0]); if (pr[1]) (void)hipEventDestroy(pr[1]); }
+    for (auto &pr : ix->kev) for (auto &e : pr) if (e) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     if (ix->fstream) (void)hipStreamDestroy(ix->fstream);
     if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
@@ -622,19 +621,54 @@ static void harvest_kernel_times(dr_index *ix, bool publish)
     // pairs are recorded in launch order on one stream: the finished ones are a prefix of the ring
     int done = 0;
     while (done < ix->kev_pending && hipEventQuery(ix->kev[done][1]) == hipSuccess) {
-        float a = 0;
+        float a = 0, l = 0;
         if (hipEventElapsedTime(&a, ix->kev[done][0], ix->kev[done][1]) == hipSuccess) { ix->kms_sum += a; ix->kms_n++; }
+        if (ix->kev_lut[done] && hipEventElapsedTime(&l, ix->kev[done][2], ix->kev[done][0]) == hipSuccess) ix->lms_sum += l;
         done++;
     }
     (void)hipGetLastError();      // hipErrorNotReady from the query of an unfinished pair is not an error
     if (done) {
         std::rotate(&ix->kev[0], &ix->kev[done], &ix->kev[ix->kev_pending]);
+        std::rotate(&ix->kev_lut[0], &ix->kev_lut[done], &ix->kev_lut[ix->kev_pending]);
         ix->kev_pending -= done;
     }
     if (publish && ix->kms_n) {
         ix->timing.search_kernel_ms = (float)(ix->kms_sum / ix->kms_n);
-        ix->kms_sum = 0.0; ix->kms_n = 0;
+        ix->timing.lut_kernel_ms = (float)(ix->lms_sum / ix->kms_n);
+        ix->kms_sum = 0.0; ix->lms_sum = 0.0; ix->kms_n = 0;
     }
+}
+
+// A2 for a whole batch (engine_kernels.hpp lut_build_kernel): out[nq][m][256] on the engine's stream.
+static int launch_lut_build(dr_index *ix, const float *d_queries, uint32_t nq, float *d_out)
+{
+    const float *cbp = ix->codebook.p; const float *qp0 = d_queries; uint32_t nqv = nq, Dv = ix->D, mv = ix->m, sdv = ix->sd; float *op = d_out;
+    const void *lfn = nullptr;
+    switch (ix->sd) {
+    case 2: lfn = reinterpret_cast<const void *>(&lut_build_kernel<2>); break;
+    case 3: lfn = reinterpret_cast<const void *>(&lut_build_kernel<3>); break;
+    case 4: lfn = reinterpret_cast<const void *>(&lut_build_kernel<4>); break;
+    case 6: lfn = reinterpret_cast<const void *>(&lut_build_kernel<6>); break;
+    case 8: lfn = reinterpret_cast<const void *>(&lut_build_kernel<8>); break;
+    case 12: lfn = reinterpret_cast<const void *>(&lut_build_kernel<12>); break;
+    case 16: lfn = reinterpret_cast<const void *>(&lut_build_kernel<16>); break;
+    case 24: lfn = reinterpret_cast<const void *>(&lut_build_kernel<24>); break;
+    case 32: lfn = reinterpret_cast<const void *>(&lut_build_kernel<32>); break;
+    case 48: lfn = reinterpret_cast<const void *>(&lut_build_kernel<48>); break;
+    case 64: lfn = reinterpret_cast<const void *>(&lut_build_kernel<64>); break;
+    case 96: lfn = reinterpret_cast<const void *>(&lut_build_kernel<96>); break;
+    default: break;
+    }
+    // workgroups: m sub-quantisers x as many query strides as fill the chip a few times over
+    const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nq, ((uint64_t)ix->num_cu * 16 + ix->m - 1) / ix->m));
+    if (lfn) {
+        void *largs[] = { &cbp, &qp0, &nqv, &Dv, &mv, &op };
+        HIPCHK(hipLaunchKernel(lfn, dim3(gx, ix->m), dim3(256), largs, 0, ix->stream));
+    } else {
+        void *largs[] = { &cbp, &qp0, &nqv, &Dv, &mv, &sdv, &op };
+        HIPCHK(hipLaunchKernel(reinterpret_cast<const void *>(&lut_build_generic_kernel), dim3(gx, ix->m), dim3(256), largs, 0, ix->stream));
+    }
+    return 0;
 }
 
 static int finish_job_locked(dr_index *ix, int j);
@@ -668,20 +702,28 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // uses 1). The byte variants need integer-valued data / queries and are skipped otherwise.
     static const int NCHR_OF_SC[DR_NUM_SIZECLASS] = { 1, 2, 4, 8, 16 };
     auto lds_of = [&](int kd) -> size_t {
-        const int rb = DR_KIND_RB[kd];
-        const bool qorig_lds = DR_KIND_PQ[kd] && !DR_KIND_LUT[kd] && !rb;          // search_kernel.hpp QORIG_LDS
-        const size_t bloom = (rb || DR_KIND_CB[kd] || ix->D <= 256) ? 512 : 0;      // search_kernel.hpp VB_BITS / 8
-        const bool adc_only = (kd == 2 || kd == 5);                  // no exact distances: no chain-major query copy in LDS
-        const bool adjpre = DR_KIND_QB[kd];                          // search_kernel.hpp ADJPRE
-        const size_t pw = (DR_KIND_LUT[kd] ? (size_t)ix->m * 256 * 4 : 0) + (qorig_lds ? (size_t)ix->D * 4 : 0) +
-                          ((ix->D > 256 && !adc_only) ? (size_t)ix->D * 4 : 0) + 512 + bloom + (adjpre ? 528 : 0) +
-                          (rb ? (size_t)rb * ix->D * (DR_KIND_U8[kd] ? 1 : 4) : (size_t)NCHR_OF_SC[sc] * 64 * 12);
-        return (DR_KIND_CB[kd] ? (size_t)256 * ix->D * 4 : 0) + (size_t)DR_KIND_NW[kd] * pw;
+        const KindDesc &d = DR_KINDS[dr_kind_pos(kd)];
+        const bool qorig_lds = d.pq && !d.lut && !d.rb;                          // search_kernel.hpp QORIG_LDS
+        const size_t bloom = (d.rb || d.cb || ix->D <= 256) ? 512 : 0;           // search_kernel.hpp VB_BITS / 8
+        const bool adc_only = (kd == 2 || kd == 5 || kd == 15);      // no exact distances: no chain-major query copy in LDS
+        const size_t tab = d.lut ? (size_t)(ix->m > (uint32_t)d.treg ? ix->m - d.treg : 0) * 256 * 4 : 0;   // table rows in LDS (the rest in registers)
+        const size_t pw = tab + (qorig_lds ? (size_t)ix->D * 4 : 0) +
+                          ((ix->D > 256 && !adc_only) ? (size_t)ix->D * 4 : 0) + 512 + bloom + (d.qb ? 528 : 0) +     // (528: search_kernel.hpp ADJPRE)
+                          (d.rb ? (size_t)d.rb * ix->D * (d.u8 ? 1 : 4) : (size_t)NCHR_OF_SC[sc] * 64 * 12);
+        return (d.cb ? (size_t)256 * ix->D * 4 : 0) + (size_t)d.nw * pw;
     };
     if (!ov && ix->vec8_state == 0) { const int rcb8 = build_byte_rows(ix); if (rcb8) return rcb8; }
-    auto usable = [&](int kd) { return ix->kern->search[kd][sc] != nullptr && lds_of(kd) <= 160 * 1024 && (!DR_KIND_U8[kd] || ix->vec8_state == 1) &&
-                                       (!DR_KIND_QB[kd] || (ix->cs->q_u8 && !ov)); };
-    static const int PREF_M1[] = { 13, 11, 9, 3, 0 }, PREF_ADC[] = { 5, 2 }, PREF_EX[] = { 14, 12, 8, 1 }, PREF_BUILD[] = { 1, 8 };
+    auto usable = [&](int kd) {
+        const int pos = dr_kind_pos(kd);
+        if (pos < 0 || ix->kern->search[pos][sc] == nullptr || lds_of(kd) > 160 * 1024) return false;
+        const KindDesc &d = DR_KINDS[pos];
+        if (d.treg && ((ix->m & 15u) != 0 || ix->m < 32u || ix->m > 64u || ix->nbcodes.p)) return false;     // (register rows: whole 16-byte code pieces, gathered code words)
+        return (!d.u8 || ix->vec8_state == 1) && (!d.qb || (ix->cs->q_u8 && !ov));
+    };
+    // ADC-only traversals: shared codebook (D <= 128) > table split between LDS and registers (15: twice the wavefronts
+    // per CU of 2 at m = 32; DR_NO_TREG=1 switches it off for A/B) > table in LDS
+    static const bool no_treg = getenv("DR_NO_TREG") != nullptr;
+    static const int PREF_M1[] = { 13, 11, 9, 3, 0 }, PREF_ADC[] = { 5, 15, 2 }, PREF_ADC_NOTREG[] = { 5, 2, 2 }, PREF_EX[] = { 14, 12, 8, 1 }, PREF_BUILD[] = { 1, 8 };
     static const int PREF_M1_LIVE_LUT[] = { 0, 3, 13, 11, 9 }, PREF_M1_LIVE_CB[] = { 3, 0, 13, 11, 9 };
     const bool k_m1 = (mode == DR_MODE_M1), k_adc = pq_only;
     // M1 has two regimes. On SIFT-scale data the rerank policy A4 is provably true for almost every expansion (Q1),
@@ -691,8 +733,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // MEASURED on the first M1 batch an index state serves (its counters are read once that launch has finished, see
     // the end of this function); until then the SIFT-scale preference applies. Results never depend on the variant.
     static const int PREF_BUILD_PQ[] = { 2 };
-    const int *pref = k_m1 ? PREF_M1 : (ov && ov->sdc) ? PREF_BUILD_PQ : k_adc ? PREF_ADC : ov ? PREF_BUILD : PREF_EX;
-    const int npref = k_m1 ? 5 : (ov && ov->sdc) ? 1 : k_adc ? 2 : ov ? 2 : 4;
+    const int *pref = k_m1 ? PREF_M1 : (ov && ov->sdc) ? PREF_BUILD_PQ : k_adc ? (no_treg ? PREF_ADC_NOTREG : PREF_ADC) : ov ? PREF_BUILD : PREF_EX;
+    const int npref = k_m1 ? 5 : (ov && ov->sdc) ? 1 : k_adc ? 3 : ov ? 2 : 4;
     if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 8 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
     int kind = -1;
     for (int i = 0; i < npref && kind < 0; i++) if (usable(pref[i])) kind = pref[i];
@@ -700,14 +742,15 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         static bool env_read = false;
         if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e && !g_force_kind_set) g_force_kind = atoi(e); env_read = true; }
         const int g = g_force_kind;
-        if (g >= 0 && g < DR_NUM_KINDS && usable(g)) {
-            const bool g_m1 = (g == 0 || g == 3 || g == 9 || g == 11 || g == 13), g_adc = (g == 2 || g == 5), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
+        if (g >= 0 && g <= DR_MAX_KIND_ID && usable(g) && !(ov && ov->sdc)) {
+            const bool g_m1 = (g == 0 || g == 3 || g == 9 || g == 11 || g == 13), g_adc = (g == 2 || g == 5 || g == 15), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
             if ((g_m1 && k_m1) || (g_adc && k_adc) || (g_ex && !k_m1 && !k_adc)) kind = g;
         }
     }
     if (kind < 0) return fail(DR_E_UNSUPPORTED, "no kernel variant fits in LDS (D=%u, m=%u, capacity %u)", ix->D, ix->m, cap);
-    const void *kfn = ix->kern->search[kind][sc];
-    const int NW = DR_KIND_NW[kind];
+    const KindDesc &kd_desc = DR_KINDS[dr_kind_pos(kind)];
+    const void *kfn = ix->kern->search[dr_kind_pos(kind)][sc];
+    const int NW = kd_desc.nw;
     const size_t lds = lds_of(kind);
     if (lds > 160 * 1024) return fail(DR_E_UNSUPPORTED, "LDS footprint %zu B exceeds 160 KiB", lds);
     // (kernel attribute + occupancy are asked once per (variant, LDS size): a single-query call is all overhead)
@@ -762,17 +805,6 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.vecp = ix->vecp.p; p.adj = ix->adj.p; p.first = ix->first.p; p.codes = ix->codes.p; p.codebook = ix->codebook.p;
     p.adjr = (!ov && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
     p.nbcodes = (!ov && ix->inline_codes && ix->nbcodes_valid) ? ix->nbcodes.p : nullptr;
-    p.codebook_p = nullptr;
-    if (DR_KIND_LUT[kind] && !(ov && ov->sdc) && ix->D > 256 && (ix->sd == 16 || ix->sd == 24 || ix->sd == 32 || ix->sd == 48)) {      // build_lut_wave's octet cases
-        if (!ix->codebook_p_valid) {
-            if (ix->codebook_p.reserve((size_t)256 * ix->D)) return DR_E_NODEVICE;
-            const uint64_t total = (uint64_t)256 * ix->D;
-            hipLaunchKernelGGL(codebook_perm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ix->stream, ix->codebook.p, ix->codebook_p.p, total, ix->sd);
-            HIPCHK(hipGetLastError());
-            ix->codebook_p_valid = true;
-        }
-        p.codebook_p = ix->codebook_p.p;
-    }
     p.vec8 = ix->vec8_state == 1 ? ix->vec8.p : nullptr;
     p.queries = ix->cs->q.p; p.queries_p = ix->cs->qp.p;
     p.N = ix->N; p.D = ix->D; p.R = ix->R; p.m = ix->m; p.sd = ix->sd; p.medoid = ix->medoid; p.nq = nq;
@@ -821,8 +853,19 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     bs.ticket_base += nq;
     if (!ov && ix->kev_pending == dr_index::KEV) harvest_kernel_times(ix, false);
     if (!ov && ix->kev_pending == dr_index::KEV) { HIPCHK(hipStreamSynchronize(ix->stream)); harvest_kernel_times(ix, false); }
+    p.lut_g = nullptr;
+    const bool want_lut = kd_desc.lut && !(ov && ov->sdc);
+    if (want_lut) {
+        // The per-query tables T[q][j][c] (A2, fast_pq.py:294-318) of the whole batch, built at full occupancy right
+        // before the search kernel that lands them in LDS (engine_kernels.hpp lut_build_kernel). Built by EVERY search --
+        // a table is part of its query's search, not of the upload -- and timed separately (dr_timing.lut_kernel_ms).
+        if (ix->cs->lut.reserve((size_t)nq * ix->m * 256)) return DR_E_NODEVICE;
+        if (!ov) HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][2], ix->stream));
+        { const int rcl = launch_lut_build(ix, ix->cs->q.p, nq, ix->cs->lut.p); if (rcl) return rcl; }
+        p.lut_g = ix->cs->lut.p;
+    }
     void *args[] = { &p };
-    if (!ov) HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][0], ix->stream));
+    if (!ov) { ix->kev_lut[ix->kev_pending] = want_lut; HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][0], ix->stream)); }
     {
         const hipError_t le = hipLaunchKernel(kfn, dim3(grid), dim3(64 * NW), args, lds, ix->stream);
         if (le != hipSuccess) { bs.counters_zeroed = false; return fail(DR_E_NODEVICE, "search kernel launch failed: %s", hipGetErrorString(le)); }
@@ -950,7 +993,7 @@ static int download_locked(dr_index *ix, uint32_t *out_ids, float *out_dist, uin
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ix->ev[4], ix->ev[5]);
     ix->timing.d2h_ms = ms;
-    ix->timing.total_ms = ix->timing.h2d_ms + ix->timing.search_kernel_ms + ix->timing.finalize_kernel_ms + ms;
+    ix->timing.total_ms = ix->timing.h2d_ms + ix->timing.lut_kernel_ms + ix->timing.search_kernel_ms + ix->timing.finalize_kernel_ms + ms;
     return 0;
 }
 
@@ -1049,6 +1092,10 @@ extern "C" int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq,
         }
     }
     const bool q_u8 = (ix->vec8_state == 1 || (ix->vec8_state == 0 && ix->D == 128)) && queries_are_u8(src, (size_t)nq * ix->D);
+    // From here on copies that read jb.pin_in / write jb.pin_out may be queued: a failure must not hand the slot back
+    // (jb.active stays false, the next submit would overwrite the staging buffers under a copy in flight) before those
+    // copies have drained.
+    const int rcq = [&]() -> int {
     int rc = upload_slot_async(ix, qs, src, nq, ix->up_stream);
     if (rc) return rc;
     qs.q_u8 = q_u8;
@@ -1081,6 +1128,17 @@ extern "C" int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq,
     HIPCHK(hipMemcpyAsync(hp + 2 * b_ids + b_cnt, bs.stats.p, b_st, hipMemcpyDeviceToHost, ix->down_stream));
     HIPCHK(hipMemcpyAsync(hp + 2 * b_ids + b_cnt + b_st, ix->fin_stat.p, 4, hipMemcpyDeviceToHost, ix->down_stream));
     HIPCHK(hipEventRecord(jb.down_done, ix->down_stream));
+    return 0;
+    }();
+    if (rcq) {
+        const std::string keep_msg = g_err;       // (the drain below must not replace the message of the real failure)
+        for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) (void)hipStreamSynchronize(st);
+        (void)hipGetLastError();
+        g_err = keep_msg;
+        return rcq;
+    }
+    const int set = ix->last_set;
+    dr_index::BatchSet &bs = ix->sets[set];
     jb.active = true; jb.ticket = ix->next_ticket++; jb.set = set; jb.nq = nq; jb.k = k;
     jb.out_ids = out_ids; jb.out_dist = out_dist; jb.out_count = out_count; jb.stats = stats;
     bs.owner_job = j;
@@ -1259,10 +1317,7 @@ extern "C" int dr_distance_table(dr_index *ix, const float *queries, uint32_t nq
     if (rc) return rc;
     DevBuf<float> o;
     if (o.reserve((size_t)nq * ix->m * 256)) return DR_E_NODEVICE;
-    const size_t lds = (size_t)ix->D * 4 + (size_t)ix->m * 256 * 4;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&lut_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(lut_kernel, dim3(nq), dim3(64), lds, ix->stream, ix->codebook.p, ix->cs->q.p, ix->D, ix->m, ix->sd, o.p);
-    HIPCHK(hipGetLastError());
+    { const int rcl = launch_lut_build(ix, ix->cs->q.p, nq, o.p); if (rcl) return rcl; }      // the kernel the searches use
     HIPCHK(hipMemcpyAsync(out, o.p, (size_t)nq * ix->m * 256 * 4, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
     o.release();
@@ -1314,11 +1369,19 @@ extern "C" int dr_pq_scan(dr_index *ix, const float *queries, uint32_t nq, float
 
 // Flat scan of all N code words per query (pq_scan_kernel): out_sq (optional) gets every squared ADC distance,
 // out_best_id / out_best_sq (optional) the nearest code word per query (smallest id among equal sums).
+static int pq_scan_best_locked(dr_index *ix, const float *queries, uint32_t nq, float *out_sq, uint32_t *out_best_id,
+                               float *out_best_sq, float *kernel_ms);
 extern "C" int dr_pq_scan_best(dr_index *ix, const float *queries, uint32_t nq, float *out_sq, uint32_t *out_best_id,
                                float *out_best_sq, float *kernel_ms)
 {
     if (!ix || !queries || nq == 0) return fail(DR_E_ARG, "bad argument");
     std::lock_guard<std::mutex> lk(ix->mu);
+    return pq_scan_best_locked(ix, queries, nq, out_sq, out_best_id, out_best_sq, kernel_ms);
+}
+// (the caller holds ix->mu: the PQ-only builder scans for its medoid in the middle of a build)
+static int pq_scan_best_locked(dr_index *ix, const float *queries, uint32_t nq, float *out_sq, uint32_t *out_best_id,
+                               float *out_best_sq, float *kernel_ms)
+{
     if (ix->m == 0) return fail(DR_E_NOPQ, "no PQ data");
     const uint32_t m = ix->m;
     if ((m & 15u) != 0 || m > 64) {
@@ -1454,7 +1517,7 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
     if (L_build == 0 || L_build > 256) return fail(DR_E_ARG, "L_build must be in 1..256");
     if (ix->R > 128) return fail(DR_E_UNSUPPORTED, "builder supports R <= 128");
     if (passes == 0) passes = 2;
-    std::unique_lock<std::mutex> lk(ix->mu);
+    std::lock_guard<std::mutex> lk(ix->mu);
     if (!pq) { const int rcv = need_vectors(ix, "dr_build_vamana"); if (rcv) return rcv; }
     if (pq && ix->m == 0) return fail(DR_E_NOPQ, "dr_build_vamana_pq needs the code words (dr_index_create_codes_empty + dr_pq_encode_rows)");
     HIPCHK(hipSetDevice(ix->device));
@@ -1463,7 +1526,8 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
     const uint32_t D = ix->D, R = ix->R;
     const uint32_t RX = R + 64;                       // slack slots for reverse edges inside one batch
     if (max_batch == 0) max_batch = 32768;
-    hipEvent_t t0, t1;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    struct EvPair { hipEvent_t &a, &b; ~EvPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evp{ t0, t1 };   // every early return frees them
     HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
     HIPCHK(hipEventRecord(t0, ix->stream));
 
@@ -1512,10 +1576,8 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
                 mean[jq * ix->sd + t] = (float)(a / (double)N);
             }
         // flat scan for the nearest code word (pq_scan_kernel through the regular entry point's machinery)
-        ix->mu.unlock();
         uint32_t best = 0; float bsq = 0, kms = 0;
-        const int rcs = dr_pq_scan_best(ix, mean.data(), 1, nullptr, &best, &bsq, &kms);
-        ix->mu.lock();
+        const int rcs = pq_scan_best_locked(ix, mean.data(), 1, nullptr, &best, &bsq, &kms);
         if (rcs) return rcs;
         ix->medoid = best;
     }
@@ -1667,7 +1729,6 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
     HIPCHK(hipStreamSynchronize(ix->stream));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, t0, t1);
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     adjb.release(); deg.release(); order.release(); fwd.release(); fwd_n.release(); ovf_list.release(); ovf_count.release();
     ix->cs->nq = 0;
     if (out_medoid) *out_medoid = ix->medoid;
@@ -1956,7 +2017,6 @@ extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uin
     HIPCHK(hipStreamSynchronize(ix->stream));
     ix->m = m; ix->sd = ix->D / m;
     for (auto &qs : ix->slots) qs.pq_ub_valid = false;
-    ix->codebook_p_valid = false;
     ix->adc_live = -1; ix->nbcodes_valid = false;
     return 0;
 }
@@ -1995,7 +2055,7 @@ extern "C" int dr_index_inline_codes(dr_index *ix, int enable)
 
 extern "C" int dr_debug_force_kind(dr_index *ix, int kind, int *out_adc_live)
 {
-    if (kind >= DR_NUM_KINDS) return fail(DR_E_ARG, "unknown kernel variant %d", kind);
+    if (kind > DR_MAX_KIND_ID || (kind >= 0 && dr_kind_pos(kind) < 0)) return fail(DR_E_ARG, "unknown kernel variant %d", kind);
     g_force_kind = kind < 0 ? -1 : kind;
     g_force_kind_set = true;
     if (ix && out_adc_live) { std::lock_guard<std::mutex> lk(ix->mu); *out_adc_live = ix->adc_live; }

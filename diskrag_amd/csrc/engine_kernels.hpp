@@ -196,21 +196,47 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeParams p)
     }
 }
 
-// ---- PQ entry points
-__global__ __launch_bounds__(64) void lut_kernel(const float *__restrict__ codebook, const float *__restrict__ queries,
-                                                 u32 D, u32 m, u32 sd, float *__restrict__ out)
+// ---- A2 for a whole batch: T[q][j][c] = sum((C_j[c] - q_j)^2) in numpy's order (fast_pq.py:294-318) ----------------------
+// The per-query-table search variants used to build their table inside the search kernel: one wavefront, 4-8 wavefronts
+// per CU (the table itself caps them), 128 dependent round trips to the codebook at D = 1536 -- a quarter of the c3 kernel
+// and 40 % of the PQ-only traversal. The table does not depend on the traversal, so it is built for the whole batch by
+// this kernel at full occupancy: a workgroup owns one sub-quantiser j, thread c keeps centroid c of j in registers, and
+// walks the batch's queries -- the query's sub-vector is wave-uniform (scalar loads, SGPR operands), the centroid never
+// moves, every store is a coalesced KiB. Same operations in the same order as build_lut_sd (pw_run_regs): the same bits.
+// 10 000 queries x 1536 (m = 32): 1.2e10 lane operations and 320 MB written.
+template <int SD>
+__global__ __launch_bounds__(256) void lut_build_kernel(const float *__restrict__ codebook, const float *__restrict__ queries,
+                                                        u32 nq, u32 D, u32 m, float *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *q = reinterpret_cast<float *>(smem);
-    float *lut = q + D;
-    const u32 qi = blockIdx.x;
-    for (u32 i = threadIdx.x; i < D; i += 64) q[i] = queries[(size_t)qi * D + i];
-    WSYNC();
-    build_lut_wave(lut, codebook, q, m, sd);
-    WSYNC();
-    for (u32 e = threadIdx.x; e < m * 256; e += 64) out[(size_t)qi * m * 256 + e] = lut[e];
+    const u32 jq = blockIdx.y, c = threadIdx.x;
+    float cen[SD];
+    const float *src = codebook + ((size_t)jq * 256 + c) * SD;
+    if constexpr (SD % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < SD; i += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + i);
+            cen[i] = v.x; cen[i + 1] = v.y; cen[i + 2] = v.z; cen[i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SD; i++) cen[i] = src[i];
+    }
+    for (u32 q = blockIdx.x; q < nq; q += gridDim.x) {
+        const float *qs = queries + (size_t)q * D + jq * SD;       // uniform over the workgroup
+        out[((size_t)q * m + jq) * 256 + c] = pw_run_regs<SD>(cen, qs);
+    }
+}
+// any other sub_dim (<= 128): the centroid is read from global memory (L2) per query
+__global__ __launch_bounds__(256) void lut_build_generic_kernel(const float *__restrict__ codebook, const float *__restrict__ queries,
+                                                                u32 nq, u32 D, u32 m, u32 sd, float *__restrict__ out)
+{
+    const u32 jq = blockIdx.y, c = threadIdx.x;
+    const float *src = codebook + ((size_t)jq * 256 + c) * sd;
+    for (u32 q = blockIdx.x; q < nq; q += gridDim.x)
+        out[((size_t)q * m + jq) * 256 + c] = pw_run_lane(src, queries + (size_t)q * D + jq * sd, (int)sd);
 }
 
+// ---- PQ entry points
 // ADC for listed nodes (ids != nullptr) or a flat scan of all N codes (ids == nullptr): the table sits in LDS,
 // each lane owns one code word and adds its m table entries in sub-quantiser order.
 __global__ __launch_bounds__(256) void adc_kernel(const float *__restrict__ codebook, const float *__restrict__ queries,
@@ -553,19 +579,5 @@ __global__ void inline_codes_kernel(const u32 *__restrict__ adj, const u8 *__res
         u32 v = 0u;
         if ((u64)id < N) v = reinterpret_cast<const u32 *>(codes + (size_t)id * m)[w];
         reinterpret_cast<u32 *>(nbcodes)[t] = v;
-    }
-}
-
-// Chain-major copy of the codebook for build_lut_octet (search_kernel.hpp): within every entry of sd floats (one leaf of
-// the pairwise tree: sd <= 128, sd % 8 == 0) element 8t + j moves to g*32 + j*4 + u for t = 4g + u < 4G, and to
-// G*32 + j*REM + (t - 4G) for the remaining REM = (sd/8) % 4 steps -- pw_build_perm_rec's layout for a leaf.
-__global__ void codebook_perm_kernel(const float *__restrict__ cb, float *__restrict__ cbp, u64 total, u32 sd)
-{
-    const u32 S = sd / 8, G = S / 4, rem = S % 4;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
-        const u64 e = i / sd;
-        const u32 k = (u32)(i - e * sd), t = k / 8, j = k % 8, g = t / 4, u = t % 4;
-        const u32 pos = (g < G) ? g * 32 + j * 4 + u : G * 32 + j * rem + (t - 4 * G);
-        cbp[e * sd + pos] = cb[i];
     }
 }

@@ -64,7 +64,7 @@ struct SearchParams {
     const u8 *codes;         // [N][m]
     const u8 *nbcodes;       // [N][R][m] code words of every adjacency slot's neighbour, or nullptr (dr_index_inline_codes)
     const float *codebook;   // [m][256][sd]
-    const float *codebook_p; // the same with every entry stored chain-major (sub_dim % 8 == 0, >= 16), or nullptr: build_lut_octet
+    const float *lut_g;      // [nq][m][256] the per-query tables T[j][c] of the batch (lut_build_kernel), per-query-table variants
     const float *queries;    // [nq][D] original element order
     const float *queries_p;  // [nq][D] chain-major
     u64 N;
@@ -323,112 +323,12 @@ DEV void build_lut_sd(float *lut, const float *__restrict__ codebook, const floa
     }
 }
 
-// A2 for sub_dim >= 16 (the large dimensions: D = 1536 / m = 32 has 48 floats per centroid, 1.5 MB of codebook per
-// query). The lane-per-entry form above reads its centroids with a 4*SD-byte stride between lanes (every load instruction
-// touches 64 cache lines) and exposes one memory round trip per trip of 64 entries: 128 dependent trips, 580 k cycles per
-// query -- a quarter of the c3 kernel and 40 % of the PQ-only traversal. Here an OCTET scores one entry the way exact
-// distances are scored (lane j owns accumulator chain j, octet_combine), from a copy of the codebook whose entries are
-// stored chain-major (codebook_perm_kernel: position g*32 + j*4 + u of an entry = its element 8*(4g+u) + j, then the
-// remaining steps j*REM + r), so that a wave instruction reads 8 consecutive entries as one contiguous run, and UP
-// passes (8*UP entries) are in flight at once. Same arithmetic in the same order: the same bits.
-// q: the query in its original element order (global memory); the lane's S values of the NEXT sub-quantiser are fetched
-// while this one is computed.
-template <int SD> struct LutBuf {
-    static constexpr int S = SD / 8, G = S / 4, REM = S % 4;
-    static constexpr int UP = SD >= 32 ? 8 : 16;          // passes per batch: 8*UP entries, UP*(G + (REM > 0)) loads
-    float4 g4[UP][G > 0 ? G : 1];
-    float rr[UP][REM > 0 ? REM : 1];
-};
-template <int SD> DEV void lut_issue(LutBuf<SD> &b, const float *__restrict__ base, u32 e0, int j, int oct)
-{
-    constexpr int G = LutBuf<SD>::G, REM = LutBuf<SD>::REM, UP = LutBuf<SD>::UP;
-#pragma unroll
-    for (int u = 0; u < UP; u++) {
-        const float *ent = base + (size_t)(e0 + u * 8 + oct) * SD;
-#pragma unroll
-        for (int g = 0; g < G; g++) b.g4[u][g] = *reinterpret_cast<const float4 *>(ent + g * 32 + j * 4);
-#pragma unroll
-        for (int r = 0; r < REM; r++) b.rr[u][r] = ent[G * 32 + j * REM + r];
-    }
-}
-template <int SD> DEV void lut_reduce(const LutBuf<SD> &b, const float (&qv)[SD / 8], float *lut_row, u32 e0, int j, int oct)
-{
-    constexpr int G = LutBuf<SD>::G, REM = LutBuf<SD>::REM, UP = LutBuf<SD>::UP;
-#pragma unroll
-    for (int u = 0; u < UP; u++) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            const float4 v = b.g4[u][g];
-            const float s0 = sqd(v.x, qv[g * 4 + 0]), s1 = sqd(v.y, qv[g * 4 + 1]);
-            const float s2 = sqd(v.z, qv[g * 4 + 2]), s3 = sqd(v.w, qv[g * 4 + 3]);
-            acc = (g == 0) ? s0 : f_add(acc, s0);
-            acc = f_add(acc, s1);
-            acc = f_add(acc, s2);
-            acc = f_add(acc, s3);
-        }
-#pragma unroll
-        for (int r = 0; r < REM; r++) {
-            const float sv = sqd(b.rr[u][r], qv[G * 4 + r]);
-            acc = (G == 0 && r == 0) ? sv : f_add(acc, sv);
-        }
-        acc = octet_combine(acc);
-        if (j == 0) lut_row[e0 + u * 8 + oct] = acc;
-    }
-}
-// Two batches alternate: while one is reduced the other's loads are in flight (also across sub-quantisers; the batch
-// issued after the last one re-reads the last sub-quantiser's first entries instead of branching, so that the compiler's
-// wait counts stay exact).
-template <int SD>
-DEV void build_lut_octet(float *lut, const float *__restrict__ cbp, const float *__restrict__ q, u32 m)
-{
-    constexpr int S = SD / 8, UP = LutBuf<SD>::UP, NE = 256 / (8 * UP);
-    static_assert(SD % 8 == 0 && SD >= 16 && SD <= 128 && NE >= 2 && NE % 2 == 0, "octet form");
-    const int lane = lane_id(), j = lane & 7, oct = lane >> 3;
-    LutBuf<SD> A, B;
-    float qn[S];
-#pragma unroll
-    for (int t = 0; t < S; t++) qn[t] = q[8 * t + j];
-    lut_issue<SD>(A, cbp, 0, j, oct);
-#pragma unroll 1
-    for (u32 jq = 0; jq < m; jq++) {
-        float qv[S];
-#pragma unroll
-        for (int t = 0; t < S; t++) qv[t] = qn[t];
-        const u32 jn = min(jq + 1, m - 1);
-#pragma unroll
-        for (int t = 0; t < S; t++) qn[t] = q[jn * SD + 8 * t + j];
-        const float *base = cbp + (size_t)jq * 256 * SD;
-        const float *base_n = cbp + (size_t)jn * 256 * SD;
-        float *row = lut + jq * 256;
-#pragma unroll
-        for (int ne = 0; ne < NE; ne += 2) {
-            lut_issue<SD>(B, base, (u32)(ne + 1) * 8 * UP, j, oct);
-            lut_reduce<SD>(A, qv, row, (u32)ne * 8 * UP, j, oct);
-            if (ne + 2 < NE) lut_issue<SD>(A, base, (u32)(ne + 2) * 8 * UP, j, oct);
-            else lut_issue<SD>(A, base_n, 0, j, oct);
-            lut_reduce<SD>(B, qv, row, (u32)(ne + 1) * 8 * UP, j, oct);
-        }
-    }
-}
-
-// A2: whole table for one query, entries spread over the wave. q in original order (LDS).
-// OCTET: instantiate the octet forms (their double buffers cost up to 96 VGPRs: only where sub_dim >= 16 is a real
-// configuration and 512 registers are available, D > 256 -- inlined into the D = 96 kernels they made the register allocator spill 215 dwords)
-template <bool OCTET = false>
-DEV void build_lut_wave(float *lut, const float *__restrict__ codebook, const float *q, u32 m, u32 sd,
-                        const float *__restrict__ codebook_p = nullptr)
+// A2: whole table for one query, entries spread over the wave. q in original order (LDS). (The search kernels no longer
+// build their tables: lut_build_kernel below fills them for the whole batch at full occupancy; this form serves the flat
+// scan and the PQ-only builder's companions.)
+DEV void build_lut_wave(float *lut, const float *__restrict__ codebook, const float *q, u32 m, u32 sd)
 {
     const u32 total = m * 256;
-    if constexpr (OCTET) if (codebook_p != nullptr) {      // chain-major copy of the codebook (global memory) and q in global memory: octet form
-        switch (sd) {
-        case 16: build_lut_octet<16>(lut, codebook_p, q, m); return;
-        case 24: build_lut_octet<24>(lut, codebook_p, q, m); return;
-        case 32: build_lut_octet<32>(lut, codebook_p, q, m); return;
-        case 48: build_lut_octet<48>(lut, codebook_p, q, m); return;
-        default: break;     // (wider centroids keep the lane-per-entry form: their double buffers would set the kernel's register count)
-        }
-    }
     switch (sd) {
     case 2: build_lut_sd<2>(lut, codebook, q, total); return;
     case 3: build_lut_sd<3>(lut, codebook, q, total); return;
@@ -506,6 +406,43 @@ DEV float adc_lut16(const float *lut, const uint4 cw, u32 jbase, float s)
 #pragma unroll
     for (int i = 0; i < 16; i++) s = f_add(s, t[i]);
     return s;
+}
+
+// A3 for the split table (variant 15): the rows of the LAST 16 sub-quantisers live in registers -- tv[jj*4 + v] of lane l
+// holds T[m-16+jj][64 v + l] -- and an entry T[j][c] is fetched from lane c & 63 of register jj*4 + (c >> 6) with
+// ds_bpermute (four of them per sub-quantiser, one per register, then a select on c >> 6); the other rows are read from
+// LDS as before. The same 16 values per piece, added in the same strict order: the same bits. Must be called by the
+// whole wavefront (an inactive source lane reads as 0).
+DEV float adc_reg16(const float (&tv)[64], const uint4 cw, float s)
+{
+    const u32 words[4] = { cw.x, cw.y, cw.z, cw.w };
+    float t[16];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int jj = u * 4 + b;
+            const u32 c = (words[u] >> (8 * b)) & 255u;
+            const int addr = (int)((c & 63u) << 2);
+            const u32 r0 = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)__float_as_uint(tv[jj * 4 + 0]));
+            const u32 r1 = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)__float_as_uint(tv[jj * 4 + 1]));
+            const u32 r2 = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)__float_as_uint(tv[jj * 4 + 2]));
+            const u32 r3 = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)__float_as_uint(tv[jj * 4 + 3]));
+            const u32 lo = (c & 64u) ? r1 : r0, hi = (c & 64u) ? r3 : r2;
+            t[jj] = __uint_as_float((c & 128u) ? hi : lo);
+        }
+#pragma unroll
+    for (int i = 0; i < 16; i++) s = f_add(s, t[i]);
+    return s;
+}
+// m in { 32, 48, 64 }: pieces 0 .. m/16 - 2 from the LDS rows, the last piece from the register rows
+DEV float adc_split16(const float *lut, const float (&tv)[64], const uint4 c0, const uint4 c1v, const uint4 c2, const uint4 c3, u32 m)
+{
+    const uint4 cl = (m == 32u) ? c1v : (m == 48u) ? c2 : c3;
+    float s = adc_lut16(lut, c0, 0, 0.0f);
+    if (m > 32u) s = adc_lut16(lut, c1v, 16, s);
+    if (m > 48u) s = adc_lut16(lut, c2, 32, s);
+    return adc_reg16(tv, cl, s);
 }
 
 template <bool CBLDS>
@@ -609,9 +546,10 @@ DEV u32 a4_threshold_bits(float pq, float thr, bool &ok) {
     return cb;
 }
 
-template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false>
+template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false, int TREG = 0>
 DEV void search_body(const SearchParams &p)
 {
+    static_assert(TREG == 0 || (TREG == 16 && KIND == DIST_ADC_SQ && !FILTER && !CBLDS && RB == 0), "register table rows: the ADC-only per-query-table variant");
     constexpr bool QREG = (D <= 256);
     constexpr bool SPLIT = QREG && split_form_ok<D>();
     constexpr bool ROWLDS = RB > 0;
@@ -664,12 +602,13 @@ DEV void search_body(const SearchParams &p)
     // the chain-major query copy in LDS (large D) is only read by exact distances
     constexpr bool QPERM_LDS = !QREG && KIND != DIST_ADC_SQ;
     constexpr size_t ADJPRE_BYTES = 528;    // 64 ids + 64 bit positions + the 8-byte mask word, padded to 16
-    const size_t per_wave = ((NEED_PQ && !CBLDS) ? (size_t)p.m * 256 * 4 : 0) + (QORIG_LDS ? (size_t)D * 4 : 0) + (QPERM_LDS ? (size_t)D * 4 : 0) + 512 +
+    const u32 m_lds = p.m - (u32)TREG;      // table rows (sub-quantisers) kept in LDS; the last TREG rows live in registers
+    const size_t per_wave = ((NEED_PQ && !CBLDS) ? (size_t)m_lds * 256 * 4 : 0) + (QORIG_LDS ? (size_t)D * 4 : 0) + (QPERM_LDS ? (size_t)D * 4 : 0) + 512 +
                             (size_t)VB_BITS / 8 + (ADJPRE ? ADJPRE_BYTES : 0) + (ROWLDS ? (size_t)RB * ROW_BYTES : MERGE_BYTES);
     unsigned char *wbase = smem + off + (size_t)wave * per_wave;
     size_t woff = 0;
     float *lut = reinterpret_cast<float *>(wbase);
-    if constexpr (NEED_PQ && !CBLDS) woff += (size_t)p.m * 256 * 4;
+    if constexpr (NEED_PQ && !CBLDS) woff += (size_t)m_lds * 256 * 4;
     float *qorig_lds = reinterpret_cast<float *>(wbase + woff);
     if constexpr (QORIG_LDS) woff += (size_t)D * 4;
     float *qperm = reinterpret_cast<float *>(wbase + woff);
@@ -717,6 +656,7 @@ DEV void search_body(const SearchParams &p)
         PH_BEGIN();
         // ---- per-query setup
         QueryRegs<D> qreg;
+        float tv[TREG > 0 ? TREG * 4 : 1];
         const float *qorig = QORIG_LDS ? qorig_lds : p.queries + (size_t)qi * D;
         if (!(KIND == DIST_ADC_SQ && p.sdc != nullptr)) {      // (the PQ-only builder has no query vectors)
             const float *qg = p.queries + (size_t)qi * D;
@@ -743,7 +683,7 @@ DEV void search_body(const SearchParams &p)
         }
         WSYNC();
         if constexpr (NEED_PQ && !CBLDS) {
-            if (KIND == DIST_ADC_SQ && p.sdc != nullptr) {
+            if (TREG == 0 && KIND == DIST_ADC_SQ && p.sdc != nullptr) {      // (the PQ-only builder runs the all-LDS variant)
                 // the point's code word in whole 16-byte pieces, then the table rows of a piece, sixteen loads in flight
                 // (every loop over the bytes is unrolled: no register array is indexed dynamically)
                 const u8 *mycodes = p.codes + (size_t)p.build_pts[qi] * p.m;
@@ -769,7 +709,19 @@ DEV void search_body(const SearchParams &p)
                             reinterpret_cast<const float4 *>(p.sdc + ((size_t)jq * 256 + mycodes[jq]) * 256)[lane];
                 }
             } else {
-                build_lut_wave<(D > 256)>(lut, p.codebook, p.queries + (size_t)qi * D, p.m, p.sd, p.codebook_p);
+                // the query's table was built by lut_build_kernel (A2 for the whole batch, every CU busy): land its
+                // m KiB in LDS, 1 KiB per wave instruction, all in flight, one wait
+                const float *tg = p.lut_g + (size_t)qi * p.m * 256 + lane * 4;
+                for (u32 e = 0; e < m_lds * 256; e += 256)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tg + e),
+                        (__attribute__((address_space(3))) void *)(lut + e), 16, 0, 0);
+                if constexpr (TREG > 0) {
+                    // rows m-16 .. m-1 stay in registers: tv[jj*4 + v] of lane l = T[m-16+jj][64 v + l]
+                    const float *tr = p.lut_g + ((size_t)qi * p.m + m_lds) * 256 + lane;
+#pragma unroll
+                    for (int i = 0; i < TREG * 4; i++) tv[i] = tr[i * 64];
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             WSYNC();
         }
@@ -821,7 +773,13 @@ DEV void search_body(const SearchParams &p)
             nvisited = 1;
             float d0;
             if constexpr (KIND == DIST_ADC_SQ) {
-                d0 = adc_lane<CBLDS>(pq_tab, qorig, p.sd, p.codes + (size_t)start * p.m, p.m);
+                if constexpr (TREG > 0) {
+                    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
+                    adc_load_codes(w0, w1, w2, w3, p.codes + (size_t)start * p.m, p.m);
+                    d0 = adc_split16(pq_tab, tv, w0, w1, w2, w3, p.m);
+                } else {
+                    d0 = adc_lane<CBLDS>(pq_tab, qorig, p.sd, p.codes + (size_t)start * p.m, p.m);
+                }
                 npq++;
             } else {
                 d0 = pw_row_stream<0, D, D, QREG>(p.vecp + (size_t)start * D, &qreg, qperm, j);
@@ -1223,7 +1181,13 @@ DEV void search_body(const SearchParams &p)
                     }
                 } else {
                     if constexpr (!SPEC_CODES) { if (isnew) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m); }
-                    if (isnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
+                    if constexpr (TREG > 0) {
+                        // every lane takes part (ds_bpermute reads 0 from inactive source lanes); lanes without a new
+                        // neighbour look up whatever their code registers hold and are ignored below
+                        adc_s = adc_split16(pq_tab, tv, cw0, cw1, cw2, cw3, p.m);
+                    } else {
+                        if (isnew) adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
+                    }
                     e = adc_s;
                     npq += nnew; npq_eval += nnew;
                     PH(4);
@@ -1502,11 +1466,12 @@ DEV void search_body(const SearchParams &p)
     if (lane == 0) p.vis_epoch[slot_id] = vstamp;
 }
 
-template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false>
+template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false, int TREG = 0>
 // (minimum wavefronts per SIMD: 2 for the one-wavefront workgroups at D <= 256, which are register-limited -- forcing 3 on
 // the exact traversals (168 VGPRs, 25 spilled) measured 0...+5 % slower at the c4 shape; the large dimensions hold a
 // 32-KiB table or the row pipeline's buffers: 1)
-__global__ __launch_bounds__(64 * NW, (NW == 1 && D <= 256) ? 2 : 1) void search_kernel(const SearchParams p)
+// the register-table variant exists to run two wavefronts per SIMD: 256 registers each)
+__global__ __launch_bounds__(64 * NW, ((NW == 1 && D <= 256) || TREG > 0) ? 2 : 1) void search_kernel(const SearchParams p)
 {
-    search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB, U8, QB>(p);
+    search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB, U8, QB, TREG>(p);
 }

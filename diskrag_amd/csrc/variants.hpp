@@ -3,31 +3,64 @@
 #pragma once
 #include <stddef.h>
 
-// kind: which search_kernel instantiation
+// A search-kernel VARIANT is one instantiation family of search_kernel (search_kernel.hpp). Variants are known by a stable
+// id (dr_timing.variant, dr_debug_force_kind, the committed profiles); ids of variants that were retired (4, 6, 7, 10:
+// superseded forms) are simply absent from the table below -- a kernel table row is its POSITION in DR_KINDS, not its id.
 //   0 M1 (ADC filter + exact), per-query table in LDS, 1 wave per workgroup
 //   1 exact traversal (M2, M4, M3 without PQ, builder), 1 wave per workgroup
-//   2 ADC-only traversal (M3 with PQ), per-query table
-//   3 M1, codebook shared in LDS, 8 waves per workgroup      (D <= 128 only, else nullptr)
-//   4 (retired)
-//   5 ADC-only traversal, codebook shared in LDS, 8 waves    (D <= 128 only)
-//   6, 7 (retired: superseded by 9)
+//   2 ADC-only traversal (M3 with PQ, DR_MODE_PQ), per-query table in LDS
+//   3 M1, codebook shared in LDS, 8 waves per workgroup      (D <= 128)
+//   5 ADC-only traversal, codebook shared in LDS, 8 waves    (D <= 128)
 //   8 exact traversal, vectors landed in LDS, 8 waves                                          (D = 128)
 //   9 M1, vectors landed in LDS, 24 rows/burst, 12 waves                                       (D = 128)
-//  10 (retired: the 12-wave form of 11)
 //  11 M1, BYTE vectors landed in LDS (lossless copy of integer-valued data), 64 rows/burst, 16 waves (D = 128;
 //     128 VGPRs: a few spilled dwords, 7 % faster than 12 waves once the row bytes are quartered)
 //  12 exact traversal (M2, M4, M3 without PQ) on BYTE vectors, 64 rows/burst, 16 waves          (D = 128)
 //  13 = 11 with BYTE queries as well (every component of the batch an integer in [0, 255]): v_dot4_u32_u8 distances
 //  14 = 12 with byte queries
+//  15 = 2 with the table rows of the LAST 16 sub-quantisers held in VGPRs (64 registers, looked up with ds_bpermute) and
+//     only the first m - 16 rows in LDS: at m = 32 a table costs 16 KiB of LDS instead of 32, so 8 wavefronts fit a CU
+//     instead of 4 (two per SIMD: the traversal is bound by instruction latency, not by memory)  (m % 16 == 0, m >= 32)
 // (tried in round 2 and removed: 16-wave forms of 3 and 5 for D <= 96 -- twice the queries in flight, 30 % slower than the
 //  per-query table at the c4 shape: that kernel is bound by its number of memory requests, not by latency)
-// sizeclass: result capacity <= 64 / 128 / 256 / 512 / 1024 (the last one: one-wavefront-per-workgroup variants 0, 1, 2 only)
-#define DR_NUM_KINDS 15
+// sizeclass: result capacity <= 64 / 128 / 256 / 512 / 1024 (the last one: one-wavefront-per-workgroup variants only)
+struct KindDesc {
+    int id;
+    int nw;       // wavefronts per workgroup
+    bool cb;      // codebook copied to LDS
+    int rb;       // rows per LDS burst (0: no row landing)
+    bool lut;     // per-query table (built for the batch by lut_build_kernel)
+    bool pq;      // reads PQ data
+    bool u8, qb;  // byte rows, byte queries
+    int treg;     // table rows (sub-quantisers) held in registers instead of LDS
+};
+static const KindDesc DR_KINDS[] = {
+    { 0, 1, false, 0, true, true, false, false, 0 },
+    { 1, 1, false, 0, false, false, false, false, 0 },
+    { 2, 1, false, 0, true, true, false, false, 0 },
+    { 3, 8, true, 0, false, true, false, false, 0 },
+    { 5, 8, true, 0, false, true, false, false, 0 },
+    { 8, 8, false, 32, false, false, false, false, 0 },
+    { 9, 12, false, 24, false, true, false, false, 0 },
+    { 11, 16, false, 64, false, true, true, false, 0 },
+    { 12, 16, false, 64, false, false, true, false, 0 },
+    { 13, 16, false, 64, false, true, true, true, 0 },
+    { 14, 16, false, 64, false, false, true, true, 0 },
+    { 15, 1, false, 0, true, true, false, false, 16 },
+};
+#define DR_NUM_KINDS ((int)(sizeof(DR_KINDS) / sizeof(DR_KINDS[0])))
+#define DR_MAX_KIND_ID 15
 #define DR_NUM_SIZECLASS 5
 #define DR_MAX_CAPACITY 1024u
+// position of variant `id` in DR_KINDS (= its row in DimKernels::search), or -1
+static inline int dr_kind_pos(int id)
+{
+    for (int i = 0; i < DR_NUM_KINDS; i++) if (DR_KINDS[i].id == id) return i;
+    return -1;
+}
 struct DimKernels {
     int D;
-    const void *search[DR_NUM_KINDS][DR_NUM_SIZECLASS];
+    const void *search[sizeof(DR_KINDS) / sizeof(DR_KINDS[0])][DR_NUM_SIZECLASS];     // [position in DR_KINDS][sizeclass]; nullptr: not built for this dimension
     const void *exact;
     const void *bruteforce;
     const void *prune;
@@ -35,13 +68,6 @@ struct DimKernels {
     const void *search_f64;   // M1 / M2 with float64 queries (the CLI path), search_f64.hpp
     const void *rerank;       // aux_kernels.hpp rerank_kernel (DR_MODE_PQ + DR_F_RERANK)
 };
-static const int DR_KIND_NW[DR_NUM_KINDS] = { 1, 1, 1, 8, 16, 8, 8, 16, 8, 12, 12, 16, 16, 16, 16 };
-static const bool DR_KIND_CB[DR_NUM_KINDS] = { false, false, false, true, true, true, false, false, false, false, false, false, false, false, false };   // codebook copied to LDS
-static const int DR_KIND_RB[DR_NUM_KINDS] = { 0, 0, 0, 0, 0, 0, 32, 16, 32, 24, 64, 64, 64, 64, 64 };                                       // rows per LDS burst
-static const bool DR_KIND_LUT[DR_NUM_KINDS] = { true, false, true, false, false, false, false, false, false, false, false, false, false, false, false };     // per-query table in LDS
-static const bool DR_KIND_PQ[DR_NUM_KINDS] = { true, false, true, true, true, true, true, true, false, true, true, true, false, true, false };
-static const bool DR_KIND_U8[DR_NUM_KINDS] = { false, false, false, false, false, false, false, false, false, false, true, true, true, true, true };    // byte rows
-static const bool DR_KIND_QB[DR_NUM_KINDS] = { false, false, false, false, false, false, false, false, false, false, false, false, false, true, true };  // byte queries
 
 const DimKernels *dr_dim_kernels(int D);
 

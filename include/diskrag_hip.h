@@ -74,6 +74,8 @@ typedef struct {
     float h2d_ms, search_kernel_ms, finalize_kernel_ms, d2h_ms, total_ms;
     uint32_t grid, block, lds_bytes, waves_per_cu;
     uint32_t variant; /* which search_kernel instantiation ran (csrc/variants.hpp) */
+    float lut_kernel_ms; /* MEAN duration of the table-build kernel that precedes the search kernel of the per-query-table
+                            variants (A2 for the whole batch, fast_pq.py:294-318); 0 for the other variants */
 } dr_timing;
 
 int dr_device_count(void);

@@ -38,11 +38,17 @@ def run(tag, kind=-1, **kw):
     t = ix.timing()
     alg = float((4.0 * D + st["steps"] * 4.0 * R + st["pq_evaluated"] * float(m) + st["exact"] * 4.0 * D + 80).sum())
     chk = int(np.bitwise_xor.reduce(ids.astype(np.uint64).ravel() * np.uint64(0x9E3779B97F4A7C15) + dist.view(np.uint32).astype(np.uint64).ravel()))
-    print(f"{tag:34s} kind {t['variant']:2d} w/CU {t['waves_per_cu']:2d} kernel_ms {min(ms):8.3f} (med {sorted(ms)[1]:8.3f}) recall {recall_at_k(ids, gt, 10):.4f} "
+    print(f"{tag:34s} kind {t['variant']:2d} w/CU {t['waves_per_cu']:2d} kernel_ms {min(ms):8.3f} (med {sorted(ms)[1]:8.3f}) lut_ms {t.get('lut_kernel_ms', 0.0):6.3f} recall {recall_at_k(ids, gt, 10):.4f} "
           f"steps {st['steps'].mean():6.1f} exact {st['exact'].mean():7.1f} pq_eval {st['pq_evaluated'].mean():7.1f} alg_frac {alg / (min(ms) * 1e-3) / 8e12:.3f} "
           f"status {int(st['status'].max())} chk {chk:016x}", flush=True)
 
 
+if shape == "c5s":      # the PQ-only traversal: kinds = the ADC-only variants to compare (2: table in LDS, 15: split LDS / registers)
+    for kd in kinds:
+        for L, bw in ((100, 8), (200, 0), (400, 0), (800, 0)):
+            run(f"PQ_L{L}_bw{bw or 'None'}[k{kd}]", kd, L=L, beam_width=bw, mode=_ffi.MODE_PQ)
+        run(f"M3_PQ_k10_bw64[k{kd}]", kd, L=10, beam_width=64, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
+    sys.exit(0)
 for kd in kinds:
     run(f"M1_L100_bw8[k{kd}]", kd, L=100, beam_width=8, mode=_ffi.MODE_M1)
     run(f"M1_L100_notrim[k{kd}]", kd, L=100, beam_width=0, mode=_ffi.MODE_M1)

@@ -17,7 +17,9 @@ shape, n = sys.argv[1], int(sys.argv[2])
 nq = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
 spec = sys.argv[4] if len(sys.argv) > 4 else "full"
 quick = spec == "quick"
-D, m, ncl, latent = {"c3": (1536, 32, 4096, 64), "c4": (96, 16, 4096, 32)}[shape]
+# d256 / d768 / d960: the other entries of the reference's SUPPORTED_DIMENSIONS (preprocessing/config.py:88), unit-norm mixture
+D, m, ncl, latent = {"c3": (1536, 32, 4096, 64), "c4": (96, 16, 4096, 32), "d256": (256, 32, 4096, 32), "d768": (768, 32, 4096, 64),
+                     "d960": (960, 32, 4096, 64)}[shape]
 R = 64
 path = f"gpurun_out/op_{shape}_{n}{'' if spec in ('full', 'quick') else '_' + spec}.jsonl"
 out = open(path, "w")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC evidence for the c3 / c4 shapes: FETCH_SIZE, WRITE_SIZE and the SQ wait / instruction counters of
-# the M1 kernel, separate passes. usage: pmc_shape.sh c3 1000000 | c4 10000000   -> gpurun_out/pmc_<shape>/summary.json
+# the M1 kernel, separate passes. usage: pmc_shape.sh c3 1000000 | c4 10000000 | c5s 4000000   -> gpurun_out/pmc_<shape>/summary.json
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 S=$1; N=$2; OUT=gpurun_out/pmc_$S; rm -rf $OUT; mkdir -p $OUT
 run() { rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/$1 -- python3 scripts/pmc_target_shape.py $S $N > $OUT/$1.out 2> $OUT/$1.err; }
@@ -11,7 +11,7 @@ run sqb "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_L
 python3 - $S $N <<'PY'
 import csv, glob, json, sys
 S, N = sys.argv[1], int(sys.argv[2])
-out = {"shape": S, "N": N, "source": "scripts/pmc_shape.sh: rocprofv3 --pmc, separate passes over scripts/pmc_target_shape.py (M1, L=100, beam_width 8, 10000 queries; mean of the last launches)",
+out = {"shape": S, "N": N, "source": "scripts/pmc_shape.sh: rocprofv3 --pmc, separate passes over scripts/pmc_target_shape.py (M1 -- c5s: DR_MODE_PQ on R = 32 rows --, L=100, beam_width 8, 10000 queries; mean of the last launches)",
        "units": "FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE doubled (gfx950: 128-byte requests tallied at 64 B, calibrated on the brute-force stream of the whole vector table); SQ_* are summed over wavefronts"}
 def rows(d):
     f = glob.glob(f"gpurun_out/pmc_{S}/{d}/*/*counter_collection.csv")
@@ -26,7 +26,10 @@ for line in open(f"gpurun_out/pmc_{S}/fetch.out"):
     if p and p[0] == "KERNEL_MS": out["kernel_ms_under_profiler"] = float(p[1]); out["variant"] = int(p[3])
     if p and p[0] == "PER_QUERY": out["per_query"] = line.strip()
 f, w = rows("fetch"), rows("write")
-names = sorted({r["Kernel_Name"] for r in f if kern in r["Kernel_Name"] and "true" in r["Kernel_Name"].split(",")[1]})
+def wanted(nm):      # M1 kernels have FILTER = true; the PQ-only traversal (c5s) is <D, false, 2 (DIST_ADC_SQ), ...>
+    a = [t.strip() for t in nm.split(",")]
+    return kern in nm and len(a) > 2 and ((a[1] == "false" and a[2] == "2") if S == "c5s" else a[1] == "true")
+names = sorted({r["Kernel_Name"] for r in f if wanted(r["Kernel_Name"])})
 out["kernel"] = names[0] if names else None
 sub = names[0] if names else kern
 fs, ws = mean_last(f, "FETCH_SIZE", sub), mean_last(w, "WRITE_SIZE", sub)
@@ -47,3 +50,5 @@ if "SQ_WAVE_CYCLES" in sq and "SQ_WAIT_ANY" in sq: out["wave_cycles_waiting"] = 
 json.dump(out, open(f"gpurun_out/pmc_{S}/summary.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "sq"}, indent=1))
 PY
+# the raw counter CSVs (one row per dispatch, the builder launches hundreds of thousands) stay on the box: gpurun_out is capped at 64 MiB
+rm -rf $OUT/fetch $OUT/write $OUT/sqa $OUT/sqb

@@ -47,3 +47,59 @@ def test_bench_imports_no_torch_and_gpus_flag_is_used():
     src = (ROOT / "bench.py").read_text()
     assert "import torch" not in src
     assert "args.gpus" in src
+
+
+def _torchrun_pair(tmp_path, run_id, extra=()):
+    procs = []
+    for r in range(2):
+        env = _env(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29500",
+                   TORCHELASTIC_RUN_ID=run_id, TMPDIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                       "--batches-per-step", "3", *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1] for o in outs]
+    return json.loads(outs[0][0].strip())
+
+
+def test_two_runs_with_the_same_run_id_never_share_files(tmp_path):
+    """plain torchrun gives every job port 29500 and run id 'none'. A second job (and one started over the
+    leftovers of a crashed job) must not read the first one's barrier / time files."""
+    base = tmp_path / "diskrag_bench_29500_none"
+    base.mkdir()
+    # leftovers of a crashed earlier job: a join / assign pair with a foreign nonce, old barrier and time files
+    (base / "join.1").write_text("deadbeef")
+    (base / "assign.1").write_text("deadbeef\n" + str(base / "job_stale"))
+    (base / "job_stale").mkdir()
+    for name in ("b1.0", "b1.1", "b2.0", "b2.1", "here.1"):
+        (base / "job_stale" / name).write_text("x")
+    (base / "job_stale" / "t.1").write_text("123.0")
+    d1 = _torchrun_pair(tmp_path, "none")
+    d2 = _torchrun_pair(tmp_path, "none")
+    for d in (d1, d2):
+        assert d["n_gpus"] == 2 and len(d["config"]["per_rank_seconds"]) == 2
+        assert max(d["config"]["per_rank_seconds"]) < 5.0            # nobody read the stale 123 s
+    # each job removed its own scratch directory; only the crashed job's leftovers remain
+    assert sorted(p.name for p in base.iterdir() if p.name.startswith("job_")) == ["job_stale"]
+
+
+def test_strong_scaling_slices_tile_the_batch(tmp_path):
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batches-per-step", "3",
+                        "--scaling", "strong", "--num-queries", "10001"], env=_env(), capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2
+    sl = sorted(d["config"]["per_rank_slice"])
+    assert sl[0][0] == 0 and sl[-1][1] == 10001 and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))      # exactly once
+    # whole-job value: ONE batch stream, not one per rank
+    assert abs(d["value"] - 10001 * 2 * 3 / max(d["config"]["per_rank_seconds"])) < 1e-6 * d["value"]
+
+
+def test_a_failing_rank_ends_the_job_at_once():
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=_env(DR_BENCH_STUB_FAIL_RANK="1"), capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0
+    assert time.time() - t0 < 60          # not the 1800 s barrier timeout

@@ -45,6 +45,26 @@ def test_pipelined_submit_wait_equals_blocking_calls(name):
     ix.batch_sync()
 
 
+def test_a_dropped_pipelined_job_does_not_lose_its_buffers():
+    """the library copies a batch's results into the caller's arrays when the batch is FINISHED (a later submit
+    that reuses its slot, or wait). A PendingSearch dropped without wait() must keep those arrays alive until then."""
+    import gc
+    from diskrag_amd import _ffi
+    g = load_golden("sift128_R64_m32")
+    ix = get_index("sift128_R64_m32")
+    want = ix.search_batch(g.queries, 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
+    for _ in range(8):
+        ix.search_submit(np.array(g.queries), 10, L=100, beam_width=8, mode=_ffi.MODE_M1)      # dropped at once
+        gc.collect()
+        junk = [np.empty(len(g.queries) * 10, dtype=np.uint32) for _ in range(4)]              # churn the allocator
+        del junk
+    assert len(ix.__dict__["_inflight"]) <= _ffi.PIPE_DEPTH
+    j = ix.search_submit(g.queries, 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
+    ids, dist, cnt, st = j.wait()
+    assert np.array_equal(ids, want[0]) and np.array_equal(bits(dist), bits(want[1]))
+    ix.batch_sync()
+
+
 def test_resident_batches_are_independent():
     from diskrag_amd import _ffi
     g = load_golden("sift128_R64_m32")
@@ -99,6 +119,42 @@ def test_pq_mode_matches_its_oracle_restatement(name):
         with pytest.raises(_ffi.DiskragHipError):        # the rerank needs the stored vectors
             shard.search_batch(g.queries, 10, L=50, beam_width=8, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)
     finally:
+        shard.close()
+
+
+@pytest.mark.parametrize("name", ["unit1536_R16_m32", "unit1536_R16_m64"])
+def test_split_table_variant_returns_the_same_bits(name):
+    """Variant 15 (round 3): the table rows of the last 16 sub-quantisers in registers (ds_bpermute lookups), the rest in LDS
+    -- against variant 2 (whole table in LDS) and the oracle, for the engine's PQ traversal and the reference's M3 with PQ,
+    on a full index and on a PQ-only shard, every list-size class."""
+    from diskrag_amd import HipIndex, _ffi
+    from oracle import pyoracle as orc
+    g = load_golden(name)
+    ix = get_index(name)
+    shard = HipIndex.create_codes(g.adj, g.medoid, g.vectors.shape[1], g.codebook, g.codes)
+    try:
+        for (L, bw, k) in ((100, 8, 10), (40, 0, 10), (200, 16, 25), (300, 0, 10), (600, 8, 10), (1024, 0, 10)):
+            w = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, codes=g.codes, codebook=g.codebook)
+            for eng in (ix, shard):
+                for kind in (15, 2):
+                    eng.debug_force_kind(kind)
+                    ids, dist, cnt, st = eng.search_batch(g.queries, k, L=L, beam_width=bw, mode=_ffi.MODE_PQ)
+                    assert eng.timing()["variant"] == kind
+                    assert int(st["status"].max()) == 0
+                    valid = w[0] != 0xFFFFFFFF
+                    assert np.array_equal(ids, w[0]) and np.array_equal(bits(dist)[valid], bits(w[1].astype(np.float32))[valid]), (name, L, bw, kind)
+                    assert np.array_equal(cnt, w[2]) and np.array_equal(_stats4(st), w[3])
+        w3 = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.M3, 10, L=10, bw=8, flags=orc.F_USE_PQ, codes=g.codes, codebook=g.codebook)
+        for kind in (15, 2):
+            shard.debug_force_kind(kind)
+            i3, d3, c3, s3 = shard.search_batch(g.queries, 10, L=10, beam_width=8, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
+            assert shard.timing()["variant"] == kind
+            assert np.array_equal(i3, w3[0]) and np.array_equal(c3, w3[2]) and np.array_equal(_stats4(s3), w3[3])
+        shard.debug_force_kind(-1)
+        shard.search_batch(g.queries, 10, L=100, beam_width=8, mode=_ffi.MODE_PQ)
+        assert shard.timing()["variant"] == 15 and shard.timing()["lut_kernel_ms"] > 0.0      # the engine's own choice
+    finally:
+        ix.debug_force_kind(-1)
         shard.close()
 
 
