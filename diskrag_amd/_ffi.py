@@ -15,7 +15,7 @@ PAD = 0xFFFFFFFF
 MODE_M1, MODE_M2, MODE_M3, MODE_M4 = 1, 2, 3, 4
 PIPE_DEPTH = 3          # DR_PIPE_DEPTH (csrc/engine.hip): batches in flight per handle
 MODE_PQ = 5      # engine mode without a reference counterpart: M1's loop on squared ADC distances only (diskrag_hip.h)
-F_USE_PQ, F_SQDIST, F_RERANK = 1, 2, 4
+F_USE_PQ, F_SQDIST, F_RERANK, F_COSINE = 1, 2, 4, 8
 MAX_RESIDENT = 16
 COMM_ID_BYTES = 128
 
@@ -47,7 +47,7 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_batch_select", "dr_search_submit", "dr_search_wait", "dr_host_alloc", "dr_host_free",
            "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_merge_topk",
            "dr_debug_prune", "dr_pq_train_ex", "dr_index_create_codes_empty", "dr_pq_encode_rows", "dr_build_vamana_pq",
-           "dr_scalar_kernels", "dr_index_inline_codes"]
+           "dr_scalar_kernels", "dr_index_inline_codes", "dr_pq_scan_topk"]
 
 _lib = None
 
@@ -481,6 +481,19 @@ class HipIndex:
         _check(load_library().dr_pq_scan_best(self._h, _p(q, C.c_float), nq, _p(out, C.c_float), _p(bid, C.c_uint32),
                                               _p(bsq, C.c_float), C.byref(ms)))
         return (bid, bsq, ms.value, out) if want_output else (bid, bsq, ms.value)
+
+    def pq_scan_topk(self, queries, k):
+        """Brute-force ADC search (flat scan of every code word): (ids[nq, k], squared ADC distances, scan kernel ms)."""
+        q = self._queries(queries)
+        ids = np.empty((q.shape[0], k), dtype=np.uint32)
+        sq = np.empty((q.shape[0], k), dtype=np.float32)
+        ms = C.c_float(0)
+        L = load_library()
+        L.dr_pq_scan_topk.restype = C.c_int
+        L.dr_pq_scan_topk.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float)]
+        _check(L.dr_pq_scan_topk(self._h, _p(q, C.c_float), q.shape[0], int(k), _p(ids, C.c_uint32), _p(sq, C.c_float), C.byref(ms)))
+        return ids, sq, ms.value
 
     def bruteforce_topk(self, queries, k):
         q = self._queries(queries)

@@ -68,8 +68,12 @@ template <int D> __global__ __launch_bounds__(64) void rerank_kernel(const float
 
 // brute-force exact top-k (recall ground truth). One wave per query streams all N stored vectors, 8 per pass,
 // and keeps the k best in LDS (k <= 64), ties broken towards the smaller id.
+// With `part` != nullptr the rows are cut into gridDim.y slices (small batches on large tables: one wavefront per query
+// leaves the chip empty): block (q, s) scans rows [s*N/S, (s+1)*N/S) and leaves its k keys (distance bits << 32 | id,
+// ~0 = empty) in part[q][s][k]; topk_merge_kernel (engine_kernels.hpp) folds the slices.
 template <int D> __global__ __launch_bounds__(64) void bruteforce_kernel(const float *__restrict__ vecp, u64 N,
-        const float *__restrict__ queries_p, u32 nq, u32 k, u32 *__restrict__ out_ids, float *__restrict__ out_dist)
+        const float *__restrict__ queries_p, u32 nq, u32 k, u32 *__restrict__ out_ids, float *__restrict__ out_dist,
+        u64 *__restrict__ part)
 {
     constexpr bool QREG = (D <= 256);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -86,10 +90,12 @@ template <int D> __global__ __launch_bounds__(64) void bruteforce_kernel(const f
     WSYNC();
     int bn = 0;
     float W = __uint_as_float(0x7F800000u);
-    for (u64 base = 0; base < N; base += 8) {
-        const u64 row = base + oct < N ? base + oct : N - 1;
+    const u64 row_lo = part ? (N * blockIdx.y) / gridDim.y : 0ull;
+    const u64 row_hi = part ? (N * (blockIdx.y + 1)) / gridDim.y : N;
+    for (u64 base = row_lo; base < row_hi; base += 8) {
+        const u64 row = base + oct < row_hi ? base + oct : row_hi - 1;
         const float e = pw_row_stream<0, D, D, QREG>(vecp + row * D, &qreg, qperm, j);
-        const bool cand = (j == 0) && (base + oct < N) && (bn < (int)k || e < W);
+        const bool cand = (j == 0) && (base + oct < row_hi) && (bn < (int)k || e < W);
         u64 cm = __ballot(cand);
         while (cm) {
             const int f = __ffsll((long long)cm) - 1;
@@ -113,6 +119,7 @@ template <int D> __global__ __launch_bounds__(64) void bruteforce_kernel(const f
     WSYNC();
     if (lane < (int)k) {
         const u64 key = lane < bn ? best[lane] : ~0ull;
+        if (part) { part[((size_t)q * gridDim.y + blockIdx.y) * k + lane] = key; return; }
         out_ids[(size_t)q * k + lane] = lane < bn ? (u32)key : 0xFFFFFFFFu;
         out_dist[(size_t)q * k + lane] = lane < bn ? key_dist(key) : __uint_as_float(0x7FC00000u);
     }

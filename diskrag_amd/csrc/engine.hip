@@ -121,6 +121,26 @@ struct PipeJob {
     uint32_t *out_ids = nullptr; float *out_dist = nullptr; uint32_t *out_count = nullptr; dr_stats *stats = nullptr;
 };
 
+// Persistent work area of dr_sharded_search (comm.inc), owned by the first shard of the call: staging arrays, events, the
+// exchange stream and a page-locked slab for the results live across calls (a call used to hipMalloc nine arrays and
+// create three events).
+struct ShardScratch {
+    std::mutex mu;
+    DevBuf<uint32_t> loc_ids, send_ids, all_ids, fin_ids, status;
+    DevBuf<float> loc_dist, send_dist, all_dist, fin_dist, q;
+    hipEvent_t e[4] = {};                 // start, local lists ready, exchange done, final merge done
+    std::vector<hipEvent_t> shard_done;   // one per local shard
+    hipStream_t xs = nullptr;             // merge / exchange / download stream (without a communicator)
+    void *pin = nullptr; size_t pin_bytes = 0;
+    ~ShardScratch()
+    {
+        for (auto &x : e) if (x) (void)hipEventDestroy(x);
+        for (auto &x : shard_done) if (x) (void)hipEventDestroy(x);
+        if (xs) (void)hipStreamDestroy(xs);
+        if (pin) (void)hipHostFree(pin);
+    }
+};
+
 struct dr_index {
     int device = 0;
     uint64_t N = 0;
@@ -150,6 +170,7 @@ struct dr_index {
     DevBuf<uint32_t> perm;
     std::vector<uint32_t> h_perm;
     // bit order of the visited bitmaps (build_bit_order): rank[id] = bit position, adjr = rank of every adjacency slot
+    DevBuf<float> vnorm2;         // squared norms of the stored vectors, built by the first cosine search (DR_F_COSINE)
     DevBuf<uint32_t> rank, adjr;
     // lossless byte copy of the vectors (integer-valued data, D = 128): 0 not checked yet, 1 present, -1 data does not qualify
     DevBuf<uint8_t> vec8;
@@ -195,6 +216,7 @@ struct dr_index {
     DevBuf<u64> phase;
     uint32_t last_k = 0;
     dr_timing timing = {};
+    ShardScratch *shs = nullptr;  // dr_sharded_search's work area when this handle is the call's first shard
 };
 
 extern "C" int dr_device_count(void)
@@ -415,9 +437,10 @@ extern "C" void dr_index_close(dr_index *ix)
         if (bs.fin_start) (void)hipEventDestroy(bs.fin_start);
         if (bs.fin_done) (void)hipEventDestroy(bs.fin_done);
     }
-    ix->phase.release(); ix->rank.release(); ix->adjr.release(); ix->fin_stat.release(); ix->vec8.release();
+    ix->phase.release(); ix->vnorm2.release(); ix->rank.release(); ix->adjr.release(); ix->fin_stat.release(); ix->vec8.release();
     ix->f64_q.release(); ix->f64_dist.release(); ix->f64_ids.release(); ix->f64_cnt.release(); ix->f64_vis.release(); ix->f64_stats.release();
     if (ix->pinned) (void)hipHostFree(ix->pinned);
+    delete ix->shs;
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
     for (auto &pr : ix->kev) for (auto &e : pr) if (e) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -451,7 +474,7 @@ static bool queries_are_u8(const float *queries, size_t n)
 static int upload_slot_async(dr_index *ix, QSlot &qs, const float *src, uint32_t nq, hipStream_t st)
 {
     if (qs.q.reserve((size_t)nq * ix->D) || qs.qp.reserve((size_t)nq * ix->D)) return DR_E_NODEVICE;
-    HIPCHK(hipMemcpyAsync(qs.q.p, src, (size_t)nq * ix->D * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(qs.q.p, src, (size_t)nq * ix->D * 4, hipMemcpyDefault, st));      // (host or device source)
     hipLaunchKernelGGL(permute_queries_kernel, dim3(nq), dim3(64), 0, st, qs.q.p, nq, ix->D, ix->perm.p, qs.qp.p);
     HIPCHK(hipGetLastError());
     qs.nq = nq;
@@ -717,7 +740,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         const int pos = dr_kind_pos(kd);
         if (pos < 0 || ix->kern->search[pos][sc] == nullptr || lds_of(kd) > 160 * 1024) return false;
         const KindDesc &d = DR_KINDS[pos];
-        if (d.treg && ((ix->m & 15u) != 0 || ix->m < 32u || ix->m > 64u || ix->nbcodes.p)) return false;     // (register rows: whole 16-byte code pieces, gathered code words)
+        if (d.treg && ((ix->m & 15u) != 0 || ix->m < 32u || ix->m > 64u)) return false;     // (register rows: the last whole 16-byte code piece)
         return (!d.u8 || ix->vec8_state == 1) && (!d.qb || (ix->cs->q_u8 && !ov));
     };
     // ADC-only traversals: shared codebook (D <= 128) > table split between LDS and registers (15: twice the wavefronts
@@ -732,9 +755,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // per-query table (0) when 8 of them fit a CU, else the shared codebook (3). Which regime an index is in is
     // MEASURED on the first M1 batch an index state serves (its counters are read once that launch has finished, see
     // the end of this function); until then the SIFT-scale preference applies. Results never depend on the variant.
-    static const int PREF_BUILD_PQ[] = { 2 };
-    const int *pref = k_m1 ? PREF_M1 : (ov && ov->sdc) ? PREF_BUILD_PQ : k_adc ? (no_treg ? PREF_ADC_NOTREG : PREF_ADC) : ov ? PREF_BUILD : PREF_EX;
-    const int npref = k_m1 ? 5 : (ov && ov->sdc) ? 1 : k_adc ? 3 : ov ? 2 : 4;
+    static const int PREF_BUILD_PQ[] = { 15, 2 }, PREF_BUILD_PQ_NOTREG[] = { 2, 2 };
+    const int *pref = k_m1 ? PREF_M1 : (ov && ov->sdc) ? (no_treg ? PREF_BUILD_PQ_NOTREG : PREF_BUILD_PQ) : k_adc ? (no_treg ? PREF_ADC_NOTREG : PREF_ADC) : ov ? PREF_BUILD : PREF_EX;
+    const int npref = k_m1 ? 5 : (ov && ov->sdc) ? 2 : k_adc ? 3 : ov ? 2 : 4;
     if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 8 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
     int kind = -1;
     for (int i = 0; i < npref && kind < 0; i++) if (usable(pref[i])) kind = pref[i];
@@ -819,6 +842,16 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.out_ids = bs.out_ids.p; p.out_dist = bs.out_dist.p; p.out_count = bs.out_count.p;
     p.phase = nullptr;
     p.pq_ub = nullptr;
+    p.vnorm2 = nullptr;
+    if (flags & DR_F_COSINE) {
+        if (mode != DR_MODE_M3 || (flags & DR_F_USE_PQ)) return fail(DR_E_ARG, "DR_F_COSINE goes with DR_MODE_M3 without DR_F_USE_PQ (the reference's only cosine traversal)");
+        if (!ix->vnorm2.p) {
+            if (ix->vnorm2.reserve(ix->N)) return DR_E_NODEVICE;
+            hipLaunchKernelGGL(row_norm2_kernel, dim3((unsigned)std::min<uint64_t>((ix->N + 255) / 256, 1u << 16)), dim3(256), 0, ix->stream, ix->vecp.p, ix->N, ix->D, ix->vnorm2.p);
+            HIPCHK(hipGetLastError());
+        }
+        p.vnorm2 = ix->vnorm2.p;
+    }
     if (mode == DR_MODE_M1) {
         // per-query ADC upper bounds: a function of (queries, codebook) only, computed once per uploaded batch
         if (!ix->cs->pq_ub_valid) {
@@ -1436,6 +1469,56 @@ static int pq_scan_best_locked(dr_index *ix, const float *queries, uint32_t nq, 
     return 0;
 }
 
+// Brute-force ADC search: the k nearest code words per query by a flat scan (pq_scan_topk_kernel + topk_merge_kernel).
+extern "C" int dr_pq_scan_topk(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t *out_ids, float *out_sq,
+                               float *kernel_ms)
+{
+    if (!ix || !queries || !out_ids || nq == 0 || k == 0 || k > 64) return fail(DR_E_ARG, "bad argument (k <= 64)");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->m == 0) return fail(DR_E_NOPQ, "no PQ data");
+    const uint32_t m = ix->m;
+    if ((m & 15u) != 0 || m > 64) return fail(DR_E_UNSUPPORTED, "dr_pq_scan_topk needs n_subvectors in {16, 32, 48, 64}");
+    HIPCHK(hipSetDevice(ix->device));
+    const size_t lds = (size_t)m * 1024 + 4 * 64 * 8;
+    const void *kfn = m == 16 ? reinterpret_cast<const void *>(&pq_scan_topk_kernel<1>) : m == 32 ? reinterpret_cast<const void *>(&pq_scan_topk_kernel<2>)
+                    : m == 48 ? reinterpret_cast<const void *>(&pq_scan_topk_kernel<3>) : reinterpret_cast<const void *>(&pq_scan_topk_kernel<4>);
+    HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 1;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds));
+    if (occ < 1) occ = 1;
+    // queries are scanned in groups that fill the chip once: `per_q` blocks per query, `group` queries per launch
+    const uint64_t n = ix->N;
+    const uint32_t slots = (uint32_t)occ * ix->num_cu;
+    const uint32_t per_q = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 16383) / 16384, std::min<uint32_t>(slots, 256)));
+    const uint32_t group = std::max<uint32_t>(1, std::min<uint32_t>(nq, 4 * slots / per_q));
+    DevBuf<float> lut, osq; DevBuf<u64> part; DevBuf<uint32_t> oid;
+    if (lut.reserve((size_t)group * m * 256) || part.reserve((size_t)group * per_q * 4 * k) || oid.reserve((size_t)nq * k) || osq.reserve((size_t)nq * k))
+        return DR_E_NODEVICE;
+    float ms_sum = 0;
+    for (uint32_t q0 = 0; q0 < nq; q0 += group) {
+        const uint32_t g = std::min(group, nq - q0);
+        int rc = upload_queries_locked(ix, queries + (size_t)q0 * ix->D, g);
+        if (rc) return rc;
+        rc = launch_lut_build(ix, ix->cs->q.p, g, lut.p);
+        if (rc) return rc;
+        const float *lp = lut.p; const uint8_t *cdp = ix->codes.p; uint64_t nn = n; uint32_t kk = k; u64 *pp = part.p;
+        void *args[] = { &lp, &cdp, &nn, &kk, &pp };
+        HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
+        HIPCHK(hipLaunchKernel(kfn, dim3(per_q, g), dim3(256), args, lds, ix->stream));
+        HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
+        hipLaunchKernelGGL(topk_merge_kernel, dim3(g), dim3(64), 0, ix->stream, part.p, per_q * 4, k, oid.p + (size_t)q0 * k, osq.p + (size_t)q0 * k);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ix->ev[2], ix->ev[3]);
+        ms_sum += ms;
+    }
+    HIPCHK(hipMemcpy(out_ids, oid.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    if (out_sq) HIPCHK(hipMemcpy(out_sq, osq.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+    if (kernel_ms) *kernel_ms = ms_sum;
+    return 0;
+}
+
 extern "C" int dr_bruteforce_topk(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t *out_ids,
                                   float *out_dist)
 {
@@ -1447,9 +1530,15 @@ extern "C" int dr_bruteforce_topk(dr_index *ix, const float *queries, uint32_t n
     DevBuf<uint32_t> oi; DevBuf<float> od;
     if (oi.reserve((size_t)nq * k) || od.reserve((size_t)nq * k)) return DR_E_NODEVICE;
     const float *vecp = ix->vecp.p; const float *qp = ix->cs->qp.p; uint64_t N = ix->N; uint32_t *oip = oi.p; float *odp = od.p;
-    void *args[] = { &vecp, &N, &qp, &nq, &k, &oip, &odp };
+    // small batches: the rows are cut into S slices per query so that the launch still has a few thousand wavefronts
+    const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(64, N / 4096 + 1), ((uint64_t)ix->num_cu * 16) / nq));
+    DevBuf<u64> part;
+    if (S > 1 && part.reserve((size_t)nq * S * k)) return DR_E_NODEVICE;
+    u64 *pp = S > 1 ? part.p : nullptr;
+    void *args[] = { &vecp, &N, &qp, &nq, &k, &oip, &odp, &pp };
     const size_t lds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 64 * 8;
-    HIPCHK(hipLaunchKernel(ix->kern->bruteforce, dim3(nq), dim3(64), args, lds, ix->stream));
+    HIPCHK(hipLaunchKernel(ix->kern->bruteforce, dim3(nq, S), dim3(64), args, lds, ix->stream));
+    if (S > 1) { hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(64), 0, ix->stream, part.p, S, k, oi.p, od.p); HIPCHK(hipGetLastError()); }
     HIPCHK(hipMemcpyAsync(out_ids, oi.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
     if (out_dist) HIPCHK(hipMemcpyAsync(out_dist, od.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
@@ -1549,9 +1638,16 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
         DevBuf<uint32_t> oi; DevBuf<float> od;
         if (oi.reserve(1) || od.reserve(1)) return DR_E_NODEVICE;
         const float *vecp = ix->vecp.p; const float *qp = ix->cs->qp.p; uint64_t NN = N; uint32_t one = 1; uint32_t *oip = oi.p; float *odp = od.p;
-        void *args[] = { &vecp, &NN, &qp, &one, &one, &oip, &odp };
+        // (one query: the rows are cut into slices, one wavefront each, folded by topk_merge_kernel -- same winner as one
+        // wavefront over all rows: smallest distance, then smallest id)
+        const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, N / 4096));
+        DevBuf<u64> part;
+        if (S > 1 && part.reserve(S)) return DR_E_NODEVICE;
+        u64 *pp = S > 1 ? part.p : nullptr;
+        void *args[] = { &vecp, &NN, &qp, &one, &one, &oip, &odp, &pp };
         const size_t lds = (D > 256 ? (size_t)D * 4 : 0) + 64 * 8;
-        HIPCHK(hipLaunchKernel(ix->kern->bruteforce, dim3(1), dim3(64), args, lds, ix->stream));
+        HIPCHK(hipLaunchKernel(ix->kern->bruteforce, dim3(1, S), dim3(64), args, lds, ix->stream));
+        if (S > 1) { hipLaunchKernelGGL(topk_merge_kernel, dim3(1), dim3(64), 0, ix->stream, part.p, S, 1u, oi.p, od.p); HIPCHK(hipGetLastError()); }
         uint32_t med = 0;
         HIPCHK(hipMemcpyAsync(&med, oi.p, 4, hipMemcpyDeviceToHost, ix->stream));
         HIPCHK(hipStreamSynchronize(ix->stream));
@@ -1838,51 +1934,12 @@ static int pq_assign(dr_index *ix, const uint32_t *d_ids, uint64_t n, uint32_t m
     return 0;
 }
 
-// runs fn(j) for j in [0, n) on up to `hardware_concurrency` host threads
-template <class F> static void parallel_for(uint32_t n, F fn)
-{
-    const uint32_t nt = std::max(1u, std::min<uint32_t>(n, std::thread::hardware_concurrency()));
-    if (nt <= 1) { for (uint32_t j = 0; j < n; j++) fn(j); return; }
-    std::vector<std::thread> th;
-    std::atomic<uint32_t> next{0};
-    for (uint32_t t = 0; t < nt; t++) th.emplace_back([&] { for (uint32_t j = next.fetch_add(1); j < n; j = next.fetch_add(1)) fn(j); });
-    for (auto &t : th) t.join();
-}
-
-// Greedy k-means++ seeding of one sub-quantiser (Arthur & Vassilvitskii 2007 with sklearn's 2 + log k local trials per
-// step: sklearn.cluster._kmeans._kmeans_plusplus is what DiskANNPQ.fit reaches through init='k-means++', fast_pq.py:231-238).
-static void kmeanspp_init(const float *x, uint32_t ns, uint32_t D, uint32_t off, uint32_t sd, uint64_t seed, float *cb /*[256][sd]*/)
-{
-    uint64_t rng = seed;
-    auto unif = [&]() { return (double)(splitmix64(rng) >> 11) * (1.0 / 9007199254740992.0); };
-    const uint32_t K = 256, trials = 2 + (uint32_t)std::log((double)K);
-    std::vector<double> d2(ns), cand_d2((size_t)trials * ns);
-    auto dist2 = [&](uint32_t i, const float *c) { double s2 = 0; const float *xi = x + (size_t)i * D + off; for (uint32_t t = 0; t < sd; t++) { const double d = (double)xi[t] - c[t]; s2 += d * d; } return s2; };
-    const uint32_t first = (uint32_t)(unif() * ns) % ns;
-    memcpy(cb, x + (size_t)first * D + off, sd * 4);
-    double pot = 0;
-    for (uint32_t i = 0; i < ns; i++) { d2[i] = dist2(i, cb); pot += d2[i]; }
-    std::vector<uint32_t> cand(trials);
-    for (uint32_t c = 1; c < K; c++) {
-        // candidates with probability proportional to the squared distance to the nearest chosen centre
-        std::vector<double> r(trials);
-        for (auto &v : r) v = unif() * pot;
-        std::sort(r.begin(), r.end());
-        { double acc = 0; uint32_t ti = 0; for (uint32_t i = 0; i < ns && ti < trials; i++) { acc += d2[i]; while (ti < trials && r[ti] < acc) cand[ti++] = i; } while (ti < trials) cand[ti++] = ns - 1; }
-        double best_pot = -1; uint32_t best_t = 0;
-        for (uint32_t t = 0; t < trials; t++) {
-            const float *cc = x + (size_t)cand[t] * D + off;
-            double np = 0;
-            double *cd = &cand_d2[(size_t)t * ns];
-            for (uint32_t i = 0; i < ns; i++) { const double dn = std::min(d2[i], dist2(i, cc)); cd[i] = dn; np += dn; }
-            if (best_pot < 0 || np < best_pot) { best_pot = np; best_t = t; }
-        }
-        memcpy(cb + (size_t)c * sd, x + (size_t)cand[best_t] * D + off, sd * 4);
-        memcpy(d2.data(), &cand_d2[(size_t)best_t * ns], (size_t)ns * 8);
-        pot = best_pot;
-    }
-}
-
+// DiskANNPQ.fit (pq/fast_pq.py:188-243) runs m independent sklearn KMeans(256, init='k-means++', n_init, max_iter, tol).
+// Everything runs on the device (engine_kernels.hpp, "k-means on the device"): greedy k-means++ seeding with sklearn's
+// 2 + log k local trials (one workgroup per sub-quantiser, uniform numbers from the host's splitmix64 stream), Lloyd
+// iterations = nearest-centre assignment + fixed-point centre sums + centre update, sklearn's stopping rule (total squared
+// centre shift <= tol * mean per-feature variance), n_init restarts keeping the lowest inertia per sub-quantiser. The host
+// only reads m shifts per iteration and m inertias per restart. Deterministic for a given seed.
 extern "C" int dr_pq_train_ex(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t max_iter, uint32_t n_init, float tol, uint64_t seed,
                               float *out_codebook, double *out_inertia)
 {
@@ -1907,84 +1964,71 @@ extern "C" int dr_pq_train_ex(dr_index *ix, uint32_t m, uint32_t n_sample, uint3
             for (uint32_t i = 0; i < ns; i++) { uint64_t jx = i + splitmix64(rng) % (ix->N - i); std::swap(all[i], all[jx]); ids[i] = all[i]; }
         }
     }
-    DevBuf<uint32_t> d_ids; DevBuf<float> d_x, d_cb; DevBuf<uint8_t> d_assign;
-    if (d_ids.reserve(ns) || d_x.reserve((size_t)ns * D) || d_cb.reserve((size_t)256 * D) || d_assign.reserve((size_t)ns * m))
+    DevBuf<uint32_t> d_ids, d_counts; DevBuf<float> d_x, d_cb, d_d2, d_maxabs; DevBuf<uint8_t> d_assign;
+    DevBuf<double> d_var, d_unif, d_shift, d_inertia; DevBuf<int> d_fix; DevBuf<unsigned long long> d_sums;
+    if (d_ids.reserve(ns) || d_x.reserve((size_t)ns * D) || d_cb.reserve((size_t)256 * D) || d_assign.reserve((size_t)ns * m) ||
+        d_d2.reserve((size_t)ns * m) || d_maxabs.reserve(m) || d_var.reserve(m) || d_unif.reserve((size_t)m * 256 * 8) || d_shift.reserve(m) ||
+        d_inertia.reserve(m) || d_fix.reserve(m) || d_sums.reserve((size_t)256 * D, true) || d_counts.reserve((size_t)m * 256, true))
         return DR_E_NODEVICE;
     HIPCHK(hipMemcpyAsync(d_ids.p, ids.data(), (size_t)ns * 4, hipMemcpyHostToDevice, ix->stream));
     hipLaunchKernelGGL(gather_subvectors_kernel, dim3(ns), dim3(64), 0, ix->stream, ix->vecp.p, ix->perm.p, d_ids.p, ns, D, d_x.p);
     HIPCHK(hipGetLastError());
-    std::vector<float> x((size_t)ns * D);
-    HIPCHK(hipMemcpyAsync(x.data(), d_x.p, (size_t)ns * D * 4, hipMemcpyDeviceToHost, ix->stream));
+    // sklearn's stopping rule: total squared centre shift <= tol * mean per-feature variance (KMeans tol, default 1e-4);
+    // the fixed-point scale of the centre sums: the largest exponent that cannot overflow 63 bits over ns terms
+    hipLaunchKernelGGL(km_stats_kernel, dim3(m), dim3(DR_KM_THREADS), 0, ix->stream, d_x.p, ns, D, sd, d_var.p, d_maxabs.p);
+    HIPCHK(hipGetLastError());
+    std::vector<double> var_mean(m);
+    std::vector<float> max_abs(m);
+    HIPCHK(hipMemcpyAsync(var_mean.data(), d_var.p, (size_t)m * 8, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipMemcpyAsync(max_abs.data(), d_maxabs.p, (size_t)m * 4, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
-
-    // sklearn's stopping rule: total squared centre shift <= tol * mean per-feature variance (KMeans tol, default 1e-4)
-    std::vector<double> tol_j(m, 0.0);
-    parallel_for(m, [&](uint32_t jq) {
-        double vsum = 0;
-        for (uint32_t t = 0; t < sd; t++) {
-            double s1 = 0, s2 = 0;
-            for (uint32_t i = 0; i < ns; i++) { const double v = x[(size_t)i * D + jq * sd + t]; s1 += v; s2 += v * v; }
-            const double mu = s1 / ns;
-            vsum += s2 / ns - mu * mu;
-        }
-        tol_j[jq] = (double)tol * vsum / sd;
-    });
+    std::vector<double> tol_j(m);
+    std::vector<int> fix(m);
+    for (uint32_t jq = 0; jq < m; jq++) {
+        tol_j[jq] = (double)tol * var_mean[jq];
+        int e = 0;
+        (void)std::frexp((double)max_abs[jq] * (double)ns + 1.0, &e);      // value < 2^e
+        fix[jq] = 61 - e;
+    }
+    HIPCHK(hipMemcpyAsync(d_fix.p, fix.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, ix->stream));
+    const size_t acc_lds_full = (size_t)256 * sd * 8 + 1024;
+    const int use_lds = acc_lds_full <= 128 * 1024 ? 1 : 0;
+    const size_t acc_lds = use_lds ? acc_lds_full : 1024;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&km_accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds));
+    const unsigned acc_gx = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>((ns + 255) / 256, std::max<uint32_t>(1, (uint32_t)ix->num_cu / m)));
 
     std::vector<float> cb((size_t)m * 256 * sd), best_cb((size_t)m * 256 * sd);
-    std::vector<double> best_inertia(m, -1.0), inertia(m), shift(m);
-    std::vector<uint8_t> assign((size_t)ns * m);
-    auto assign_step = [&]() -> int {
-        HIPCHK(hipMemcpyAsync(d_cb.p, cb.data(), cb.size() * 4, hipMemcpyHostToDevice, ix->stream));
-        const int rc = pq_assign(ix, d_ids.p, ns, m, d_cb.p, d_assign.p);
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(assign.data(), d_assign.p, assign.size(), hipMemcpyDeviceToHost, ix->stream));
-        HIPCHK(hipStreamSynchronize(ix->stream));
-        return 0;
-    };
+    std::vector<double> best_inertia(m, -1.0), inertia(m), shift(m), unif((size_t)m * 256 * 8);
     for (uint32_t r = 0; r < n_init; r++) {
-        parallel_for(m, [&](uint32_t jq) {
-            kmeanspp_init(x.data(), ns, D, jq * sd, sd, (seed ? seed : 42) * 0x9E3779B97F4A7C15ull + ((uint64_t)r << 32) + jq + 1,
-                          &cb[(size_t)jq * 256 * sd]);
-        });
+        // the restart's random numbers: per sub-quantiser its own splitmix64 stream (seed, restart, jq)
+        for (uint32_t jq = 0; jq < m; jq++) {
+            uint64_t rng = (seed ? seed : 42) * 0x9E3779B97F4A7C15ull + ((uint64_t)r << 32) + jq + 1;
+            for (uint32_t e = 0; e < 256 * 8; e++) unif[(size_t)jq * 2048 + e] = (double)(splitmix64(rng) >> 11) * (1.0 / 9007199254740992.0);
+        }
+        HIPCHK(hipMemcpyAsync(d_unif.p, unif.data(), unif.size() * 8, hipMemcpyHostToDevice, ix->stream));
+        hipLaunchKernelGGL(kmeanspp_kernel, dim3(m), dim3(DR_KM_THREADS), 0, ix->stream, d_x.p, ns, D, sd, d_unif.p, d_d2.p, d_cb.p);
+        HIPCHK(hipGetLastError());
         for (uint32_t it = 0; it < max_iter; it++) {
-            const int rc = assign_step();
+            int rc = pq_assign(ix, d_ids.p, ns, m, d_cb.p, d_assign.p);
             if (rc) return rc;
-            parallel_for(m, [&](uint32_t jq) {
-                std::vector<double> sums((size_t)256 * sd, 0.0);
-                std::vector<uint32_t> cnt(256, 0u);
-                for (uint32_t i = 0; i < ns; i++) {
-                    const uint32_t c = assign[(size_t)i * m + jq];
-                    cnt[c]++;
-                    const float *xi = &x[(size_t)i * D + jq * sd];
-                    for (uint32_t t = 0; t < sd; t++) sums[(size_t)c * sd + t] += xi[t];
-                }
-                double sh = 0;
-                for (uint32_t c = 0; c < 256; c++)
-                    if (cnt[c])
-                        for (uint32_t t = 0; t < sd; t++) {
-                            float &dst = cb[((size_t)jq * 256 + c) * sd + t];
-                            const float nv = (float)(sums[(size_t)c * sd + t] / cnt[c]);
-                            sh += ((double)nv - dst) * ((double)nv - dst);
-                            dst = nv;
-                        }
-                shift[jq] = sh;
-            });
+            hipLaunchKernelGGL(km_accumulate_kernel, dim3(acc_gx, m), dim3(256), acc_lds, ix->stream, d_x.p, d_assign.p, ns, D, m, sd, d_fix.p,
+                               d_sums.p, d_counts.p, use_lds);
+            hipLaunchKernelGGL(km_finalize_kernel, dim3(m), dim3(256), 0, ix->stream, d_cb.p, sd, d_fix.p, d_sums.p, d_counts.p, d_shift.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(shift.data(), d_shift.p, (size_t)m * 8, hipMemcpyDeviceToHost, ix->stream));
+            HIPCHK(hipStreamSynchronize(ix->stream));
             bool done = true;
             for (uint32_t jq = 0; jq < m; jq++) done = done && shift[jq] <= tol_j[jq];
             if (done) break;
         }
         // labels and inertia of the final centres
-        const int rc = assign_step();
+        const int rc = pq_assign(ix, d_ids.p, ns, m, d_cb.p, d_assign.p);
         if (rc) return rc;
-        parallel_for(m, [&](uint32_t jq) {
-            double in = 0;
-            for (uint32_t i = 0; i < ns; i++) {
-                const float *c = &cb[((size_t)jq * 256 + assign[(size_t)i * m + jq]) * sd];
-                const float *xi = &x[(size_t)i * D + jq * sd];
-                for (uint32_t t = 0; t < sd; t++) { const double d = (double)xi[t] - c[t]; in += d * d; }
-            }
-            inertia[jq] = in;
-        });
+        hipLaunchKernelGGL(km_inertia_kernel, dim3(m), dim3(DR_KM_THREADS), 0, ix->stream, d_x.p, d_assign.p, ns, D, m, sd, d_cb.p, d_inertia.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(inertia.data(), d_inertia.p, (size_t)m * 8, hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipMemcpyAsync(cb.data(), d_cb.p, cb.size() * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
         for (uint32_t jq = 0; jq < m; jq++)
             if (best_inertia[jq] < 0 || inertia[jq] < best_inertia[jq]) {
                 best_inertia[jq] = inertia[jq];

@@ -329,6 +329,98 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(const float *__restrict__ 
     }
 }
 
+// Flat PQ scan keeping the k nearest code words per query (brute-force ADC search: the ground truth of the PQ-only
+// traversals, and what a PQ-only shard falls back to when no graph exists). Tables come from lut_build_kernel (global
+// memory, landed in LDS once per block); every wavefront keeps its own ascending list of k keys (distance bits << 32 | id:
+// the smaller id wins a tie) in LDS and a wave-uniform threshold, so after the first few thousand code words a candidate
+// is rare and the loop runs at the pace of pq_scan_kernel. Lists go to part[query][block * 4 + wave][k]; topk_merge_kernel
+// folds them.
+template <int M16>
+__global__ __launch_bounds__(256) void pq_scan_topk_kernel(const float *__restrict__ lut_g, const u8 *__restrict__ codes, u64 n, u32 k,
+                                                           u64 *__restrict__ part)
+{
+    constexpr u32 m = 16u * M16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *lut = reinterpret_cast<float *>(smem);
+    u64 *best = reinterpret_cast<u64 *>(smem + (size_t)m * 1024) + (threadIdx.x >> 6) * 64;
+    const u32 qi = blockIdx.y, lane = threadIdx.x & 63;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(lut_g + (size_t)qi * m * 256);
+        float4 *dst = reinterpret_cast<float4 *>(lut);
+        for (u32 e = threadIdx.x; e < m * 64; e += 256) dst[e] = src[e];
+    }
+    best[lane] = ~0ull;
+    __syncthreads();
+    u64 Wk = ~0ull;       // the wave's k-th smallest key so far (wave-uniform)
+    int bn = 0;
+    const uint4 *c4 = reinterpret_cast<const uint4 *>(codes);
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+        const u64 i = i0 + lane;
+        float s = 0.0f;
+        if (i < n) {
+#pragma unroll
+            for (int w = 0; w < M16; w++) s = adc_lut16(lut, c4[i * M16 + w], (u32)w * 16, s);
+        }
+        const u64 key = ((u64)__float_as_uint(s) << 32) | (u32)i;
+        u64 cm = __ballot(i < n && key < Wk);
+        while (cm) {
+            const int f = __ffsll((long long)cm) - 1;
+            cm &= cm - 1;
+            const u64 kf = readlane64(key, f);
+            if (kf < Wk) {
+                const u64 mine = ((int)lane < bn) ? best[lane] : ~0ull;
+                const int pos = __popcll(__ballot((int)lane < bn && mine < kf));
+                WSYNC();
+                if ((int)lane < bn && (int)lane >= pos && lane + 1 < k) best[lane + 1] = mine;
+                if (lane == 0) best[pos] = kf;
+                WSYNC();
+                if (bn < (int)k) bn++;
+                if (bn == (int)k) Wk = best[k - 1];
+            }
+        }
+    }
+    WSYNC();
+    if (lane < k) part[((size_t)qi * gridDim.x * 4 + blockIdx.x * 4 + (threadIdx.x >> 6)) * k + lane] = ((int)lane < bn) ? best[lane] : ~0ull;
+}
+// one wavefront per query: the k smallest of its P partial lists of k keys
+__global__ __launch_bounds__(64) void topk_merge_kernel(const u64 *__restrict__ part, u32 P, u32 k, u32 *__restrict__ out_ids, float *__restrict__ out_sq)
+{
+    __shared__ u64 best[64];
+    const u32 qi = blockIdx.x, lane = threadIdx.x;
+    best[lane] = ~0ull;
+    WSYNC();
+    u64 Wk = ~0ull;
+    int bn = 0;
+    const u64 *src = part + (size_t)qi * P * k;
+    const u32 total = P * k;
+    for (u32 i0 = 0; i0 < total; i0 += 64) {
+        const u64 key = (i0 + lane < total) ? src[i0 + lane] : ~0ull;
+        u64 cm = __ballot(key < Wk);
+        while (cm) {
+            const int f = __ffsll((long long)cm) - 1;
+            cm &= cm - 1;
+            const u64 kf = readlane64(key, f);
+            if (kf < Wk) {
+                const u64 mine = ((int)lane < bn) ? best[lane] : ~0ull;
+                const int pos = __popcll(__ballot((int)lane < bn && mine < kf));
+                WSYNC();
+                if ((int)lane < bn && (int)lane >= pos && lane + 1 < k) best[lane + 1] = mine;
+                if (lane == 0) best[pos] = kf;
+                WSYNC();
+                if (bn < (int)k) bn++;
+                if (bn == (int)k) Wk = best[k - 1];
+            }
+        }
+    }
+    WSYNC();
+    if (lane < k) {
+        const u64 key = ((int)lane < bn) ? best[lane] : ~0ull;
+        out_ids[(size_t)qi * k + lane] = ((int)lane < bn) ? (u32)key : 0xFFFFFFFFu;
+        out_sq[(size_t)qi * k + lane] = ((int)lane < bn) ? key_dist(key) : __uint_as_float(0x7FC00000u);
+    }
+}
+
 // ---- builder helpers (build_kernels.hpp has the per-dimension prune kernel) ---------------------------------
 __global__ void gather_rows_kernel(const float *__restrict__ src, const u32 *__restrict__ ids, u32 n, u32 D,
                                    float *__restrict__ dst)
@@ -502,6 +594,193 @@ __global__ void pq_assign_kernel(const float *__restrict__ vecp, const u32 *__re
     }
 }
 
+// ---- k-means on the device (round 3: seeding and centroid update used to run on host threads) ------------------------
+// All kernels work on the gathered sample xs[ns][D] (original element order); one workgroup (or grid row) per
+// sub-quantiser jq. Every reduction is a fixed tree or an integer sum: two trainings with one seed give the same bits.
+#define DR_KM_THREADS 1024
+#define DR_KM_TRIALS 7      // sklearn: 2 + int(log(n_clusters)) local trials per seeding step (k = 256)
+
+// deterministic block sum of one double per thread (tree over LDS; every thread gets the total)
+DEV double km_block_sum(double v, double *red)
+{
+    const u32 t = threadIdx.x;
+    __syncthreads();
+    red[t] = v;
+    __syncthreads();
+    for (u32 o = blockDim.x >> 1; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+DEV float km_dist2(const float *__restrict__ x, const float *c, u32 sd)
+{
+    float s2 = 0.0f;
+    for (u32 t = 0; t < sd; t++) { const float d = x[t] - c[t]; s2 += d * d; }
+    return s2;
+}
+
+// per sub-quantiser: mean per-feature variance (sklearn's tol scaling, _kmeans.py _tolerance) and the largest |x|
+__global__ __launch_bounds__(DR_KM_THREADS) void km_stats_kernel(const float *__restrict__ xs, u32 ns, u32 D, u32 sd, double *__restrict__ var_mean,
+                                                                  float *__restrict__ max_abs)
+{
+    __shared__ double red[DR_KM_THREADS];
+    const u32 jq = blockIdx.x;
+    double vsum = 0.0, mx = 0.0;
+    for (u32 t = 0; t < sd; t++) {
+        double s1 = 0.0, s2 = 0.0, m1 = 0.0;
+        for (u32 i = threadIdx.x; i < ns; i += blockDim.x) { const double v = xs[(size_t)i * D + jq * sd + t]; s1 += v; s2 += v * v; m1 = fmax(m1, fabs(v)); }
+        s1 = km_block_sum(s1, red); s2 = km_block_sum(s2, red);
+        // max through the same tree (max is exact in any order)
+        __syncthreads(); red[threadIdx.x] = m1; __syncthreads();
+        for (u32 o = blockDim.x >> 1; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+        mx = fmax(mx, red[0]);
+        const double mu = s1 / ns;
+        vsum += s2 / ns - mu * mu;
+    }
+    if (threadIdx.x == 0) { var_mean[jq] = vsum / sd; max_abs[jq] = (float)mx; }
+}
+
+// Greedy k-means++ seeding (Arthur & Vassilvitskii 2007 with sklearn's local trials: sklearn.cluster._kmeans._kmeans_plusplus,
+// what DiskANNPQ.fit reaches through init='k-means++', pq/fast_pq.py:231-238). One workgroup per sub-quantiser; the
+// uniform random numbers come from the host (unif[jq][step][0..7): step 0 slot 0 picks the first centre, later steps use
+// DR_KM_TRIALS slots), so the choice sequence is a function of the seed alone. d2[jq][i]: squared distance of sample i to its
+// nearest chosen centre.
+__global__ __launch_bounds__(DR_KM_THREADS) void kmeanspp_kernel(const float *__restrict__ xs, u32 ns, u32 D, u32 sd, const double *__restrict__ unif,
+                                                                  float *__restrict__ d2_all, float *__restrict__ cb /*[m][256][sd]*/)
+{
+    __shared__ double red[DR_KM_THREADS];
+    __shared__ float cand_v[DR_KM_TRIALS][128];
+    __shared__ u32 cand_i[DR_KM_TRIALS];
+    __shared__ double thr[DR_KM_TRIALS];
+    const u32 jq = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const float *x0 = xs + jq * sd;
+    float *d2 = d2_all + (size_t)jq * ns;
+    float *cbj = cb + (size_t)jq * 256 * sd;
+    const double *uj = unif + (size_t)jq * 256 * 8;
+    // first centre
+    const u32 first = min((u32)(uj[0] * ns), ns - 1);
+    for (u32 t = tid; t < sd; t += nt) { const float v = x0[(size_t)first * D + t]; cand_v[0][t] = v; cbj[t] = v; }
+    __syncthreads();
+    double part = 0.0;
+    for (u32 i = tid; i < ns; i += nt) { const float d = km_dist2(x0 + (size_t)i * D, cand_v[0], sd); d2[i] = d; part += d; }
+    double pot = km_block_sum(part, red);
+    const u32 cs = (ns + nt - 1) / nt;      // contiguous chunk per thread for the sampling pass
+    for (u32 c = 1; c < 256; c++) {
+        // (a) DR_KM_TRIALS candidates with probability proportional to d2: first index whose running sum exceeds r
+        if (tid < DR_KM_TRIALS) { thr[tid] = uj[c * 8 + tid] * pot; cand_i[tid] = ns - 1; }
+        const u32 lo = min(tid * cs, ns), hi = min(lo + cs, ns);
+        double loc = 0.0;
+        for (u32 i = lo; i < hi; i++) loc += d2[i];
+        __syncthreads();
+        red[tid] = loc;
+        __syncthreads();
+        // exclusive prefix of the chunk sums: a fixed serial pass by one thread (1024 adds) keeps the order simple and exact
+        if (tid == 0) { double acc = 0.0; for (u32 u = 0; u < nt; u++) { const double v = red[u]; red[u] = acc; acc += v; } }
+        __syncthreads();
+        const double base = red[tid];
+        for (int q = 0; q < DR_KM_TRIALS; q++) {
+            const double r = thr[q];
+            if (r >= base && r < base + loc) {
+                double acc = base; u32 pick = hi - 1;
+                for (u32 i = lo; i < hi; i++) { acc += d2[i]; if (r < acc) { pick = i; break; } }
+                cand_i[q] = pick;
+            }
+        }
+        __syncthreads();
+        for (u32 e = tid; e < DR_KM_TRIALS * sd; e += nt) { const u32 q = e / sd, t = e - q * sd; cand_v[q][t] = x0[(size_t)cand_i[q] * D + t]; }
+        __syncthreads();
+        // (b) potential of every candidate
+        double np[DR_KM_TRIALS];
+#pragma unroll
+        for (int q = 0; q < DR_KM_TRIALS; q++) np[q] = 0.0;
+        for (u32 i = tid; i < ns; i += nt) {
+            const float *xi = x0 + (size_t)i * D;
+            const float cur = d2[i];
+#pragma unroll
+            for (int q = 0; q < DR_KM_TRIALS; q++) np[q] += (double)fminf(cur, km_dist2(xi, cand_v[q], sd));
+        }
+        int best = 0; double best_pot = 0.0;
+#pragma unroll
+        for (int q = 0; q < DR_KM_TRIALS; q++) {
+            const double tot = km_block_sum(np[q], red);
+            if (q == 0 || tot < best_pot) { best_pot = tot; best = q; }
+        }
+        // (c) the winner becomes centre c
+        for (u32 i = tid; i < ns; i += nt) d2[i] = fminf(d2[i], km_dist2(x0 + (size_t)i * D, cand_v[best], sd));
+        for (u32 t = tid; t < sd; t += nt) cbj[(size_t)c * sd + t] = cand_v[best][t];
+        pot = best_pot;
+        __syncthreads();
+    }
+}
+
+// Lloyd update, step 1: per-centre coordinate sums in FIXED POINT (x * 2^shift[jq] as a 64-bit integer: integer addition is
+// associative, so the sums do not depend on the order the atomics arrive in) and member counts. LDS accumulators when
+// they fit (256 * sd * 8 bytes), flushed with global atomics; grid (chunks, m).
+__global__ __launch_bounds__(256) void km_accumulate_kernel(const float *__restrict__ xs, const u8 *__restrict__ assign, u32 ns, u32 D, u32 m, u32 sd,
+                                                            const int *__restrict__ shift, unsigned long long *__restrict__ sums /*[m][256][sd]*/,
+                                                            u32 *__restrict__ counts /*[m][256]*/, int use_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *ls = reinterpret_cast<unsigned long long *>(smem);
+    u32 *lc = reinterpret_cast<u32 *>(ls + (use_lds ? (size_t)256 * sd : 0));
+    const u32 jq = blockIdx.y;
+    const double scale = ldexp(1.0, shift[jq]);
+    unsigned long long *gs = sums + (size_t)jq * 256 * sd;
+    u32 *gc = counts + (size_t)jq * 256;
+    if (use_lds) { for (u32 e = threadIdx.x; e < 256 * sd; e += blockDim.x) ls[e] = 0ull; }
+    for (u32 e = threadIdx.x; e < 256; e += blockDim.x) lc[e] = 0u;
+    __syncthreads();
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+        const u32 c = assign[(size_t)i * m + jq];
+        atomicAdd(&lc[c], 1u);
+        const float *xi = xs + (size_t)i * D + jq * sd;
+        unsigned long long *dst = (use_lds ? ls : gs) + (size_t)c * sd;
+        for (u32 t = 0; t < sd; t++) atomicAdd(&dst[t], (unsigned long long)(long long)llrint((double)xi[t] * scale));
+    }
+    __syncthreads();
+    if (use_lds) { for (u32 e = threadIdx.x; e < 256 * sd; e += blockDim.x) if (ls[e]) atomicAdd(&gs[e], ls[e]); }
+    for (u32 e = threadIdx.x; e < 256; e += blockDim.x) if (lc[e]) atomicAdd(&gc[e], lc[e]);
+}
+// step 2: centres = sums / counts (empty clusters keep their centre), total squared shift per sub-quantiser; clears the
+// accumulators for the next iteration. One workgroup of 256 threads (thread c = centre c) per sub-quantiser.
+__global__ __launch_bounds__(256) void km_finalize_kernel(float *__restrict__ cb, u32 sd, const int *__restrict__ shift, unsigned long long *__restrict__ sums,
+                                                          u32 *__restrict__ counts, double *__restrict__ out_shift)
+{
+    __shared__ double red[256];
+    const u32 jq = blockIdx.x, c = threadIdx.x;
+    const double inv = ldexp(1.0, -shift[jq]);
+    const u32 n = counts[(size_t)jq * 256 + c];
+    double sh = 0.0;
+    for (u32 t = 0; t < sd; t++) {
+        const size_t e = ((size_t)jq * 256 + c) * sd + t;
+        if (n) {
+            const float nv = (float)((double)(long long)sums[e] * inv / (double)n);
+            const double d = (double)nv - (double)cb[e];
+            sh += d * d;
+            cb[e] = nv;
+        }
+        sums[e] = 0ull;
+    }
+    counts[(size_t)jq * 256 + c] = 0u;
+    const double tot = km_block_sum(sh, red);
+    if (c == 0) out_shift[jq] = tot;
+}
+// quantisation error of the sample for the current centres and labels
+__global__ __launch_bounds__(DR_KM_THREADS) void km_inertia_kernel(const float *__restrict__ xs, const u8 *__restrict__ assign, u32 ns, u32 D, u32 m, u32 sd,
+                                                                   const float *__restrict__ cb, double *__restrict__ out)
+{
+    __shared__ double red[DR_KM_THREADS];
+    const u32 jq = blockIdx.x;
+    double s = 0.0;
+    for (u32 i = threadIdx.x; i < ns; i += blockDim.x) {
+        const float *c = cb + ((size_t)jq * 256 + assign[(size_t)i * m + jq]) * sd;
+        const float *xi = xs + (size_t)i * D + jq * sd;
+        for (u32 t = 0; t < sd; t++) { const double d = (double)xi[t] - (double)c[t]; s += d * d; }
+    }
+    const double tot = km_block_sum(s, red);
+    if (threadIdx.x == 0) out[jq] = tot;
+}
+
 __global__ void gather_subvectors_kernel(const float *__restrict__ vecp, const u32 *__restrict__ perm,
                                          const u32 *__restrict__ ids, u32 n, u32 D, float *__restrict__ out)
 {
@@ -535,6 +814,17 @@ __global__ __launch_bounds__(256) void pq_bound_kernel(const float *__restrict__
         __syncthreads();
     }
     if (tid == 0) out[qi] = f_sqrt(s);
+}
+
+// squared norm of every stored vector (cosine traversal): one thread per row, double accumulator (any element order)
+__global__ void row_norm2_kernel(const float *__restrict__ vecp, u64 N, u32 D, float *__restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        const float *r = vecp + i * D;
+        for (u32 t = 0; t < D; t++) s += (double)r[t] * (double)r[t];
+        out[i] = (float)s;
+    }
 }
 
 // adjr[i][s] = bit position of neighbour adj[i][s] in the visited bitmap (pad slots: 0)

@@ -90,6 +90,7 @@ struct SearchParams {
     u32 *out_count;          // [nq]
     u64 *phase;              // [nq][8] cycle sums (DR_PHASE_TIMING builds only)
     const float *pq_ub;      // [nq] precomputed sqrt-ADC upper bounds (pq_bound_kernel) or nullptr
+    const float *vnorm2;     // [N] squared norms of the stored vectors (DR_F_COSINE: M3 with distance_metric='cosine') or nullptr
     // builder over a PQ-only shard (no stored vectors): query qi IS the stored point build_pts[qi], known by its code
     // word only, and its table T[j][c] = |C_j[c] - C_j[code_j]|^2 is m rows of the centroid-pair table sdc[m][256][256]
     const float *sdc;
@@ -535,6 +536,19 @@ DEV float wave_max(float x)
 // A4 as a threshold on the worst distance: returns the bits of x = the largest float W >= 0 with f_mul(W, thr) <= pq.
 // f_mul(., thr) is monotone, so the reference's test `pq < thr * W` (search_engine.py:390-395) holds exactly for
 // W > x. `ok` is cleared if the fix-up did not reach the boundary (reported through stats.status, never silent).
+// Cosine distance of the reference's in-memory M3 (compute_query_distance(metric='cosine'), vamana_graph.py:324-329 ->
+// cosine_similarity_cython, cython_utils.pyx:53-70: 1 - dot / (sqrt(nx) sqrt(ny)), 0 when a norm is 0) from the squared L2
+// distance the kernel already has: dot = (nx + ny - |x - y|^2) / 2, in double. The reference sums in float32 under
+// -ffast-math (order unpinned, held to 1e-5 like its own test); a value that rounds below zero is returned as 0 (the
+// lists order non-negative float bits).
+DEV float cosine_from_l2(float l2, float nx, float ny)
+{
+    if (nx == 0.0f || ny == 0.0f) return 0.0f;
+    const double dot = 0.5 * ((double)nx + (double)ny - (double)l2);
+    const double d = 1.0 - dot / (__builtin_sqrt((double)nx) * __builtin_sqrt((double)ny));
+    return d > 0.0 ? (float)d : 0.0f;
+}
+
 DEV u32 a4_threshold_bits(float pq, float thr, bool &ok) {
     if (!(pq < __builtin_inff())) return 0x7F800000u;    // never passes
     u32 cb = __float_as_uint(pq / thr);
@@ -566,6 +580,7 @@ DEV void search_body(const SearchParams &p)
     const bool has_first = FILTER ? true : (p.first != nullptr);
     const bool has_out = FILTER ? true : (p.out_ids != nullptr);
     const bool has_ties = FILTER ? true : (p.tie_list != nullptr);
+    const bool kcos = !FILTER && KIND == DIST_EXACT && p.vnorm2 != nullptr;      // traversal metric: cosine distance (M3)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
@@ -667,6 +682,13 @@ DEV void search_body(const SearchParams &p)
             }
             if constexpr (QREG) load_query_regs<0, D, D>(qpg, j, qreg);
         }
+        float qn2 = 0.0f;
+        if (kcos) {
+            const float *qg = p.queries + (size_t)qi * D;
+            for (int i = lane; i < D; i += 64) qn2 += qg[i] * qg[i];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) qn2 += __shfl_xor(qn2, o);
+        }
         if constexpr (VB_BITS > 0) { for (int i = lane; i < VB_BITS / 32; i += 64) blm[i] = 0u; }
         // Byte queries (the engine selects this variant only when EVERY component of EVERY query of the batch is an
         // integer in [0, 255], like the rows): the same 16 chain steps of lane j packed into four words, and sum q^2.
@@ -683,14 +705,14 @@ DEV void search_body(const SearchParams &p)
         }
         WSYNC();
         if constexpr (NEED_PQ && !CBLDS) {
-            if (TREG == 0 && KIND == DIST_ADC_SQ && p.sdc != nullptr) {      // (the PQ-only builder runs the all-LDS variant)
+            if (KIND == DIST_ADC_SQ && p.sdc != nullptr) {
                 // the point's code word in whole 16-byte pieces, then the table rows of a piece, sixteen loads in flight
                 // (every loop over the bytes is unrolled: no register array is indexed dynamically)
                 const u8 *mycodes = p.codes + (size_t)p.build_pts[qi] * p.m;
                 if ((p.m & 15u) == 0 && p.m <= 64) {
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        if (i * 16 < (int)p.m) {
+                        if (i * 16 < (int)m_lds) {
                             const uint4 w = reinterpret_cast<const uint4 *>(mycodes)[i];
                             const u32 words[4] = { w.x, w.y, w.z, w.w };
                             float4 r[16];
@@ -703,7 +725,19 @@ DEV void search_body(const SearchParams &p)
                             for (int t = 0; t < 16; t++) reinterpret_cast<float4 *>(lut + (size_t)(i * 16 + t) * 256)[lane] = r[t];
                         }
                     }
-                } else {
+                    if constexpr (TREG > 0) {
+                        // the last piece's rows go to registers: tv[t*4 + v] of lane l = T[m-16+t][64 v + l]
+                        const uint4 w = reinterpret_cast<const uint4 *>(mycodes)[m_lds >> 4];
+                        const u32 words[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+                        for (int t = 0; t < 16; t++) {
+                            const u32 c = (words[t >> 2] >> (8 * (t & 3))) & 255u;
+                            const float *row = p.sdc + ((size_t)(m_lds + t) * 256 + c) * 256 + lane;
+#pragma unroll
+                            for (int v = 0; v < 4; v++) tv[t * 4 + v] = row[v * 64];
+                        }
+                    }
+                } else if constexpr (TREG == 0) {
                     for (u32 jq = 0; jq < p.m; jq++)
                         reinterpret_cast<float4 *>(lut + (size_t)jq * 256)[lane] =
                             reinterpret_cast<const float4 *>(p.sdc + ((size_t)jq * 256 + mycodes[jq]) * 256)[lane];
@@ -784,6 +818,7 @@ DEV void search_body(const SearchParams &p)
             } else {
                 d0 = pw_row_stream<0, D, D, QREG>(p.vecp + (size_t)start * D, &qreg, qperm, j);
                 d0 = __uint_as_float(readlane32(__float_as_uint(d0), 0));
+                if (kcos) d0 = cosine_from_l2(d0, p.vnorm2[start], qn2);
                 if (knorm) d0 = f_sqrt(d0);
                 nexact++;
             }
@@ -1175,6 +1210,7 @@ DEV void search_body(const SearchParams &p)
                     }
                     WSYNC();
                     e = rowlane ? nb_e[myrow] : __builtin_inff();
+                    if (kcos && rowlane) e = cosine_from_l2(e, p.vnorm2[myid], qn2);
                     if constexpr (FILTER) {
                         npq += nnew;            // the reference counts one PQ distance per new neighbour
                         if (need_adc) npq_eval += nnew;

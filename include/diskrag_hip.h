@@ -41,6 +41,11 @@ extern "C" {
 #define DR_F_RERANK 4u /* DR_MODE_PQ: score the final result list with exact squared L2 (A1, search_engine.py:374-379) and
                           return the k best in (distance, id) order; needs the stored vectors */
 
+#define DR_F_COSINE 8u /* M3 without DR_F_USE_PQ: the in-memory graph's distance_metric='cosine' -- compute_query_distance ->
+                          cosine_similarity_cython (vamana_graph.py:324-329, cython_utils.pyx:53-70): 1 - cos, 0 when a norm is
+                          0; out_dist = sqrt of it (vamana_graph.py:598). The reference sums in float32 under -ffast-math
+                          (order unpinned; its own test holds 1e-5): ids equal up to near-ties, distances to 1e-5 */
+
 /* error codes */
 #define DR_OK 0
 #define DR_E_ARG (-1)        /* bad argument (ValueError in the reference facade) */
@@ -212,6 +217,12 @@ int dr_pq_scan(dr_index *ix, const float *queries, uint32_t nq, float *out_sq /*
  * (scripts/bench_pq_scan.py). out_sq may be null. */
 int dr_pq_scan_best(dr_index *ix, const float *queries, uint32_t nq, float *out_sq, uint32_t *out_best_id,
                     float *out_best_sq, float *kernel_ms);
+/* Brute-force ADC search: the k (<= 64) nearest code words per query by a flat scan of all N code words, in (distance, id)
+ * order -- sums as asymmetric_distance_sq (pq/fast_pq.py:320-328), tables as compute_distance_table (:294-318). The ground
+ * truth of the PQ-only traversals on shards whose vectors were never stored. kernel_ms (may be NULL):
+ * summed duration of the scan launches. n_subvectors in {16, 32, 48, 64}. */
+int dr_pq_scan_topk(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t *out_ids /*[nq][k]*/,
+                    float *out_sq /*[nq][k] or NULL*/, float *kernel_ms);
 /* Brute-force exact top-k (recall ground truth), squared L2 in the A1 summation order. */
 int dr_bruteforce_topk(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t *out_ids,
                        float *out_dist);
@@ -266,8 +277,9 @@ int dr_debug_prune(dr_index *ix, uint32_t point, const uint32_t *candidates, uin
 
 /* PQ build on the device. dr_pq_train_ex: m independent k-means with 256 centroids on a sample of the
  * stored vectors, as DiskANNPQ.fit runs sklearn's KMeans (pq/fast_pq.py:188-243): greedy k-means++ seeding, n_init
- * restarts keeping the lowest inertia per sub-quantiser, Lloyd iterations (assignment on the device, centroid update on
- * host threads) until the total squared centre shift is <= tol * mean feature variance or max_iter is reached.
+ * restarts keeping the lowest inertia per sub-quantiser, Lloyd iterations until the total squared centre shift is
+ * <= tol * mean feature variance or max_iter is reached -- seeding, assignment and centre update all on the device
+ * (deterministic for a given seed: fixed reduction trees, fixed-point centre sums).
  * out_inertia (may be NULL) receives the summed quantisation error on the sample. Codebooks are not bit-comparable with
  * sklearn's (different random streams): the golden fixtures ship reference codebooks, and the trainer is held to the
  * reference's quantisation error (tests/test_gpu_round2.py). dr_pq_train = one restart, `iters` iterations, tol 1e-4.

@@ -14,7 +14,7 @@ LIB_PATH = HERE / "libdiskrag_oracle.so"
 PAD = 0xFFFFFFFF
 M1, M2, M3, M4 = 1, 2, 3, 4
 PQ = 5    # engine mode DR_MODE_PQ (no reference counterpart): M1's loop on squared ADC distances only
-F_USE_PQ, F_CYTHON, F_QUERY_F64, F_PAIRWISE, F_RERANK = 1, 2, 4, 8, 16
+F_USE_PQ, F_CYTHON, F_QUERY_F64, F_PAIRWISE, F_RERANK, F_COSINE = 1, 2, 4, 8, 16, 32
 
 _lib = None
 

@@ -2,7 +2,10 @@
 The vectors are generated chunk by chunk on the host (UnitMixtureStream), encoded on the device and forgotten -- they
 are never stored (1.25e8 x 1536 x 4 B = 768 GB); the Vamana graph is built from the code words alone
 (dr_build_vamana_pq) and searched with the engine's PQ-only traversal (DR_MODE_PQ) and the reference's (M3 with PQ).
-Usage: python scripts/c5_shard.py [N] [chunk_rows] [n_gt_queries]  -> gpurun_out/scale_c5_shard.json"""
+Ground truth for NGT queries, both kinds: EXACT top-10 (a running brute-force merge over the streamed chunks: every chunk
+is a temporary index, dr_bruteforce_topk, ids offset by the chunk's first row) and ADC top-10 (dr_pq_scan_topk, a flat
+scan of the finished code table).
+Usage: python scripts/c5_shard.py [N] [chunk_rows] [n_gt_queries] [R] [L_build] [m] [n_clusters]  -> gpurun_out/scale_c5_shard.json"""
 import json
 import os
 import sys
@@ -14,19 +17,26 @@ import numpy as np  # noqa: E402
 
 sys.path.insert(0, ".")
 from diskrag_amd import HipIndex, _ffi                       # noqa: E402
+from diskrag_amd.parallel import merge_topk                   # noqa: E402
 from diskrag_amd.synth import UnitMixtureStream, recall_at_k  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 125_000_000
-CH = int(sys.argv[2]) if len(sys.argv) > 2 else 4 * 1024 * 1024
-NGT = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-D, m, R, nq = 1536, 32, 32, 10000
+argv = sys.argv[1:] + [None] * 8
+N = int(argv[0] or 125_000_000)
+CH = int(argv[1] or 4 * 1024 * 1024)
+NGT = int(argv[2] or 1000)
+R = int(argv[3] or 32)
+LB = int(argv[4] or 64)
+m = int(argv[5] or 32)
+NCL = int(argv[6] or 4096)
+D, nq = 1536, 10000
 CH -= CH % UnitMixtureStream.BLOCK
-out = {"shape": "c5 shard", "N": N, "D": D, "m": m, "R": R, "nq": nq, "chunk_rows": CH}
-gen = UnitMixtureStream(d=D, n_clusters=4096, seed=11, latent=64, threads=96)
+out = {"shape": "c5 shard", "N": N, "D": D, "m": m, "R": R, "L_build": LB, "n_clusters": NCL, "nq": nq, "chunk_rows": CH}
+gen = UnitMixtureStream(d=D, n_clusters=NCL, seed=11, latent=64, threads=96)
+OUT = os.environ.get("C5_OUT", "gpurun_out/scale_c5_shard.json")
 
 
 def save():
-    json.dump(out, open("gpurun_out/scale_c5_shard.json", "w"), indent=1)
+    json.dump(out, open(OUT, "w"), indent=1)
 
 
 # codebook from a sample of the first chunk (DiskANNPQ.fit on a sample: k-means++ seeding, Lloyd)
@@ -38,8 +48,10 @@ tmp.close()
 out["codebook_s"] = time.perf_counter() - t0
 del sample
 
+q = gen.draw(0, nq, stream=1)
 sh = HipIndex.create_codes_empty(N, D, R, cb)
-t_gen = t_enc = 0.0
+t_gen = t_enc = t_gt = 0.0
+gt_ids = gt_dist = None
 t0 = time.perf_counter()
 for r0 in range(0, N, CH):
     rows = min(CH, N - r0)
@@ -48,13 +60,21 @@ for r0 in range(0, N, CH):
     t2 = time.perf_counter()
     sh.encode_rows(x, r0)
     t3 = time.perf_counter()
-    t_gen += t2 - t1; t_enc += t3 - t2
+    if NGT:
+        # exact top-10 of this chunk, merged into the running lists in canonical (distance, id) order
+        part = HipIndex.create_empty(x, R=1)
+        ci, cd = part.bruteforce_topk(q[:NGT], 10)
+        part.close()
+        ci = (ci.astype(np.uint64) + r0).astype(np.uint32)
+        gt_ids, gt_dist = (ci, cd) if gt_ids is None else merge_topk([gt_ids, ci], [gt_dist, cd], 10)
+    t4 = time.perf_counter()
+    t_gen += t2 - t1; t_enc += t3 - t2; t_gt += t4 - t3
     del x
-out["generate_s"], out["encode_s"], out["stream_total_s"] = t_gen, t_enc, time.perf_counter() - t0
+out["generate_s"], out["encode_s"], out["exact_ground_truth_s"], out["stream_total_s"] = t_gen, t_enc, t_gt, time.perf_counter() - t0
 save()
 print("encoded", out, flush=True)
 
-medoid, bsec = sh.build_vamana_pq(L_build=64, alpha=1.2, passes=2, seed=7)
+medoid, bsec = sh.build_vamana_pq(L_build=LB, alpha=1.2, passes=2, seed=7)
 out["build_s"], out["medoid"] = bsec, medoid
 out["memory_bytes"] = {"codes": N * m, "adjacency": N * R * 4, "first_masks": N * 8, "codebook": 256 * D * 4, "centroid_pair_table": m * 65536 * 4,
                        "build_scratch_rows": N * (R + 64) * 4, "visited_words_per_slot": ((N + 23) // 24 + 3) // 4 * 16,
@@ -62,18 +82,12 @@ out["memory_bytes"] = {"codes": N * m, "adjacency": N * R * 4, "first_masks": N 
 save()
 print("built", bsec, flush=True)
 
-q = gen.draw(0, nq, stream=1)
-# ground truth in the shard's own metric: brute-force ADC top-10 of the first NGT queries (flat scan of all code words)
+# ground truth in the shard's own metric: brute-force ADC top-10 (flat scan of all code words, top-k kept on the device)
 t0 = time.perf_counter()
-gt = np.empty((NGT, 10), dtype=np.uint32)
-scan_ms = []
-for i in range(NGT):
-    _, _, ms, d_all = sh.pq_scan_best(q[i:i + 1], want_output=True)
-    part = np.argpartition(d_all[0], 10)[:10]
-    gt[i] = part[np.lexsort((part, d_all[0][part]))]
-    scan_ms.append(ms)
-out["ground_truth"] = {"queries": NGT, "seconds": time.perf_counter() - t0, "flat_scan_kernel_ms": float(np.mean(scan_ms)),
-                       "flat_scan_GBps": N * m / (float(np.mean(scan_ms)) * 1e-3) / 1e9}
+gt_adc, _, scan_ms = sh.pq_scan_topk(q[:max(NGT, 1)], 10)
+out["ground_truth"] = {"queries": NGT, "adc_seconds": time.perf_counter() - t0, "flat_scan_kernel_ms_per_query": scan_ms / max(NGT, 1),
+                       "flat_scan_GBps": N * m * max(NGT, 1) / (scan_ms * 1e-3) / 1e9,
+                       "adc_top10_vs_exact_top10": recall_at_k(gt_adc, gt_ids, 10) if NGT else None}
 save()
 
 sh.batch_upload(q)
@@ -90,17 +104,22 @@ def run(tag, **kw):
     ids, dist, cnt, st = sh.batch_download()
     t = sh.timing()
     alg = float((4.0 * D + st["steps"] * 4.0 * R + st["pq_evaluated"] * float(m) + 80).sum())
-    out["runs"][tag] = {"qps": nq / dt, "kernel_ms": t["search_kernel_ms"], "variant": t["variant"], "waves_per_cu": t["waves_per_cu"],
-                        "recall_at_10_vs_bruteforce_adc": recall_at_k(ids[:NGT], gt, 10), "steps": float(st["steps"].mean()),
+    out["runs"][tag] = {"qps": nq / dt, "kernel_ms": t["search_kernel_ms"], "table_build_kernel_ms": t["lut_kernel_ms"], "variant": t["variant"],
+                        "waves_per_cu": t["waves_per_cu"],
+                        "recall_at_10_vs_bruteforce_adc": recall_at_k(ids[:NGT], gt_adc, 10),
+                        "recall_at_10_vs_exact": recall_at_k(ids[:NGT], gt_ids, 10) if NGT else None, "steps": float(st["steps"].mean()),
                         "pq_evaluated": float(st["pq_evaluated"].mean()), "status_max": int(st["status"].max()),
                         "alg_bytes_per_query": alg / nq, "alg_frac_of_8TBps": alg / (t["search_kernel_ms"] * 1e-3) / 8e12}
     save()
     print(tag, out["runs"][tag], flush=True)
 
 
-for L in (100, 200, 400):
+for L in (100, 200, 400, 800):
     for bw in (8, 0):
         run(f"PQ_L{L}_bw{bw or 'None'}", L=L, beam_width=bw, mode=_ffi.MODE_PQ)
+sh.debug_force_kind(2)
+run("PQ_L400_bwNone_variant2_table_in_LDS", L=400, beam_width=0, mode=_ffi.MODE_PQ)
+sh.debug_force_kind(-1)
 run("M3_PQ_k10_bw8_reference_faithful", L=10, beam_width=8, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
 run("M3_PQ_k10_bw64_reference_faithful", L=10, beam_width=64, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
 sh.close()

@@ -17,6 +17,9 @@ x, q = gen(n, D, n_queries=10000, n_clusters=ncl, seed=11, latent=latent)
 ix = HipIndex.create_empty(x, R=R)
 ix.build_vamana(L_build=100 if shape != "c5s" else 64, alpha=1.2, passes=2, seed=7)
 cb = ix.pq_train(m, n_sample=100000, iters=5); ix.pq_encode(cb)
+import os
+if os.environ.get("DR_INLINE") == "1":
+    ix.inline_codes(True)               # code words of a node's neighbours beside its adjacency row (dr_index_inline_codes)
 ix.bruteforce_topk(q[:1], 10)           # calibration: streams the whole vector table once
 ix.batch_upload(q)
 for _ in range(4):

@@ -273,3 +273,27 @@ def test_flat_pq_scan_generic_m():
             assert bits(np.float32(bsq[qi])) == bits(want.min()) == bits(np.float32(bsq2[qi]))
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("name", ["randn128_R16_m32", "unit1536_R16_m32", "deep96_R32_m16"])
+def test_m3_cosine_traversal(name):
+    """DR_F_COSINE: the in-memory M3 with distance_metric='cosine' (vamana_graph.py:324-329, cython_utils.pyx:53-70) against
+    the reference's goldens (tests/golden/gen_golden_cosine.py) at the reference's own tolerance for this kernel (1e-5; its
+    -ffast-math summation order is unpinned) -- ids equal except where two distances lie within that tolerance."""
+    import json
+    from diskrag_amd import _ffi
+    from tests.conftest import GOLDEN
+    g = load_golden(name)
+    z = np.load(GOLDEN / f"cos_{name}.npz")
+    ix = get_index(name, mem=True)
+    for ci, c in enumerate(json.loads(str(z["cases"]))):
+        ids, dist, cnt, st = ix.search_batch(g.queries, c["k"], L=c["k"], beam_width=c["bw"], mode=_ffi.MODE_M3, flags=_ffi.F_COSINE)
+        assert int(st["status"].max()) == 0
+        w_ids, w_dist = z[f"c{ci}_ids"], z[f"c{ci}_dist"]
+        assert np.array_equal(cnt, z[f"c{ci}_count"])
+        valid = w_ids != 0xFFFFFFFF
+        assert np.allclose(dist[valid], w_dist[valid], rtol=0, atol=1e-5), (name, c)
+        for qi, pos in np.argwhere(ids != w_ids):      # a swap is only allowed between near-equal distances
+            assert abs(float(dist[qi, pos]) - float(w_dist[qi, pos])) <= 1e-5
+    with pytest.raises(_ffi.DiskragHipError):
+        ix.search_batch(g.queries, 5, L=5, beam_width=8, mode=_ffi.MODE_M1, flags=_ffi.F_COSINE)

@@ -158,6 +158,33 @@ def test_split_table_variant_returns_the_same_bits(name):
         shard.close()
 
 
+@pytest.mark.parametrize("name", ["sift128_R64_m32", "unit1536_R16_m64", "deep96_R32_m16"])
+def test_pq_scan_topk_equals_the_sorted_flat_scan(name):
+    """dr_pq_scan_topk (brute-force ADC search, the ground truth of the PQ-only traversals) == the k smallest
+    (distance, id) pairs of the full flat scan, whose sums are pinned on the reference's ADC bits."""
+    g = load_golden(name)
+    ix = get_index(name)
+    full, _ = ix.pq_scan(g.queries)
+    for k in (1, 10, 64):
+        ids, sq, ms = ix.pq_scan_topk(g.queries, k)
+        for qi in range(len(g.queries)):
+            order = np.lexsort((np.arange(full.shape[1]), full[qi]))[:k]
+            assert np.array_equal(ids[qi], order.astype(np.uint32)), (name, k, qi)
+            assert np.array_equal(bits(sq[qi]), bits(full[qi][order]))
+    # duplicated code words: ties go to the smaller id
+    from diskrag_amd import HipIndex
+    codes = np.repeat(g.codes[:50], 3, axis=0)
+    sh = HipIndex.create_codes(np.zeros((150, 4), dtype=np.uint32), 0, g.vectors.shape[1], g.codebook, codes)
+    try:
+        ids, sq, _ = sh.pq_scan_topk(g.queries[:4], 12)
+        f2, _ = sh.pq_scan(g.queries[:4])
+        for qi in range(4):
+            order = np.lexsort((np.arange(150), f2[qi]))[:12]
+            assert np.array_equal(ids[qi], order.astype(np.uint32))
+    finally:
+        sh.close()
+
+
 @pytest.mark.parametrize("name", ["randn128_R16_m32", "unit1536_R16_m32"])
 def test_result_lists_up_to_1024_entries(name):
     from diskrag_amd import _ffi

@@ -172,3 +172,22 @@ def test_m4_ids(name, ci):
         assert c["ids"][qi, j] in row, (name, ci, qi, j)
         pos = row.index(c["ids"][qi, j])
         assert abs(dist[qi, pos] - dist[qi, j]) <= 1e-5 * abs(dist[qi, j]), (name, ci, qi, j)
+
+
+COSINE_FIXTURES = ["randn128_R16_m32", "unit1536_R16_m32", "deep96_R32_m16"]
+
+
+@pytest.mark.parametrize("name", COSINE_FIXTURES)
+def test_m3_cosine_against_the_reference(name):
+    """M3 with distance_metric='cosine' (compute_query_distance -> cosine_similarity_cython, vamana_graph.py:324-329,
+    cython_utils.pyx:53-70), goldens from tests/golden/gen_golden_cosine.py: the reference sums in float32 under
+    -ffast-math (order unpinned), so ids are held equal (no near-ties on these fixtures) and distances to 1e-5."""
+    import json
+    from tests.conftest import GOLDEN
+    g = load_golden(name)
+    z = np.load(GOLDEN / f"cos_{name}.npz")
+    for ci, c in enumerate(json.loads(str(z["cases"]))):
+        ids, dist, cnt, _ = orc.search_batch(g.vectors, g.mem_adj, g.queries, g.medoid, orc.M3, c["k"], L=c["k"], bw=c["bw"], flags=orc.F_COSINE)
+        assert np.array_equal(ids, z[f"c{ci}_ids"]) and np.array_equal(cnt, z[f"c{ci}_count"])
+        valid = ids != 0xFFFFFFFF
+        assert np.allclose(dist[valid], z[f"c{ci}_dist"][valid], rtol=0, atol=1e-5)
