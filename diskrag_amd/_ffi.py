@@ -47,7 +47,7 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_batch_select", "dr_search_submit", "dr_search_wait", "dr_host_alloc", "dr_host_free",
            "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_merge_topk",
            "dr_debug_prune", "dr_pq_train_ex", "dr_index_create_codes_empty", "dr_pq_encode_rows", "dr_build_vamana_pq",
-           "dr_scalar_kernels", "dr_index_inline_codes", "dr_pq_scan_topk"]
+           "dr_scalar_kernels", "dr_index_inline_codes", "dr_pq_scan_topk", "dr_index_copy_codes"]
 
 _lib = None
 
@@ -253,6 +253,14 @@ class HipIndex:
         ix = cls(h, N, D, R, 0)
         ix.m = m
         return ix
+
+    def copy_codes_from(self, other):
+        """Code table + codebook of `other` (same N, D, device) copied on the device (dr_index_copy_codes)."""
+        L = load_library()
+        L.dr_index_copy_codes.restype = C.c_int
+        L.dr_index_copy_codes.argtypes = [C.c_void_p, C.c_void_p]
+        _check(L.dr_index_copy_codes(self._h, other._h))
+        self.m = other.m
 
     def encode_rows(self, vectors, row0):
         v = np.ascontiguousarray(vectors, dtype=np.float32)

@@ -102,9 +102,10 @@ struct QSlot {
     uint32_t nq = 0;
     DevBuf<float> q, qp, pq_ub;
     DevBuf<float> lut;           // [nq][m][256] per-query tables of the batch (lut_build_kernel), rebuilt by every search that uses them
+    bool qp_valid = false;       // qp holds the chain-major copy of q (dr_search_submit skips it at D <= 256: the register variants read q)
     bool pq_ub_valid = false;    // pq_ub matches these queries and the attached codebook
     bool q_u8 = false;           // every component is an integer in [0, 255] (byte-query variants 13/14)
-    void release() { q.release(); qp.release(); pq_ub.release(); lut.release(); nq = 0; pq_ub_valid = false; q_u8 = false; }
+    void release() { q.release(); qp.release(); pq_ub.release(); lut.release(); nq = 0; pq_ub_valid = false; q_u8 = false; qp_valid = false; }
 };
 #define DR_PIPE_DEPTH 3
 
@@ -471,12 +472,15 @@ static bool queries_are_u8(const float *queries, size_t n)
 }
 
 // queues the copy of a batch into a slot and its chain-major twin on `st`
-static int upload_slot_async(dr_index *ix, QSlot &qs, const float *src, uint32_t nq, hipStream_t st)
+static int upload_slot_async(dr_index *ix, QSlot &qs, const float *src, uint32_t nq, hipStream_t st, bool with_qp = true)
 {
     if (qs.q.reserve((size_t)nq * ix->D) || qs.qp.reserve((size_t)nq * ix->D)) return DR_E_NODEVICE;
     HIPCHK(hipMemcpyAsync(qs.q.p, src, (size_t)nq * ix->D * 4, hipMemcpyDefault, st));      // (host or device source)
-    hipLaunchKernelGGL(permute_queries_kernel, dim3(nq), dim3(64), 0, st, qs.q.p, nq, ix->D, ix->perm.p, qs.qp.p);
-    HIPCHK(hipGetLastError());
+    if (with_qp) {
+        hipLaunchKernelGGL(permute_queries_kernel, dim3(nq), dim3(64), 0, st, qs.q.p, nq, ix->D, ix->perm.p, qs.qp.p);
+        HIPCHK(hipGetLastError());
+    }
+    qs.qp_valid = with_qp;
     qs.nq = nq;
     qs.pq_ub_valid = false;
     return 0;
@@ -662,6 +666,32 @@ static void harvest_kernel_times(dr_index *ix, bool publish)
     }
 }
 
+// sqrt-ADC upper bound per query (search_kernel.hpp "exact skip"): the one-lane-per-query kernel for the usual sub_dims
+static int launch_pq_bound(dr_index *ix, const float *d_queries, uint32_t nq, float *d_out, hipStream_t st)
+{
+    const float *cbp = ix->codebook.p; uint32_t nqv = nq, Dv = ix->D, mv = ix->m;
+    const void *fn = nullptr;
+    switch (ix->sd) {
+    case 2: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<2>); break;
+    case 3: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<3>); break;
+    case 4: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<4>); break;
+    case 6: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<6>); break;
+    case 8: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<8>); break;
+    case 12: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<12>); break;
+    case 16: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<16>); break;
+    default: break;
+    }
+    static const bool old_form = getenv("DR_PQ_BOUND_BLOCK") != nullptr;      // A/B: the block-per-query form
+    if (fn && !old_form) {
+        void *args[] = { &cbp, &d_queries, &nqv, &Dv, &mv, &d_out };
+        HIPCHK(hipLaunchKernel(fn, dim3((nq + 63) / 64), dim3(64), args, 0, st));
+    } else {
+        hipLaunchKernelGGL(pq_bound_kernel, dim3(nq), dim3(256), (size_t)ix->D * 4 + 16, st, ix->codebook.p, d_queries, ix->D, ix->m, ix->sd, d_out);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
 // A2 for a whole batch (engine_kernels.hpp lut_build_kernel): out[nq][m][256] on the engine's stream.
 static int launch_lut_build(dr_index *ix, const float *d_queries, uint32_t nq, float *d_out)
 {
@@ -829,7 +859,14 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.adjr = (!ov && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
     p.nbcodes = (!ov && ix->inline_codes && ix->nbcodes_valid) ? ix->nbcodes.p : nullptr;
     p.vec8 = ix->vec8_state == 1 ? ix->vec8.p : nullptr;
-    p.queries = ix->cs->q.p; p.queries_p = ix->cs->qp.p;
+    // chain-major copy of the batch: the builder hands nothing else; a batch uploaded without it (dr_search_submit, D <= 256)
+    // gets it here if this search needs it (large dimensions keep the query in LDS chain-major; the rerank pass reads it)
+    if (!ov && !ix->cs->qp_valid && (ix->D > 256 || rerank)) {
+        hipLaunchKernelGGL(permute_queries_kernel, dim3(nq), dim3(64), 0, ix->stream, ix->cs->q.p, nq, ix->D, ix->perm.p, ix->cs->qp.p);
+        HIPCHK(hipGetLastError());
+        ix->cs->qp_valid = true;
+    }
+    p.queries = ix->cs->q.p; p.queries_p = (ov || ix->cs->qp_valid) ? ix->cs->qp.p : nullptr;
     p.N = ix->N; p.D = ix->D; p.R = ix->R; p.m = ix->m; p.sd = ix->sd; p.medoid = ix->medoid; p.nq = nq;
     p.mode = mode; p.k = k; p.cap = cap; p.L = L; p.bw = bw; p.policy = policy; p.flags = flags;
     p.norm = (mode == DR_MODE_M2 || (mode == DR_MODE_M4 && !(flags & DR_F_SQDIST))) ? 1u : 0u;
@@ -856,9 +893,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         // per-query ADC upper bounds: a function of (queries, codebook) only, computed once per uploaded batch
         if (!ix->cs->pq_ub_valid) {
             if (ix->cs->pq_ub.reserve(nq)) return DR_E_NODEVICE;
-            hipLaunchKernelGGL(pq_bound_kernel, dim3(nq), dim3(256), (size_t)ix->D * 4 + 16, ix->stream, ix->codebook.p, ix->cs->q.p,
-                               ix->D, ix->m, ix->sd, ix->cs->pq_ub.p);
-            HIPCHK(hipGetLastError());
+            { const int rcb = launch_pq_bound(ix, ix->cs->q.p, nq, ix->cs->pq_ub.p, ix->stream); if (rcb) return rcb; }
             ix->cs->pq_ub_valid = true;
         }
         p.pq_ub = ix->cs->pq_ub.p;
@@ -1129,15 +1164,14 @@ extern "C" int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq,
     // (jb.active stays false, the next submit would overwrite the staging buffers under a copy in flight) before those
     // copies have drained.
     const int rcq = [&]() -> int {
-    int rc = upload_slot_async(ix, qs, src, nq, ix->up_stream);
+    static const bool always_permute = getenv("DR_SUBMIT_PERMUTE") != nullptr;      // A/B: the round-2 upload (copy + permute kernel)
+    int rc = upload_slot_async(ix, qs, src, nq, ix->up_stream, ix->D > 256 || always_permute);
     if (rc) return rc;
     qs.q_u8 = q_u8;
     if (mode == DR_MODE_M1 && ix->m) {
         // the per-query ADC bounds travel with the upload, off the search stream
         if (qs.pq_ub.reserve(nq)) return DR_E_NODEVICE;
-        hipLaunchKernelGGL(pq_bound_kernel, dim3(nq), dim3(256), (size_t)ix->D * 4 + 16, ix->up_stream, ix->codebook.p, qs.q.p,
-                           ix->D, ix->m, ix->sd, qs.pq_ub.p);
-        HIPCHK(hipGetLastError());
+        { const int rcb = launch_pq_bound(ix, qs.q.p, nq, qs.pq_ub.p, ix->up_stream); if (rcb) return rcb; }
         qs.pq_ub_valid = true;
     }
     HIPCHK(hipEventRecord(jb.up_done, ix->up_stream));
@@ -1852,6 +1886,28 @@ extern "C" int dr_index_create_codes_empty(dr_index **out, uint64_t N, uint32_t 
     if (rc) { dr_index_close(ix); return rc; }
     ix->m = m; ix->sd = D / m;
     *out = ix;
+    return 0;
+}
+
+// the code table (and codebook) of `src` copied into `dst` on the device: a second shard handle over the same points with
+// another degree R -- the streamed vectors are gone, only the code words can be reused
+extern "C" int dr_index_copy_codes(dr_index *dst, dr_index *src)
+{
+    if (!dst || !src || dst == src) return fail(DR_E_ARG, "bad argument");
+    std::lock(dst->mu, src->mu);
+    std::lock_guard<std::mutex> l1(dst->mu, std::adopt_lock), l2(src->mu, std::adopt_lock);
+    if (dst->N != src->N || dst->D != src->D || dst->device != src->device) return fail(DR_E_ARG, "the two handles differ in N, D or device");
+    if (src->m == 0 || !src->codes.p) return fail(DR_E_NOPQ, "the source holds no code words");
+    HIPCHK(hipSetDevice(dst->device));
+    { const int rcq = quiesce_locked(dst); if (rcq) return rcq; }
+    { const int rcq = quiesce_locked(src); if (rcq) return rcq; }
+    if (dst->codes.reserve((size_t)src->N * src->m) || dst->codebook.reserve((size_t)256 * src->D)) return DR_E_NODEVICE;
+    HIPCHK(hipMemcpy(dst->codes.p, src->codes.p, (size_t)src->N * src->m, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(dst->codebook.p, src->codebook.p, (size_t)256 * src->D * 4, hipMemcpyDeviceToDevice));
+    dst->m = src->m; dst->sd = src->sd;
+    dst->sdc.release();
+    for (auto &qs : dst->slots) qs.pq_ub_valid = false;
+    dst->adc_live = -1; dst->nbcodes_valid = false;
     return 0;
 }
 

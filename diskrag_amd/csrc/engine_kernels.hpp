@@ -827,6 +827,34 @@ __global__ void row_norm2_kernel(const float *__restrict__ vecp, u64 N, u32 D, f
     }
 }
 
+// The same bound with ONE LANE per query (compile-time sub_dim): the centroid of the running (j, c) is the same for every
+// lane, so it travels through scalar loads and SGPR operands, the query's sub-vector sits in the lane's registers, and a
+// batch of 10 000 queries is 157 wavefronts instead of 40 000 -- the bound kernel shares the upload stream with the search
+// kernel's tails, where wavefront slots are what is scarce. Same entries (pw_run_regs: A2's order), same max, same sum order.
+template <int SD>
+__global__ __launch_bounds__(64) void pq_bound_lane_kernel(const float *__restrict__ codebook, const float *__restrict__ queries, u32 nq,
+                                                           u32 D, u32 m, float *__restrict__ out)
+{
+    const u32 qi = blockIdx.x * 64 + threadIdx.x;
+    const float *qrow = queries + (size_t)min(qi, nq - 1) * D;
+    float s = 0.0f;
+    for (u32 jq = 0; jq < m; jq++) {
+        float qv[SD];
+#pragma unroll
+        for (int t = 0; t < SD; t++) qv[t] = qrow[jq * SD + t];
+        float mx = 0.0f;          // (entries are sums of squares: >= 0)
+        const float *cj = codebook + (size_t)jq * 256 * SD;
+        for (u32 c = 0; c < 256; c++) {
+            float cen[SD];
+#pragma unroll
+            for (int t = 0; t < SD; t++) cen[t] = cj[c * SD + t];      // uniform: scalar loads
+            mx = fmaxf(mx, pw_run_regs<SD>(cen, qv));
+        }
+        s = f_add(s, mx);
+    }
+    if (qi < nq) out[qi] = f_sqrt(s);
+}
+
 // adjr[i][s] = bit position of neighbour adj[i][s] in the visited bitmap (pad slots: 0)
 __global__ void map_adjacency_kernel(const u32 *__restrict__ adj, u64 total, u64 N, const u32 *__restrict__ rank,
                                      u32 *__restrict__ adjr)

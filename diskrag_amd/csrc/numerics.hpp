@@ -110,6 +110,21 @@ template <int OFF, int N, int D> DEV void load_query_regs(const float *qp, int j
     }
 }
 
+// The same registers from a query in its ORIGINAL element order: entry t of a leaf's chain j is element OFF + 8 t + j (what
+// the chain-major layout stores at g*32 + j*4 + u for t = 4g + u). Sixteen 4-byte loads per lane at D = 128, the eight
+// lanes of an octet contiguous: the pipelined submit path needs no permuted copy of the batch (permute_queries_kernel).
+template <int OFF, int N, int D> DEV void load_query_regs_orig(const float *q, int j, QueryRegs<D> &qr)
+{
+    if constexpr (N <= 128) {
+#pragma unroll
+        for (int t = 0; t < N / 8; t++) qr.v[OFF / 8 + t] = q[OFF + 8 * t + j];
+    } else {
+        constexpr int N2 = (N / 2) - ((N / 2) % 8);
+        load_query_regs_orig<OFF, N2, D>(q, j, qr);
+        load_query_regs_orig<OFF + N2, N - N2, D>(q, j, qr);
+    }
+}
+
 // ---- streaming form: loads and arithmetic interleaved (any D % 8 == 0) ----------------------------------
 // row: chain-major stored vector (global). qreg != nullptr -> registers, else qlds (chain-major, LDS).
 template <int OFF, int N, int D, bool QREG>

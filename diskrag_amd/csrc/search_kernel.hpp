@@ -680,7 +680,12 @@ DEV void search_body(const SearchParams &p)
                 if constexpr (QORIG_LDS) qorig_lds[i] = qg[i];
                 if constexpr (QPERM_LDS) qperm[i] = qpg[i];
             }
-            if constexpr (QREG) load_query_regs<0, D, D>(qpg, j, qreg);
+            if constexpr (QREG) {
+                // (register variants read the original-order batch when no chain-major copy was made: dr_search_submit at
+                // D <= 256 skips permute_queries_kernel; the builder hands chain-major rows only)
+                if (p.queries_p != nullptr) load_query_regs<0, D, D>(qpg, j, qreg);
+                else load_query_regs_orig<0, D, D>(qg, j, qreg);
+            }
         }
         float qn2 = 0.0f;
         if (kcos) {

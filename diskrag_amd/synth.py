@@ -102,6 +102,17 @@ def recall_at_k(ids, gt, k=10):
     return hit / (k * len(ids))
 
 
+def recall_at_k_ties(dist, gt_dist, k=10):
+    """Distance-based recall@k (what ANN benchmarks use when distances tie): a returned entry is a hit when its distance
+    is <= the k-th ground-truth distance. With PQ-only shards many points share a code word, hence an ADC distance, and
+    the id-based recall_at_k charges a search for returning a DIFFERENT member of a tie than the brute force picked
+    (smallest ids). dist[nq, >=k] as returned by the search (NaN padded), gt_dist[nq, >=k] in the SAME arithmetic."""
+    d = np.asarray(dist)[:, :k]
+    thr = np.asarray(gt_dist)[:, k - 1:k]
+    hit = (d <= thr) & ~np.isnan(d)
+    return float(hit.sum()) / (k * len(d))
+
+
 class UnitMixtureStream:
     """The unit_mixture family as a row-addressable stream: rows [start, start + rows) are a pure function of
     (seed, row block), so a dataset far larger than host memory (config c5: 1.25e8 x 1536 per shard) can be generated,

@@ -265,6 +265,9 @@ int dr_index_create_codes_empty(dr_index **out, uint64_t N, uint32_t D, uint32_t
 int dr_pq_encode_rows(dr_index *ix, const float *vectors /*[rows][D]*/, uint64_t row0, uint64_t rows);
 int dr_build_vamana_pq(dr_index *ix, uint32_t L_build, float alpha, uint32_t passes, uint64_t seed, uint32_t max_batch,
                        uint32_t *out_medoid, float *out_seconds);
+/* Copies the code table and codebook of `src` into `dst` (same N, D and device; device-to-device): a second shard handle
+ * with another degree R over points whose vectors were streamed and forgotten. */
+int dr_index_copy_codes(dr_index *dst, dr_index *src);
 
 /* Test seam for the builder: the robust prune of ONE point over an explicit candidate list (n <= 448), run by the kernel
  * the builder launches; out_selected[R] receives the picked ids in pick order (DR_PAD padded). It is the textbook form

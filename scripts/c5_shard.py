@@ -5,7 +5,7 @@ are never stored (1.25e8 x 1536 x 4 B = 768 GB); the Vamana graph is built from 
 Ground truth for NGT queries, both kinds: EXACT top-10 (a running brute-force merge over the streamed chunks: every chunk
 is a temporary index, dr_bruteforce_topk, ids offset by the chunk's first row) and ADC top-10 (dr_pq_scan_topk, a flat
 scan of the finished code table).
-Usage: python scripts/c5_shard.py [N] [chunk_rows] [n_gt_queries] [R] [L_build] [m] [n_clusters]  -> gpurun_out/scale_c5_shard.json"""
+Usage: python scripts/c5_shard.py [N] [chunk_rows] [n_gt_queries] [R:L_build[,R:L_build...]] [m] [n_clusters]  -> gpurun_out/scale_c5_shard.json"""
 import json
 import os
 import sys
@@ -18,19 +18,19 @@ import numpy as np  # noqa: E402
 sys.path.insert(0, ".")
 from diskrag_amd import HipIndex, _ffi                       # noqa: E402
 from diskrag_amd.parallel import merge_topk                   # noqa: E402
-from diskrag_amd.synth import UnitMixtureStream, recall_at_k  # noqa: E402
+from diskrag_amd.synth import UnitMixtureStream, recall_at_k, recall_at_k_ties  # noqa: E402
 
 argv = sys.argv[1:] + [None] * 8
 N = int(argv[0] or 125_000_000)
 CH = int(argv[1] or 4 * 1024 * 1024)
 NGT = int(argv[2] or 1000)
-R = int(argv[3] or 32)
-LB = int(argv[4] or 64)
-m = int(argv[5] or 32)
-NCL = int(argv[6] or 4096)
+CFG = [tuple(int(v) for v in c.split(":")) for c in (argv[3] or "32:64").split(",")]      # "R:L_build[,R:L_build...]": graphs built over ONE code table
+R, LB = CFG[0]
+m = int(argv[4] or 32)
+NCL = int(argv[5] or 4096)
 D, nq = 1536, 10000
 CH -= CH % UnitMixtureStream.BLOCK
-out = {"shape": "c5 shard", "N": N, "D": D, "m": m, "R": R, "L_build": LB, "n_clusters": NCL, "nq": nq, "chunk_rows": CH}
+out = {"shape": "c5 shard", "N": N, "D": D, "m": m, "graphs": [{"R": r, "L_build": l} for r, l in CFG], "n_clusters": NCL, "nq": nq, "chunk_rows": CH}
 gen = UnitMixtureStream(d=D, n_clusters=NCL, seed=11, latent=64, threads=96)
 OUT = os.environ.get("C5_OUT", "gpurun_out/scale_c5_shard.json")
 
@@ -74,26 +74,6 @@ out["generate_s"], out["encode_s"], out["exact_ground_truth_s"], out["stream_tot
 save()
 print("encoded", out, flush=True)
 
-medoid, bsec = sh.build_vamana_pq(L_build=LB, alpha=1.2, passes=2, seed=7)
-out["build_s"], out["medoid"] = bsec, medoid
-out["memory_bytes"] = {"codes": N * m, "adjacency": N * R * 4, "first_masks": N * 8, "codebook": 256 * D * 4, "centroid_pair_table": m * 65536 * 4,
-                       "build_scratch_rows": N * (R + 64) * 4, "visited_words_per_slot": ((N + 23) // 24 + 3) // 4 * 16,
-                       "stored_vectors": 0, "vectors_if_stored": N * D * 4}
-save()
-print("built", bsec, flush=True)
-
-# ground truth in the shard's own metric: brute-force ADC top-10 (flat scan of all code words, top-k kept on the device)
-t0 = time.perf_counter()
-gt_adc, _, scan_ms = sh.pq_scan_topk(q[:max(NGT, 1)], 10)
-out["ground_truth"] = {"queries": NGT, "adc_seconds": time.perf_counter() - t0, "flat_scan_kernel_ms_per_query": scan_ms / max(NGT, 1),
-                       "flat_scan_GBps": N * m * max(NGT, 1) / (scan_ms * 1e-3) / 1e9,
-                       "adc_top10_vs_exact_top10": recall_at_k(gt_adc, gt_ids, 10) if NGT else None}
-save()
-
-sh.batch_upload(q)
-out["runs"] = {}
-
-
 def run(tag, **kw):
     sh.batch_run(10, **kw); sh.batch_sync()
     t1 = time.perf_counter()
@@ -107,6 +87,8 @@ def run(tag, **kw):
     out["runs"][tag] = {"qps": nq / dt, "kernel_ms": t["search_kernel_ms"], "table_build_kernel_ms": t["lut_kernel_ms"], "variant": t["variant"],
                         "waves_per_cu": t["waves_per_cu"],
                         "recall_at_10_vs_bruteforce_adc": recall_at_k(ids[:NGT], gt_adc, 10),
+                        # distance-based (ties count): a returned code word as near as the 10th of the brute force is a hit
+                        "recall_at_10_vs_bruteforce_adc_by_distance": recall_at_k_ties(dist[:NGT], gt_adc_sq, 10),
                         "recall_at_10_vs_exact": recall_at_k(ids[:NGT], gt_ids, 10) if NGT else None, "steps": float(st["steps"].mean()),
                         "pq_evaluated": float(st["pq_evaluated"].mean()), "status_max": int(st["status"].max()),
                         "alg_bytes_per_query": alg / nq, "alg_frac_of_8TBps": alg / (t["search_kernel_ms"] * 1e-3) / 8e12}
@@ -114,13 +96,41 @@ def run(tag, **kw):
     print(tag, out["runs"][tag], flush=True)
 
 
-for L in (100, 200, 400, 800):
-    for bw in (8, 0):
-        run(f"PQ_L{L}_bw{bw or 'None'}", L=L, beam_width=bw, mode=_ffi.MODE_PQ)
-sh.debug_force_kind(2)
-run("PQ_L400_bwNone_variant2_table_in_LDS", L=400, beam_width=0, mode=_ffi.MODE_PQ)
-sh.debug_force_kind(-1)
-run("M3_PQ_k10_bw8_reference_faithful", L=10, beam_width=8, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
-run("M3_PQ_k10_bw64_reference_faithful", L=10, beam_width=64, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
+# ground truth in the shard's own metric: brute-force ADC top-10 (flat scan of all code words, top-k kept on the device)
+t0 = time.perf_counter()
+gt_adc, gt_adc_sq, scan_ms = sh.pq_scan_topk(q[:max(NGT, 1)], 10)
+# how much of the table shares code words: distinct ADC distances among each query's 64 nearest code words
+t64 = sh.pq_scan_topk(q[:min(max(NGT, 1), 100)], 64)[1]
+out["adc_ties"] = {"distinct_distances_among_64_nearest_mean": float(np.mean([len(np.unique(r)) for r in t64])),
+                   "queries_whose_10th_and_11th_distance_tie": float(np.mean(t64[:, 9] == t64[:, 10]))}
+out["ground_truth"] = {"queries": NGT, "adc_seconds": time.perf_counter() - t0, "flat_scan_kernel_ms_per_query": scan_ms / max(NGT, 1),
+                       "flat_scan_GBps": N * m * max(NGT, 1) / (scan_ms * 1e-3) / 1e9,
+                       "adc_top10_vs_exact_top10": recall_at_k(gt_adc, gt_ids, 10) if NGT else None}
+save()
+
+out["runs"] = {}
+for gi, (R, LB) in enumerate(CFG):
+    if gi > 0:      # another degree over the same code table (the vectors are gone: the code words are copied on the device)
+        nxt = HipIndex.create_codes_empty(N, D, R, cb)
+        nxt.copy_codes_from(sh)
+        sh.close()
+        sh = nxt
+    medoid, bsec = sh.build_vamana_pq(L_build=LB, alpha=1.2, passes=2, seed=7)
+    G = f"R{R}_Lb{LB}"
+    out.setdefault("build", {})[G] = {"build_s": bsec, "medoid": medoid,
+                                      "memory_bytes": {"codes": N * m, "adjacency": N * R * 4, "first_masks": N * 8 * ((R + 63) // 64), "codebook": 256 * D * 4,
+                                                       "centroid_pair_table": m * 65536 * 4, "build_scratch_rows": N * (R + 64) * 4,
+                                                       "visited_words_per_slot": ((N + 23) // 24 + 3) // 4 * 16, "stored_vectors": 0, "vectors_if_stored": N * D * 4}}
+    save()
+    print("built", G, bsec, flush=True)
+    sh.batch_upload(q)
+    for L in (100, 200, 400, 800):
+        for bw in (8, 0):
+            run(f"{G}/PQ_L{L}_bw{bw or 'None'}", L=L, beam_width=bw, mode=_ffi.MODE_PQ)
+    sh.debug_force_kind(2)
+    run(f"{G}/PQ_L400_bwNone_variant2_table_in_LDS", L=400, beam_width=0, mode=_ffi.MODE_PQ)
+    sh.debug_force_kind(-1)
+    run(f"{G}/M3_PQ_k10_bw8_reference_faithful", L=10, beam_width=8, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
+    run(f"{G}/M3_PQ_k10_bw64_reference_faithful", L=10, beam_width=64, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
 sh.close()
 print(json.dumps(out))
