@@ -1266,13 +1266,23 @@ DEV void search_body(const SearchParams &p)
 #pragma unroll
                     for (int ch = 0; ch < NCHR; ch++) sT[ch] = 0u;
                     if (cm != 0ull) {
+                        // (1) counts against the old list. Few candidates (the steady state of a full list: only
+                        // neighbours that beat the worst entry are candidates): one wave-wide compare per list chunk
+                        // and candidate inside the mask loop below -- the list is sorted in REGISTERS, a ballot counts
+                        // it, nothing waits for LDS. Many candidates (a filling list, up to 64): the per-lane binary
+                        // search over the list staged in LDS, 7-11 dependent reads but one pass for all lanes. Same
+                        // counts either way. (One-wavefront workgroups only: the 16-wave variants have no registers to spare.)
+                        constexpr bool BALLOT_COUNTS = (NW == 1);
+                        const bool by_ballot = BALLOT_COUNTS && __popcll(cm) * NCHR <= 24;
+                        if (!by_ballot) {
 #pragma unroll
-                        for (int ch = 0; ch < NCHR; ch++) if (ch * 64 + lane < rn) mk[ch * 64 + lane] = rk.v[ch];
-                        WSYNC();
+                            for (int ch = 0; ch < NCHR; ch++) if (ch * 64 + lane < rn) mk[ch * 64 + lane] = rk.v[ch];
+                            WSYNC();
+                        }
                         const bool iscand = ((cm >> lane) & 1ull) != 0ull;
                         int lb_lo = 0, lb_hi = rn, ut_lo = 0, ut_hi = rn, ux_lo = 0, ux_hi = rn;
                         const u64 key_ut = ((u64)tbits << 32) | 0xFFFFFFFFull, key_ux = ((u64)xbits << 32) | 0xFFFFFFFFull;
-                        if (iscand) {
+                        if (iscand && !by_ballot) {
                             constexpr int ITER = (NCHR == 1) ? 7 : (NCHR == 2) ? 8 : (NCHR == 4) ? 9 : (NCHR == 8) ? 10 : 11;
 #pragma unroll
                             for (int it = 0; it < ITER; it++) {
@@ -1308,6 +1318,23 @@ DEV void search_body(const SearchParams &p)
                                 ls |= (kf < mykey) ? bit : 0u;
 #pragma unroll
                                 for (int ch = 0; ch < NCHR; ch++) om[ch] |= (kf < rk.v[ch]) ? bit : 0u;
+                                if constexpr (BALLOT_COUNTS) {
+                                    if (by_ballot) {
+                                        // candidate f's counts (unused list slots hold ~0: above every key and every bound)
+                                        const u64 kut = ((u64)readlane32(tbits, f) << 32) | 0xFFFFFFFFull;
+                                        const u64 kux = ((u64)readlane32(xbits, f) << 32) | 0xFFFFFFFFull;
+                                        int c_lb = NCHR * 64, c_ut = 0, c_ux = 0;
+#pragma unroll
+                                        for (int ch = 0; ch < NCHR; ch++) {
+                                            c_lb -= __popcll(__ballot(kf < rk.v[ch]));       // keys are distinct: list entries below kf
+                                            c_ut += __popcll(__ballot(rk.v[ch] <= kut));
+                                            if (count_pass) c_ux += __popcll(__ballot(rk.v[ch] <= kux));
+                                        }
+                                        lb_lo = (lane == f) ? c_lb : lb_lo;
+                                        ut_lo = (lane == f) ? c_ut : ut_lo;
+                                        if (count_pass) ux_lo = (lane == f) ? c_ux : ux_lo;
+                                    }
+                                }
                             }
                             Mt |= (u64)mt << (32 * half); Mx |= (u64)mx << (32 * half); lessm |= (u64)ls << (32 * half);
 #pragma unroll

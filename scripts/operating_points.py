@@ -63,7 +63,7 @@ def run(tag, **kw):
         t = ix.timing()
         alg = float((4.0 * D + st["steps"] * 4.0 * R + st["pq_evaluated"] * float(m) + st["exact"] * 4.0 * D + 80).sum())
         emit({"run": tag, "args": {k: int(v) for k, v in kw.items()}, "qps": nq / dt, "recall_at_10": recall_at_k(ids, gt, 10),
-              "kernel_ms": t["search_kernel_ms"], "variant": t["variant"], "waves_per_cu": t["waves_per_cu"],
+              "kernel_ms": t["search_kernel_ms"], "table_build_kernel_ms": t.get("lut_kernel_ms", 0.0), "variant": t["variant"], "waves_per_cu": t["waves_per_cu"],
               "steps": float(st["steps"].mean()), "exact": float(st["exact"].mean()), "pq_evaluated": float(st["pq_evaluated"].mean()),
               "status_max": int(st["status"].max()), "alg_bytes_per_query": alg / nq,
               "alg_frac_of_8TBps": alg / (t["search_kernel_ms"] * 1e-3) / 8e12})
