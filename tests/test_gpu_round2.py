@@ -361,6 +361,28 @@ def test_pq_trainer_reaches_the_reference_quantisation_error(name, m):
     assert abs(err - inertia) <= 1e-3 * inertia          # the encoder assigns what the trainer assigned
     assert inertia <= 1.02 * ref_inertia, (inertia, ref_inertia)
 
+def test_copy_codes_gives_a_second_shard_over_the_same_points():
+    """dr_index_copy_codes: another degree R over points whose vectors are gone -- the copy scans like the source."""
+    from diskrag_amd import HipIndex, _ffi
+    g = load_golden("unit1536_R16_m32")
+    a = HipIndex.create_codes(g.adj, g.medoid, g.vectors.shape[1], g.codebook, g.codes)
+    b = HipIndex.create_codes_empty(len(g.vectors), g.vectors.shape[1], 48, g.codebook[:, ::-1].copy())     # (another codebook: replaced by the copy)
+    try:
+        b.copy_codes_from(a)
+        fa, _ = a.pq_scan(g.queries)
+        fb, _ = b.pq_scan(g.queries)
+        assert np.array_equal(bits(fa), bits(fb))
+        b.build_vamana_pq(L_build=32, alpha=1.2, passes=2, seed=3)
+        ids, dist, cnt, st = b.search_batch(g.queries, 10, L=64, beam_width=0, mode=_ffi.MODE_PQ)
+        gt = a.pq_scan_topk(g.queries, 10)[0]
+        from diskrag_amd.synth import recall_at_k
+        assert int(st["status"].max()) == 0 and recall_at_k(ids, gt, 10) > 0.8
+        with pytest.raises(_ffi.DiskragHipError):
+            b.copy_codes_from(b)
+    finally:
+        a.close(); b.close()
+
+
 def test_pq_only_builder_makes_a_searchable_shard():
     """c5's construction at test scale: code words streamed in chunks (vectors never resident), Vamana graph built from the
     code words alone (dr_build_vamana_pq), searched with DR_MODE_PQ. No reference counterpart: held to graph quality --
