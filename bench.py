@@ -596,7 +596,10 @@ def worker_c2(args, rk):
                                  "pq_evaluated": float(st["pq_evaluated"].mean()), "exact_distances": float(st["exact"].mean()),
                                  "algorithmic_bytes": float(per_q.mean())},
                    "launch": {k_: tm_head[k_] for k_ in ("variant", "grid", "block", "lds_bytes", "waves_per_cu")},
-                   "finalize_kernel_ms": tm_head["finalize_kernel_ms"], "secondary_no_trim": secondary,
+                   "finalize_kernel_ms": tm_head["finalize_kernel_ms"],
+                   # queries whose returned top-k holds equal distances: what the tie-order pass (finalize_kernel) replays per batch
+                   "tied_queries_per_batch": float((dist_out[:, 1:] == dist_out[:, :-1]).any(axis=1).sum()) / nb,
+                   "secondary_no_trim": secondary,
                    "row_storage": ("u8: lossless byte copy of the integer-valued vectors (every component checked; distances "
                                    "bit-identical); roofline.achieved counts D bytes per scored vector, roofline.reference_accounting 4*D, "
                                    "roofline.traffic is what HBM really moved") if byte_rows else "f32",

@@ -187,6 +187,9 @@ struct dr_index {
     hipStream_t up_stream = nullptr, down_stream = nullptr;
     uint32_t last_nq = 0;         // batch size of the last launch (dr_batch_download)
     DevBuf<uint32_t> vis, vis_epoch;   // visited words [slots][vis_words] + the per-slot query stamp (search_kernel.hpp)
+    DevBuf<uint32_t> vis2, vis_epoch2; // the same for the second search lane (small pipelined batches, run_locked)
+    hipStream_t stream2 = nullptr;
+    int cur_lane = 0;
     // per-step outputs are triple-buffered: the tie-order pass (finalize) of step i runs on its own stream while
     // the search kernels of steps i+1 and i+2 fill the other sets
     struct BatchSet {
@@ -248,6 +251,7 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     HIPCHK(hipStreamCreateWithFlags(&ix->fstream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ix->up_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ix->down_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
     for (auto &jb : ix->jobs) { HIPCHK(hipEventCreateWithFlags(&jb.up_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&jb.down_done, hipEventDisableTiming)); }
     for (auto &e : ix->ev) HIPCHK(hipEventCreate(&e));
     for (auto &pr : ix->kev) { HIPCHK(hipEventCreate(&pr[0])); HIPCHK(hipEventCreate(&pr[1])); HIPCHK(hipEventCreate(&pr[2])); }
@@ -422,7 +426,8 @@ extern "C" void dr_index_close(dr_index *ix)
 {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) if (st) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : { ix->up_stream, ix->stream, ix->stream2, ix->fstream, ix->down_stream }) if (st) (void)hipStreamSynchronize(st);
+    ix->vis2.release(); ix->vis_epoch2.release();
     ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release(); ix->nbcodes.release(); ix->sdc.release();
     ix->perm.release(); ix->vis.release(); ix->vis_epoch.release();
     for (auto &qs : ix->slots) qs.release();
@@ -445,6 +450,7 @@ extern "C" void dr_index_close(dr_index *ix)
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
     for (auto &pr : ix->kev) for (auto &e : pr) if (e) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    if (ix->stream2) (void)hipStreamDestroy(ix->stream2);
     if (ix->fstream) (void)hipStreamDestroy(ix->fstream);
     if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
     if (ix->down_stream) (void)hipStreamDestroy(ix->down_stream);
@@ -693,8 +699,9 @@ static int launch_pq_bound(dr_index *ix, const float *d_queries, uint32_t nq, fl
 }
 
 // A2 for a whole batch (engine_kernels.hpp lut_build_kernel): out[nq][m][256] on the engine's stream.
-static int launch_lut_build(dr_index *ix, const float *d_queries, uint32_t nq, float *d_out)
+static int launch_lut_build(dr_index *ix, const float *d_queries, uint32_t nq, float *d_out, hipStream_t st = nullptr)
 {
+    if (!st) st = ix->stream;
     const float *cbp = ix->codebook.p; const float *qp0 = d_queries; uint32_t nqv = nq, Dv = ix->D, mv = ix->m, sdv = ix->sd; float *op = d_out;
     const void *lfn = nullptr;
     switch (ix->sd) {
@@ -716,10 +723,10 @@ static int launch_lut_build(dr_index *ix, const float *d_queries, uint32_t nq, f
     const unsigned gx = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nq, ((uint64_t)ix->num_cu * 16 + ix->m - 1) / ix->m));
     if (lfn) {
         void *largs[] = { &cbp, &qp0, &nqv, &Dv, &mv, &op };
-        HIPCHK(hipLaunchKernel(lfn, dim3(gx, ix->m), dim3(256), largs, 0, ix->stream));
+        HIPCHK(hipLaunchKernel(lfn, dim3(gx, ix->m), dim3(256), largs, 0, st));
     } else {
         void *largs[] = { &cbp, &qp0, &nqv, &Dv, &mv, &sdv, &op };
-        HIPCHK(hipLaunchKernel(reinterpret_cast<const void *>(&lut_build_generic_kernel), dim3(gx, ix->m), dim3(256), largs, 0, ix->stream));
+        HIPCHK(hipLaunchKernel(reinterpret_cast<const void *>(&lut_build_generic_kernel), dim3(gx, ix->m), dim3(256), largs, 0, st));
     }
     return 0;
 }
@@ -747,6 +754,12 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (cap == 0) return fail(DR_E_ARG, "result-list capacity is zero (L / beam_width / k)");
     if (cap > DR_MAX_CAPACITY) return fail(DR_E_UNSUPPORTED, "result-list capacity %u > %u", cap, DR_MAX_CAPACITY);
     HIPCHK(hipSetDevice(ix->device));
+    // Search lane: small pipelined batches (fewer queries than the chip has wavefront slots: the per-GPU slices of a
+    // strong-scaling job) alternate between two streams with their own visited-set scratch, so that consecutive
+    // launches overlap instead of each leaving most of the chip idle; everything else runs on lane 0.
+    const int lane = ov ? 0 : ix->cur_lane;
+    hipStream_t st = lane ? ix->stream2 : ix->stream;
+    DevBuf<uint32_t> &vis = lane ? ix->vis2 : ix->vis, &vis_epoch = lane ? ix->vis_epoch2 : ix->vis_epoch;
 
     const int sc = cap <= 64 ? 0 : cap <= 128 ? 1 : cap <= 256 ? 2 : cap <= 512 ? 3 : 4;
     // kernel variant (variants.hpp): the first available variant of the mode's preference list whose LDS footprint
@@ -828,12 +841,12 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // visited set: per wavefront slot one word per 24 bit positions (+ an 8-bit query stamp: nothing is cleared
     // between queries, search_kernel.hpp) and the slot's stamp counter
     const uint32_t vis_words = (uint32_t)(((ix->N + 23) / 24 + 3) & ~3ull);
-    if ((size_t)slots * vis_words > ix->vis.n || slots > ix->vis_epoch.n) {
+    if ((size_t)slots * vis_words > vis.n || slots > vis_epoch.n) {
         // (re)allocation: fresh words and stamps -- queued launches still use the old buffers
-        if (ix->vis.p) HIPCHK(hipStreamSynchronize(ix->stream));
-        if (ix->vis.reserve((size_t)slots * vis_words) || ix->vis_epoch.reserve(slots)) return DR_E_NODEVICE;
-        HIPCHK(hipMemsetAsync(ix->vis.p, 0, ix->vis.n * 4, ix->stream));
-        HIPCHK(hipMemsetAsync(ix->vis_epoch.p, 0, ix->vis_epoch.n * 4, ix->stream));
+        if (vis.p) HIPCHK(hipStreamSynchronize(st));
+        if (vis.reserve((size_t)slots * vis_words) || vis_epoch.reserve(slots)) return DR_E_NODEVICE;
+        HIPCHK(hipMemsetAsync(vis.p, 0, vis.n * 4, st));
+        HIPCHK(hipMemsetAsync(vis_epoch.p, 0, vis_epoch.n * 4, st));
     }
     // accepted-insert log per query (tie replay): 4096 entries cover L <= 256 with room to spare, deeper lists get more
     const uint32_t logcap = std::max<uint32_t>(4096, 16 * cap);
@@ -843,7 +856,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (bs.fin_pending) {
         // this set's buffers may still be read by the tie-order pass of the step that used it last
         if (ov) HIPCHK(hipStreamSynchronize(ix->fstream));
-        else HIPCHK(hipStreamWaitEvent(ix->stream, bs.fin_done, 0));
+        else HIPCHK(hipStreamWaitEvent(st, bs.fin_done, 0));
     }
     if (bs.counter.reserve(2) || bs.res_n.reserve(nq) || bs.tie.reserve(nq) || bs.stats.reserve(nq) ||
         bs.res_keys.reserve((size_t)nq * cap) || bs.log.reserve((size_t)nq * logcap) ||
@@ -862,7 +875,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // chain-major copy of the batch: the builder hands nothing else; a batch uploaded without it (dr_search_submit, D <= 256)
     // gets it here if this search needs it (large dimensions keep the query in LDS chain-major; the rerank pass reads it)
     if (!ov && !ix->cs->qp_valid && (ix->D > 256 || rerank)) {
-        hipLaunchKernelGGL(permute_queries_kernel, dim3(nq), dim3(64), 0, ix->stream, ix->cs->q.p, nq, ix->D, ix->perm.p, ix->cs->qp.p);
+        hipLaunchKernelGGL(permute_queries_kernel, dim3(nq), dim3(64), 0, st, ix->cs->q.p, nq, ix->D, ix->perm.p, ix->cs->qp.p);
         HIPCHK(hipGetLastError());
         ix->cs->qp_valid = true;
     }
@@ -871,7 +884,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.mode = mode; p.k = k; p.cap = cap; p.L = L; p.bw = bw; p.policy = policy; p.flags = flags;
     p.norm = (mode == DR_MODE_M2 || (mode == DR_MODE_M4 && !(flags & DR_F_SQDIST))) ? 1u : 0u;
     p.max_steps = (uint32_t)std::min<uint64_t>(max_steps, 0xFFFFFFFFull);
-    p.vis = ix->vis.p; p.vis_words = vis_words; p.vis_epoch = ix->vis_epoch.p;
+    p.vis = vis.p; p.vis_words = vis_words; p.vis_epoch = vis_epoch.p;
     p.counter = bs.counter.p;
     p.res_keys = bs.res_keys.p; p.res_n = bs.res_n.p; p.stats = bs.stats.p;
     p.tie_list = bs.tie.p; p.tie_count = bs.counter.p + 1;
@@ -884,7 +897,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         if (mode != DR_MODE_M3 || (flags & DR_F_USE_PQ)) return fail(DR_E_ARG, "DR_F_COSINE goes with DR_MODE_M3 without DR_F_USE_PQ (the reference's only cosine traversal)");
         if (!ix->vnorm2.p) {
             if (ix->vnorm2.reserve(ix->N)) return DR_E_NODEVICE;
-            hipLaunchKernelGGL(row_norm2_kernel, dim3((unsigned)std::min<uint64_t>((ix->N + 255) / 256, 1u << 16)), dim3(256), 0, ix->stream, ix->vecp.p, ix->N, ix->D, ix->vnorm2.p);
+            hipLaunchKernelGGL(row_norm2_kernel, dim3((unsigned)std::min<uint64_t>((ix->N + 255) / 256, 1u << 16)), dim3(256), 0, st, ix->vecp.p, ix->N, ix->D, ix->vnorm2.p);
             HIPCHK(hipGetLastError());
         }
         p.vnorm2 = ix->vnorm2.p;
@@ -893,7 +906,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         // per-query ADC upper bounds: a function of (queries, codebook) only, computed once per uploaded batch
         if (!ix->cs->pq_ub_valid) {
             if (ix->cs->pq_ub.reserve(nq)) return DR_E_NODEVICE;
-            { const int rcb = launch_pq_bound(ix, ix->cs->q.p, nq, ix->cs->pq_ub.p, ix->stream); if (rcb) return rcb; }
+            { const int rcb = launch_pq_bound(ix, ix->cs->q.p, nq, ix->cs->pq_ub.p, st); if (rcb) return rcb; }
             ix->cs->pq_ub_valid = true;
         }
         p.pq_ub = ix->cs->pq_ub.p;
@@ -912,7 +925,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
 
     static const bool dbg = getenv("DR_DEBUG") != nullptr;
     if (dbg) { fprintf(stderr, "[dr] search kind=%d sc=%d NW=%d grid=%u lds=%zu occ=%d nq=%u cap=%u slots=%u vis_words=%u\n", kind, sc, NW, grid, lds, occ, nq, cap, slots, vis_words); fflush(stderr); }
-    if (!bs.counters_zeroed) { HIPCHK(hipMemsetAsync(bs.counter.p, 0, 8, ix->stream)); bs.counters_zeroed = true; bs.ticket_base = 0; }
+    if (!bs.counters_zeroed) { HIPCHK(hipMemsetAsync(bs.counter.p, 0, 8, st)); bs.counters_zeroed = true; bs.ticket_base = 0; }
     // Ticket counter: slot s starts on query s and every later query is a ticket; the started slots draw
     // (nq - started) successful tickets plus one failing ticket each = exactly nq per launch, so the counter is
     // monotonic and the launch only needs its starting value (no per-step memset on the search stream). The tie-list
@@ -920,7 +933,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.ticket_base = bs.ticket_base;
     bs.ticket_base += nq;
     if (!ov && ix->kev_pending == dr_index::KEV) harvest_kernel_times(ix, false);
-    if (!ov && ix->kev_pending == dr_index::KEV) { HIPCHK(hipStreamSynchronize(ix->stream)); harvest_kernel_times(ix, false); }
+    if (!ov && ix->kev_pending == dr_index::KEV) { HIPCHK(hipStreamSynchronize(ix->stream)); HIPCHK(hipStreamSynchronize(ix->stream2)); harvest_kernel_times(ix, false); }
     p.lut_g = nullptr;
     const bool want_lut = kd_desc.lut && !(ov && ov->sdc);
     if (want_lut) {
@@ -928,18 +941,18 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         // before the search kernel that lands them in LDS (engine_kernels.hpp lut_build_kernel). Built by EVERY search --
         // a table is part of its query's search, not of the upload -- and timed separately (dr_timing.lut_kernel_ms).
         if (ix->cs->lut.reserve((size_t)nq * ix->m * 256)) return DR_E_NODEVICE;
-        if (!ov) HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][2], ix->stream));
-        { const int rcl = launch_lut_build(ix, ix->cs->q.p, nq, ix->cs->lut.p); if (rcl) return rcl; }
+        if (!ov) HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][2], st));
+        { const int rcl = launch_lut_build(ix, ix->cs->q.p, nq, ix->cs->lut.p, st); if (rcl) return rcl; }
         p.lut_g = ix->cs->lut.p;
     }
     void *args[] = { &p };
-    if (!ov) { ix->kev_lut[ix->kev_pending] = want_lut; HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][0], ix->stream)); }
+    if (!ov) { ix->kev_lut[ix->kev_pending] = want_lut; HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][0], st)); }
     {
-        const hipError_t le = hipLaunchKernel(kfn, dim3(grid), dim3(64 * NW), args, lds, ix->stream);
+        const hipError_t le = hipLaunchKernel(kfn, dim3(grid), dim3(64 * NW), args, lds, st);
         if (le != hipSuccess) { bs.counters_zeroed = false; return fail(DR_E_NODEVICE, "search kernel launch failed: %s", hipGetErrorString(le)); }
     }
     if (ov) return 0;   // the builder consumes res_keys / res_n directly on the stream
-    HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][1], ix->stream));
+    HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][1], st));
     ix->kev_pending++;
     if (rerank) {
         // DR_MODE_PQ + DR_F_RERANK: exact squared L2 of the final list's entries, k best in (distance, id) order
@@ -948,13 +961,13 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         KStats *stp = bs.stats.p;
         void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp };
         const size_t rlds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)cap * 8;
-        HIPCHK(hipLaunchKernel(ix->kern->rerank, dim3(std::min<uint32_t>(nq, (uint32_t)ix->num_cu * 16)), dim3(64), rargs, rlds, ix->stream));
+        HIPCHK(hipLaunchKernel(ix->kern->rerank, dim3(std::min<uint32_t>(nq, (uint32_t)ix->num_cu * 16)), dim3(64), rargs, rlds, st));
     }
 
     // tie replay for the queries the search kernel listed: one wavefront per query, heap in registers. It runs on
     // its own stream so that it overlaps the NEXT step's search kernel (it needs 19 VGPRs and no LDS, so its
     // wavefronts fit beside the search kernel's); dr_batch_sync / dr_batch_download wait for it.
-    HIPCHK(hipEventRecord(bs.search_done, ix->stream));
+    HIPCHK(hipEventRecord(bs.search_done, st));
     HIPCHK(hipStreamWaitEvent(ix->fstream, bs.search_done, 0));
     FinalizeParams f;
     f.res_keys = bs.res_keys.p; f.res_n = bs.res_n.p; f.tie_list = bs.tie.p; f.tie_count = bs.counter.p + 1;
@@ -985,7 +998,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (k_m1 && ix->adc_live < 0) {
         // regime of this (graph, PQ) state: did the rerank policy really consult the ADC on this batch? (the one
         // launch per index state that is waited for on the host)
-        HIPCHK(hipStreamSynchronize(ix->stream));
+        HIPCHK(hipStreamSynchronize(st));
         std::vector<KStats> st(std::min<uint32_t>(nq, 1024));
         HIPCHK(hipMemcpy(st.data(), bs.stats.p, st.size() * sizeof(KStats), hipMemcpyDeviceToHost));
         uint64_t evald = 0, all = 0;
@@ -1004,6 +1017,7 @@ static int sync_locked(dr_index *ix)
 {
     HIPCHK(hipStreamSynchronize(ix->up_stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream2));
     HIPCHK(hipStreamSynchronize(ix->fstream));
     HIPCHK(hipStreamSynchronize(ix->down_stream));
     harvest_kernel_times(ix, true);
@@ -1077,7 +1091,7 @@ extern "C" int dr_batch_sync(dr_index *ix)
 static int quiesce_locked(dr_index *ix)
 {
     for (int j = 0; j < DR_PIPE_DEPTH; j++) if (ix->jobs[j].active) { const int rc = finish_job_locked(ix, j); if (rc) return rc; }
-    for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) HIPCHK(hipStreamSynchronize(st));
+    for (hipStream_t st : { ix->up_stream, ix->stream, ix->stream2, ix->fstream, ix->down_stream }) HIPCHK(hipStreamSynchronize(st));
     return 0;
 }
 
@@ -1175,10 +1189,16 @@ extern "C" int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq,
         qs.pq_ub_valid = true;
     }
     HIPCHK(hipEventRecord(jb.up_done, ix->up_stream));
-    HIPCHK(hipStreamWaitEvent(ix->stream, jb.up_done, 0));
+    // a batch smaller than the chip's wavefront slots cannot fill it: consecutive small batches go to alternating search
+    // lanes (streams) and overlap (DR_ONE_LANE=1 switches that off for A/B)
+    static const bool one_lane = getenv("DR_ONE_LANE") != nullptr;
+    const int lane = (!one_lane && (uint64_t)nq < (uint64_t)ix->num_cu * 16) ? (int)(ix->next_ticket & 1) : 0;
+    HIPCHK(hipStreamWaitEvent(lane ? ix->stream2 : ix->stream, jb.up_done, 0));
     QSlot *const keep = ix->cs;
     ix->cs = &qs;
+    ix->cur_lane = lane;
     rc = run_locked(ix, k, L, beam_width, mode, band_policy, flags);
+    ix->cur_lane = 0;
     ix->cs = keep;
     if (rc) return rc;
     const int set = ix->last_set;
@@ -1199,7 +1219,7 @@ extern "C" int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq,
     }();
     if (rcq) {
         const std::string keep_msg = g_err;       // (the drain below must not replace the message of the real failure)
-        for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) (void)hipStreamSynchronize(st);
+        for (hipStream_t st : { ix->up_stream, ix->stream, ix->stream2, ix->fstream, ix->down_stream }) (void)hipStreamSynchronize(st);
         (void)hipGetLastError();
         g_err = keep_msg;
         return rcq;

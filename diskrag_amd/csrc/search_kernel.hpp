@@ -1273,7 +1273,8 @@ DEV void search_body(const SearchParams &p)
                         // search over the list staged in LDS, 7-11 dependent reads but one pass for all lanes. Same
                         // counts either way. (One-wavefront workgroups only: the 16-wave variants have no registers to spare.)
                         constexpr bool BALLOT_COUNTS = (NW == 1);
-                        const bool by_ballot = BALLOT_COUNTS && __popcll(cm) * NCHR <= 24;
+                        // (break-even: a candidate costs 3 compares + counts per list chunk, the search 7-11 dependent LDS reads)
+                        const bool by_ballot = BALLOT_COUNTS && __popcll(cm) * (NCHR + 2) <= 48;
                         if (!by_ballot) {
 #pragma unroll
                             for (int ch = 0; ch < NCHR; ch++) if (ch * 64 + lane < rn) mk[ch * 64 + lane] = rk.v[ch];
