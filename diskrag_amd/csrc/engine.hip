@@ -100,12 +100,12 @@ template <class T> struct DevBuf {
 // distinct batches); the pipelined dr_search_submit path owns DR_PIPE_DEPTH more.
 struct QSlot {
     uint32_t nq = 0;
-    DevBuf<float> q, qp, pq_ub;
+    DevBuf<float> q, qp, pq_ub, pq_max;
     DevBuf<float> lut;           // [nq][m][256] per-query tables of the batch (lut_build_kernel), rebuilt by every search that uses them
     bool qp_valid = false;       // qp holds the chain-major copy of q (dr_search_submit skips it at D <= 256: the register variants read q)
     bool pq_ub_valid = false;    // pq_ub matches these queries and the attached codebook
     bool q_u8 = false;           // every component is an integer in [0, 255] (byte-query variants 13/14)
-    void release() { q.release(); qp.release(); pq_ub.release(); lut.release(); nq = 0; pq_ub_valid = false; q_u8 = false; qp_valid = false; }
+    void release() { q.release(); qp.release(); pq_ub.release(); pq_max.release(); lut.release(); nq = 0; pq_ub_valid = false; q_u8 = false; qp_valid = false; }
 };
 #define DR_PIPE_DEPTH 3
 
@@ -672,27 +672,31 @@ static void harvest_kernel_times(dr_index *ix, bool publish)
     }
 }
 
-// sqrt-ADC upper bound per query (search_kernel.hpp "exact skip"): the one-lane-per-query kernel for the usual sub_dims
-static int launch_pq_bound(dr_index *ix, const float *d_queries, uint32_t nq, float *d_out, hipStream_t st)
+// sqrt-ADC upper bound per query (search_kernel.hpp "exact skip"): per-(query, sub-quantiser) maxima, then the ordered sum
+static int launch_pq_bound(dr_index *ix, QSlot &qs, uint32_t nq, hipStream_t st)
 {
-    const float *cbp = ix->codebook.p; uint32_t nqv = nq, Dv = ix->D, mv = ix->m;
+    const float *cbp = ix->codebook.p; const float *qp = qs.q.p; uint32_t nqv = nq, Dv = ix->D;
     const void *fn = nullptr;
     switch (ix->sd) {
-    case 2: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<2>); break;
-    case 3: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<3>); break;
-    case 4: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<4>); break;
-    case 6: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<6>); break;
-    case 8: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<8>); break;
-    case 12: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<12>); break;
-    case 16: fn = reinterpret_cast<const void *>(&pq_bound_lane_kernel<16>); break;
+    case 2: fn = reinterpret_cast<const void *>(&pq_bound_max_kernel<2>); break;
+    case 3: fn = reinterpret_cast<const void *>(&pq_bound_max_kernel<3>); break;
+    case 4: fn = reinterpret_cast<const void *>(&pq_bound_max_kernel<4>); break;
+    case 6: fn = reinterpret_cast<const void *>(&pq_bound_max_kernel<6>); break;
+    case 8: fn = reinterpret_cast<const void *>(&pq_bound_max_kernel<8>); break;
+    case 12: fn = reinterpret_cast<const void *>(&pq_bound_max_kernel<12>); break;
+    case 16: fn = reinterpret_cast<const void *>(&pq_bound_max_kernel<16>); break;
     default: break;
     }
     static const bool old_form = getenv("DR_PQ_BOUND_BLOCK") != nullptr;      // A/B: the block-per-query form
     if (fn && !old_form) {
-        void *args[] = { &cbp, &d_queries, &nqv, &Dv, &mv, &d_out };
-        HIPCHK(hipLaunchKernel(fn, dim3((nq + 63) / 64), dim3(64), args, 0, st));
+        if (qs.pq_max.reserve((size_t)nq * ix->m)) return DR_E_NODEVICE;
+        float *mxp = qs.pq_max.p;
+        void *args[] = { &cbp, &qp, &nqv, &Dv, &mxp };
+        HIPCHK(hipLaunchKernel(fn, dim3((nq + 63) / 64, ix->m), dim3(64), args, 0, st));
+        hipLaunchKernelGGL(pq_bound_sum_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, qs.pq_max.p, nq, ix->m, qs.pq_ub.p);
+        HIPCHK(hipGetLastError());
     } else {
-        hipLaunchKernelGGL(pq_bound_kernel, dim3(nq), dim3(256), (size_t)ix->D * 4 + 16, st, ix->codebook.p, d_queries, ix->D, ix->m, ix->sd, d_out);
+        hipLaunchKernelGGL(pq_bound_kernel, dim3(nq), dim3(256), (size_t)ix->D * 4 + 16, st, ix->codebook.p, qs.q.p, ix->D, ix->m, ix->sd, qs.pq_ub.p);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -710,11 +714,17 @@ static int launch_lut_build(dr_index *ix, const float *d_queries, uint32_t nq, f
     case 4: lfn = reinterpret_cast<const void *>(&lut_build_kernel<4>); break;
     case 6: lfn = reinterpret_cast<const void *>(&lut_build_kernel<6>); break;
     case 8: lfn = reinterpret_cast<const void *>(&lut_build_kernel<8>); break;
+    case 10: lfn = reinterpret_cast<const void *>(&lut_build_kernel<10>); break;      // (D = 960: m = 96 / 64 / 48 / 32 / 24 / 16 -> 10 / 15 / 20 / 30 / 40 / 60)
     case 12: lfn = reinterpret_cast<const void *>(&lut_build_kernel<12>); break;
+    case 15: lfn = reinterpret_cast<const void *>(&lut_build_kernel<15>); break;
     case 16: lfn = reinterpret_cast<const void *>(&lut_build_kernel<16>); break;
+    case 20: lfn = reinterpret_cast<const void *>(&lut_build_kernel<20>); break;
     case 24: lfn = reinterpret_cast<const void *>(&lut_build_kernel<24>); break;
+    case 30: lfn = reinterpret_cast<const void *>(&lut_build_kernel<30>); break;
     case 32: lfn = reinterpret_cast<const void *>(&lut_build_kernel<32>); break;
+    case 40: lfn = reinterpret_cast<const void *>(&lut_build_kernel<40>); break;
     case 48: lfn = reinterpret_cast<const void *>(&lut_build_kernel<48>); break;
+    case 60: lfn = reinterpret_cast<const void *>(&lut_build_kernel<60>); break;
     case 64: lfn = reinterpret_cast<const void *>(&lut_build_kernel<64>); break;
     case 96: lfn = reinterpret_cast<const void *>(&lut_build_kernel<96>); break;
     default: break;
@@ -906,7 +916,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         // per-query ADC upper bounds: a function of (queries, codebook) only, computed once per uploaded batch
         if (!ix->cs->pq_ub_valid) {
             if (ix->cs->pq_ub.reserve(nq)) return DR_E_NODEVICE;
-            { const int rcb = launch_pq_bound(ix, ix->cs->q.p, nq, ix->cs->pq_ub.p, st); if (rcb) return rcb; }
+            { const int rcb = launch_pq_bound(ix, *ix->cs, nq, st); if (rcb) return rcb; }
             ix->cs->pq_ub_valid = true;
         }
         p.pq_ub = ix->cs->pq_ub.p;
@@ -1185,7 +1195,7 @@ extern "C" int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq,
     if (mode == DR_MODE_M1 && ix->m) {
         // the per-query ADC bounds travel with the upload, off the search stream
         if (qs.pq_ub.reserve(nq)) return DR_E_NODEVICE;
-        { const int rcb = launch_pq_bound(ix, qs.q.p, nq, qs.pq_ub.p, ix->up_stream); if (rcb) return rcb; }
+        { const int rcb = launch_pq_bound(ix, qs, nq, ix->up_stream); if (rcb) return rcb; }
         qs.pq_ub_valid = true;
     }
     HIPCHK(hipEventRecord(jb.up_done, ix->up_stream));

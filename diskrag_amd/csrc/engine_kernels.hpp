@@ -827,32 +827,40 @@ __global__ void row_norm2_kernel(const float *__restrict__ vecp, u64 N, u32 D, f
     }
 }
 
-// The same bound with ONE LANE per query (compile-time sub_dim): the centroid of the running (j, c) is the same for every
-// lane, so it travels through scalar loads and SGPR operands, the query's sub-vector sits in the lane's registers, and a
-// batch of 10 000 queries is 157 wavefronts instead of 40 000 -- the bound kernel shares the upload stream with the search
-// kernel's tails, where wavefront slots are what is scarce. Same entries (pw_run_regs: A2's order), same max, same sum order.
+// The same bound with one LANE per (query, sub-quantiser): wavefront (q-tile, j) holds 64 queries' sub-vectors of j in
+// registers and walks j's 256 centroids, which are the same for every lane -- scalar loads, SGPR operands, no LDS, no
+// barriers -- keeping max_c T[j][c] per lane; pq_bound_sum_kernel then adds the m maxima of a query in A3's order. A batch
+// of 10 000 queries is 157 x m short wavefronts (3.4 k instructions each) instead of 40 000 of 1.5 k with barriers: the
+// bound shares the upload stream with the search kernel's tails, where wavefront slots are what is scarce. (One lane per
+// query with the loop over j inside was tried first: 157 wavefronts of 107 k dependent instructions took 2 ms in the
+// search kernel's shadow and stalled the pipeline -- 7.3 -> 4.4 M QPS, profiles/r03/ab/ab_c2_companions_v2_slow_bound.log.)
+// Same entries (pw_run_regs: A2's order), same max, same sum order as pq_bound_kernel: the same bits.
 template <int SD>
-__global__ __launch_bounds__(64) void pq_bound_lane_kernel(const float *__restrict__ codebook, const float *__restrict__ queries, u32 nq,
-                                                           u32 D, u32 m, float *__restrict__ out)
+__global__ __launch_bounds__(64) void pq_bound_max_kernel(const float *__restrict__ codebook, const float *__restrict__ queries, u32 nq,
+                                                          u32 D, float *__restrict__ out_max /*[m][nq]*/)
 {
-    const u32 qi = blockIdx.x * 64 + threadIdx.x;
-    const float *qrow = queries + (size_t)min(qi, nq - 1) * D;
-    float s = 0.0f;
-    for (u32 jq = 0; jq < m; jq++) {
-        float qv[SD];
+    const u32 qi = blockIdx.x * 64 + threadIdx.x, jq = blockIdx.y;
+    const float *qrow = queries + (size_t)min(qi, nq - 1) * D + jq * SD;
+    float qv[SD];
 #pragma unroll
-        for (int t = 0; t < SD; t++) qv[t] = qrow[jq * SD + t];
-        float mx = 0.0f;          // (entries are sums of squares: >= 0)
-        const float *cj = codebook + (size_t)jq * 256 * SD;
-        for (u32 c = 0; c < 256; c++) {
-            float cen[SD];
+    for (int t = 0; t < SD; t++) qv[t] = qrow[t];
+    float mx = 0.0f;          // (entries are sums of squares: >= 0)
+    const float *cj = codebook + (size_t)jq * 256 * SD;
+    for (u32 c = 0; c < 256; c++) {
+        float cen[SD];
 #pragma unroll
-            for (int t = 0; t < SD; t++) cen[t] = cj[c * SD + t];      // uniform: scalar loads
-            mx = fmaxf(mx, pw_run_regs<SD>(cen, qv));
-        }
-        s = f_add(s, mx);
+        for (int t = 0; t < SD; t++) cen[t] = cj[c * SD + t];      // uniform: scalar loads
+        mx = fmaxf(mx, pw_run_regs<SD>(cen, qv));
     }
-    if (qi < nq) out[qi] = f_sqrt(s);
+    if (qi < nq) out_max[(size_t)jq * nq + qi] = mx;
+}
+__global__ void pq_bound_sum_kernel(const float *__restrict__ mx, u32 nq, u32 m, float *__restrict__ out)
+{
+    const u32 qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    float s = 0.0f;
+    for (u32 jq = 0; jq < m; jq++) s = f_add(s, mx[(size_t)jq * nq + qi]);
+    out[qi] = f_sqrt(s);
 }
 
 // adjr[i][s] = bit position of neighbour adj[i][s] in the visited bitmap (pad slots: 0)

@@ -372,11 +372,12 @@ def test_copy_codes_gives_a_second_shard_over_the_same_points():
         fa, _ = a.pq_scan(g.queries)
         fb, _ = b.pq_scan(g.queries)
         assert np.array_equal(bits(fa), bits(fb))
-        b.build_vamana_pq(L_build=32, alpha=1.2, passes=2, seed=3)
+        medoid, _ = b.build_vamana_pq(L_build=32, alpha=1.2, passes=2, seed=3)
         ids, dist, cnt, st = b.search_batch(g.queries, 10, L=64, beam_width=0, mode=_ffi.MODE_PQ)
-        gt = a.pq_scan_topk(g.queries, 10)[0]
-        from diskrag_amd.synth import recall_at_k
-        assert int(st["status"].max()) == 0 and recall_at_k(ids, gt, 10) > 0.8
+        # the copy's searches are the oracle's on the graph it built, with the SOURCE's code words and codebook
+        from oracle import pyoracle as orc
+        w = orc.search_batch(g.vectors, b.get_adjacency(), g.queries, medoid, orc.PQ, 10, L=64, bw=0, codes=g.codes, codebook=g.codebook)
+        assert int(st["status"].max()) == 0 and np.array_equal(ids, w[0]) and np.array_equal(_stats4(st), w[3])
         with pytest.raises(_ffi.DiskragHipError):
             b.copy_codes_from(b)
     finally:
