@@ -16,12 +16,13 @@ from diskrag_amd.synth import unit_mixture, unit_mixture_parallel, recall_at_k  
 shape, n = sys.argv[1], int(sys.argv[2])
 nq = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
 spec = sys.argv[4] if len(sys.argv) > 4 else "full"
-quick = spec == "quick"
+quick = spec.startswith("quick")
+both = spec.endswith("+extra") and spec != "extra"       # "quick+extra" / "full+extra": the grid, then the extra pass, on ONE built index
 # d256 / d768 / d960: the other entries of the reference's SUPPORTED_DIMENSIONS (preprocessing/config.py:88), unit-norm mixture
 D, m, ncl, latent = {"c3": (1536, 32, 4096, 64), "c4": (96, 16, 4096, 32), "d256": (256, 32, 4096, 32), "d768": (768, 32, 4096, 64),
                      "d960": (960, 32, 4096, 64)}[shape]
 R = 64
-path = f"gpurun_out/op_{shape}_{n}{'' if spec in ('full', 'quick') else '_' + spec}.jsonl"
+path = f"gpurun_out/op_{shape}_{n}{'' if spec in ('full', 'quick') else '_' + spec.replace('+', '_')}.jsonl"
 out = open(path, "w")
 
 
@@ -71,7 +72,7 @@ def run(tag, **kw):
         emit({"run": tag, "error": str(e)})
 
 
-if spec == "extra":
+def extra_pass():
     # second pass: pin the first operating points at recall >= 0.95 between the grid points of the full sweep, and the
     # exact beam search (M2, beam_search_from_disk) with wider beams
     for bwx in (96, 128, 192, 256):
@@ -81,6 +82,9 @@ if spec == "extra":
         run(f"M1_L{L}_bw8_policy0", L=L, beam_width=8, mode=_ffi.MODE_M1, band_policy=0)
     for L in ((300, 350) if shape == "c4" else (250, 300, 350)):
         run(f"PQ_rerank_L{L}_bwNone", L=L, beam_width=0, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)
+
+if spec == "extra":
+    extra_pass()
     ix.close()
     sys.exit(0)
 Ls = (100, 200, 400) if quick else (100, 200, 400, 800)
@@ -93,4 +97,6 @@ for L in Ls:
         run(f"PQ_rerank_L{L}_bw{bw or 'None'}", L=L, beam_width=bw, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)
 run("M2_bw8", L=100, beam_width=8, mode=_ffi.MODE_M2)
 run("M2_bw64", L=100, beam_width=64, mode=_ffi.MODE_M2)
+if both:
+    extra_pass()
 ix.close()
