@@ -6,7 +6,7 @@ N = 1,000,000 x d = 128 L2, R = 64 slots, PQ m = 32, L_search = 100, batch = 10,
 What is measured:
   * `value`: queries per second of a stream of 10k-query batches that start in HOST memory and end as results in HOST
     memory -- dr_search_submit / dr_search_wait (include/diskrag_hip.h): upload, search, tie-order pass and download
-    of consecutive batches overlap on separate HIP streams, three batches in flight. Distinct batches rotate
+    of consecutive batches overlap on separate HIP streams, four batches in flight. Distinct batches rotate
     (--distinct-batches, default 8), so no step replays the previous step's queries.
   * `config.qps_resident`: the same rotation with every batch already resident in HBM (dr_batch_select / dr_batch_run).
   * a "step" is --batches-per-step (default 40) consecutive 10k-query batches, so that the timed region of the
@@ -441,7 +441,7 @@ def worker_c2(args, rk):
         t1 = time.perf_counter()
         for i in range(n_launch):
             jobs.append(ix.search_submit(sources[i % len(sources)], k, L=args.L, beam_width=args.bw, mode=mode, reuse_outputs=True))
-            if len(jobs) - done >= 3:
+            if len(jobs) - done >= _ffi.PIPE_DEPTH:
                 jobs[done].wait(); jobs[done] = None; done += 1
         last = None
         for j in range(done, len(jobs)):
@@ -578,8 +578,8 @@ def worker_c2(args, rk):
         "data": "synthetic",
         "config": {"workload": "SIFT1M-shaped synthetic (configs[1]): N=%d d=%d L2, R=%d, L_search=%d, PQ m=%d, beam_width=%s, "
                                "k=%d, batch=%d queries, mode=M1 reference-faithful; a step = %d consecutive batches, %d distinct "
-                               "batches per GPU rotating; value = host memory -> host memory (dr_search_submit/wait, 3 batches in flight)"
-                               % (args.n, D, args.R, args.L, args.m, args.bw or None, k, nq_job, args.bps, nb)
+                               "batches per GPU rotating; value = host memory -> host memory (dr_search_submit/wait, %d batches in flight)"
+                               % (args.n, D, args.R, args.L, args.m, args.bw or None, k, nq_job, args.bps, nb, _ffi.PIPE_DEPTH)
                                + ("; STRONG scaling: every batch is cut into %d contiguous slices, one per GPU (slice of rank 0: %d queries)" % (rk.world, nq) if strong else ""),
                    "recall_at_10": recall, "build_seconds": build_s,
                    "parallelism": ("query-sharded replicas x%d, one batch split over the ranks" if strong else "query-sharded replicas x%d") % rk.world,

@@ -13,7 +13,7 @@ LIB_PATH = Path(_os.environ["DR_LIB"]) if _os.environ.get("DR_LIB") else PKG_DIR
 
 PAD = 0xFFFFFFFF
 MODE_M1, MODE_M2, MODE_M3, MODE_M4 = 1, 2, 3, 4
-PIPE_DEPTH = 3          # DR_PIPE_DEPTH (csrc/engine.hip): batches in flight per handle
+PIPE_DEPTH = 4          # DR_PIPE_DEPTH (csrc/engine.hip): batches in flight per handle
 MODE_PQ = 5      # engine mode without a reference counterpart: M1's loop on squared ADC distances only (diskrag_hip.h)
 F_USE_PQ, F_SQDIST, F_RERANK, F_COSINE = 1, 2, 4, 8
 MAX_RESIDENT = 16
@@ -388,17 +388,17 @@ class HipIndex:
 
     def search_submit(self, queries, k, L=100, beam_width=0, mode=MODE_M1, band_policy=0, flags=0, reuse_outputs=False):
         """Pipelined dr_search_batch: queues upload, search, tie-order pass and download and returns a PendingSearch;
-        its .wait() gives (ids, dist, count, stats). Up to 3 batches are in flight per index. With reuse_outputs the
-        result arrays come from a ring of four sets (valid until the fourth submit after this one)."""
+        its .wait() gives (ids, dist, count, stats). Up to PIPE_DEPTH batches are in flight per index. With reuse_outputs the
+        result arrays come from a ring of PIPE_DEPTH + 1 sets (valid until that many submits after this one)."""
         q = self._queries(queries)
         nq = q.shape[0]
         if reuse_outputs:
             ring = self.__dict__.setdefault("_out_ring", {})
             key = (nq, int(k))
             if key not in ring:
-                ring[key] = [[PendingSearch(self, None, nq, int(k)) for _ in range(4)], 0]
+                ring[key] = [[PendingSearch(self, None, nq, int(k)) for _ in range(PIPE_DEPTH + 1)], 0]
             sets, pos = ring[key]
-            job = sets[pos % 4]
+            job = sets[pos % (PIPE_DEPTH + 1)]
             ring[key][1] = pos + 1
             job._q = q
         else:

@@ -107,7 +107,9 @@ struct QSlot {
     bool q_u8 = false;           // every component is an integer in [0, 255] (byte-query variants 13/14)
     void release() { q.release(); qp.release(); pq_ub.release(); pq_max.release(); lut.release(); nq = 0; pq_ub_valid = false; q_u8 = false; qp_valid = false; }
 };
-#define DR_PIPE_DEPTH 3
+#define DR_PIPE_DEPTH 4     // (3 until round 3: a job is finished only after its tie-order pass, which finds room in the TAIL of the next search
+                            // kernel -- its latency, not its work, starved a 3-deep pipeline: profiles/r03/ab/ab_c2_companions_v3.log)
+#define DR_NUM_SETS (DR_PIPE_DEPTH + 1)
 
 // One in-flight dr_search_submit: upload, search, tie-order pass and download are queued on four streams; the host
 // only touches it again in dr_search_wait.
@@ -204,7 +206,7 @@ struct dr_index {
         uint32_t ticket_base = 0;     // every launch draws exactly nq tickets from counter[0]: never reset
         void release() { counter.release(); res_n.release(); tie.release(); out_ids.release(); out_count.release();
                          res_keys.release(); log.release(); stats.release(); out_dist.release(); }
-    } sets[4];      // four sets (three in-flight pipelined jobs + the one being queued): the tie-order pass of step i only finds room in the TAILS of the next search kernels
+    } sets[DR_NUM_SETS];      // one set per in-flight pipelined job + the one being queued: the tie-order pass of step i only finds room in the TAILS of the next search kernels
                     // (its 19 VGPRs do not fit beside 3 x 168 per SIMD), so it gets two steps to finish, not one
     int parity = 0, last_set = 0;
     hipStream_t fstream = nullptr;
@@ -1018,7 +1020,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     ix->last_k = k;
     ix->last_nq = nq;
     ix->last_set = set;
-    ix->parity = (ix->parity + 1) % 4;
+    ix->parity = (ix->parity + 1) % DR_NUM_SETS;
     return 0;
 }
 
@@ -1200,9 +1202,11 @@ extern "C" int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq,
     }
     HIPCHK(hipEventRecord(jb.up_done, ix->up_stream));
     // a batch smaller than the chip's wavefront slots cannot fill it: consecutive small batches go to alternating search
-    // lanes (streams) and overlap (DR_ONE_LANE=1 switches that off for A/B)
-    static const bool one_lane = getenv("DR_ONE_LANE") != nullptr;
-    const int lane = (!one_lane && (uint64_t)nq < (uint64_t)ix->num_cu * 16) ? (int)(ix->next_ticket & 1) : 0;
+    // lanes (streams) and overlap
+    // -- measured SLOWER (profiles/r03/ab/ab_small_batches_two_search_lanes.json: 2500 queries per batch 4.03 -> 2.69 M QPS,
+    // 1250: 2.09 -> 1.58 M): off unless DR_TWO_LANES=1
+    static const bool two_lanes = getenv("DR_TWO_LANES") != nullptr;
+    const int lane = (two_lanes && (uint64_t)nq < (uint64_t)ix->num_cu * 16) ? (int)(ix->next_ticket & 1) : 0;
     HIPCHK(hipStreamWaitEvent(lane ? ix->stream2 : ix->stream, jb.up_done, 0));
     QSlot *const keep = ix->cs;
     ix->cs = &qs;

@@ -189,8 +189,8 @@ int dr_batch_select(dr_index *ix, uint32_t slot);
 
 /* Asynchronous, pipelined form of dr_search_batch (same arguments and results): dr_search_submit queues the upload
  * of the batch, its search, the tie-order pass and the download on separate HIP streams and returns a ticket;
- * dr_search_wait blocks until that batch's results are in the caller's output buffers. Up to 3 batches are in flight
- * per handle (a fourth submit first finishes the oldest), so the copies of batch i+1 / i-1 overlap the search kernel of
+ * dr_search_wait blocks until that batch's results are in the caller's output buffers. Up to 4 batches are in flight
+ * per handle (a fifth submit first finishes the oldest), so the copies of batch i+1 / i-1 overlap the search kernel of
  * batch i and the throughput of a stream of host-resident batches approaches the HBM-resident rate. nq <= 32768 per
  * submit. The query buffer may be reused as soon as dr_search_submit returns when it is pageable memory (it is staged);
  * memory from dr_host_alloc (pinned: the copy engine reads it directly, no staging copy) must stay untouched until the
