@@ -16,3 +16,26 @@ for d in ("a","b"):
             agg.setdefault(r["Counter_Name"],[]).append(float(r["Counter_Value"]))
     for k,v in agg.items(): print(d,k,sum(v)/len(v), len(v))
 PY
+python3 - <<'PY'
+import csv, glob, json
+out = {"source": "scripts/pmc_sq.sh: rocprofv3 --pmc SQ_* (two passes) over scripts/pmc_target.py: the c2 workload, search_kernel<128, true, ...> (M1), mean per launch, summed over wavefronts"}
+for d in ("a", "b"):
+    fs = glob.glob(f"gpurun_out/pmcsq/{d}/*/*counter_collection.csv")
+    if not fs: continue
+    agg = {}
+    for r in csv.DictReader(open(fs[0])):
+        if "search_kernel<128, true" in r["Kernel_Name"]:
+            agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            out["kernel"] = r["Kernel_Name"]
+    for k, v in agg.items(): out[k] = sum(v) / len(v)
+for line in open("gpurun_out/pmcsq/a.out"):
+    p = line.split()
+    if p and p[0] == "EXPANSIONS_PER_LAUNCH": out["expansions_per_launch"] = float(p[1])
+if "expansions_per_launch" in out:
+    e = out["expansions_per_launch"]
+    out["per_expansion"] = {k.replace("SQ_INSTS_", "").lower(): out[k] / e for k in out if k.startswith("SQ_INSTS_")}
+if "SQ_WAIT_ANY" in out and "SQ_WAVE_CYCLES" in out: out["wave_cycles_waiting"] = out["SQ_WAIT_ANY"] / out["SQ_WAVE_CYCLES"]
+json.dump(out, open("gpurun_out/pmcsq/sq_counters.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
+rm -rf $OUT/a $OUT/b

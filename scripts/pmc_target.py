@@ -20,3 +20,4 @@ S, V, X = st["steps"].astype(np.float64), st["pq_evaluated"].astype(np.float64),
 print("ALG_BYTES_PER_LAUNCH", float((4 * 128 + S * 4 * 64 + V * 32 + X * 4 * 128 + 80).sum() + 4 * 256 * 128))
 print("CALIB_BYTES", 1000000 * 128 * 4)
 print("BEAM_WIDTH", bw)
+print("EXPANSIONS_PER_LAUNCH", float(S.sum()))

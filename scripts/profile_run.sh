@@ -28,10 +28,12 @@ for bw in (8, 0):
 json.dump(out, open('gpurun_out/prof/pmc_traffic.json', 'w'), indent=1)
 print(json.dumps({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if 'bytes' in kk}) for k, v in out.items()}, indent=1))
 PY
-# the bench line quotes roofline.traffic from profiles/r02/pmc_traffic.json: refresh it first, then run the bench
-mkdir -p profiles/r02; cp $OUT/pmc_traffic.json profiles/r02/pmc_traffic.json
+# the bench line quotes roofline.traffic from profiles/r03/pmc_traffic.json: refresh it first, then run the bench
+mkdir -p profiles/r03; cp $OUT/pmc_traffic.json profiles/r03/pmc_traffic.json
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
-cp $OUT/bench.json profiles/r02/bench.json; cp $OUT/bench_under_rocprof.json profiles/r02/bench_under_rocprof.json
-cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) profiles/r02/kernel_stats.csv
-mkdir -p gpurun_out/r02; cp profiles/r02/* gpurun_out/r02/
+cp $OUT/bench.json profiles/r03/bench.json; cp $OUT/bench_under_rocprof.json profiles/r03/bench_under_rocprof.json
+cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) profiles/r03/kernel_stats.csv
+mkdir -p gpurun_out/r03prof; cp profiles/r03/bench.json profiles/r03/bench_under_rocprof.json profiles/r03/kernel_stats.csv profiles/r03/pmc_traffic.json gpurun_out/r03prof/
+# the raw traces stay on the box (gpurun_out is capped at 64 MiB)
+rm -rf $OUT/stats $OUT/pmc_fetch_bw8 $OUT/pmc_fetch_bw0 $OUT/pmc_write_bw8 $OUT/pmc_write_bw0
