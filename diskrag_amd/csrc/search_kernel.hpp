@@ -141,15 +141,6 @@ DEV u32 wave_min_u32(u32 x)
     return readlane32(x, 63);
 }
 
-// min over the wave of a u64 (identity ~0), result broadcast: the high words first, then the low words of the lanes that
-// hold the minimal high word
-DEV u64 wave_min_u64(u64 x)
-{
-    const u32 hi = wave_min_u32((u32)(x >> 32));
-    const u32 lo = wave_min_u32(((u32)(x >> 32) == hi) ? (u32)x : 0xFFFFFFFFu);
-    return ((u64)hi << 32) | lo;
-}
-
 // ---- register-resident sorted lists -----------------------------------------------------------------------
 // Ascending array of NCH*64 keys; lane l of chunk c holds index c*64+l. Result list key = dist bits << 32 | ~id
 // (last element = what heapq pops from the reference's max-heap of (-dist, id): largest distance, smallest id
@@ -796,8 +787,8 @@ DEV void search_body(const SearchParams &p)
 
         u32 npq_eval = 0;
         u32 steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0, ninserts = 0;
-        u32 pre_id = 0xFFFFFFFFu;   // node whose adjacency row is (being) landed in pre_buf; none at query start (its frontier
-                                    // key waits in the area's last 8 bytes for the late correction: no register across the burst)
+        u32 pre_id = 0xFFFFFFFFu;   // node whose adjacency row is (being) landed in pre_buf; none at query start
+        bool pre_landed = false;    // a full memory wait (the row burst's) has happened since that prefetch was issued
         u32 npre_hit = 0;
         const bool pre_on = ADJPRE && has_first && p.adjr != nullptr && p.R == 64u;
 #ifdef DR_TRACE_VIS
@@ -906,7 +897,12 @@ DEV void search_body(const SearchParams &p)
                 u32 nbid_l, nbpos_l;
                 u64 aux_w;
                 if (ADJPRE && pre_hit) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // The prefetch was issued at the top of the previous expansion and that expansion's row burst has
+                    // waited for every earlier memory operation: the row is in LDS. Waiting for vmcnt(0) HERE would wait
+                    // for the acknowledgement of the insert-log store the merge issued a moment ago -- a full write
+                    // round trip at the top of every "hit" (round 3: the phase build showed the adjacency phase of a hit
+                    // costing as much as a miss). Only an expansion that fetched no rows leaves the prefetch unwaited.
+                    if (!pre_landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     nbid_l = pre_buf[lane]; nbpos_l = pre_buf[64 + lane];
                     aux_w = *reinterpret_cast<const u64 *>(pre_buf + 128);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // read before the next prefetch reuses the area
@@ -916,12 +912,12 @@ DEV void search_body(const SearchParams &p)
                 // prediction holds the next expansion starts without its first global round trip.
                 if constexpr (ADJPRE) {
                     pre_id = 0xFFFFFFFFu;
+                    pre_landed = false;
                     if (pre_on) {
                         const int ia2 = frontier_first<NCHR>(rk, fl, rn);
                         const u64 ka2 = (ia2 >= 0) ? fkey(list_get<NCHR>(rk, ia2)) : ~0ull;
                         const u64 kb2 = (tn > 0) ? readlane64(tl.v[0], 0) : ~0ull;
                         const u64 kn = ka2 <= kb2 ? ka2 : kb2;
-                        if (lane == 0) *reinterpret_cast<u64 *>(pre_buf + 130) = kn;
                         if (kn != ~0ull) {
                             pre_id = (u32)kn;
                             const u32 *gi = p.adj + (size_t)pre_id * 64 + lane, *gp = p.adjr + (size_t)pre_id * 64 + lane;
@@ -1121,6 +1117,7 @@ DEV void search_body(const SearchParams &p)
                                 }
                             }
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            pre_landed = true;
                             for (int r8 = 0; r8 < nb; r8 += 8) {
                                 const int row = min(r8 + oct, nb - 1);
                                 const uint4 w = *reinterpret_cast<const uint4 *>(rowbuf8 + (size_t)row * D + j * 16);
@@ -1241,34 +1238,6 @@ DEV void search_body(const SearchParams &p)
                     WSYNC();
                     e = rowlane ? nb_e[myrow] : __builtin_inff();
                     if (kcos && rowlane) e = cosine_from_l2(e, p.vnorm2[myid], qn2);
-                    // Late correction of the adjacency prefetch (round 3): the prediction made at the start of this
-                    // expansion fails exactly when one of ITS new neighbours comes out nearer than every entry that was
-                    // left -- and that is known now, before the decisions, the merge and the trim. The nearest new
-                    // neighbour's row is landed over the predicted one (whose loads have long arrived: the row burst
-                    // waited for everything), and travels while the list work runs: the 42 % of expansions (beam_width 8)
-                    // that used to start with a global round trip start from LDS too. Still only a hint: the next
-                    // expansion uses the area iff the node it pops is the one the area was filled for.
-                    if constexpr (ADJPRE) {
-                        if (pre_on) {
-                            const u64 mine = (rowlane && !kcos) ? (((u64)__float_as_uint(e) << 32) | myid) : ~0ull;
-                            const u64 nbest = wave_min_u64(mine);
-                            const u64 pre_key = *reinterpret_cast<const u64 *>(pre_buf + 130);
-                            if (nbest < pre_key) {
-                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                pre_id = (u32)nbest;
-                                const u32 *gi = p.adj + (size_t)pre_id * 64 + lane, *gp = p.adjr + (size_t)pre_id * 64 + lane;
-                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gi,
-                                    (__attribute__((address_space(3))) void *)pre_buf, 4, 0, 0);
-                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
-                                    (__attribute__((address_space(3))) void *)(pre_buf + 64), 4, 0, 0);
-                                if (lane < 2) {
-                                    const u32 *gm = reinterpret_cast<const u32 *>(p.first + (size_t)pre_id) + lane;
-                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gm,
-                                        (__attribute__((address_space(3))) void *)(pre_buf + 128), 4, 0, 0);
-                                }
-                            }
-                        }
-                    }
                     if constexpr (FILTER) {
                         npq += nnew;            // the reference counts one PQ distance per new neighbour
                         if (need_adc) npq_eval += nnew;
