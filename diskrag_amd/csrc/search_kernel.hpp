@@ -788,7 +788,6 @@ DEV void search_body(const SearchParams &p)
         u32 npq_eval = 0;
         u32 steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0, ninserts = 0;
         u32 pre_id = 0xFFFFFFFFu;   // node whose adjacency row is (being) landed in pre_buf; none at query start
-        bool pre_landed = false;    // a full memory wait (the row burst's) has happened since that prefetch was issued
         u32 npre_hit = 0;
         const bool pre_on = ADJPRE && has_first && p.adjr != nullptr && p.R == 64u;
 #ifdef DR_TRACE_VIS
@@ -897,12 +896,7 @@ DEV void search_body(const SearchParams &p)
                 u32 nbid_l, nbpos_l;
                 u64 aux_w;
                 if (ADJPRE && pre_hit) {
-                    // The prefetch was issued at the top of the previous expansion and that expansion's row burst has
-                    // waited for every earlier memory operation: the row is in LDS. Waiting for vmcnt(0) HERE would wait
-                    // for the acknowledgement of the insert-log store the merge issued a moment ago -- a full write
-                    // round trip at the top of every "hit" (round 3: the phase build showed the adjacency phase of a hit
-                    // costing as much as a miss). Only an expansion that fetched no rows leaves the prefetch unwaited.
-                    if (!pre_landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     nbid_l = pre_buf[lane]; nbpos_l = pre_buf[64 + lane];
                     aux_w = *reinterpret_cast<const u64 *>(pre_buf + 128);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // read before the next prefetch reuses the area
@@ -912,7 +906,6 @@ DEV void search_body(const SearchParams &p)
                 // prediction holds the next expansion starts without its first global round trip.
                 if constexpr (ADJPRE) {
                     pre_id = 0xFFFFFFFFu;
-                    pre_landed = false;
                     if (pre_on) {
                         const int ia2 = frontier_first<NCHR>(rk, fl, rn);
                         const u64 ka2 = (ia2 >= 0) ? fkey(list_get<NCHR>(rk, ia2)) : ~0ull;
@@ -1117,7 +1110,6 @@ DEV void search_body(const SearchParams &p)
                                 }
                             }
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            pre_landed = true;
                             for (int r8 = 0; r8 < nb; r8 += 8) {
                                 const int row = min(r8 + oct, nb - 1);
                                 const uint4 w = *reinterpret_cast<const uint4 *>(rowbuf8 + (size_t)row * D + j * 16);
