@@ -149,23 +149,11 @@ template <int NCH> struct RegList { u64 v[NCH]; };
 
 template <int NCH> DEV u64 list_get(const RegList<NCH> &L, int idx)
 {
-    if constexpr (NCH == 4 || NCH == 8) {
-        // long lists: a scalar branch to the chunk's own pair of v_readlane (the select chain below reads EVERY chunk: 16
-        // readlanes and as many selects at 8 chunks, three times per expansion)
-        const int c = __builtin_amdgcn_readfirstlane(idx >> 6), l = idx & 63;
-        switch (c) {
-#define DR_LG(C) case C: if constexpr (C < NCH) return readlane64(L.v[C < NCH ? C : 0], l); else return 0ull;
-        DR_LG(0) DR_LG(1) DR_LG(2) DR_LG(3) DR_LG(4) DR_LG(5) DR_LG(6) DR_LG(7)
-#undef DR_LG
-        default: return 0ull;
-        }
-    } else {
-        u64 r = 0;
+    u64 r = 0;
 #pragma unroll
-        for (int c = 0; c < NCH; c++)
-            if ((idx >> 6) == c) r = readlane64(L.v[c], idx & 63);
-        return r;
-    }
+    for (int c = 0; c < NCH; c++)
+        if ((idx >> 6) == c) r = readlane64(L.v[c], idx & 63);
+    return r;
 }
 
 // Inserts key (n entries, capacity cap <= NCH*64). When full, the largest entry falls off the end (or the key
@@ -803,7 +791,6 @@ DEV void search_body(const SearchParams &p)
         vstamp++;
         const u32 vtag = vstamp << 24;
         int rn = 0, cnT = 0, tn = 0;   // results; live (unexpanded, untrimmed) result entries; tie side list
-        u32 Wb = 0u;
         u32 junk = 0;   // evicted frontier entries that are worse than every result (only their count matters)
         RegList<NCHR> rk;
         FlagList<NCHR> fl;
@@ -843,7 +830,6 @@ DEV void search_body(const SearchParams &p)
             const u32 db = __float_as_uint(d0);
             u64 dr; u32 df; bool dd;
             rn = list_insert_f<NCHR>(rk, fl, 0, cap, ((u64)db << 32) | (u32)(~start), dr, df, dd);
-            Wb = db;          // distance bits of the list's last entry (the worst result): follows every merge below
             cnT = 1;
             if (lane == 0 && p.logcap > 0) qlog[0] = ((u64)db << 32) | start;
             ninserts = 1;
@@ -871,7 +857,7 @@ DEV void search_body(const SearchParams &p)
             const bool pre_hit = ADJPRE && pre_on && cur == pre_id;
             if (pre_hit) npre_hit++;
             {
-                const float W = __uint_as_float(Wb);
+                const float W = key_dist(list_get<NCHR>(rk, rn - 1));
                 bool stop;
                 if (kmode == 3u) stop = (cd > W) && (rn == cap);
                 else if (kmode == 4u) stop = (cd > W);
@@ -1070,7 +1056,7 @@ DEV void search_body(const SearchParams &p)
                         xbits = a4_threshold_bits(pq_d, p.policy == 0u ? 1.2f : 0.8f, ok);
                         if (__ballot(isnew && !ok) != 0ull) status |= DR_ST_INTERNAL;
                         if (rn == cap) {
-                            const u32 W0b = Wb;
+                            const u32 W0b = (u32)(list_get<NCHR>(rk, rn - 1) >> 32);
                             rowlane = isnew && xbits < W0b;
                         }
                         PH(4);
@@ -1269,7 +1255,7 @@ DEV void search_body(const SearchParams &p)
                     const u32 ebits = __float_as_uint(e);
                     const u32 tbits = max(ebits, xbits);
                     const bool full0 = (rn == cap);
-                    const u32 W0b = Wb;
+                    const u32 W0b = (u32)(list_get<NCHR>(rk, rn - 1) >> 32);
                     // lanes that can still be scored (superset of those that can be accepted)
                     const u64 cm = __ballot(isnew && (!full0 || (count_pass ? xbits : ebits) < W0b));
                     const u64 mykey = ((u64)ebits << 32) | (u32)(~myid);
@@ -1286,7 +1272,7 @@ DEV void search_body(const SearchParams &p)
                         // it, nothing waits for LDS. Many candidates (a filling list, up to 64): the per-lane binary
                         // search over the list staged in LDS, 7-11 dependent reads but one pass for all lanes. Same
                         // counts either way. (One-wavefront workgroups only: the 16-wave variants have no registers to spare.)
-                        constexpr bool BALLOT_COUNTS = true;
+                        constexpr bool BALLOT_COUNTS = (NW == 1);
                         // (break-even: a candidate costs 3 compares + counts per list chunk, the search 7-11 dependent LDS reads)
                         const bool by_ballot = BALLOT_COUNTS && __popcll(cm) * (NCHR + 2) <= 48;
                         if (!by_ballot) {
@@ -1395,7 +1381,6 @@ DEV void search_body(const SearchParams &p)
                         if (isacc && npA < cap) { mk[npA] = mykey; mf[npA] = 0u; }
                         WSYNC();
                         const u32 Wfb = (u32)(mk[rn2 - 1] >> 32);
-                        Wb = Wfb;
                         // entries pushed out: live ones stay in the reference's frontier (search_engine.py:469-474):
                         // worse than every result -> only counted; tied with the new worst distance -> side list
                         int nlive_out = 0;
