@@ -101,3 +101,28 @@ def test_shard_slice_and_merge_padding():
     ids, d = merge_topk([a_ids, b_ids], [a_d, b_d], 4)
     assert ids.tolist() == [[5, 9, 7, int(PAD)]]
     assert d[0, :3].tolist() == [1.0, 1.0, 3.0] and np.isnan(d[0, 3])
+
+
+def test_distance_based_recall_counts_ties():
+    """recall_at_k_ties (diskrag_amd/synth.py): a returned entry as near as the k-th ground-truth entry is a hit, whatever its id."""
+    from diskrag_amd.synth import recall_at_k, recall_at_k_ties
+    gt_ids = np.array([[0, 1, 2]], dtype=np.uint32)
+    gt_dist = np.array([[1.0, 2.0, 2.0]], dtype=np.float32)
+    got_ids = np.array([[0, 7, 9]], dtype=np.uint32)             # 7 and 9 tie with the 2nd / 3rd ground-truth entries
+    got_dist = np.array([[1.0, 2.0, 2.0]], dtype=np.float32)
+    assert recall_at_k(got_ids, gt_ids, 3) == 1 / 3
+    assert recall_at_k_ties(got_dist, gt_dist, 3) == 1.0
+    assert recall_at_k_ties(np.array([[1.0, 2.5, np.nan]], dtype=np.float32), gt_dist, 3) == 1 / 3
+
+
+def test_strong_scaling_slices_tile_any_batch():
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for nq in (1, 7, 1250, 10000, 10001):
+        for world in (1, 2, 3, 8):
+            sl = [bench.slice_of(nq, world, r) for r in range(world)]
+            assert sl[0][0] == 0 and sl[-1][1] == nq and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+            assert max(h - l for l, h in sl) - min(h - l for l, h in sl) <= 1
