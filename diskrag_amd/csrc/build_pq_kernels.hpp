@@ -59,26 +59,70 @@ struct PrunePQParams {
     u32 *fwd; u32 *fwd_n;
 };
 
-// prune_kernel's twin on code words: one wavefront per point, the point's (then each pick's) m table rows staged in LDS,
-// one lane per candidate for the m-term sums.
-__global__ __launch_bounds__(64) void prune_pq_kernel(const PrunePQParams p)
+// 16 terms of a centroid-pair sum from table rows held in registers: tv[jj * 4 + k] of lane l = row_jj[l * 4 + k] (the lane's
+// float4 of the 1 KiB row), the entry of code c is register c & 3 of lane c >> 2 (ds_bpermute; every lane takes part)
+DEV float sdc_reg16(const float *tv, const uint4 cw, float s)
+{
+    const u32 words[4] = { cw.x, cw.y, cw.z, cw.w };
+    float t[16];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int jj = u * 4 + b;
+            const u32 c = (words[u] >> (8 * b)) & 255u;
+            const int addr = (int)(c & 252u);                       // lane (c >> 2), in bytes
+            const u32 r0 = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)__float_as_uint(tv[jj * 4 + 0]));
+            const u32 r1 = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)__float_as_uint(tv[jj * 4 + 1]));
+            const u32 r2 = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)__float_as_uint(tv[jj * 4 + 2]));
+            const u32 r3 = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)__float_as_uint(tv[jj * 4 + 3]));
+            const u32 lo = (c & 1u) ? r1 : r0, hi = (c & 1u) ? r3 : r2;
+            t[jj] = __uint_as_float((c & 2u) ? hi : lo);
+            if (b == 3) __builtin_amdgcn_sched_barrier(0);         // (16 lookups in flight, not 128: the rows take half the registers)
+        }
+#pragma unroll
+    for (int i = 0; i < 16; i++) s = f_add(s, t[i]);
+    return s;
+}
+
+// prune_kernel's twin on code words: one wavefront per point, the m table rows of the point (then of each pick) staged, one
+// lane per candidate for the m-term sums. M16 = m / 16 in {1, 2}: the rows live in REGISTERS (64 per 16 sub-quantisers,
+// lookups by ds_bpermute) and the block's LDS holds only the candidate lists: 8 wavefronts per CU instead of 2 (the kernel
+// waits on the row loads of pick after pick; its rate is the number of points in flight). M16 = 0: any m, rows in LDS.
+// Same sums in the same order either way: the graph does not depend on the form.
+template <int M16>
+__global__ __launch_bounds__(64, M16 == 2 ? 2 : 1) void prune_pq_kernel(const PrunePQParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *rows = reinterpret_cast<float *>(smem);                                    // [m][256]
-    u64 *keyA = reinterpret_cast<u64 *>(smem + (size_t)p.m * 1024);                   // [MAXC]
-    u64 *keyB = keyA + DR_PRUNE_MAXC;
-    u32 *raw = reinterpret_cast<u32 *>(keyB + DR_PRUNE_MAXC);
-    u32 *keep = raw + DR_PRUNE_MAXC;
-    u32 *outsel = keep + DR_PRUNE_MAXC;                                               // [256]
-    u32 *cslot2 = outsel + 256;                                                       // [MAXC] second slot array of the compaction
-    u8 *ccode = reinterpret_cast<u8 *>(cslot2 + DR_PRUNE_MAXC);                       // [DR_PRUNE_PQ_MAXC][m] candidates' code words
+    constexpr int KC = DR_PRUNE_PQ_MAXC;                                              // candidates per prune (nraw is clipped to it)
+    float *rows = reinterpret_cast<float *>(smem);                                    // [m][256] (M16 == 0)
+    u64 *keyA = reinterpret_cast<u64 *>(smem + (M16 ? 0 : (size_t)p.m * 1024));       // [KC]
+    u64 *keyB = keyA + KC;
+    u32 *raw = reinterpret_cast<u32 *>(keyB + KC);
+    u32 *outsel = raw + KC;                                                           // [256]
+    u32 *cslot2 = outsel + 256;                                                       // [KC] second slot array of the compaction
+    u8 *ccode = reinterpret_cast<u8 *>(cslot2 + KC);                                  // [KC][m] candidates' code words
     const int lane = lane_id();
+    float tv[M16 ? M16 * 64 : 1];
     // (code words are read as whole 16-byte pieces, and every loop over their bytes is unrolled: the m row loads / table
     // reads that depend on a piece are issued together, and no register array is indexed dynamically)
     const bool wide = (p.m & 15u) == 0 && p.m <= 64;
-    auto stage_rows = [&](const u8 *cd) {       // cd: a code word (global memory, or the LDS copy of a candidate's)
+    auto stage_rows = [&](const u8 *cd) {       // cd: ONE code word for the whole wavefront (global memory, or the LDS copy of a candidate's)
         WSYNC();
-        if (wide) {
+        if constexpr (M16 > 0) {
+#pragma unroll
+            for (int i = 0; i < M16; i++) {
+                const uint4 w = reinterpret_cast<const uint4 *>(cd)[i];
+                const u32 words[4] = { (u32)__builtin_amdgcn_readfirstlane((int)w.x), (u32)__builtin_amdgcn_readfirstlane((int)w.y),
+                                       (u32)__builtin_amdgcn_readfirstlane((int)w.z), (u32)__builtin_amdgcn_readfirstlane((int)w.w) };
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const u32 c = (words[t >> 2] >> (8 * (t & 3))) & 255u;
+                    const float4 r = reinterpret_cast<const float4 *>(p.sdc + ((size_t)(i * 16 + t) * 256 + c) * 256)[lane];
+                    tv[(i * 16 + t) * 4 + 0] = r.x; tv[(i * 16 + t) * 4 + 1] = r.y; tv[(i * 16 + t) * 4 + 2] = r.z; tv[(i * 16 + t) * 4 + 3] = r.w;
+                }
+            }
+        } else if (wide) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 if (i * 16 < (int)p.m) {
@@ -101,20 +145,24 @@ __global__ __launch_bounds__(64) void prune_pq_kernel(const PrunePQParams p)
         }
         WSYNC();
     };
-    // sum_j rows[j][code[j]], A3's order; `cd` points at a code word (LDS copy of a candidate's, or global)
+    // sum_j rows[j][code[j]], A3's order; `cd` points at the lane's code word (LDS copy of a candidate's, or global). With the
+    // rows in registers EVERY lane has to call it (a lane without a candidate passes any valid code word).
     auto dist_code = [&](const u8 *cd) {
         float s2 = 0.0f;
-        if (wide) {
+        if constexpr (M16 > 0) {
+#pragma unroll
+            for (int i = 0; i < M16; i++) s2 = sdc_reg16(tv + i * 64, reinterpret_cast<const uint4 *>(cd)[i], s2);
+        } else if (wide) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 if (i * 16 < (int)p.m) {
                     const uint4 w = reinterpret_cast<const uint4 *>(cd)[i];
                     const u32 words[4] = { w.x, w.y, w.z, w.w };
-                    float tv[16];
+                    float tt[16];
 #pragma unroll
-                    for (int t = 0; t < 16; t++) tv[t] = rows[(i * 16 + t) * 256 + ((words[t >> 2] >> (8 * (t & 3))) & 255u)];
+                    for (int t = 0; t < 16; t++) tt[t] = rows[(i * 16 + t) * 256 + ((words[t >> 2] >> (8 * (t & 3))) & 255u)];
 #pragma unroll
-                    for (int t = 0; t < 16; t++) s2 = f_add(s2, tv[t]);
+                    for (int t = 0; t < 16; t++) s2 = f_add(s2, tt[t]);
                 }
             }
         } else {
@@ -152,7 +200,12 @@ __global__ __launch_bounds__(64) void prune_pq_kernel(const PrunePQParams p)
         }
         if (nraw > DR_PRUNE_PQ_MAXC) nraw = DR_PRUNE_PQ_MAXC;
         stage_rows(p.codes + (size_t)pt * p.m);
-        for (int i = lane; i < nraw; i += 64) keyA[i] = ((u64)__float_as_uint(dist_code(p.codes + (size_t)raw[i] * p.m)) << 32) | raw[i];
+        for (int base = 0; base < nraw; base += 64) {       // (whole wavefront in every trip: see dist_code)
+            const int i = base + lane;
+            const u32 id = (i < nraw) ? raw[i] : pt;
+            const float dpc = dist_code(p.codes + (size_t)id * p.m);
+            keyA[i] = ((u64)__float_as_uint(dpc) << 32) | id;       // (i < KC, a multiple of 64: slots past nraw are never read)
+        }
         WSYNC();
         for (int base = 0; base < nraw; base += 64) {
             const int i = base + lane;
@@ -192,17 +245,18 @@ __global__ __launch_bounds__(64) void prune_pq_kernel(const PrunePQParams p)
             nsel++;
             if (na == 1 || nsel >= (int)p.R) break;
             stage_rows(ccode + (size_t)scur[0] * p.m);
-            for (int i = 1 + lane; i < na; i += 64) {
-                const u64 kc = cur[i];
-                keep[i] = (f_mul(p.alpha, dist_code(ccode + (size_t)scur[i] * p.m)) <= key_dist(kc)) ? 0u : 1u;   // pruned when alpha * d(p*, c) <= d(p, c)
-            }
-            WSYNC();
+            // distance of every remaining candidate to the pick and the compaction of the survivors in one sweep (the
+            // ballot also keeps the sums out of a branch: the looked-up values are consumed as they arrive)
             int nn = 0;
             for (int base = 1; base < na; base += 64) {
                 const int i = base + lane;
-                const bool ok = (i < na) && keep[i] != 0u;
+                const bool have = i < na;
+                const u64 kc = cur[have ? i : 0];
+                const u32 sl = scur[have ? i : 0];
+                const float dsc = dist_code(ccode + (size_t)sl * p.m);
+                const bool ok = have && !(f_mul(p.alpha, dsc) <= key_dist(kc));          // pruned when alpha * d(p*, c) <= d(p, c)
                 const u64 mm = __ballot(ok);
-                if (ok) { const int o = nn + __popcll(mm & lanemask_lt()); nxt[o] = cur[i]; snxt[o] = scur[i]; }
+                if (ok) { const int o = nn + __popcll(mm & lanemask_lt()); nxt[o] = kc; snxt[o] = sl; }
                 nn += __popcll(mm);
             }
             WSYNC();

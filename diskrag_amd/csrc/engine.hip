@@ -1667,6 +1667,24 @@ static uint64_t splitmix64(uint64_t &x)
     return z ^ (z >> 31);
 }
 
+// prune_pq_kernel for q.npoints points: rows in registers (8 wavefronts per CU) when m is 16 or 32, in LDS otherwise
+// (DR_PQ_PRUNE_LDS=1 forces the LDS form: A/B, and the check that both build the same graph).
+static int launch_prune_pq(dr_index *ix, const PrunePQParams &q)
+{
+    static const bool force_lds = getenv("DR_PQ_PRUNE_LDS") != nullptr;
+    const int m16 = (!force_lds && (ix->m == 16 || ix->m == 32)) ? (int)(ix->m / 16) : 0;
+    const size_t lds = (m16 ? 0 : (size_t)ix->m * 1024) + (size_t)DR_PRUNE_PQ_MAXC * 24 + 1024 + (size_t)DR_PRUNE_PQ_MAXC * ix->m;
+    const dim3 grid(std::min<unsigned>(q.npoints, (unsigned)ix->num_cu * (m16 ? 8 : 4)));
+    if (m16 == 2) hipLaunchKernelGGL(prune_pq_kernel<2>, grid, dim3(64), lds, ix->stream, q);
+    else if (m16 == 1) hipLaunchKernelGGL(prune_pq_kernel<1>, grid, dim3(64), lds, ix->stream, q);
+    else {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&prune_pq_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(prune_pq_kernel<0>, grid, dim3(64), lds, ix->stream, q);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint32_t passes, uint64_t seed,
                                uint32_t pad_with_zero, uint32_t max_batch, uint32_t *out_medoid, float *out_seconds, bool pq)
 {
@@ -1772,9 +1790,7 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
     // DR_PQ_BUILD_SLACK (diagnosis): how far a row of the PQ-only builder may exceed R before it is re-pruned (default: a quarter of the slack slots: 4x fewer re-prunes at 2 points of recall, profiles/r02/scale_c5_small_4M.json)
     static const char *slack_env = getenv("DR_PQ_BUILD_SLACK");
     const uint32_t pq_slack = slack_env ? std::min<uint32_t>((uint32_t)atoi(slack_env), RX - R - 1) : (RX - R) / 4;
-    const size_t prune_lds = pq ? (size_t)ix->m * 1024 + (size_t)DR_PRUNE_MAXC * 28 + 1024 + (size_t)DR_PRUNE_PQ_MAXC * ix->m
-                                : (D > 256 ? (size_t)D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024;
-    if (pq) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&prune_pq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)prune_lds));
+    const size_t prune_lds = (D > 256 ? (size_t)D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024;
     std::vector<uint32_t> horder(N);
     uint64_t rng = seed ? seed : 1;
     int rc = 0;
@@ -1807,8 +1823,8 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
             pq_pp.alpha = a; pq_pp.points = pts; pq_pp.npoints = b; pq_pp.res_keys = pp.res_keys; pq_pp.res_n = pp.res_n; pq_pp.cap = L_build;
             pq_pp.fwd = fwd.p; pq_pp.fwd_n = fwd_n.p;
             if (pq) {
-                hipLaunchKernelGGL(prune_pq_kernel, dim3(std::min<unsigned>(b, (unsigned)ix->num_cu * 4)), dim3(64), prune_lds, ix->stream, pq_pp);
-                HIPCHK(hipGetLastError());
+                const int rcp = launch_prune_pq(ix, pq_pp);
+                if (rcp) return rcp;
             } else {
                 void *args[] = { &pp };
                 const unsigned g = std::min<unsigned>(b, (unsigned)ix->num_cu * 16);
@@ -1846,8 +1862,8 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
                 if (pq) {
                     PrunePQParams qo = pq_pp;
                     qo.points = ovf_list.p; qo.npoints = novf; qo.res_keys = nullptr; qo.res_n = nullptr; qo.cap = 0; qo.fwd = nullptr; qo.fwd_n = nullptr;
-                    hipLaunchKernelGGL(prune_pq_kernel, dim3(std::min<unsigned>(novf, (unsigned)ix->num_cu * 4)), dim3(64), prune_lds, ix->stream, qo);
-                    HIPCHK(hipGetLastError());
+                    const int rcp = launch_prune_pq(ix, qo);
+                    if (rcp) return rcp;
                 } else {
                 void *args[] = { &po };
                 const unsigned g = std::min<unsigned>(novf, (unsigned)ix->num_cu * 16);
@@ -1870,8 +1886,8 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
             PrunePQParams qo;
             qo.codes = ix->codes.p; qo.sdc = ix->sdc.p; qo.m = ix->m; qo.adjb = adjb.p; qo.deg = deg.p; qo.RX = RX; qo.R = R; qo.alpha = alpha;
             qo.points = ovf_list.p; qo.npoints = novf; qo.res_keys = nullptr; qo.res_n = nullptr; qo.cap = 0; qo.fwd = nullptr; qo.fwd_n = nullptr;
-            hipLaunchKernelGGL(prune_pq_kernel, dim3(std::min<unsigned>(novf, (unsigned)ix->num_cu * 4)), dim3(64), prune_lds, ix->stream, qo);
-            HIPCHK(hipGetLastError());
+            const int rcp = launch_prune_pq(ix, qo);
+            if (rcp) return rcp;
         }
     }
     if (!rc) {
