@@ -19,29 +19,6 @@ __global__ __launch_bounds__(256) void sdc_table_kernel(const float *__restrict_
     sdc[(size_t)ja * 256 + b] = pw_run_lane(cbp, ca, (int)sd);
 }
 
-// nearest-centroid codes for `rows` row-major vectors (a streamed chunk; DiskANNPQ.encode, fast_pq.py:245-267)
-__global__ void pq_assign_rows_kernel(const float *__restrict__ x, u64 rows, u32 D, u32 m, u32 sd,
-                                      const float *__restrict__ codebook, u8 *__restrict__ out)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *cb = reinterpret_cast<float *>(smem);
-    const u32 jq = blockIdx.y;
-    for (u32 e = threadIdx.x; e < 256 * sd; e += blockDim.x) cb[e] = codebook[(size_t)jq * 256 * sd + e];
-    __syncthreads();
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (u64)gridDim.x * blockDim.x) {
-        float v[128];
-        for (u32 t = 0; t < sd; t++) v[t] = x[i * D + jq * sd + t];
-        float best = 3.4e38f;
-        u32 bi = 0;
-        for (u32 c = 0; c < 256; c++) {
-            float s2 = 0.0f;
-            for (u32 t = 0; t < sd; t++) { const float d = v[t] - cb[c * sd + t]; s2 += d * d; }
-            if (s2 < best) { best = s2; bi = c; }
-        }
-        out[i * m + jq] = (u8)bi;
-    }
-}
-
 // per sub-quantiser histogram of the code words (the mean of the decoded vectors follows from it: medoid)
 __global__ void code_histogram_kernel(const u8 *__restrict__ codes, u64 n, u32 m, u32 *__restrict__ hist /*[m][256]*/)
 {

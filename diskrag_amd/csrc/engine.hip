@@ -704,6 +704,14 @@ static int launch_pq_bound(dr_index *ix, QSlot &qs, uint32_t nq, hipStream_t st)
     return 0;
 }
 
+// the encode kernels are instantiated for the sub-vector lengths of the supported shapes (register-resident sub-vector);
+// any other length runs the generic form
+#define DR_ASSIGN_SD_CASES(F) \
+    switch (sd) { \
+    case 3: F(3); break; case 4: F(4); break; case 6: F(6); break; case 8: F(8); break; case 12: F(12); break; case 16: F(16); break; \
+    case 24: F(24); break; case 30: F(30); break; case 32: F(32); break; case 48: F(48); break; case 64: F(64); break; case 96: F(96); break; \
+    default: F(0); break; }
+
 // A2 for a whole batch (engine_kernels.hpp lut_build_kernel): out[nq][m][256] on the engine's stream.
 static int launch_lut_build(dr_index *ix, const float *d_queries, uint32_t nq, float *d_out, hipStream_t st = nullptr)
 {
@@ -1973,14 +1981,19 @@ extern "C" int dr_pq_encode_rows(dr_index *ix, const float *vectors, uint64_t ro
     DevBuf<float> tmp;
     if (tmp.reserve((size_t)std::min(chunk, rows) * D)) return DR_E_NODEVICE;
     const size_t lds = (size_t)256 * sd * 4;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_assign_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void *afn = nullptr;
+#define DR_PICK(SDV) afn = reinterpret_cast<const void *>(&pq_assign_rows_kernel<SDV>)
+    DR_ASSIGN_SD_CASES(DR_PICK)
+#undef DR_PICK
+    HIPCHK(hipFuncSetAttribute(afn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (uint64_t r0 = 0; r0 < rows; r0 += chunk) {
         const uint64_t n = std::min(chunk, rows - r0);
         HIPCHK(hipMemcpyAsync(tmp.p, vectors + (size_t)r0 * D, (size_t)n * D * 4, hipMemcpyHostToDevice, ix->stream));
         const unsigned gx = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ix->num_cu * 4);
-        hipLaunchKernelGGL(pq_assign_rows_kernel, dim3(gx, m), dim3(256), lds, ix->stream, tmp.p, n, D, m, sd, ix->codebook.p,
-                           ix->codes.p + (size_t)(row0 + r0) * m);
-        HIPCHK(hipGetLastError());
+        const float *xin = tmp.p; uint64_t nn = n; uint32_t Dv = D, mv = m, sdv = sd; const float *cbk = ix->codebook.p;
+        u8 *outp = ix->codes.p + (size_t)(row0 + r0) * m;
+        void *args[] = { &xin, &nn, &Dv, &mv, &sdv, &cbk, &outp };
+        HIPCHK(hipLaunchKernel(afn, dim3(gx, m), dim3(256), args, lds, ix->stream));
         HIPCHK(hipStreamSynchronize(ix->stream));
     }
     ix->adc_live = -1; ix->nbcodes_valid = false;
@@ -2032,11 +2045,15 @@ static int pq_assign(dr_index *ix, const uint32_t *d_ids, uint64_t n, uint32_t m
 {
     const uint32_t sd = ix->D / m;
     const size_t lds = (size_t)256 * sd * 4;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void *afn = nullptr;
+#define DR_PICK(SDV) afn = reinterpret_cast<const void *>(&pq_assign_kernel<SDV>)
+    DR_ASSIGN_SD_CASES(DR_PICK)
+#undef DR_PICK
+    HIPCHK(hipFuncSetAttribute(afn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned gx = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ix->num_cu * 4);
-    hipLaunchKernelGGL(pq_assign_kernel, dim3(gx, m), dim3(256), lds, ix->stream, ix->vecp.p, ix->perm.p, d_ids, n, ix->D, m, sd,
-                       d_codebook, d_out);
-    HIPCHK(hipGetLastError());
+    const float *vp = ix->vecp.p; const u32 *pm = ix->perm.p; uint64_t nn = n; uint32_t Dv = ix->D, mv = m, sdv = sd;
+    void *args[] = { &vp, &pm, &d_ids, &nn, &Dv, &mv, &sdv, &d_codebook, &d_out };
+    HIPCHK(hipLaunchKernel(afn, dim3(gx, m), dim3(256), args, lds, ix->stream));
     return 0;
 }
 

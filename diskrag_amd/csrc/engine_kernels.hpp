@@ -568,8 +568,33 @@ __global__ void column_sum_kernel(const float *__restrict__ vecp, u64 N, u32 D, 
 }
 
 // ---- PQ training / encoding (DiskANNPQ.fit / encode, pq/fast_pq.py:197-267) -----------------
+// Nearest centroid of a sub-vector among the 256 of cb[256][sd] (LDS): plain squared L2 in element order, ties to the
+// lowest centroid index (argmin). SD > 0: the sub-vector is a register array and the loops are unrolled (SD = 0: any sd,
+// the array is indexed dynamically and lives in scratch -- an order of magnitude slower).
+template <int SD>
+DEV u32 nearest_centroid(const float *x, const float *cb, u32 sd)
+{
+    float best = 3.4e38f;
+    u32 bi = 0;
+    if constexpr (SD > 0) {
+        for (u32 c = 0; c < 256; c++) {
+            float s = 0.0f;
+#pragma unroll
+            for (int t = 0; t < SD; t++) { const float d = x[t] - cb[c * SD + t]; s += d * d; }
+            if (s < best) { best = s; bi = c; }
+        }
+    } else {
+        for (u32 c = 0; c < 256; c++) {
+            float s = 0.0f;
+            for (u32 t = 0; t < sd; t++) { const float d = x[t] - cb[c * sd + t]; s += d * d; }
+            if (s < best) { best = s; bi = c; }
+        }
+    }
+    return bi;
+}
+
 // Nearest centroid of sub-vector j of stored vector ids[i] (or i when ids == nullptr); one thread per (i, j).
-// Distances are plain squared L2 in element order; ties go to the lowest centroid index (argmin).
+template <int SD>
 __global__ void pq_assign_kernel(const float *__restrict__ vecp, const u32 *__restrict__ perm,
                                  const u32 *__restrict__ ids, u64 n, u32 D, u32 m, u32 sd,
                                  const float *__restrict__ codebook, u8 *__restrict__ out)
@@ -581,16 +606,36 @@ __global__ void pq_assign_kernel(const float *__restrict__ vecp, const u32 *__re
     __syncthreads();
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
         const u64 node = ids ? ids[i] : i;
-        float x[128];
-        for (u32 t = 0; t < sd; t++) x[t] = vecp[node * D + perm[jq * sd + t]];
-        float best = 3.4e38f;
-        u32 bi = 0;
-        for (u32 c = 0; c < 256; c++) {
-            float s = 0.0f;
-            for (u32 t = 0; t < sd; t++) { const float d = x[t] - cb[c * sd + t]; s += d * d; }
-            if (s < best) { best = s; bi = c; }
+        float x[SD > 0 ? SD : 128];
+        if constexpr (SD > 0) {
+#pragma unroll
+            for (int t = 0; t < SD; t++) x[t] = vecp[node * D + perm[jq * SD + t]];
+        } else {
+            for (u32 t = 0; t < sd; t++) x[t] = vecp[node * D + perm[jq * sd + t]];
         }
-        out[i * m + jq] = (u8)bi;
+        out[i * m + jq] = (u8)nearest_centroid<SD>(x, cb, sd);
+    }
+}
+
+// nearest-centroid codes for `rows` row-major vectors (a streamed chunk; DiskANNPQ.encode, fast_pq.py:245-267)
+template <int SD>
+__global__ void pq_assign_rows_kernel(const float *__restrict__ x, u64 rows, u32 D, u32 m, u32 sd,
+                                      const float *__restrict__ codebook, u8 *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *cb = reinterpret_cast<float *>(smem);
+    const u32 jq = blockIdx.y;
+    for (u32 e = threadIdx.x; e < 256 * sd; e += blockDim.x) cb[e] = codebook[(size_t)jq * 256 * sd + e];
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (u64)gridDim.x * blockDim.x) {
+        float v[SD > 0 ? SD : 128];
+        if constexpr (SD > 0) {
+#pragma unroll
+            for (int t = 0; t < SD; t++) v[t] = x[i * D + jq * SD + t];
+        } else {
+            for (u32 t = 0; t < sd; t++) v[t] = x[i * D + jq * sd + t];
+        }
+        out[i * m + jq] = (u8)nearest_centroid<SD>(v, cb, sd);
     }
 }
 

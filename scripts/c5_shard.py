@@ -11,7 +11,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("OPENBLAS_NUM_THREADS", "64")     # the image's BLAS is built for 64 threads; 96 generator threads call into it
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "64")     # the image's BLAS is built for 64 threads: no more generator threads than that (more end in "Bad memory unallocation" at exit)
 
 import numpy as np  # noqa: E402
 
@@ -31,7 +31,7 @@ NCL = int(argv[5] or 4096)
 D, nq = 1536, 10000
 CH -= CH % UnitMixtureStream.BLOCK
 out = {"shape": "c5 shard", "N": N, "D": D, "m": m, "graphs": [{"R": r, "L_build": l} for r, l in CFG], "n_clusters": NCL, "nq": nq, "chunk_rows": CH}
-gen = UnitMixtureStream(d=D, n_clusters=NCL, seed=11, latent=64, threads=96)
+gen = UnitMixtureStream(d=D, n_clusters=NCL, seed=11, latent=64, threads=64)
 OUT = os.environ.get("C5_OUT", "gpurun_out/scale_c5_shard.json")
 
 

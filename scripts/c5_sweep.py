@@ -30,7 +30,7 @@ def emit(rec):
     print(json.dumps(rec), flush=True)
 
 
-gen = UnitMixtureStream(d=D, n_clusters=NCL, seed=11, latent=64, threads=96)
+gen = UnitMixtureStream(d=D, n_clusters=NCL, seed=11, latent=64, threads=64)
 t0 = time.perf_counter()
 x = gen.draw(0, N)
 q = gen.draw(0, nq, stream=1)

@@ -9,7 +9,7 @@ from diskrag_amd.synth import UnitMixtureStream, recall_at_k
 N, NCL = int(sys.argv[1]), int(sys.argv[2])
 ns = int(sys.argv[3]) if len(sys.argv) > 3 else 50000
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 15
-gen = UnitMixtureStream(d=1536, n_clusters=NCL, seed=11, latent=64, threads=96)
+gen = UnitMixtureStream(d=1536, n_clusters=NCL, seed=11, latent=64, threads=64)
 x = gen.draw(0, N); q = gen.draw(0, 200, stream=1)
 ix = HipIndex.create_empty(x, R=32)
 t0 = time.perf_counter()

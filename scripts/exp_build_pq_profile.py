@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 from diskrag_amd import HipIndex
 from diskrag_amd.synth import UnitMixtureStream
 N, R, LB = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-gen = UnitMixtureStream(d=1536, n_clusters=4096, seed=11, latent=64, threads=96)
+gen = UnitMixtureStream(d=1536, n_clusters=4096, seed=11, latent=64, threads=64)
 x = gen.draw(0, N)
 tmp = HipIndex.create_empty(x[:262144], R=R)
 cb, _ = tmp.pq_train_ex(32, n_sample=50000, max_iter=15, n_init=1, seed=5)
