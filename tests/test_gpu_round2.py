@@ -2,6 +2,7 @@
 PQ-only traversal (DR_MODE_PQ, checked against the oracle's restatement of it) with and without the exact rerank,
 result lists up to 1024 entries, the device merge kernel, the sharded search with its RCCL exchange, and the PQ
 encoder against the reference-produced codes of every golden fixture."""
+import os
 import numpy as np
 import pytest
 
@@ -424,6 +425,46 @@ def test_pq_only_builder_makes_a_searchable_shard():
         assert np.array_equal(ids, w[0]) and np.array_equal(bits(dist), bits(w[1].astype(np.float32)))
     finally:
         sh.close()
+
+_PRUNE_FORMS_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, ".")
+from diskrag_amd import HipIndex
+from diskrag_amd.synth import unit_mixture
+m = int(sys.argv[1])
+x, q = unit_mixture(30000, 128, n_queries=8, n_clusters=64, seed=4, latent=24)
+full = HipIndex.create_empty(x[:8192], R=32)
+cb = full.pq_train(m, n_sample=8192, iters=6)
+full.close()
+sh = HipIndex.create_codes_empty(len(x), 128, 32, cb)
+sh.encode_rows(x, 0)
+sh.build_vamana_pq(L_build=64, alpha=1.2, passes=2, seed=3)
+print("GRAPH", hashlib.sha1(sh.get_adjacency().tobytes()).hexdigest())
+"""
+
+
+@pytest.mark.parametrize("m", [16, 32])
+def test_pq_prune_forms_build_the_same_graph(m, tmp_path):
+    """prune_pq_kernel keeps its centroid-pair rows in registers (m = 16, 32: ds_bpermute lookups, 8 wavefronts per CU) or in
+    LDS (any m; DR_PQ_PRUNE_LDS=1 forces it): the same sums in the same order, so the built graph is the same bit for bit.
+    The switch is read once per process: one child process per form."""
+    import subprocess
+    import sys
+    script = tmp_path / "build_once.py"
+    script.write_text(_PRUNE_FORMS_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hashes = []
+    for force_lds in (False, True):
+        env = dict(os.environ)
+        env.pop("DR_PQ_PRUNE_LDS", None)
+        if force_lds:
+            env["DR_PQ_PRUNE_LDS"] = "1"
+        r = subprocess.run([sys.executable, str(script), str(m)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hashes.append([ln for ln in r.stdout.splitlines() if ln.startswith("GRAPH")][-1])
+    assert hashes[0] == hashes[1]
+
 
 @pytest.mark.parametrize("d", [7, 64, 96, 128, 130, 960, 1536])
 def test_scalar_kernels_on_the_device(d):
