@@ -16,6 +16,7 @@ MODE_M1, MODE_M2, MODE_M3, MODE_M4 = 1, 2, 3, 4
 PIPE_DEPTH = 4          # DR_PIPE_DEPTH (csrc/engine.hip): batches in flight per handle
 MODE_PQ = 5      # engine mode without a reference counterpart: M1's loop on squared ADC distances only (diskrag_hip.h)
 F_USE_PQ, F_SQDIST, F_RERANK, F_COSINE = 1, 2, 4, 8
+TIER_HBM, TIER_HOST = 0, 1       # where the full-precision rows live (dr_index_*_tiered)
 MAX_RESIDENT = 16
 COMM_ID_BYTES = 128
 
@@ -38,7 +39,7 @@ STATS_DTYPE = np.dtype([("steps", "<u4"), ("visited", "<u4"), ("exact", "<u4"), 
 
 # every symbol include/diskrag_hip.h declares
 EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create", "dr_index_set_pq",
-           "dr_index_set_adjacency", "dr_search_batch", "dr_batch_upload", "dr_batch_run", "dr_batch_download",
+           "dr_index_set_adjacency", "dr_index_open_tiered", "dr_index_create_tiered", "dr_index_create_empty_tiered", "dr_search_batch", "dr_batch_upload", "dr_batch_run", "dr_batch_download",
            "dr_get_timing", "dr_exact_distances", "dr_distance_table", "dr_adc", "dr_pq_scan",
            "dr_bruteforce_topk", "dr_get_node", "dr_index_close", "dr_index_create_empty", "dr_build_vamana",
            "dr_get_adjacency", "dr_pq_train", "dr_pq_encode", "dr_debug_phase_cycles", "dr_batch_sync",
@@ -76,6 +77,12 @@ def load_library():
     L.dr_index_open.argtypes = [C.POINTER(vp), C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
     L.dr_index_create.restype = C.c_int
     L.dr_index_create.argtypes = [C.POINTER(vp), fp, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.dr_index_open_tiered.restype = C.c_int
+    L.dr_index_open_tiered.argtypes = [C.POINTER(vp), C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
+    L.dr_index_create_tiered.restype = C.c_int
+    L.dr_index_create_tiered.argtypes = [C.POINTER(vp), fp, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
+    L.dr_index_create_empty_tiered.restype = C.c_int
+    L.dr_index_create_empty_tiered.argtypes = [C.POINTER(vp), fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
     L.dr_pq_scan_best.restype = C.c_int
     L.dr_pq_scan_best.argtypes = [vp, fp, C.c_uint32, fp, u32p, fp, fp]
     L.dr_index_create_codes.restype = C.c_int
@@ -194,14 +201,15 @@ class HipIndex:
 
     # -- construction
     @classmethod
-    def open(cls, index_dat, N, D, R, medoid, device=0):
+    def open(cls, index_dat, N, D, R, medoid, device=0, vector_tier=TIER_HBM):
+        """vector_tier=TIER_HOST keeps the full-precision rows in pinned host memory (graph and codes stay in HBM)."""
         L = load_library()
         h = C.c_void_p()
-        _check(L.dr_index_open(C.byref(h), str(index_dat).encode(), int(N), int(D), int(R), int(medoid), int(device)))
+        _check(L.dr_index_open_tiered(C.byref(h), str(index_dat).encode(), int(N), int(D), int(R), int(medoid), int(device), int(vector_tier)))
         return cls(h, N, D, R, medoid)
 
     @classmethod
-    def create(cls, vectors, adj, medoid, device=0):
+    def create(cls, vectors, adj, medoid, device=0, vector_tier=TIER_HBM):
         L = load_library()
         vectors = np.ascontiguousarray(vectors, dtype=np.float32)
         adj = np.ascontiguousarray(adj, dtype=np.uint32)
@@ -209,18 +217,18 @@ class HipIndex:
         if adj.shape[0] != N:
             raise ValueError("adjacency rows != number of vectors")
         h = C.c_void_p()
-        _check(L.dr_index_create(C.byref(h), _p(vectors, C.c_float), _p(adj, C.c_uint32), N, D, adj.shape[1],
-                                 int(medoid), int(device)))
+        _check(L.dr_index_create_tiered(C.byref(h), _p(vectors, C.c_float), _p(adj, C.c_uint32), N, D, adj.shape[1],
+                                        int(medoid), int(device), int(vector_tier)))
         return cls(h, N, D, adj.shape[1], medoid)
 
     @classmethod
-    def create_empty(cls, vectors, R, device=0):
+    def create_empty(cls, vectors, R, device=0, vector_tier=TIER_HBM):
         """Vectors only; the graph is then built on the device with build_vamana()."""
         L = load_library()
         vectors = np.ascontiguousarray(vectors, dtype=np.float32)
         N, D = vectors.shape
         h = C.c_void_p()
-        _check(L.dr_index_create_empty(C.byref(h), _p(vectors, C.c_float), N, D, int(R), int(device)))
+        _check(L.dr_index_create_empty_tiered(C.byref(h), _p(vectors, C.c_float), N, D, int(R), int(device), int(vector_tier)))
         return cls(h, N, D, R, 0)
 
     @classmethod

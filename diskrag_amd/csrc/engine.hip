@@ -77,6 +77,7 @@ static int quiesce_locked(dr_index *ix);
 template <class T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool host = false;            // pinned host memory mapped into the device's address space (the host tier of the stored vectors)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -84,15 +85,20 @@ template <class T> struct DevBuf {
     int reserve(size_t want, bool zero = false)
     {
         if (want <= n) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
-        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
-        if (e != hipSuccess) return fail(DR_E_NODEVICE, "hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
+        release();
+        hipError_t e = host ? hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocMapped) : hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(DR_E_NODEVICE, "%s(%zu bytes) failed: %s", host ? "hipHostMalloc" : "hipMalloc", want * sizeof(T), hipGetErrorString(e));
+        }
         n = want;
-        if (zero) { e = hipMemset(p, 0, want * sizeof(T)); if (e != hipSuccess) return fail(DR_E_NODEVICE, "hipMemset failed"); }
+        if (zero) {
+            if (host) memset(p, 0, want * sizeof(T));
+            else { e = hipMemset(p, 0, want * sizeof(T)); if (e != hipSuccess) return fail(DR_E_NODEVICE, "hipMemset failed"); }
+        }
         return 0;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p) (void)(host ? hipHostFree(p) : hipFree(p)); p = nullptr; n = 0; }
 };
 
 // One resident query batch: queries in original and chain-major order, the per-query ADC bounds of M1, and what the
@@ -178,6 +184,7 @@ struct dr_index {
     // lossless byte copy of the vectors (integer-valued data, D = 128): 0 not checked yet, 1 present, -1 data does not qualify
     DevBuf<uint8_t> vec8;
     int vec8_state = 0;
+    uint32_t vector_tier = DR_TIER_HBM;     // where vecp lives (DR_TIER_HOST: pinned host memory read over PCIe / xGMI)
     bool rank_valid = false, adjr_valid = false, use_adjr = false;
     uint32_t medoid_pos = 0;
 
@@ -234,8 +241,10 @@ extern "C" int dr_device_count(void)
 
 extern "C" const char *dr_last_error(void) { return g_err.c_str(); }
 
-static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, uint32_t medoid, int device, bool with_vectors = true)
+static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, uint32_t medoid, int device, bool with_vectors = true,
+                              uint32_t vector_tier = DR_TIER_HBM)
 {
+    if (vector_tier != DR_TIER_HBM && vector_tier != DR_TIER_HOST) return fail(DR_E_ARG, "vector_tier must be DR_TIER_HBM or DR_TIER_HOST");
     if (N == 0 || D == 0 || R == 0) return fail(DR_E_ARG, "N, D and R must be positive");
     if (medoid >= N) return fail(DR_E_ARG, "medoid %u out of range (N=%llu)", medoid, (unsigned long long)N);
     if (N >= 0xFFFFFFFFull) return fail(DR_E_UNSUPPORTED, "N must fit in 32-bit ids");
@@ -263,6 +272,8 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     if (ix->perm.reserve(D)) return DR_E_NODEVICE;
     HIPCHK(hipMemcpy(ix->perm.p, ix->h_perm.data(), D * sizeof(uint32_t), hipMemcpyHostToDevice));
     ix->has_vectors = with_vectors;
+    ix->vector_tier = vector_tier;
+    ix->vecp.host = (vector_tier == DR_TIER_HOST);
     if (with_vectors && ix->vecp.reserve((size_t)N * D)) return DR_E_NODEVICE;
     if (ix->adj.reserve((size_t)N * R)) return DR_E_NODEVICE;
     if (ix->first.reserve((size_t)N * ((R + 63) / 64))) return DR_E_NODEVICE;
@@ -311,9 +322,15 @@ static int ingest_chunk(dr_index *ix, const void *src, uint64_t row0, uint64_t r
 extern "C" int dr_index_create(dr_index **out, const float *vectors, const uint32_t *adj, uint64_t N, uint32_t D,
                                uint32_t R, uint32_t medoid, int device)
 {
+    return dr_index_create_tiered(out, vectors, adj, N, D, R, medoid, device, DR_TIER_HBM);
+}
+
+extern "C" int dr_index_create_tiered(dr_index **out, const float *vectors, const uint32_t *adj, uint64_t N, uint32_t D,
+                                      uint32_t R, uint32_t medoid, int device, uint32_t vector_tier)
+{
     if (!out || !vectors || !adj) return fail(DR_E_ARG, "null argument");
     dr_index *ix = new dr_index();
-    int rc = index_alloc_common(ix, N, D, R, medoid, device);
+    int rc = index_alloc_common(ix, N, D, R, medoid, device, true, vector_tier);
     if (rc) { dr_index_close(ix); return rc; }
     DevBuf<uint32_t> staging;
     const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / (D * 4));
@@ -333,6 +350,12 @@ extern "C" int dr_index_create(dr_index **out, const float *vectors, const uint3
 extern "C" int dr_index_open(dr_index **out, const char *index_dat, uint64_t N, uint32_t D, uint32_t R,
                              uint32_t medoid, int device)
 {
+    return dr_index_open_tiered(out, index_dat, N, D, R, medoid, device, DR_TIER_HBM);
+}
+
+extern "C" int dr_index_open_tiered(dr_index **out, const char *index_dat, uint64_t N, uint32_t D, uint32_t R,
+                                    uint32_t medoid, int device, uint32_t vector_tier)
+{
     if (!out || !index_dat) return fail(DR_E_ARG, "null argument");
     int fd = open(index_dat, O_RDONLY);
     if (fd < 0) return fail(DR_E_IO, "cannot open %s", index_dat);
@@ -348,7 +371,7 @@ extern "C" int dr_index_open(dr_index **out, const char *index_dat, uint64_t N, 
     close(fd);
     if (map == MAP_FAILED) return fail(DR_E_IO, "mmap failed for %s", index_dat);
     dr_index *ix = new dr_index();
-    int rc = index_alloc_common(ix, N, D, R, medoid, device);
+    int rc = index_alloc_common(ix, N, D, R, medoid, device, true, vector_tier);
     DevBuf<uint32_t> staging;
     const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / rec_bytes);
     for (uint64_t r0 = 0; r0 < N && !rc; r0 += chunk) {
@@ -626,7 +649,7 @@ static int build_byte_rows(dr_index *ix)
 {
     static const bool off = getenv("DR_NO_BYTEROWS") != nullptr;
     ix->vec8_state = -1;
-    if (off || ix->D != 128 || !ix->has_vectors) return 0;
+    if (off || ix->D != 128 || !ix->has_vectors || ix->vector_tier != DR_TIER_HBM) return 0;     // (a host-tier index keeps its HBM for graph and codes)
     DevBuf<uint32_t> bad;
     if (bad.reserve(1, true) || ix->vec8.reserve((size_t)ix->N * ix->D)) return DR_E_NODEVICE;
     hipLaunchKernelGGL(pack_u8_kernel, dim3((unsigned)std::min<uint64_t>((ix->N * ix->D + 255) / 256, 1u << 16)), dim3(256), 0, ix->stream,
@@ -1630,7 +1653,7 @@ extern "C" int dr_get_node(dr_index *ix, uint64_t node_id, float *out_vec, uint3
     { const int rcv = need_vectors(ix, "dr_get_node"); if (rcv) return rcv; }
     HIPCHK(hipSetDevice(ix->device));
     std::vector<float> tmp(ix->D);
-    HIPCHK(hipMemcpy(tmp.data(), ix->vecp.p + node_id * ix->D, (size_t)ix->D * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tmp.data(), ix->vecp.p + node_id * ix->D, (size_t)ix->D * 4, hipMemcpyDefault));     // (HBM or the host tier)
     for (uint32_t e = 0; e < ix->D; e++) out_vec[e] = tmp[ix->h_perm[e]];
     HIPCHK(hipMemcpy(out_nbrs, ix->adj.p + node_id * ix->R, (size_t)ix->R * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -1640,9 +1663,15 @@ extern "C" int dr_get_node(dr_index *ix, uint64_t node_id, float *out_vec, uint3
 
 extern "C" int dr_index_create_empty(dr_index **out, const float *vectors, uint64_t N, uint32_t D, uint32_t R, int device)
 {
+    return dr_index_create_empty_tiered(out, vectors, N, D, R, device, DR_TIER_HBM);
+}
+
+extern "C" int dr_index_create_empty_tiered(dr_index **out, const float *vectors, uint64_t N, uint32_t D, uint32_t R, int device,
+                                            uint32_t vector_tier)
+{
     if (!out || !vectors) return fail(DR_E_ARG, "null argument");
     dr_index *ix = new dr_index();
-    int rc = index_alloc_common(ix, N, D, R, 0, device);
+    int rc = index_alloc_common(ix, N, D, R, 0, device, true, vector_tier);
     if (rc) { dr_index_close(ix); return rc; }
     DevBuf<uint32_t> staging;
     const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / (D * 4));

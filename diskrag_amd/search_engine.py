@@ -52,7 +52,12 @@ def export_codebook(pq_model_pkl, out_path=None):
 
 class SearchEngineCorrect:
     def __init__(self, collection_name: str, use_thread_safe_stats: bool = True, base_dir: Optional[Path] = None,
-                 device: int = 0, text_lookup: Optional[Callable[[int], Optional[Tuple[str, dict]]]] = None):
+                 device: int = 0, text_lookup: Optional[Callable[[int], Optional[Tuple[str, dict]]]] = None,
+                 vector_tier: str = "hbm"):
+        # vector_tier "host": the full-precision rows of index.dat stay in pinned host memory (the counterpart of the
+        # reference's MMapNodeReader tier, diskann_persist.py:201-234); graph and PQ codes are resident in HBM either way
+        if vector_tier not in ("hbm", "host"):
+            raise ValueError("vector_tier must be 'hbm' or 'host'")
         self.collection_name = collection_name
         base = Path(base_dir) if base_dir else Path("collections")
         cdir = base / collection_name
@@ -71,7 +76,7 @@ class SearchEngineCorrect:
         self.medoid_idx = int(self.meta.get("medoid_idx", 0))
         self.R = int(self.meta.get("R", 32))
         self.index = _ffi.HipIndex.open(index_path, int(self.meta["N"]), self.dimension, self.R, self.medoid_idx,
-                                        device=device)
+                                        device=device, vector_tier=_ffi.TIER_HOST if vector_tier == "host" else _ffi.TIER_HBM)
         self.use_pq = bool(self.meta.get("use_pq", True))
         self.n_subvectors = 0
         self.sub_dim = 0

@@ -98,6 +98,25 @@ int dr_index_open(dr_index **out, const char *index_dat, uint64_t N, uint32_t D,
 int dr_index_create(dr_index **out, const float *vectors, const uint32_t *adj, uint64_t N, uint32_t D,
                     uint32_t R, uint32_t medoid, int device);
 
+/* The vector tier (SURVEY.md 8f N3's optional tier below the resident index; the reference's counterpart is
+ * MMapNodeReader serving get_node from index.dat through the OS page cache, pydiskann/io/diskann_persist.py:201-234).
+ * DR_TIER_HBM (what dr_index_open / dr_index_create / dr_index_create_empty use): everything lives in HBM.
+ * DR_TIER_HOST: adjacency, code words, codebook and visited words stay in HBM; the N*D*4 bytes of full-precision rows
+ * live in pinned host memory mapped into the device's address space and are read by the same kernels over PCIe / xGMI --
+ * DiskANN's split (compressed vectors + graph in the fast tier, full vectors in the slow one) for an index whose rows
+ * do not fit next to the graph. Every mode and entry point works unchanged and returns the same bits; what is meant to
+ * run at speed is DR_MODE_PQ with DR_F_RERANK (the traversal never touches a row, the rerank reads L rows per query
+ * at the link's rate) and M3 with DR_F_USE_PQ. Byte rows (the D = 128 integer-data copy) are not made for a host-tier
+ * index. */
+#define DR_TIER_HBM 0u
+#define DR_TIER_HOST 1u
+int dr_index_open_tiered(dr_index **out, const char *index_dat, uint64_t N, uint32_t D, uint32_t R, uint32_t medoid,
+                         int device, uint32_t vector_tier);
+int dr_index_create_tiered(dr_index **out, const float *vectors, const uint32_t *adj, uint64_t N, uint32_t D,
+                           uint32_t R, uint32_t medoid, int device, uint32_t vector_tier);
+int dr_index_create_empty_tiered(dr_index **out, const float *vectors, uint64_t N, uint32_t D, uint32_t R, int device,
+                                 uint32_t vector_tier);
+
 /* Attaches PQ data: codebook[m][256][D/m] (kmeans_list[j].cluster_centers_, T3) and codes[N][m]
  * (pq_codes.bin, T2, diskann_persist.py:30-31,205-206). Replaces load_pq_codebook/load_pq_codes in
  * search_engine.py:55-59. */
