@@ -1,0 +1,51 @@
+"""Measurement (GPU box): T client threads asking ONE query per request (the /search route's shape) on the bench index --
+directly (every request its own dr_search_batch call; the handle serialises them) and through RequestBatcher.
+usage: exp_request_batcher.py  -> gpurun_out/r03/request_batcher.json"""
+import json
+import sys
+import threading
+import time
+import numpy as np
+sys.path.insert(0, ".")
+from diskrag_amd import HipIndex, _ffi
+from diskrag_amd.batching import RequestBatcher
+from diskrag_amd.synth import sift_like
+
+x, q = sift_like(1000000, 128, n_queries=20000, n_clusters=1024, seed=2024, query_seed=9000)
+ix = HipIndex.create_empty(x, R=64)
+ix.build_vamana(L_build=100, alpha=1.2, passes=2, seed=7)
+cb = ix.pq_train(32, n_sample=100000, iters=5); ix.pq_encode(cb)
+
+
+class Eng:      # the facade's search_batch over a bare handle
+    def search_batch(self, qs, k=10, L=None, beam_width=8, use_pq_search=True, band_policy=0):
+        return ix.search_batch(qs, k, L=L, beam_width=beam_width or 0, mode=_ffi.MODE_M1)
+
+
+def run(threads, per_thread, fn):
+    lat = [[] for _ in range(threads)]
+    def client(t):
+        for i in range(per_thread):
+            t0 = time.perf_counter(); fn(q[(t * per_thread + i) % len(q)]); lat[t].append(time.perf_counter() - t0)
+    th = [threading.Thread(target=client, args=(t,)) for t in range(threads)]
+    t0 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    dt = time.perf_counter() - t0
+    l = np.concatenate(lat) * 1e3
+    return {"requests_per_s": threads * per_thread / dt, "p50_ms": float(np.percentile(l, 50)), "p99_ms": float(np.percentile(l, 99))}
+
+
+out = {"index": "1M x 128, R 64, m 32 (the bench index)", "request": "M1, k 10, L 100, beam_width 8", "runs": {}}
+direct = lambda v: ix.search_batch(v, 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
+for v in q[:64]: direct(v)
+for T in (1, 16, 64, 256):
+    rec = {"direct": run(T, max(20, 2000 // T), direct)}
+    for wait in (0.0, 0.2, 1.0):
+        with RequestBatcher(Eng(), k_max=10, L=100, beam_width=8, max_batch=4096, max_wait_ms=wait) as rb:
+            r = run(T, max(20, 4000 // T), lambda v: rb.search(v))
+            r["mean_batch"] = rb.queries_sent / max(rb.batches_sent, 1)
+        rec[f"batcher_wait_{wait}ms"] = r
+    out["runs"][f"{T}_threads"] = rec
+    print(T, rec, flush=True)
+json.dump(out, open("gpurun_out/r03/request_batcher.json", "w"), indent=1)

@@ -243,3 +243,35 @@ def test_pq_load_surfaces_io_errors_and_never_writes(tmp_path):
     eng = SearchEngineCorrect("c", base_dir=tmp_path)
     assert not eng.use_pq                    # 128 centroids: refused explicitly, not reshaped wrongly
     eng.close()
+
+
+def test_request_batcher_returns_the_bits_of_direct_calls(tmp_path):
+    """Concurrent one-query requests coalesced into search_batch calls (diskrag_amd/batching.py; the serving seam of
+    app.py:84-130): every request gets exactly what its own _pq_accelerated_graph_search call returns -- the reference's
+    golden output."""
+    import threading
+    from diskrag_amd.batching import RequestBatcher
+    from diskrag_amd.search_engine import SearchEngineCorrect
+    g = load_golden("sift128_R64_m32")
+    write_collection(tmp_path, "c", g)
+    eng = SearchEngineCorrect("c", base_dir=tmp_path)
+    c = g.case(1)   # L=100, beam_width=8, k=10
+    nq = len(g.queries)
+    got = {}
+    with RequestBatcher(eng, k_max=10, L=100, beam_width=8, max_batch=32, max_wait_ms=2) as rb:
+        def client(lo, hi):
+            for qi in range(lo, hi):
+                got[qi] = rb.search(g.queries[qi], k=10 if qi % 2 else 7)
+        th = [threading.Thread(target=client, args=(i * nq // 8, (i + 1) * nq // 8)) for i in range(8)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert rb.queries_sent == nq and rb.batches_sent < nq
+    for qi in range(nq):
+        res, stats = got[qi]
+        k = 10 if qi % 2 else 7
+        n = min(int(c["count"][qi]), k)
+        assert [int(i) for _, i in res] == [int(i) for i in c["ids"][qi][:n]]
+        assert np.array_equal(np.array([d for d, _ in res], dtype=np.float32).view(np.uint32), c["dist"][qi][:n].view(np.uint32))
+        assert [stats["search_steps"], stats["nodes_visited"], stats["exact_distance_computations"],
+                stats["pq_distance_computations"]] == c["stats"][qi].tolist()
+    eng.close()
