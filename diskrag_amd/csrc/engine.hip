@@ -2116,14 +2116,17 @@ extern "C" int dr_pq_train_ex(dr_index *ix, uint32_t m, uint32_t n_sample, uint3
             for (uint32_t i = 0; i < ns; i++) { uint64_t jx = i + splitmix64(rng) % (ix->N - i); std::swap(all[i], all[jx]); ids[i] = all[i]; }
         }
     }
-    DevBuf<uint32_t> d_ids, d_counts; DevBuf<float> d_x, d_cb, d_d2, d_maxabs; DevBuf<uint8_t> d_assign;
+    DevBuf<uint32_t> d_ids, d_counts; DevBuf<float> d_x, d_xt, d_cb, d_d2, d_maxabs; DevBuf<uint8_t> d_assign;
     DevBuf<double> d_var, d_unif, d_shift, d_inertia; DevBuf<int> d_fix; DevBuf<unsigned long long> d_sums;
-    if (d_ids.reserve(ns) || d_x.reserve((size_t)ns * D) || d_cb.reserve((size_t)256 * D) || d_assign.reserve((size_t)ns * m) ||
+    if (d_ids.reserve(ns) || d_x.reserve((size_t)ns * D) || d_xt.reserve((size_t)ns * D) || d_cb.reserve((size_t)256 * D) || d_assign.reserve((size_t)ns * m) ||
         d_d2.reserve((size_t)ns * m) || d_maxabs.reserve(m) || d_var.reserve(m) || d_unif.reserve((size_t)m * 256 * 8) || d_shift.reserve(m) ||
         d_inertia.reserve(m) || d_fix.reserve(m) || d_sums.reserve((size_t)256 * D, true) || d_counts.reserve((size_t)m * 256, true))
         return DR_E_NODEVICE;
     HIPCHK(hipMemcpyAsync(d_ids.p, ids.data(), (size_t)ns * 4, hipMemcpyHostToDevice, ix->stream));
     hipLaunchKernelGGL(gather_subvectors_kernel, dim3(ns), dim3(64), 0, ix->stream, ix->vecp.p, ix->perm.p, d_ids.p, ns, D, d_x.p);
+    HIPCHK(hipGetLastError());
+    // the seeding kernel reads the sample by columns (km_transpose_kernel)
+    hipLaunchKernelGGL(km_transpose_kernel, dim3((ns + 31) / 32, (D + 31) / 32), dim3(256), 0, ix->stream, d_x.p, ns, D, d_xt.p);
     HIPCHK(hipGetLastError());
     // sklearn's stopping rule: total squared centre shift <= tol * mean per-feature variance (KMeans tol, default 1e-4);
     // the fixed-point scale of the centre sums: the largest exponent that cannot overflow 63 bits over ns terms
@@ -2158,7 +2161,7 @@ extern "C" int dr_pq_train_ex(dr_index *ix, uint32_t m, uint32_t n_sample, uint3
             for (uint32_t e = 0; e < 256 * 8; e++) unif[(size_t)jq * 2048 + e] = (double)(splitmix64(rng) >> 11) * (1.0 / 9007199254740992.0);
         }
         HIPCHK(hipMemcpyAsync(d_unif.p, unif.data(), unif.size() * 8, hipMemcpyHostToDevice, ix->stream));
-        hipLaunchKernelGGL(kmeanspp_kernel, dim3(m), dim3(DR_KM_THREADS), 0, ix->stream, d_x.p, ns, D, sd, d_unif.p, d_d2.p, d_cb.p);
+        hipLaunchKernelGGL(kmeanspp_kernel, dim3(m), dim3(DR_KM_THREADS), 0, ix->stream, d_xt.p, ns, D, sd, d_unif.p, d_d2.p, d_cb.p);
         HIPCHK(hipGetLastError());
         for (uint32_t it = 0; it < max_iter; it++) {
             int rc = pq_assign(ix, d_ids.p, ns, m, d_cb.p, d_assign.p);
