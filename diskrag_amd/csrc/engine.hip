@@ -1728,6 +1728,9 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
     if (!ix) return fail(DR_E_ARG, "null index");
     if (L_build == 0 || L_build > 256) return fail(DR_E_ARG, "L_build must be in 1..256");
     if (ix->R > 128) return fail(DR_E_UNSUPPORTED, "builder supports R <= 128");
+    // (the PQ-only prune holds its candidates' code words in LDS: the construction list plus a full row with its slack slots)
+    if (pq && L_build + ix->R + 64 > DR_PRUNE_PQ_MAXC)
+        return fail(DR_E_ARG, "dr_build_vamana_pq: L_build + R + 64 = %u exceeds the prune's %d candidates", L_build + ix->R + 64, DR_PRUNE_PQ_MAXC);
     if (passes == 0) passes = 2;
     std::lock_guard<std::mutex> lk(ix->mu);
     if (!pq) { const int rcv = need_vectors(ix, "dr_build_vamana"); if (rcv) return rcv; }

@@ -278,7 +278,8 @@ int dr_get_adjacency(dr_index *ix, uint32_t *out /*[N][R]*/);
  * pydiskann/cython_utils.pyx:26-51; entries in the table's summation order, the sum in the ADC's), read from a
  * centroid-pair table [m][256][256]. The reference never builds from codes (vamana_graph.py:405 "always exact distances
  * at build time"): this is the engine's own construction, held to graph quality (recall of DR_MODE_PQ searches against
- * the brute-force ADC ranking), not to parity. Rows are DR_PAD padded. */
+ * the brute-force ADC ranking), not to parity. Rows are DR_PAD padded. R <= 128 and L_build + R + 64 <= 320 (the prune's
+ * candidate list: the construction list plus a row with its slack slots); DR_E_ARG otherwise. */
 int dr_index_create_codes_empty(dr_index **out, uint64_t N, uint32_t D, uint32_t R, const float *codebook /*[m][256][D/m]*/,
                                 uint32_t m, int device);
 int dr_pq_encode_rows(dr_index *ix, const float *vectors /*[rows][D]*/, uint64_t row0, uint64_t rows);

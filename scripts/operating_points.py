@@ -2,8 +2,9 @@
 Sweeps the reference-faithful M1 (L, beam_width, band policy) and the engine's PQ traversal + exact rerank of the L list
 (DR_MODE_PQ | DR_F_RERANK: SURVEY.md 8d's definition of c3) on a c3- / c4-shaped index built on the device.
 Usage: python scripts/operating_points.py c3 10000000 [nq] [quick]   -> JSON lines in gpurun_out/op_<shape>_<N>.jsonl
-(one line per run, written as it goes: a run that dies keeps what it measured)."""
+(one line per run, written as it goes: a run that dies keeps what it measured). OP_R=<degree> builds the graph with another R."""
 import json
+import os
 import sys
 import time
 
@@ -21,8 +22,8 @@ both = spec.endswith("+extra") and spec != "extra"       # "quick+extra" / "full
 # d256 / d768 / d960: the other entries of the reference's SUPPORTED_DIMENSIONS (preprocessing/config.py:88), unit-norm mixture
 D, m, ncl, latent = {"c3": (1536, 32, 4096, 64), "c4": (96, 16, 4096, 32), "d256": (256, 32, 4096, 32), "d768": (768, 32, 4096, 64),
                      "d960": (960, 32, 4096, 64)}[shape]
-R = 64
-path = f"gpurun_out/op_{shape}_{n}{'' if spec in ('full', 'quick') else '_' + spec.replace('+', '_')}.jsonl"
+R = int(os.environ.get("OP_R", "64"))          # graph degree (OP_R=128: the widest the builder takes)
+path = f"gpurun_out/op_{shape}_{n}{'' if spec in ('full', 'quick') else '_' + spec.replace('+', '_')}{'' if R == 64 else '_R%d' % R}.jsonl"
 out = open(path, "w")
 
 

@@ -401,6 +401,8 @@ def test_pq_only_builder_makes_a_searchable_shard():
     try:
         for r0 in range(0, n, 7000):
             sh.encode_rows(x[r0:r0 + 7000], r0)
+        with pytest.raises(_ffi.DiskragHipError):          # the prune's candidate list: L_build + R + 64 <= 320
+            sh.build_vamana_pq(L_build=256, alpha=1.2, passes=2, seed=3)
         medoid, secs = sh.build_vamana_pq(L_build=64, alpha=1.2, passes=2, seed=3)
         adj = sh.get_adjacency()
         deg = (adj != 0xFFFFFFFF).sum(axis=1)
