@@ -1,6 +1,6 @@
 #!/bin/bash
 # repeat the GPU suite and an open/close loop: flakiness and leak check (GPU box)
-for i in 1 2 3; do timeout 300 python -m pytest tests -m gpu -q --timeout=200 -x -p no:cacheprovider 2>&1 | tail -1; done
+for i in 1 2 3; do timeout 600 python -m pytest tests -m gpu -q --timeout=300 -x -p no:cacheprovider > /tmp/stress_$i.log 2>&1; echo "run $i rc=$? $(grep -E "passed|failed|error" /tmp/stress_$i.log | tail -1)"; done     # (RCCL prints its banner last: the summary is taken from the log)
 python - <<'PY'
 import numpy as np, sys
 sys.path.insert(0, ".")
