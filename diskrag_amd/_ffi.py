@@ -47,7 +47,7 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_index_create_codes", "dr_index_drop_vectors", "dr_pq_scan_best",
            "dr_batch_select", "dr_search_submit", "dr_search_wait", "dr_host_alloc", "dr_host_free",
            "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_merge_topk",
-           "dr_debug_prune", "dr_pq_train_ex", "dr_index_create_codes_empty", "dr_pq_encode_rows", "dr_build_vamana_pq",
+           "dr_debug_prune", "dr_debug_prune_pq", "dr_pq_train_ex", "dr_index_create_codes_empty", "dr_pq_encode_rows", "dr_build_vamana_pq",
            "dr_scalar_kernels", "dr_index_inline_codes", "dr_pq_scan_topk", "dr_index_copy_codes"]
 
 _lib = None
@@ -526,6 +526,18 @@ class HipIndex:
         cnt = C.c_uint32(0)
         _check(load_library().dr_debug_prune(self._h, int(point), _p(c, C.c_uint32), c.size, float(alpha), int(R),
                                              _p(sel, C.c_uint32), C.byref(cnt)))
+        return sel[:int(cnt.value)]
+
+    def debug_prune_pq(self, point, candidates, alpha, R):
+        """The PQ-only builder's prune of one point over an explicit candidate list (code-word distances): picked ids in pick order."""
+        c = np.ascontiguousarray(candidates, dtype=np.uint32)
+        sel = np.empty(int(R), dtype=np.uint32)
+        cnt = C.c_uint32(0)
+        L = load_library()
+        L.dr_debug_prune_pq.restype = C.c_int
+        L.dr_debug_prune_pq.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_float, C.c_uint32,
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        _check(L.dr_debug_prune_pq(self._h, int(point), _p(c, C.c_uint32), c.size, float(alpha), int(R), _p(sel, C.c_uint32), C.byref(cnt)))
         return sel[:int(cnt.value)]
 
     def inline_codes(self, enable=True):

@@ -1704,6 +1704,16 @@ static uint64_t splitmix64(uint64_t &x)
     return z ^ (z >> 31);
 }
 
+// centroid-pair table S[m][256][256] (8 MB at m = 32): every distance of the PQ-only builder is a sum of its entries
+static int ensure_sdc(dr_index *ix)
+{
+    if (ix->sdc.p) return 0;
+    if (ix->sdc.reserve((size_t)ix->m * 65536)) return DR_E_NODEVICE;
+    hipLaunchKernelGGL(sdc_table_kernel, dim3(ix->m * 256), dim3(256), 0, ix->stream, ix->codebook.p, ix->m, ix->sd, ix->sdc.p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // prune_pq_kernel for q.npoints points: rows in registers (8 wavefronts per CU) when m is 16 or 32, in LDS otherwise
 // (DR_PQ_PRUNE_LDS=1 forces the LDS form: A/B, and the check that both build the same graph).
 static int launch_prune_pq(dr_index *ix, const PrunePQParams &q)
@@ -1820,12 +1830,7 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
         HIPCHK(rocprim::radix_sort_keys(nullptr, tb, rkeys_a.p, rkeys_b.p, (unsigned int)np, 0u, 64u, ix->stream));
         if (rtemp.reserve(tb + 16)) return DR_E_NODEVICE;
     }
-    if (pq && !ix->sdc.p) {
-        // centroid-pair table S[m][256][256] (8 MB at m = 32): every distance of the PQ-only builder is a sum of its entries
-        if (ix->sdc.reserve((size_t)ix->m * 65536)) return DR_E_NODEVICE;
-        hipLaunchKernelGGL(sdc_table_kernel, dim3(ix->m * 256), dim3(256), 0, ix->stream, ix->codebook.p, ix->m, ix->sd, ix->sdc.p);
-        HIPCHK(hipGetLastError());
-    }
+    if (pq) { const int rcs = ensure_sdc(ix); if (rcs) return rcs; }
 
     // DR_PQ_BUILD_SLACK (diagnosis): how far a row of the PQ-only builder may exceed R before it is re-pruned (default: a quarter of the slack slots: 4x fewer re-prunes at 2 points of recall, profiles/r02/scale_c5_small_4M.json)
     static const char *slack_env = getenv("DR_PQ_BUILD_SLACK");
@@ -2065,6 +2070,37 @@ extern "C" int dr_debug_prune(dr_index *ix, uint32_t point, const uint32_t *cand
     void *args[] = { &pp };
     const size_t prune_lds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024;
     HIPCHK(hipLaunchKernel(ix->kern->prune, dim3(1), dim3(64), args, prune_lds, ix->stream));
+    HIPCHK(hipMemcpyAsync(out_selected, fwd.p, (size_t)R * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipMemcpyAsync(out_count, fwdn.p, 4, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    return 0;
+}
+
+// The same seam for the PQ-only builder's prune (prune_pq_kernel, whichever form serves this m): candidates scored by sums of
+// centroid-pair table entries (A3's order), sorted by (distance, id), greedy picks, alpha * d(p*, c) <= d(p, c) drops c.
+extern "C" int dr_debug_prune_pq(dr_index *ix, uint32_t point, const uint32_t *candidates, uint32_t n, float alpha, uint32_t R,
+                                 uint32_t *out_selected, uint32_t *out_count)
+{
+    if (!ix || !candidates || !out_selected || !out_count) return fail(DR_E_ARG, "null argument");
+    if (point >= ix->N || n == 0 || n > DR_PRUNE_PQ_MAXC || R == 0 || R > 128)
+        return fail(DR_E_ARG, "bad prune arguments (n <= %d, R <= 128)", DR_PRUNE_PQ_MAXC);
+    for (uint32_t i = 0; i < n; i++) if (candidates[i] >= ix->N) return fail(DR_E_ARG, "candidate id %u out of range", candidates[i]);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->m == 0) return fail(DR_E_NOPQ, "dr_debug_prune_pq needs the code words");
+    HIPCHK(hipSetDevice(ix->device));
+    { const int rcs = ensure_sdc(ix); if (rcs) return rcs; }
+    DevBuf<u64> keys; DevBuf<uint32_t> resn, adjb, deg, pts, fwd, fwdn;
+    if (keys.reserve(n) || resn.reserve(1) || adjb.reserve((size_t)ix->N * R) || deg.reserve(ix->N + 2, true) || pts.reserve(1) ||
+        fwd.reserve(R) || fwdn.reserve(1)) return DR_E_NODEVICE;
+    std::vector<u64> hk(n);
+    for (uint32_t i = 0; i < n; i++) hk[i] = (u64)(uint32_t)(~candidates[i]);
+    HIPCHK(hipMemcpyAsync(keys.p, hk.data(), (size_t)n * 8, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(hipMemcpyAsync(resn.p, &n, 4, hipMemcpyHostToDevice, ix->stream));
+    HIPCHK(hipMemcpyAsync(pts.p, &point, 4, hipMemcpyHostToDevice, ix->stream));
+    PrunePQParams q;
+    q.codes = ix->codes.p; q.sdc = ix->sdc.p; q.m = ix->m; q.adjb = adjb.p; q.deg = deg.p; q.RX = R; q.R = R; q.alpha = alpha;
+    q.points = pts.p; q.npoints = 1; q.res_keys = keys.p; q.res_n = resn.p; q.cap = n; q.fwd = fwd.p; q.fwd_n = fwdn.p;
+    { const int rcp = launch_prune_pq(ix, q); if (rcp) return rcp; }
     HIPCHK(hipMemcpyAsync(out_selected, fwd.p, (size_t)R * 4, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipMemcpyAsync(out_count, fwdn.p, 4, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));

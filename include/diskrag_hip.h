@@ -297,6 +297,12 @@ int dr_index_copy_codes(dr_index *dst, dr_index *src);
  * not -- an intentional divergence. */
 int dr_debug_prune(dr_index *ix, uint32_t point, const uint32_t *candidates, uint32_t n, float alpha, uint32_t R,
                    uint32_t *out_selected /*[R]*/, uint32_t *out_count);
+/* The same seam for the PQ-only builder (dr_build_vamana_pq): the prune of ONE point over an explicit candidate list (n <= 320)
+ * scored on code words alone -- d(a, b) = sum_j |C_j[code_a[j]] - C_j[code_b[j]]|^2, every term in A2's summation order, the sum
+ * over j in A3's -- run by the kernel the builder launches (rows in registers for m = 16 / 32, in LDS otherwise). No reference
+ * counterpart (the reference never builds from codes, vamana_graph.py:405); held to its numpy restatement in the tests. */
+int dr_debug_prune_pq(dr_index *ix, uint32_t point, const uint32_t *candidates, uint32_t n, float alpha, uint32_t R,
+                      uint32_t *out_selected, uint32_t *out_count);
 
 /* PQ build on the device. dr_pq_train_ex: m independent k-means with 256 centroids on a sample of the
  * stored vectors, as DiskANNPQ.fit runs sklearn's KMeans (pq/fast_pq.py:188-243): greedy k-means++ seeding, n_init

@@ -340,6 +340,38 @@ def test_prune_kernel_equals_the_textbook_form_of_the_reference_prune(data):
     finally:
         ix.close()
 
+@pytest.mark.parametrize("D,m", [(128, 32), (128, 16), (96, 8), (256, 64)])
+def test_pq_prune_kernel_equals_its_restatement(D, m):
+    """prune_pq_kernel (rows in registers for m = 32 / 16, rows in LDS for m = 8 / 64) on explicit candidate lists ==
+    oracle/pybuild.robust_prune_pq: the textbook robust prune over code-word distances built from the oracle's A2 table and
+    A3 sum (both pinned on the reference's goldens) -- same picks in the same order. Clustered data: many code words repeat,
+    so equal distances and the (distance, id) tie order are exercised."""
+    from diskrag_amd import HipIndex
+    from diskrag_amd.synth import unit_mixture
+    from oracle import pybuild
+    rs = np.random.RandomState(11 + m)
+    x, _ = unit_mixture(3000, D, n_queries=4, n_clusters=24, seed=6, latent=12)
+    full = HipIndex.create_empty(x, R=16)
+    cb = full.pq_train(m, n_sample=3000, iters=4)
+    codes = full.pq_encode(cb, want_codes=True)
+    full.close()
+    sh = HipIndex.create_codes_empty(len(x), D, 16, cb)
+    try:
+        sh.encode_rows(x, 0)
+        for trial in range(40):
+            p = int(rs.randint(len(x)))
+            n = int(rs.choice([2, 17, 63, 64, 65, 130, 300]))
+            cands = rs.choice(len(x), size=n, replace=False).astype(np.uint32)
+            if trial % 5 == 0:
+                cands = np.concatenate([cands[:-6], cands[:5], [p]]).astype(np.uint32)      # duplicates and the point itself
+            alpha, R = float(rs.choice([1.0, 1.2, 2.0])), int(rs.choice([4, 16, 64, 128]))
+            got = sh.debug_prune_pq(p, cands, alpha, R)
+            want = pybuild.robust_prune_pq(cb, codes, p, cands, alpha, R)
+            assert got.tolist() == want.tolist(), (D, m, trial, p, n, alpha, R)
+    finally:
+        sh.close()
+
+
 @pytest.mark.parametrize("name,m", [("sift128", 32), ("deep96", 16)])
 def test_pq_trainer_reaches_the_reference_quantisation_error(name, m):
     """N2: k-means++ / n_init / Lloyd on the device vs DiskANNPQ.fit (sklearn) on the same vectors: the summed inertia is
