@@ -7,6 +7,7 @@ from . import _ffi  # noqa: F401
 from . import persist  # noqa: F401
 from ._ffi import HipIndex, DiskragHipError, device_count, load_library  # noqa: F401
 from .search_engine import SearchEngineCorrect, SearchEngine, export_codebook  # noqa: F401
+from .batching import RequestBatcher  # noqa: F401
 
 __all__ = ["HipIndex", "DiskragHipError", "device_count", "load_library", "SearchEngineCorrect", "SearchEngine",
-           "export_codebook", "persist"]
+           "export_codebook", "persist", "RequestBatcher"]
