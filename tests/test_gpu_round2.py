@@ -460,6 +460,36 @@ def test_pq_only_builder_makes_a_searchable_shard():
     finally:
         sh.close()
 
+def test_pq_only_builder_with_the_widest_row():
+    """R = 128 (two 64-lane passes per row, L_build + R + 64 = 320 candidates in the prune: both limits of dr_build_vamana_pq), the
+    degree the full-size c5 shard is built with: valid rows, a searchable graph, and the device traversal equal to the oracle's on
+    the graph it built."""
+    from diskrag_amd import HipIndex, _ffi
+    from diskrag_amd.synth import unit_mixture, recall_at_k
+    from oracle import pyoracle as orc
+    n, D, m, R = 30000, 128, 32, 128
+    x, q = unit_mixture(n, D, n_queries=100, n_clusters=64, seed=4, latent=24)
+    full = HipIndex.create_empty(x, R=16)
+    cb = full.pq_train(m, n_sample=8192, iters=6)
+    codes = full.pq_encode(cb, want_codes=True)
+    full.close()
+    sh = HipIndex.create_codes_empty(n, D, R, cb)
+    try:
+        sh.encode_rows(x, 0)
+        medoid, _ = sh.build_vamana_pq(L_build=128, alpha=1.2, passes=2, seed=3)
+        adj = sh.get_adjacency()
+        deg = (adj != 0xFFFFFFFF).sum(axis=1)
+        assert deg.min() >= 1 and deg.max() <= R and adj[adj != 0xFFFFFFFF].max() < n
+        assert all(len(set(r[r != 0xFFFFFFFF].tolist())) == int((r != 0xFFFFFFFF).sum()) for r in adj[:2000])     # no repeated neighbour
+        gt_adc = sh.pq_scan_topk(q, 10)[0]
+        ids, dist, cnt, st = sh.search_batch(q, 10, L=100, beam_width=8, mode=_ffi.MODE_PQ)
+        assert int(st["status"].max()) == 0 and recall_at_k(ids, gt_adc, 10) > 0.9
+        w = orc.search_batch(x, adj, q, medoid, orc.PQ, 10, L=100, bw=8, codes=codes, codebook=cb, nthreads=8)
+        assert np.array_equal(ids, w[0]) and np.array_equal(bits(dist), bits(w[1].astype(np.float32)))
+    finally:
+        sh.close()
+
+
 _PRUNE_FORMS_SCRIPT = r"""
 import hashlib, sys
 import numpy as np
