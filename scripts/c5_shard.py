@@ -5,7 +5,8 @@ are never stored (1.25e8 x 1536 x 4 B = 768 GB); the Vamana graph is built from 
 Ground truth for NGT queries, both kinds: EXACT top-10 (a running brute-force merge over the streamed chunks: every chunk
 is a temporary index, dr_bruteforce_topk, ids offset by the chunk's first row) and ADC top-10 (dr_pq_scan_topk, a flat
 scan of the finished code table).
-Usage: python scripts/c5_shard.py [N] [chunk_rows] [n_gt_queries] [R:L_build[,R:L_build...]] [m] [n_clusters]  -> gpurun_out/scale_c5_shard.json"""
+Usage: python scripts/c5_shard.py [N] [chunk_rows] [n_gt_queries] [R:L_build[,R:L_build...]] [m] [n_clusters]  -> gpurun_out/scale_c5_shard.json
+(C5_OUT=<path> names the output, C5_GRID="L:bw,L:bw,..." replaces the standard (L, beam_width) grid by a finer sweep)"""
 import json
 import os
 import sys
@@ -124,6 +125,11 @@ for gi, (R, LB) in enumerate(CFG):
     save()
     print("built", G, bsec, flush=True)
     sh.batch_upload(q)
+    grid = os.environ.get("C5_GRID")        # "L:bw,L:bw,...": a finer sweep around an operating point instead of the standard grid
+    if grid:
+        for L, bw in (tuple(int(v) for v in g.split(":")) for g in grid.split(",")):
+            run(f"{G}/PQ_L{L}_bw{bw or 'None'}", L=L, beam_width=bw, mode=_ffi.MODE_PQ)
+        continue
     for L in (100, 200, 400, 800):
         for bw in (8, 0):
             run(f"{G}/PQ_L{L}_bw{bw or 'None'}", L=L, beam_width=bw, mode=_ffi.MODE_PQ)
