@@ -94,3 +94,15 @@ def test_facade_argument_errors(tmp_path):
     (c / "collection_info.json").write_text(json.dumps({"dimension": 96}))
     with pytest.raises(ValueError):          # unsupported dimension (Q14)
         SearchEngineCorrect("c1", base_dir=tmp_path)
+
+
+def test_python_constants_match_the_header():
+    """The ctypes layer restates the header's modes, flags and tiers as Python numbers: they must be the header's."""
+    from diskrag_amd import _ffi
+    hdr = (Path(__file__).resolve().parent.parent / "include" / "diskrag_hip.h").read_text()
+    defs = {k: int(v.rstrip("u"), 0) for k, v in re.findall(r"^#define (DR_[A-Z0-9_]+) \(?(-?(?:0x)?[0-9A-Fa-f]+u?)\)?", hdr, flags=re.M)}
+    want = {"DR_MODE_M1": _ffi.MODE_M1, "DR_MODE_M2": _ffi.MODE_M2, "DR_MODE_M3": _ffi.MODE_M3, "DR_MODE_M4": _ffi.MODE_M4,
+            "DR_MODE_PQ": _ffi.MODE_PQ, "DR_F_USE_PQ": _ffi.F_USE_PQ, "DR_F_SQDIST": _ffi.F_SQDIST, "DR_F_RERANK": _ffi.F_RERANK,
+            "DR_F_COSINE": _ffi.F_COSINE, "DR_TIER_HBM": _ffi.TIER_HBM, "DR_TIER_HOST": _ffi.TIER_HOST}
+    for name, val in want.items():
+        assert defs[name] == val, name
