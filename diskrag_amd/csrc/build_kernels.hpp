@@ -32,9 +32,12 @@ struct PruneParams {
     u32 cap;
     u32 *fwd;             // [npoints][R] selected neighbours (PAD padded) for the reverse-edge pass, or nullptr
     u32 *fwd_n;           // [npoints]
+    u32 multi;            // 1: the launch uses prune_kernel<D, true> (the multi-pick form, D <= 256 split form)
 };
 
-template <int D> __global__ __launch_bounds__(64) void prune_kernel(const PruneParams p)
+// MULTI: the multi-pick form of step 4 (below) is compiled in -- its own instantiation, because the staged picks' registers
+// would cost the plain form occupancy at D = 256.
+template <int D, bool MULTI = false> __global__ __launch_bounds__(64) void prune_kernel(const PruneParams p)
 {
     constexpr bool QREG = (D <= 256);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -44,6 +47,10 @@ template <int D> __global__ __launch_bounds__(64) void prune_kernel(const PruneP
     u32 *raw = reinterpret_cast<u32 *>(keyB + DR_PRUNE_MAXC);                         // [MAXC]
     u32 *keep = raw + DR_PRUNE_MAXC;                                                  // [MAXC]
     u32 *outsel = keep + DR_PRUNE_MAXC;                                               // [256]
+    // multi-pick form: distances of every candidate to the TP staged picks, [TP][MAXC] (only allocated when p.multi)
+    constexpr bool MULTI_OK = MULTI && QREG && split_form_ok<D>();
+    constexpr int TP = (D <= 128) ? 4 : 2;
+    float *epick = reinterpret_cast<float *>(outsel + 256);
     const int lane = lane_id(), j = lane & 7, oct = lane >> 3;
 
     for (u32 pi = blockIdx.x; pi < p.npoints; pi += gridDim.x) {
@@ -120,6 +127,68 @@ template <int D> __global__ __launch_bounds__(64) void prune_kernel(const PruneP
         // ---- 4. greedy selection (robust_prune_fast_cython, cython_utils.pyx:459-486)
         u64 *cur = keyA, *nxt = keyB;
         int nsel = 0;
+        if constexpr (MULTI_OK) {
+            // Multi-pick form (same picks, same order): the sequential form streams every remaining candidate's row once per
+            // pick, and the kernel runs at the memory system's limit doing so. Here the first TP remaining candidates -- the
+            // only ones that can become the next picks -- are staged in registers and ONE pass over the rows scores every
+            // candidate against all of them; the picks are then resolved from those distances, one after the other, until the
+            // next survivor is not a staged one.
+            while (na > 0 && nsel < (int)p.R) {
+                const int S = min(TP, na);
+                QueryRegs<D> sq[TP];
+#pragma unroll
+                for (int t = 0; t < TP; t++) if (t < S) load_query_regs<0, D, D>(p.vecp + (size_t)(u32)cur[t] * D, j, sq[t]);
+                for (int base = 1; base < na; base += 8) {
+                    const int idx = min(base + oct, na - 1);
+                    RowRegs<D> rr;
+                    row_load<0, D, D>(p.vecp + (size_t)(u32)cur[idx] * D, j, rr);
+#pragma unroll
+                    for (int t = 0; t < TP; t++) {
+                        if (t < S) {
+                            const float e = row_reduce<0, D, D>(rr, sq[t]);
+                            if (j == 0 && base + oct < na) epick[t * DR_PRUNE_MAXC + idx] = e;
+                        }
+                    }
+                }
+                for (int i = lane; i < na; i += 64) keep[i] = 1u;
+                WSYNC();
+                int t = 0, restart = -1;      // t: position in cur of the pick being applied; restart: first survivor that is not staged
+                for (;;) {
+                    if (lane == 0) outsel[nsel] = (u32)cur[t];
+                    nsel++;
+                    if (nsel >= (int)p.R) { na = 0; break; }
+                    int nx = -1;              // first survivor after t
+                    for (int base = t + 1; base < na; base += 64) {
+                        const int i = base + lane;
+                        bool alive = false;
+                        if (i < na) {
+                            alive = keep[i] != 0u;
+                            if (alive && f_mul(p.alpha, epick[t * DR_PRUNE_MAXC + i]) <= key_dist(cur[i])) { alive = false; keep[i] = 0u; }   // pruned when alpha * d(p*, c) <= d(p, c)
+                        }
+                        const u64 mm = __ballot(alive);
+                        if (nx < 0 && mm) nx = base + __builtin_ctzll(mm);
+                    }
+                    WSYNC();
+                    if (nx < 0) { na = 0; break; }
+                    if (nx < S) { t = nx; continue; }
+                    restart = nx;
+                    break;
+                }
+                if (restart >= 0) {           // survivors from `restart` on, in order, become the new list
+                    int nn = 0;
+                    for (int base = restart; base < na; base += 64) {
+                        const int i = base + lane;
+                        const bool ok = (i < na) && keep[i] != 0u;
+                        const u64 mm = __ballot(ok);
+                        if (ok) nxt[nn + __popcll(mm & lanemask_lt())] = cur[i];
+                        nn += __popcll(mm);
+                    }
+                    WSYNC();
+                    u64 *tq = cur; cur = nxt; nxt = tq;
+                    na = nn;
+                }
+            }
+        }
         while (na > 0 && nsel < (int)p.R) {
             const u64 k0 = cur[0];
             const u32 star = (u32)k0;

@@ -1704,6 +1704,14 @@ static uint64_t splitmix64(uint64_t &x)
     return z ^ (z >> 31);
 }
 
+// the exact prune's multi-pick form (build_kernels.hpp): dimensions with the split row form only
+static uint32_t prune_multi_enabled(uint32_t D)
+{
+    static const bool off = getenv("DR_PRUNE_PLAIN") != nullptr;      // (A/B: one pass over the candidates' rows per pick)
+    const DimKernels *k = dr_dim_kernels((int)D);
+    return (!off && k && k->prune_multi) ? 1u : 0u;
+}
+
 // centroid-pair table S[m][256][256] (8 MB at m = 32): every distance of the PQ-only builder is a sum of its entries
 static int ensure_sdc(dr_index *ix)
 {
@@ -1835,7 +1843,9 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
     // DR_PQ_BUILD_SLACK (diagnosis): how far a row of the PQ-only builder may exceed R before it is re-pruned (default: a quarter of the slack slots: 4x fewer re-prunes at 2 points of recall, profiles/r02/scale_c5_small_4M.json)
     static const char *slack_env = getenv("DR_PQ_BUILD_SLACK");
     const uint32_t pq_slack = slack_env ? std::min<uint32_t>((uint32_t)atoi(slack_env), RX - R - 1) : (RX - R) / 4;
-    const size_t prune_lds = (D > 256 ? (size_t)D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024;
+    // the exact prune scores the next few likely picks in one pass over the candidates' rows (D <= 256; DR_PRUNE_PLAIN=1: one pass per pick)
+    const uint32_t prune_multi = prune_multi_enabled(D);
+    const size_t prune_lds = (D > 256 ? (size_t)D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024 + (prune_multi ? (size_t)4 * DR_PRUNE_MAXC * 4 : 0);
     std::vector<uint32_t> horder(N);
     uint64_t rng = seed ? seed : 1;
     int rc = 0;
@@ -1862,7 +1872,7 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
             PruneParams pp;
             pp.vecp = ix->vecp.p; pp.adjb = adjb.p; pp.deg = deg.p; pp.RX = RX; pp.R = R; pp.alpha = a;
             pp.points = pts; pp.npoints = b; pp.res_keys = ix->sets[0].res_keys.p; pp.res_n = ix->sets[0].res_n.p; pp.cap = L_build;
-            pp.fwd = fwd.p; pp.fwd_n = fwd_n.p;
+            pp.fwd = fwd.p; pp.fwd_n = fwd_n.p; pp.multi = prune_multi;
             PrunePQParams pq_pp;
             pq_pp.codes = ix->codes.p; pq_pp.sdc = ix->sdc.p; pq_pp.m = ix->m; pq_pp.adjb = adjb.p; pq_pp.deg = deg.p; pq_pp.RX = RX; pq_pp.R = R;
             pq_pp.alpha = a; pq_pp.points = pts; pq_pp.npoints = b; pq_pp.res_keys = pp.res_keys; pq_pp.res_n = pp.res_n; pq_pp.cap = L_build;
@@ -1873,7 +1883,7 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
             } else {
                 void *args[] = { &pp };
                 const unsigned g = std::min<unsigned>(b, (unsigned)ix->num_cu * 16);
-                HIPCHK(hipLaunchKernel(ix->kern->prune, dim3(g), dim3(64), args, prune_lds, ix->stream));
+                HIPCHK(hipLaunchKernel(prune_multi ? ix->kern->prune_multi : ix->kern->prune, dim3(g), dim3(64), args, prune_lds, ix->stream));
             }
             // 3. reverse edges
             HIPCHK(hipMemsetAsync(ovf_count.p, 0, 4, ix->stream));
@@ -1912,7 +1922,7 @@ static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint
                 } else {
                 void *args[] = { &po };
                 const unsigned g = std::min<unsigned>(novf, (unsigned)ix->num_cu * 16);
-                HIPCHK(hipLaunchKernel(ix->kern->prune, dim3(g), dim3(64), args, prune_lds, ix->stream));
+                HIPCHK(hipLaunchKernel(prune_multi ? ix->kern->prune_multi : ix->kern->prune, dim3(g), dim3(64), args, prune_lds, ix->stream));
                 }
             }
             done += b;
@@ -2067,9 +2077,10 @@ extern "C" int dr_debug_prune(dr_index *ix, uint32_t point, const uint32_t *cand
     PruneParams pp;
     pp.vecp = ix->vecp.p; pp.adjb = adjb.p; pp.deg = deg.p; pp.RX = R; pp.R = R; pp.alpha = alpha;
     pp.points = pts.p; pp.npoints = 1; pp.res_keys = keys.p; pp.res_n = resn.p; pp.cap = n; pp.fwd = fwd.p; pp.fwd_n = fwdn.p;
+    pp.multi = prune_multi_enabled(ix->D);
     void *args[] = { &pp };
-    const size_t prune_lds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024;
-    HIPCHK(hipLaunchKernel(ix->kern->prune, dim3(1), dim3(64), args, prune_lds, ix->stream));
+    const size_t prune_lds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024 + (pp.multi ? (size_t)4 * DR_PRUNE_MAXC * 4 : 0);
+    HIPCHK(hipLaunchKernel(pp.multi ? ix->kern->prune_multi : ix->kern->prune, dim3(1), dim3(64), args, prune_lds, ix->stream));
     HIPCHK(hipMemcpyAsync(out_selected, fwd.p, (size_t)R * 4, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipMemcpyAsync(out_count, fwdn.p, 4, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
