@@ -530,6 +530,42 @@ def test_pq_prune_forms_build_the_same_graph(m, tmp_path):
     assert hashes[0] == hashes[1]
 
 
+_EXACT_PRUNE_FORMS_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, ".")
+from diskrag_amd import HipIndex
+from diskrag_amd.synth import sift_like, unit_mixture
+D = int(sys.argv[1])
+x = sift_like(20000, D, n_queries=4, seed=3)[0] if D == 128 else unit_mixture(20000, D, n_queries=4, n_clusters=64, seed=4, latent=24)[0]
+ix = HipIndex.create_empty(x, R=32)
+ix.build_vamana(L_build=60, alpha=1.2, passes=2, seed=5)
+print("GRAPH", hashlib.sha1(ix.get_adjacency().tobytes()).hexdigest())
+"""
+
+
+@pytest.mark.parametrize("D", [96, 128, 256])
+def test_exact_prune_forms_build_the_same_graph(D, tmp_path):
+    """prune_kernel<D, true> (the next <= 4 likely picks scored in one pass over the candidates' rows; the default at D <= 256)
+    and the plain form (one pass per pick; DR_PRUNE_PLAIN=1) make the same picks in the same order: the same graph bit for
+    bit. The switch is read once per process: one child process per form."""
+    import subprocess
+    import sys
+    script = tmp_path / "build_once.py"
+    script.write_text(_EXACT_PRUNE_FORMS_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hashes = []
+    for plain in (False, True):
+        env = dict(os.environ)
+        env.pop("DR_PRUNE_PLAIN", None)
+        if plain:
+            env["DR_PRUNE_PLAIN"] = "1"
+        r = subprocess.run([sys.executable, str(script), str(D)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hashes.append([ln for ln in r.stdout.splitlines() if ln.startswith("GRAPH")][-1])
+    assert hashes[0] == hashes[1]
+
+
 @pytest.mark.parametrize("d", [7, 64, 96, 128, 130, 960, 1536])
 def test_scalar_kernels_on_the_device(d):
     """C8: l2_distance_fast_cython / cosine_similarity_cython on the device against the reference's own outputs
