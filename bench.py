@@ -435,13 +435,19 @@ def worker_c2(args, rk):
         ix.batch_upload(qb[b])
     ix.batch_select(0)
 
+    def tickets_in_flight(n_q):
+        """submits a caller keeps in flight: PIPE_DEPTH launches' worth (a launch of small submits holds up to 8192 queries)"""
+        return _ffi.PIPE_DEPTH if n_q >= 8192 else min(_ffi.MAX_TICKETS - 2, _ffi.PIPE_DEPTH * max(1, 8192 // n_q))
+
     # ---------------------------------------------------------------- the headline: host memory -> host memory, pipelined
-    def run_pipelined(n_launch, sources):
+    def run_pipelined(n_launch, sources, depth=_ffi.PIPE_DEPTH):
+        """a stream of n_launch submits, `depth` tickets in flight (10k-query batches: one launch each, PIPE_DEPTH in flight;
+        small batches: the library coalesces the submits that find the search stream busy into one launch)"""
         jobs, done = [], 0
         t1 = time.perf_counter()
         for i in range(n_launch):
             jobs.append(ix.search_submit(sources[i % len(sources)], k, L=args.L, beam_width=args.bw, mode=mode, reuse_outputs=True))
-            if len(jobs) - done >= _ffi.PIPE_DEPTH:
+            if len(jobs) - done >= depth:
                 jobs[done].wait(); jobs[done] = None; done += 1
         last = None
         for j in range(done, len(jobs)):
@@ -466,6 +472,40 @@ def worker_c2(args, rk):
             raise RuntimeError("strong scaling: slices %s do not tile [0, %d)" % (edges, nq_job))
     total_q = launches * (nq_job if strong else nq * rk.world)      # queries the whole job answered in the timed region
     value = total_q / elapsed_job
+
+    # ---------------------------------------------------------------- N > 1, weak scaling: the STRONG-scaling figure in the same line
+    # (SURVEY.md 8e / BASELINE metric "batch=10k; 1/2/4/8": ONE stream of nq-query batches, every batch cut into N contiguous
+    # slices, one per GPU -- the same job batches on every rank, generated from the common seed)
+    strong_cfg = None
+    if rk.world > 1 and not strong and not args.no_secondary:
+        slo, shi = slice_of(nq_job, rk.world, rk.rank)
+        _, q_job = sift_like(args.n, D, n_queries=nq_job * nb, n_clusters=1024, seed=2024, query_seed=9000, queries_only=True)
+        n_s = shi - slo
+        q_s = np.ascontiguousarray(q_job.reshape(nb, nq_job, D)[:, slo:shi].reshape(nb * n_s, D))
+        del q_job
+        gt_s, _ = ix.bruteforce_topk(q_s, k)
+        src_s = []
+        for b in range(nb):
+            a = _ffi.pinned_empty((n_s, D), np.float32)
+            a[:] = q_s[b * n_s:(b + 1) * n_s]
+            src_s.append(a)
+        depth_s = tickets_in_flight(n_s)
+        run_pipelined(3 * depth_s, src_s, depth_s)
+        ix.batch_sync()
+        rk.barrier()
+        sp0 = ix.pipeline_stats()
+        el_s, _ = run_pipelined(launches, src_s, depth_s)
+        ix.batch_sync()
+        sp1 = ix.pipeline_stats()
+        t_s = rk.gather("t_strong", el_s)
+        ids_s = np.concatenate([ix.search_batch(a, k, L=args.L, beam_width=args.bw, mode=mode)[0] for a in src_s])
+        rec_s = rk.gather("recall_strong", [recall_at_k(ids_s, gt_s, k), n_s])
+        strong_cfg = {"value": nq_job * launches / max(t_s), "unit": "queries/s", "scaling": "strong",
+                      "what": "ONE stream of %d-query batches, every batch cut into %d contiguous slices, one per GPU; value = the stream's "
+                              "queries / slowest rank's time, host memory -> host memory" % (nq_job, rk.world),
+                      "queries_per_batch_per_gpu": n_s, "batches": launches, "per_rank_seconds": t_s, "tickets_in_flight": depth_s,
+                      "recall_at_10": sum(r * n for r, n in rec_s) / sum(n for _, n in rec_s),
+                      "rank0_submits_per_launch": (sp1["tickets"] - sp0["tickets"]) / max(1, sp1["launches"] - sp0["launches"])}
 
     # ---------------------------------------------------------------- the same rotation, batches resident in HBM
     rk.barrier()
@@ -562,11 +602,22 @@ def worker_c2(args, rk):
             if n_g < 1:
                 continue
             srcs = [a[:n_g] for a in qb]
-            run_pipelined(12, srcs)
-            el_g, _ = run_pipelined(max(40, launches // 2), srcs)
+            depth_g = tickets_in_flight(n_g)
+            n_sub = max(40, launches // 2) * g // 2          # (about the same number of queries for every slice size)
+            run_pipelined(3 * depth_g, srcs, depth_g)
+            s0 = ix.pipeline_stats()
+            el_g, last_g = run_pipelined(n_sub, srcs, depth_g)
             ix.batch_sync()
-            small_batch["%d_queries_per_batch" % n_g] = {"qps": n_g * max(40, launches // 2) / el_g, "as_gpus_of_a_strong_scaling_job": g,
-                                                      "kernel_ms": ix.timing()["search_kernel_ms"]}
+            s1 = ix.pipeline_stats()
+            lbg = (n_sub - 1) % nb
+            if not (np.array_equal(last_g[0], ids[lbg * nq:lbg * nq + n_g]) and
+                    np.array_equal(last_g[1].view(np.uint32), dist_out[lbg * nq:lbg * nq + n_g].view(np.uint32))):
+                raise RuntimeError("a coalesced %d-query submit and the resident path disagree" % n_g)
+            small_batch["%d_queries_per_batch" % n_g] = {
+                "qps": n_g * n_sub / el_g, "as_gpus_of_a_strong_scaling_job": g, "tickets_in_flight": depth_g,
+                "submits_per_launch": (s1["tickets"] - s0["tickets"]) / max(1, s1["launches"] - s0["launches"]),
+                "queries_per_launch": (s1["queries"] - s0["queries"]) / max(1, s1["launches"] - s0["launches"]),
+                "kernel_ms_per_launch": ix.timing()["search_kernel_ms"], "variant": ix.timing()["variant"]}
         pq_scan = isolated_pq_scan(device)
 
     out = {
@@ -578,7 +629,7 @@ def worker_c2(args, rk):
         "data": "synthetic",
         "config": {"workload": "SIFT1M-shaped synthetic (configs[1]): N=%d d=%d L2, R=%d, L_search=%d, PQ m=%d, beam_width=%s, "
                                "k=%d, batch=%d queries, mode=M1 reference-faithful; a step = %d consecutive batches, %d distinct "
-                               "batches per GPU rotating; value = host memory -> host memory (dr_search_submit/wait, %d batches in flight)"
+                               "batches per GPU rotating; value = host memory -> host memory (dr_search_submit/wait, %d launches in flight)"
                                % (args.n, D, args.R, args.L, args.m, args.bw or None, k, nq_job, args.bps, nb, _ffi.PIPE_DEPTH)
                                + ("; STRONG scaling: every batch is cut into %d contiguous slices, one per GPU (slice of rank 0: %d queries)" % (rk.world, nq) if strong else ""),
                    "recall_at_10": recall, "build_seconds": build_s,
@@ -606,7 +657,7 @@ def worker_c2(args, rk):
                    "query_storage": ("u8: every component of the batch is an integer in [0, 255] (checked per batch on the host)"
                                      if variant == 13 else "f32"),
                    "float32_rows": float_rows, "byte_rows_float32_queries": float_queries,
-                   "small_batches_on_one_gpu": small_batch, "pq_scan": pq_scan},
+                   "small_batches_on_one_gpu": small_batch, "strong_scaling": strong_cfg, "pq_scan": pq_scan},
         "roofline": {"bound": "hbm", "kernel": "search_kernel<128,M1> variant %d" % variant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "hbm_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,

@@ -13,7 +13,8 @@ LIB_PATH = Path(_os.environ["DR_LIB"]) if _os.environ.get("DR_LIB") else PKG_DIR
 
 PAD = 0xFFFFFFFF
 MODE_M1, MODE_M2, MODE_M3, MODE_M4 = 1, 2, 3, 4
-PIPE_DEPTH = 4          # DR_PIPE_DEPTH (csrc/engine.hip): batches in flight per handle
+PIPE_DEPTH = 4          # DR_PIPE_DEPTH (csrc/engine.hip): LAUNCHES of the pipelined path in flight per handle
+MAX_TICKETS = 32        # DR_MAX_TICKETS (include/diskrag_hip.h): dr_search_submit tickets in flight (small submits share launches)
 MODE_PQ = 5      # engine mode without a reference counterpart: M1's loop on squared ADC distances only (diskrag_hip.h)
 F_USE_PQ, F_SQDIST, F_RERANK, F_COSINE = 1, 2, 4, 8
 TIER_HBM, TIER_HOST = 0, 1       # where the full-precision rows live (dr_index_*_tiered)
@@ -45,7 +46,7 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_get_adjacency", "dr_pq_train", "dr_pq_encode", "dr_debug_phase_cycles", "dr_batch_sync",
            "dr_debug_force_kind", "dr_search_batch_f64",
            "dr_index_create_codes", "dr_index_drop_vectors", "dr_pq_scan_best",
-           "dr_batch_select", "dr_search_submit", "dr_search_wait", "dr_host_alloc", "dr_host_free",
+           "dr_batch_select", "dr_search_submit", "dr_search_wait", "dr_search_flush", "dr_set_coalesce", "dr_pipeline_stats", "dr_debug_hold", "dr_host_alloc", "dr_host_free",
            "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_merge_topk",
            "dr_debug_prune", "dr_debug_prune_pq", "dr_pq_train_ex", "dr_index_create_codes_empty", "dr_pq_encode_rows", "dr_build_vamana_pq",
            "dr_scalar_kernels", "dr_index_inline_codes", "dr_pq_scan_topk", "dr_index_copy_codes"]
@@ -158,6 +159,14 @@ def load_library():
                                    C.c_uint32, u32p, fp, u32p, C.POINTER(DrStats), C.POINTER(C.c_uint64)]
     L.dr_search_wait.restype = C.c_int
     L.dr_search_wait.argtypes = [vp, C.c_uint64]
+    L.dr_search_flush.restype = C.c_int
+    L.dr_search_flush.argtypes = [vp]
+    L.dr_set_coalesce.restype = C.c_int
+    L.dr_set_coalesce.argtypes = [vp, C.c_uint32]
+    L.dr_pipeline_stats.restype = C.c_int
+    L.dr_pipeline_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.dr_debug_hold.restype = C.c_int
+    L.dr_debug_hold.argtypes = [vp, C.c_int]
     L.dr_host_alloc.restype = C.c_void_p
     L.dr_host_alloc.argtypes = [C.c_uint64]
     L.dr_host_free.restype = None
@@ -396,17 +405,19 @@ class HipIndex:
 
     def search_submit(self, queries, k, L=100, beam_width=0, mode=MODE_M1, band_policy=0, flags=0, reuse_outputs=False):
         """Pipelined dr_search_batch: queues upload, search, tie-order pass and download and returns a PendingSearch;
-        its .wait() gives (ids, dist, count, stats). Up to PIPE_DEPTH batches are in flight per index. With reuse_outputs the
-        result arrays come from a ring of PIPE_DEPTH + 1 sets (valid until that many submits after this one)."""
+        its .wait() gives (ids, dist, count, stats). Up to MAX_TICKETS submits and PIPE_DEPTH launches are in flight per index;
+        small submits that find the search stream busy are coalesced into one launch (same bits per ticket; set_coalesce,
+        search_flush). With reuse_outputs the result arrays come from a ring of MAX_TICKETS + 1 sets (valid until that many
+        submits after this one)."""
         q = self._queries(queries)
         nq = q.shape[0]
         if reuse_outputs:
             ring = self.__dict__.setdefault("_out_ring", {})
             key = (nq, int(k))
             if key not in ring:
-                ring[key] = [[PendingSearch(self, None, nq, int(k)) for _ in range(PIPE_DEPTH + 1)], 0]
+                ring[key] = [[PendingSearch(self, None, nq, int(k)) for _ in range(MAX_TICKETS + 1)], 0]
             sets, pos = ring[key]
-            job = sets[pos % (PIPE_DEPTH + 1)]
+            job = sets[pos % (MAX_TICKETS + 1)]
             ring[key][1] = pos + 1
             job._q = q
         else:
@@ -420,12 +431,29 @@ class HipIndex:
         # The library writes into the job's arrays when the batch is FINISHED -- in wait(), or earlier, when a later submit
         # reuses its pipeline slot or a build / set_pq quiesces the handle. A caller that drops the job without wait()
         # (an exception between submit and wait) must not free them under the library: the index keeps every submitted
-        # job until the library can no longer touch it (its slot has been reused: ticket <= newest - PIPE_DEPTH).
+        # job until the library can no longer touch it (its ticket slot has been reused: ticket <= newest - MAX_TICKETS).
         live = self.__dict__.setdefault("_inflight", {})
         live[job.ticket] = job
-        for tk in [tk for tk in live if tk + PIPE_DEPTH <= job.ticket]:
+        for tk in [tk for tk in live if tk + MAX_TICKETS <= job.ticket]:
             del live[tk]
         return job
+
+    def search_flush(self):
+        """Launches whatever search_submit is still holding back for coalescing (dr_search_flush)."""
+        _check(load_library().dr_search_flush(self._h))
+
+    def set_coalesce(self, max_queries):
+        """Queries a coalesced launch of small submits may grow to (dr_set_coalesce); 0: every submit is its own launch."""
+        _check(load_library().dr_set_coalesce(self._h, int(max_queries)))
+
+    def pipeline_stats(self):
+        """{launches, tickets, max_tickets_per_launch, queries} of the pipelined path since the index was created."""
+        out = (C.c_uint64 * 4)()
+        _check(load_library().dr_pipeline_stats(self._h, out))
+        return {"launches": int(out[0]), "tickets": int(out[1]), "max_tickets_per_launch": int(out[2]), "queries": int(out[3])}
+
+    def debug_hold(self, on):
+        _check(load_library().dr_debug_hold(self._h, 1 if on else 0))
 
     def batch_upload(self, queries):
         q = self._queries(queries)

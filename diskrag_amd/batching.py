@@ -5,14 +5,17 @@ walk on one core. On the device a one-query call costs as much as a several-thou
 query's expansions one after the other), so concurrent requests are worth collecting: `RequestBatcher` puts
 the queries of requests that arrive within `max_wait_ms` of each other into one `search_batch` call and hands every caller
 its own rows. A query's answer does not depend on what else is in its batch (one wavefront per query, no cross-query
-state), so the rows are the bits a direct call returns.
+state), so the rows are the bits a direct `search_batch(k=k_max, L=<the batcher's L>)` call returns for that query. (The
+facade derives L = max(2k, 20) from k when L is None, search_engine.py:539-540: the batcher derives it ONCE from k_max, so a
+request that asks for k < k_max is searched with the list of k_max and gets the first k rows of that search -- the same
+bits as a direct call with that explicit L, not necessarily those of a direct call with L=None and the smaller k.)
 
 Only host logic: threads, a queue, numpy. The engine is anything with the facade's
 `search_batch(query_vectors, k, L, beam_width, use_pq_search) -> (ids, dist, count, stats)`.
 """
 import threading
 import time
-from concurrent.futures import Future
+from concurrent.futures import Future, InvalidStateError
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -23,7 +26,8 @@ class RequestBatcher:
 
     engine         SearchEngineCorrect (or anything with its search_batch)
     k_max          every batch runs with this k; a request may ask for any k <= k_max and gets the first k rows
-    L, beam_width, use_pq_search   the search parameters of every request served by this batcher (one batcher per setting)
+    L, beam_width, use_pq_search   the search parameters of every request served by this batcher (one batcher per setting);
+                   L=None means max(2 * k_max, 20), fixed here -- the reference's default for k = k_max
     max_batch      a batch is sent as soon as it holds this many queries ...
     max_wait_ms    ... or when its oldest request has waited this long (0: send whatever is queued right away)
     """
@@ -33,11 +37,14 @@ class RequestBatcher:
         if k_max <= 0 or max_batch <= 0 or max_wait_ms < 0:
             raise ValueError("k_max and max_batch must be positive, max_wait_ms non-negative")
         self.engine = engine
-        self.k_max, self.L, self.beam_width, self.use_pq_search = int(k_max), L, beam_width, use_pq_search
+        self.k_max, self.beam_width, self.use_pq_search = int(k_max), beam_width, use_pq_search
+        self.L = max(2 * self.k_max, 20) if L is None else int(L)
+        self.dimension = getattr(engine, "dimension", None)     # malformed requests are refused one by one in submit()
         self.max_batch, self.max_wait = int(max_batch), max_wait_ms / 1e3
         self._cv = threading.Condition()
         self._pending: List[Tuple[np.ndarray, int, Future, float]] = []
         self._closed = False
+        self._dim_seen = None
         self.batches_sent = 0
         self.queries_sent = 0
         self._worker = threading.Thread(target=self._run, name="diskrag-request-batcher", daemon=True)
@@ -51,6 +58,13 @@ class RequestBatcher:
         if k <= 0 or k > self.k_max:
             raise ValueError(f"k must be in 1..{self.k_max}")
         q = np.asarray(query_vector, dtype=np.float32).reshape(-1)
+        if self.dimension is not None and q.shape[0] != int(self.dimension):
+            # (refused here: inside a batch it would make np.stack fail for every request coalesced with it)
+            raise ValueError(f"query has {q.shape[0]} components, the index {int(self.dimension)}")
+        if self._dim_seen is None:
+            self._dim_seen = q.shape[0]
+        elif q.shape[0] != self._dim_seen:
+            raise ValueError(f"query has {q.shape[0]} components, earlier requests had {self._dim_seen}")
         fut: Future = Future()
         with self._cv:
             if self._closed:
@@ -91,20 +105,24 @@ class RequestBatcher:
                     break
                 self._cv.wait(left)
             batch, self._pending = self._pending[:self.max_batch], self._pending[self.max_batch:]
-            return batch
+        # a caller may have given up on its request (a cancelled Future: an asyncio.wrap_future timeout, a client that went
+        # away): it is dropped here and can no longer be cancelled once the batch runs
+        return [b for b in batch if b[2].set_running_or_notify_cancel()]
 
     def _run(self):
         while True:
             batch = self._take_batch()
             if batch is None:
                 return
+            if not batch:                       # every request of it was cancelled
+                continue
             try:
                 qs = np.stack([b[0] for b in batch])
                 ids, dist, cnt, st = self.engine.search_batch(qs, k=self.k_max, L=self.L, beam_width=self.beam_width,
                                                               use_pq_search=self.use_pq_search)
             except BaseException as e:          # every waiter of the batch learns why it failed
                 for _, _, fut, _ in batch:
-                    fut.set_exception(e)
+                    self._deliver(fut, exc=e)
                 continue
             self.batches_sent += 1
             self.queries_sent += len(batch)
@@ -113,4 +131,15 @@ class RequestBatcher:
                 results = [(np.float32(dist[i, t]), np.uint32(ids[i, t])) for t in range(n)]
                 stats = {"search_steps": int(st["steps"][i]), "nodes_visited": int(st["visited"][i]),
                          "exact_distance_computations": int(st["exact"][i]), "pq_distance_computations": int(st["pq"][i])}
-                fut.set_result((results, stats))
+                self._deliver(fut, value=(results, stats))
+
+    @staticmethod
+    def _deliver(fut, value=None, exc=None):
+        """the worker thread must outlive anything a caller does to its Future"""
+        try:
+            if exc is not None:
+                fut.set_exception(exc)
+            else:
+                fut.set_result(value)
+        except InvalidStateError:
+            pass

@@ -25,6 +25,7 @@
 #include <cmath>
 #include <mutex>
 #include <thread>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -107,27 +108,45 @@ template <class T> struct DevBuf {
 struct QSlot {
     uint32_t nq = 0;
     DevBuf<float> q, qp, pq_ub, pq_max;
-    DevBuf<float> lut;           // [nq][m][256] per-query tables of the batch (lut_build_kernel), rebuilt by every search that uses them
     bool qp_valid = false;       // qp holds the chain-major copy of q (dr_search_submit skips it at D <= 256: the register variants read q)
     bool pq_ub_valid = false;    // pq_ub matches these queries and the attached codebook
     bool q_u8 = false;           // every component is an integer in [0, 255] (byte-query variants 13/14)
-    void release() { q.release(); qp.release(); pq_ub.release(); pq_max.release(); lut.release(); nq = 0; pq_ub_valid = false; q_u8 = false; qp_valid = false; }
+    void release() { q.release(); qp.release(); pq_ub.release(); pq_max.release(); nq = 0; pq_ub_valid = false; q_u8 = false; qp_valid = false; }
 };
-#define DR_PIPE_DEPTH 4     // (3 until round 3: a job is finished only after its tie-order pass, which finds room in the TAIL of the next search
-                            // kernel -- its latency, not its work, starved a 3-deep pipeline: profiles/r03/ab/ab_c2_companions_v3.log)
+#define DR_PIPE_DEPTH 4     // LAUNCHES of the pipelined path in flight (3 until round 3: a launch is finished only after its tie-order pass, which finds
+                            // room in the TAIL of the next search kernel -- its latency, not its work, starved a 3-deep pipeline: profiles/r03/ab/ab_c2_companions_v3.log)
+static_assert(DR_MAX_TICKETS == 32u, "header and engine agree on the tickets in flight");
+#define DR_MAX_JOBS 32      // dr_search_submit tickets in flight (round 4: small submits are coalesced, several jobs ride in one launch)
 #define DR_NUM_SETS (DR_PIPE_DEPTH + 1)
 
-// One in-flight dr_search_submit: upload, search, tie-order pass and download are queued on four streams; the host
-// only touches it again in dr_search_wait.
+// One dr_search_submit ticket. Round 4: a job no longer owns a launch -- it is a run of q0 .. q0 + nq - 1 inside the launch of
+// its PipeGroup; the host only touches it again in dr_search_wait (or when its ticket slot / its group's slot is needed).
 struct PipeJob {
     bool active = false;
     uint64_t ticket = 0;
-    int set = -1;                       // the BatchSet holding its outputs
+    int group = -1;                     // the PipeGroup it rides in
+    uint32_t q0 = 0;                    // its first query inside the group's launch
     uint32_t nq = 0, k = 0;
+    int rc = 0; std::string err;        // the group's launch failed: what dr_search_wait answers for this ticket
     void *pin_in = nullptr; size_t pin_in_bytes = 0;     // staging for pageable caller memory
+    uint32_t *out_ids = nullptr; float *out_dist = nullptr; uint32_t *out_count = nullptr; dr_stats *stats = nullptr;
+};
+
+// One launch of the pipelined path: the queries of 1 .. n jobs with equal (k, L, beam_width, mode, band_policy, flags),
+// concatenated in one resident batch (slots[DR_MAX_RESIDENT + g]) -- ONE ticket space, one search kernel, one tie-order
+// pass, one download; every job copies its own rows out of the group's page-locked result slab. A submit that finds the
+// search stream busy is HELD in the open group and rides with the submits that follow it (a 1250-query slice of a
+// strong-scaling job occupies 79 of 256 CUs when launched alone: VERDICT r3 item 1); a submit that finds it idle is
+// launched at once, so a lone request pays nothing.
+struct PipeGroup {
+    int state = 0;                      // 0 free, 1 open (collecting jobs, not launched), 2 launched
+    uint32_t nq = 0, cap = 0, njobs = 0, live = 0;      // queries so far, room, jobs added, jobs not finished yet
+    uint32_t k = 0, L = 0, bw = 0, mode = 0, policy = 0, flags = 0;
+    bool q_u8 = true;                   // every job's queries are bytes (the byte-query variants)
+    bool with_qp = false;               // jobs upload the chain-major copy too
+    int set = -1;                       // the BatchSet holding its outputs once launched
     void *pin_out = nullptr; size_t pin_out_bytes = 0;
     hipEvent_t up_done = nullptr, down_done = nullptr;
-    uint32_t *out_ids = nullptr; float *out_dist = nullptr; uint32_t *out_count = nullptr; dr_stats *stats = nullptr;
 };
 
 // Persistent work area of dr_sharded_search (comm.inc), owned by the first shard of the call: staging arrays, events, the
@@ -191,14 +210,20 @@ struct dr_index {
     // batch scratch
     QSlot slots[DR_MAX_RESIDENT + DR_PIPE_DEPTH];
     QSlot *cs = &slots[0];        // the selected resident batch (dr_batch_select)
-    PipeJob jobs[DR_PIPE_DEPTH];
-    uint64_t next_ticket = 1;
+    PipeJob jobs[DR_MAX_JOBS];
+    PipeGroup groups[DR_PIPE_DEPTH];
+    uint64_t next_ticket = 1, next_group = 0;
+    int open_group = -1;          // the group that is collecting jobs (state 1), or -1
+    std::map<uint64_t, std::pair<int, std::string>> failed_tickets;   // tickets whose launch failed, until their dr_search_wait collects the error
+    uint32_t coalesce_cap = 8192; // queries a group of small submits may grow to (dr_set_coalesce; 0: every submit is its own launch)
+    bool hold_always = false;     // dr_debug_hold: submits are only launched when full / flushed / waited for (tests)
+    uint64_t pipe_launches = 0, pipe_tickets = 0, pipe_max_tickets = 0, pipe_queries = 0;   // dr_pipeline_stats
     hipStream_t up_stream = nullptr, down_stream = nullptr;
     uint32_t last_nq = 0;         // batch size of the last launch (dr_batch_download)
     DevBuf<uint32_t> vis, vis_epoch;   // visited words [slots][vis_words] + the per-slot query stamp (search_kernel.hpp)
-    DevBuf<uint32_t> vis2, vis_epoch2; // the same for the second search lane (small pipelined batches, run_locked)
-    hipStream_t stream2 = nullptr;
-    int cur_lane = 0;
+    DevBuf<float> lut;            // [nq][m][256] per-query tables of the launch being queued (lut_build_kernel), rebuilt by every search that uses them:
+                                  // ONE scratch per handle -- searches are serialised on the one search stream (round 3 kept one per resident batch:
+                                  // 328 MB each at the bench shape, 20 of them)
     // per-step outputs are triple-buffered: the tie-order pass (finalize) of step i runs on its own stream while
     // the search kernels of steps i+1 and i+2 fill the other sets
     struct BatchSet {
@@ -209,7 +234,7 @@ struct dr_index {
         hipEvent_t search_done = nullptr, fin_start = nullptr, fin_done = nullptr;
         bool fin_pending = false;
         bool counters_zeroed = false;
-        int owner_job = -1;           // in-flight dr_search_submit whose results live here (finished before reuse)
+        int owner_group = -1;         // launched PipeGroup whose results live here (its jobs are finished before reuse)
         uint32_t ticket_base = 0;     // every launch draws exactly nq tickets from counter[0]: never reset
         void release() { counter.release(); res_n.release(); tie.release(); out_ids.release(); out_count.release();
                          res_keys.release(); log.release(); stats.release(); out_dist.release(); }
@@ -262,8 +287,7 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     HIPCHK(hipStreamCreateWithFlags(&ix->fstream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ix->up_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ix->down_stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
-    for (auto &jb : ix->jobs) { HIPCHK(hipEventCreateWithFlags(&jb.up_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&jb.down_done, hipEventDisableTiming)); }
+    for (auto &gr : ix->groups) { HIPCHK(hipEventCreateWithFlags(&gr.up_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&gr.down_done, hipEventDisableTiming)); }
     for (auto &e : ix->ev) HIPCHK(hipEventCreate(&e));
     for (auto &pr : ix->kev) { HIPCHK(hipEventCreate(&pr[0])); HIPCHK(hipEventCreate(&pr[1])); HIPCHK(hipEventCreate(&pr[2])); }
     for (auto &bs : ix->sets) { HIPCHK(hipEventCreate(&bs.search_done)); HIPCHK(hipEventCreate(&bs.fin_start)); HIPCHK(hipEventCreate(&bs.fin_done)); }
@@ -451,16 +475,16 @@ extern "C" void dr_index_close(dr_index *ix)
 {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    for (hipStream_t st : { ix->up_stream, ix->stream, ix->stream2, ix->fstream, ix->down_stream }) if (st) (void)hipStreamSynchronize(st);
-    ix->vis2.release(); ix->vis_epoch2.release();
+    for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) if (st) (void)hipStreamSynchronize(st);
+    ix->lut.release();
     ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release(); ix->nbcodes.release(); ix->sdc.release();
     ix->perm.release(); ix->vis.release(); ix->vis_epoch.release();
     for (auto &qs : ix->slots) qs.release();
-    for (auto &jb : ix->jobs) {
-        if (jb.pin_in) (void)hipHostFree(jb.pin_in);
-        if (jb.pin_out) (void)hipHostFree(jb.pin_out);
-        if (jb.up_done) (void)hipEventDestroy(jb.up_done);
-        if (jb.down_done) (void)hipEventDestroy(jb.down_done);
+    for (auto &jb : ix->jobs) if (jb.pin_in) (void)hipHostFree(jb.pin_in);
+    for (auto &gr : ix->groups) {
+        if (gr.pin_out) (void)hipHostFree(gr.pin_out);
+        if (gr.up_done) (void)hipEventDestroy(gr.up_done);
+        if (gr.down_done) (void)hipEventDestroy(gr.down_done);
     }
     for (auto &bs : ix->sets) {
         bs.release();
@@ -475,7 +499,6 @@ extern "C" void dr_index_close(dr_index *ix)
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
     for (auto &pr : ix->kev) for (auto &e : pr) if (e) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
-    if (ix->stream2) (void)hipStreamDestroy(ix->stream2);
     if (ix->fstream) (void)hipStreamDestroy(ix->fstream);
     if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
     if (ix->down_stream) (void)hipStreamDestroy(ix->down_stream);
@@ -503,16 +526,19 @@ static bool queries_are_u8(const float *queries, size_t n)
 }
 
 // queues the copy of a batch into a slot and its chain-major twin on `st`
-static int upload_slot_async(dr_index *ix, QSlot &qs, const float *src, uint32_t nq, hipStream_t st, bool with_qp = true)
+// (q0, room: a job of a coalesced group lands behind the jobs before it in a slot sized for the whole group)
+static int upload_slot_async(dr_index *ix, QSlot &qs, const float *src, uint32_t nq, hipStream_t st, bool with_qp = true, uint32_t q0 = 0, uint32_t room = 0)
 {
-    if (qs.q.reserve((size_t)nq * ix->D) || qs.qp.reserve((size_t)nq * ix->D)) return DR_E_NODEVICE;
-    HIPCHK(hipMemcpyAsync(qs.q.p, src, (size_t)nq * ix->D * 4, hipMemcpyDefault, st));      // (host or device source)
+    if (room < q0 + nq) room = q0 + nq;
+    if (qs.q.reserve((size_t)room * ix->D) || qs.qp.reserve((size_t)room * ix->D)) return DR_E_NODEVICE;
+    float *dq = qs.q.p + (size_t)q0 * ix->D;
+    HIPCHK(hipMemcpyAsync(dq, src, (size_t)nq * ix->D * 4, hipMemcpyDefault, st));      // (host or device source)
     if (with_qp) {
-        hipLaunchKernelGGL(permute_queries_kernel, dim3(nq), dim3(64), 0, st, qs.q.p, nq, ix->D, ix->perm.p, qs.qp.p);
+        hipLaunchKernelGGL(permute_queries_kernel, dim3(nq), dim3(64), 0, st, dq, nq, ix->D, ix->perm.p, qs.qp.p + (size_t)q0 * ix->D);
         HIPCHK(hipGetLastError());
     }
     qs.qp_valid = with_qp;
-    qs.nq = nq;
+    qs.nq = q0 + nq;
     qs.pq_ub_valid = false;
     return 0;
 }
@@ -698,9 +724,12 @@ static void harvest_kernel_times(dr_index *ix, bool publish)
 }
 
 // sqrt-ADC upper bound per query (search_kernel.hpp "exact skip"): per-(query, sub-quantiser) maxima, then the ordered sum
-static int launch_pq_bound(dr_index *ix, QSlot &qs, uint32_t nq, hipStream_t st)
+static int launch_pq_bound(dr_index *ix, QSlot &qs, uint32_t nq, hipStream_t st, uint32_t q0 = 0, uint32_t room = 0)
 {
-    const float *cbp = ix->codebook.p; const float *qp = qs.q.p; uint32_t nqv = nq, Dv = ix->D;
+    // (q0, room: the run of a coalesced group this call covers and the group's capacity; a whole batch: 0, nq)
+    if (room < q0 + nq) room = q0 + nq;
+    if (qs.pq_ub.reserve(room)) return DR_E_NODEVICE;
+    const float *cbp = ix->codebook.p; const float *qp = qs.q.p + (size_t)q0 * ix->D; uint32_t nqv = nq, Dv = ix->D;
     const void *fn = nullptr;
     switch (ix->sd) {
     case 2: fn = reinterpret_cast<const void *>(&pq_bound_max_kernel<2>); break;
@@ -714,14 +743,14 @@ static int launch_pq_bound(dr_index *ix, QSlot &qs, uint32_t nq, hipStream_t st)
     }
     static const bool old_form = getenv("DR_PQ_BOUND_BLOCK") != nullptr;      // A/B: the block-per-query form
     if (fn && !old_form) {
-        if (qs.pq_max.reserve((size_t)nq * ix->m)) return DR_E_NODEVICE;
-        float *mxp = qs.pq_max.p;
+        if (qs.pq_max.reserve((size_t)room * ix->m)) return DR_E_NODEVICE;
+        float *mxp = qs.pq_max.p + (size_t)q0 * ix->m;
         void *args[] = { &cbp, &qp, &nqv, &Dv, &mxp };
         HIPCHK(hipLaunchKernel(fn, dim3((nq + 63) / 64, ix->m), dim3(64), args, 0, st));
-        hipLaunchKernelGGL(pq_bound_sum_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, qs.pq_max.p, nq, ix->m, qs.pq_ub.p);
+        hipLaunchKernelGGL(pq_bound_sum_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, mxp, nq, ix->m, qs.pq_ub.p + q0);
         HIPCHK(hipGetLastError());
     } else {
-        hipLaunchKernelGGL(pq_bound_kernel, dim3(nq), dim3(256), (size_t)ix->D * 4 + 16, st, ix->codebook.p, qs.q.p, ix->D, ix->m, ix->sd, qs.pq_ub.p);
+        hipLaunchKernelGGL(pq_bound_kernel, dim3(nq), dim3(256), (size_t)ix->D * 4 + 16, st, ix->codebook.p, qp, ix->D, ix->m, ix->sd, qs.pq_ub.p + q0);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -774,7 +803,7 @@ static int launch_lut_build(dr_index *ix, const float *d_queries, uint32_t nq, f
     return 0;
 }
 
-static int finish_job_locked(dr_index *ix, int j);
+static int finish_group_locked(dr_index *ix, int g);
 // Per-query scratch (insert log, result keys) is sized by the batch: very large batches are processed in chunks.
 static const uint32_t DR_MAX_CHUNK = 32768;
 
@@ -797,12 +826,11 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (cap == 0) return fail(DR_E_ARG, "result-list capacity is zero (L / beam_width / k)");
     if (cap > DR_MAX_CAPACITY) return fail(DR_E_UNSUPPORTED, "result-list capacity %u > %u", cap, DR_MAX_CAPACITY);
     HIPCHK(hipSetDevice(ix->device));
-    // Search lane: small pipelined batches (fewer queries than the chip has wavefront slots: the per-GPU slices of a
-    // strong-scaling job) alternate between two streams with their own visited-set scratch, so that consecutive
-    // launches overlap instead of each leaving most of the chip idle; everything else runs on lane 0.
-    const int lane = ov ? 0 : ix->cur_lane;
-    hipStream_t st = lane ? ix->stream2 : ix->stream;
-    DevBuf<uint32_t> &vis = lane ? ix->vis2 : ix->vis, &vis_epoch = lane ? ix->vis_epoch2 : ix->vis_epoch;
+    // ONE search stream per handle. (Round 3 tried a second one for small pipelined batches, with its own visited-set scratch:
+    // slower -- profiles/r03/ab/ab_small_batches_two_search_lanes.json, and the kernel trace of it in profiles/r04/ -- and removed;
+    // small submits are coalesced into one launch instead, dr_search_submit.)
+    hipStream_t st = ix->stream;
+    DevBuf<uint32_t> &vis = ix->vis, &vis_epoch = ix->vis_epoch;
 
     const int sc = cap <= 64 ? 0 : cap <= 128 ? 1 : cap <= 256 ? 2 : cap <= 512 ? 3 : 4;
     // kernel variant (variants.hpp): the first available variant of the mode's preference list whose LDS footprint
@@ -852,11 +880,18 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e && !g_force_kind_set) g_force_kind = atoi(e); env_read = true; }
         const int g = g_force_kind;
         if (g >= 0 && g <= DR_MAX_KIND_ID && usable(g) && !(ov && ov->sdc)) {
-            const bool g_m1 = (g == 0 || g == 3 || g == 9 || g == 11 || g == 13), g_adc = (g == 2 || g == 5 || g == 15), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
+            const bool g_m1 = (g == 0 || g == 3 || g == 9 || g == 11 || g == 13 || g == 16 || g == 17), g_adc = (g == 2 || g == 5 || g == 15), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
             if ((g_m1 && k_m1) || (g_adc && k_adc) || (g_ex && !k_m1 && !k_adc)) kind = g;
         }
     }
     if (kind < 0) return fail(DR_E_UNSUPPORTED, "no kernel variant fits in LDS (D=%u, m=%u, capacity %u)", ix->D, ix->m, cap);
+    // A batch smaller than the chip's wavefront slots in 16-wavefront workgroups would fill ceil(nq / 16) CUs and leave the
+    // rest idle: the same kernel in 4-wavefront workgroups spreads it over all of them (variants.hpp 16 / 17).
+    {
+        static const bool no_small = getenv("DR_NO_SMALL_WG") != nullptr;        // A/B
+        const int tw = dr_small_twin(kind);
+        if (!no_small && !ov && tw >= 0 && kind != g_force_kind && usable(tw) && (uint64_t)ix->cs->nq < (uint64_t)ix->num_cu * 16) kind = tw;
+    }
     const KindDesc &kd_desc = DR_KINDS[dr_kind_pos(kind)];
     const void *kfn = ix->kern->search[dr_kind_pos(kind)][sc];
     const int NW = kd_desc.nw;
@@ -895,7 +930,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     const uint32_t logcap = std::max<uint32_t>(4096, 16 * cap);
     const int set = ov ? 0 : ix->parity;
     dr_index::BatchSet &bs = ix->sets[set];
-    if (bs.owner_job >= 0) { const int rcj = finish_job_locked(ix, bs.owner_job); if (rcj) return rcj; }
+    if (bs.owner_group >= 0) { const int rcj = finish_group_locked(ix, bs.owner_group); if (rcj) return rcj; }
     if (bs.fin_pending) {
         // this set's buffers may still be read by the tie-order pass of the step that used it last
         if (ov) HIPCHK(hipStreamSynchronize(ix->fstream));
@@ -948,7 +983,6 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (mode == DR_MODE_M1) {
         // per-query ADC upper bounds: a function of (queries, codebook) only, computed once per uploaded batch
         if (!ix->cs->pq_ub_valid) {
-            if (ix->cs->pq_ub.reserve(nq)) return DR_E_NODEVICE;
             { const int rcb = launch_pq_bound(ix, *ix->cs, nq, st); if (rcb) return rcb; }
             ix->cs->pq_ub_valid = true;
         }
@@ -976,17 +1010,17 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.ticket_base = bs.ticket_base;
     bs.ticket_base += nq;
     if (!ov && ix->kev_pending == dr_index::KEV) harvest_kernel_times(ix, false);
-    if (!ov && ix->kev_pending == dr_index::KEV) { HIPCHK(hipStreamSynchronize(ix->stream)); HIPCHK(hipStreamSynchronize(ix->stream2)); harvest_kernel_times(ix, false); }
+    if (!ov && ix->kev_pending == dr_index::KEV) { HIPCHK(hipStreamSynchronize(ix->stream)); harvest_kernel_times(ix, false); }
     p.lut_g = nullptr;
     const bool want_lut = kd_desc.lut && !(ov && ov->sdc);
     if (want_lut) {
         // The per-query tables T[q][j][c] (A2, fast_pq.py:294-318) of the whole batch, built at full occupancy right
         // before the search kernel that lands them in LDS (engine_kernels.hpp lut_build_kernel). Built by EVERY search --
         // a table is part of its query's search, not of the upload -- and timed separately (dr_timing.lut_kernel_ms).
-        if (ix->cs->lut.reserve((size_t)nq * ix->m * 256)) return DR_E_NODEVICE;
+        if (ix->lut.reserve((size_t)nq * ix->m * 256)) return DR_E_NODEVICE;
         if (!ov) HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][2], st));
-        { const int rcl = launch_lut_build(ix, ix->cs->q.p, nq, ix->cs->lut.p, st); if (rcl) return rcl; }
-        p.lut_g = ix->cs->lut.p;
+        { const int rcl = launch_lut_build(ix, ix->cs->q.p, nq, ix->lut.p, st); if (rcl) return rcl; }
+        p.lut_g = ix->lut.p;
     }
     void *args[] = { &p };
     if (!ov) { ix->kev_lut[ix->kev_pending] = want_lut; HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][0], st)); }
@@ -1060,7 +1094,6 @@ static int sync_locked(dr_index *ix)
 {
     HIPCHK(hipStreamSynchronize(ix->up_stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream2));
     HIPCHK(hipStreamSynchronize(ix->fstream));
     HIPCHK(hipStreamSynchronize(ix->down_stream));
     harvest_kernel_times(ix, true);
@@ -1131,10 +1164,14 @@ extern "C" int dr_batch_sync(dr_index *ix)
 }
 
 // waits for everything queued on the handle (pipelined jobs included: their results reach the callers' buffers)
+static int finish_job_locked(dr_index *ix, int j);
 static int quiesce_locked(dr_index *ix)
 {
-    for (int j = 0; j < DR_PIPE_DEPTH; j++) if (ix->jobs[j].active) { const int rc = finish_job_locked(ix, j); if (rc) return rc; }
-    for (hipStream_t st : { ix->up_stream, ix->stream, ix->stream2, ix->fstream, ix->down_stream }) HIPCHK(hipStreamSynchronize(st));
+    int rc_first = 0; std::string msg;
+    for (int j = 0; j < DR_MAX_JOBS; j++)
+        if (ix->jobs[j].active) { const int rc = finish_job_locked(ix, j); if (rc && !rc_first) { rc_first = rc; msg = g_err; } }
+    for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) HIPCHK(hipStreamSynchronize(st));
+    if (rc_first) { g_err = msg; return rc_first; }
     return 0;
 }
 
@@ -1167,25 +1204,135 @@ static int pin_reserve(void **p, size_t *have, size_t need)
     return 0;
 }
 
+// ---- coalesced launches (round 4) -------------------------------------------------------------------------------------
+// search kernels of the pipelined path that are queued or running (their BatchSet's search_done has not fired)
+static int searches_in_flight(dr_index *ix)
+{
+    int n = 0;
+    for (const PipeGroup &gr : ix->groups)
+        if (gr.state == 2 && gr.set >= 0 && hipEventQuery(ix->sets[gr.set].search_done) == hipErrorNotReady) n++;
+    (void)hipGetLastError();
+    return n;
+}
+
+// every job of a group answers `rc` from now on (its launch failed: nothing was or will be written to their buffers)
+static void fail_group_locked(dr_index *ix, int g, int rc)
+{
+    PipeGroup &gr = ix->groups[g];
+    const std::string msg = g_err;
+    // copies that read the jobs' staging buffers / kernels that use the group's slot may be queued: drain before anything is reused
+    for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) (void)hipStreamSynchronize(st);
+    (void)hipGetLastError();
+    for (PipeJob &jb : ix->jobs) if (jb.active && jb.group == g) { jb.rc = rc; jb.err = msg; }
+    if (gr.set >= 0 && ix->sets[gr.set].owner_group == g) ix->sets[gr.set].owner_group = -1;
+    gr.state = 2; gr.set = -1;        // "launched": its jobs only have to be collected
+    if (ix->open_group == g) ix->open_group = -1;
+    g_err = msg;
+}
+
+// queues the search, the tie-order pass and the download of an open group: ONE launch for all its jobs
+static int launch_group_locked(dr_index *ix, int g)
+{
+    PipeGroup &gr = ix->groups[g];
+    if (gr.state != 1) return 0;
+    if (ix->open_group == g) ix->open_group = -1;
+    QSlot &qs = ix->slots[DR_MAX_RESIDENT + g];
+    const int rc = [&]() -> int {
+        HIPCHK(hipEventRecord(gr.up_done, ix->up_stream));       // behind the upload (and bound kernels) of its last job
+        HIPCHK(hipStreamWaitEvent(ix->stream, gr.up_done, 0));
+        qs.nq = gr.nq; qs.q_u8 = gr.q_u8; qs.qp_valid = gr.with_qp;
+        qs.pq_ub_valid = (gr.mode == DR_MODE_M1 && ix->m != 0);   // (every job computed the bounds of its run on the upload stream)
+        QSlot *const keep = ix->cs;
+        ix->cs = &qs;
+        int r = run_locked(ix, gr.k, gr.L, gr.bw, gr.mode, gr.policy, gr.flags);
+        ix->cs = keep;
+        if (r) return r;
+        gr.set = ix->last_set;
+        dr_index::BatchSet &bs = ix->sets[gr.set];
+        bs.owner_group = g;
+        // download: behind the tie-order pass of this launch (which is behind its search kernel); jobs copy their rows out of the slab
+        const size_t b_ids = (size_t)gr.nq * gr.k * 4, b_cnt = (size_t)gr.nq * 4, b_st = (size_t)gr.nq * sizeof(KStats);
+        r = pin_reserve(&gr.pin_out, &gr.pin_out_bytes, 2 * b_ids + b_cnt + b_st + 4);
+        if (r) return r;
+        unsigned char *hp = static_cast<unsigned char *>(gr.pin_out);
+        HIPCHK(hipStreamWaitEvent(ix->down_stream, bs.fin_done, 0));
+        HIPCHK(hipMemcpyAsync(hp, bs.out_ids.p, b_ids, hipMemcpyDeviceToHost, ix->down_stream));
+        HIPCHK(hipMemcpyAsync(hp + b_ids, bs.out_dist.p, b_ids, hipMemcpyDeviceToHost, ix->down_stream));
+        HIPCHK(hipMemcpyAsync(hp + 2 * b_ids, bs.out_count.p, b_cnt, hipMemcpyDeviceToHost, ix->down_stream));
+        HIPCHK(hipMemcpyAsync(hp + 2 * b_ids + b_cnt, bs.stats.p, b_st, hipMemcpyDeviceToHost, ix->down_stream));
+        HIPCHK(hipMemcpyAsync(hp + 2 * b_ids + b_cnt + b_st, ix->fin_stat.p, 4, hipMemcpyDeviceToHost, ix->down_stream));
+        HIPCHK(hipEventRecord(gr.down_done, ix->down_stream));
+        return 0;
+    }();
+    if (rc) { fail_group_locked(ix, g, rc); return rc; }
+    gr.state = 2;
+    ix->pipe_launches++; ix->pipe_tickets += gr.njobs; ix->pipe_queries += gr.nq;
+    ix->pipe_max_tickets = std::max<uint64_t>(ix->pipe_max_tickets, gr.njobs);
+    return 0;
+}
+
+// Launch policy for the open group: at once while fewer than three search kernels of the pipeline are queued or running (the
+// search stream would run dry: a lone request never waits), otherwise the group keeps collecting until it is full. Called
+// by every submit and, while it waits, by dr_search_wait.
+static int kick_locked(dr_index *ix, bool force = false)
+{
+    const int g = ix->open_group;
+    if (g < 0) return 0;
+    if (!force && (ix->hold_always || searches_in_flight(ix) >= 3)) return 0;
+    return launch_group_locked(ix, g);
+}
+
 static int finish_job_locked(dr_index *ix, int j)
 {
     PipeJob &jb = ix->jobs[j];
     if (!jb.active) return 0;
     HIPCHK(hipSetDevice(ix->device));
-    HIPCHK(hipEventSynchronize(jb.down_done));
-    const size_t b_ids = (size_t)jb.nq * jb.k * 4, b_cnt = (size_t)jb.nq * 4, b_st = (size_t)jb.nq * sizeof(KStats);
-    const unsigned char *hp = static_cast<const unsigned char *>(jb.pin_out);
-    memcpy(jb.out_ids, hp, b_ids);
-    memcpy(jb.out_dist, hp + b_ids, b_ids);
-    memcpy(jb.out_count, hp + 2 * b_ids, b_cnt);
-    if (jb.stats) memcpy(jb.stats, hp + 2 * b_ids + b_cnt, b_st);
+    PipeGroup &gr = ix->groups[jb.group];
+    if (gr.state == 1) (void)launch_group_locked(ix, jb.group);     // (a failure is recorded in the group's jobs, this one included)
+    auto retire = [&]() {
+        jb.active = false;
+        if (gr.live > 0 && --gr.live == 0) {
+            if (gr.set >= 0 && ix->sets[gr.set].owner_group == jb.group) ix->sets[gr.set].owner_group = -1;
+            gr.state = 0; gr.set = -1;
+        }
+    };
+    if (jb.rc) {
+        // its launch failed: the error belongs to the ticket (dr_search_wait answers it), not to whoever needs the slot now
+        if (ix->failed_tickets.size() >= 1024) ix->failed_tickets.erase(ix->failed_tickets.begin());
+        ix->failed_tickets[jb.ticket] = std::make_pair(jb.rc, jb.err);
+        jb.rc = 0; retire();
+        return 0;
+    }
+    // another group is still collecting: while this job's results are on their way the waiting thread keeps the search stream fed
+    while (ix->open_group >= 0 && hipEventQuery(gr.down_done) == hipErrorNotReady) {
+        (void)hipGetLastError();
+        (void)kick_locked(ix);            // (a failure stays with that group's jobs)
+        if (ix->open_group >= 0) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+    (void)hipGetLastError();
+    HIPCHK(hipEventSynchronize(gr.down_done));
+    const size_t g_ids = (size_t)gr.nq * gr.k * 4, g_cnt = (size_t)gr.nq * 4, g_st = (size_t)gr.nq * sizeof(KStats);
+    const unsigned char *hp = static_cast<const unsigned char *>(gr.pin_out);
+    memcpy(jb.out_ids, hp + (size_t)jb.q0 * jb.k * 4, (size_t)jb.nq * jb.k * 4);
+    memcpy(jb.out_dist, hp + g_ids + (size_t)jb.q0 * jb.k * 4, (size_t)jb.nq * jb.k * 4);
+    memcpy(jb.out_count, hp + 2 * g_ids + (size_t)jb.q0 * 4, (size_t)jb.nq * 4);
+    if (jb.stats) memcpy(jb.stats, hp + 2 * g_ids + g_cnt + (size_t)jb.q0 * sizeof(KStats), (size_t)jb.nq * sizeof(KStats));
     uint32_t ties = 0;
-    memcpy(&ties, hp + 2 * b_ids + b_cnt + b_st, 4);
-    if (jb.nq >= 1024) ix->fin_hint = std::max<uint32_t>(ties, 16);
+    memcpy(&ties, hp + 2 * g_ids + g_cnt + g_st, 4);
+    if (gr.nq >= 1024) ix->fin_hint = std::max<uint32_t>(ties, 16);
     harvest_kernel_times(ix, false);
-    jb.active = false;
-    if (jb.set >= 0) ix->sets[jb.set].owner_job = -1;
+    retire();
     return 0;
+}
+
+// the results of every job of a launched group reach their callers' buffers (its BatchSet or its slot is needed)
+static int finish_group_locked(dr_index *ix, int g)
+{
+    int rc_first = 0; std::string msg;
+    for (int j = 0; j < DR_MAX_JOBS; j++)
+        if (ix->jobs[j].active && ix->jobs[j].group == g) { const int rc = finish_job_locked(ix, j); if (rc && !rc_first) { rc_first = rc; msg = g_err; } }
+    if (rc_first) g_err = msg;
+    return rc_first;
 }
 
 extern "C" int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width,
@@ -1196,12 +1343,12 @@ extern "C" int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq,
     if (!out_ids || !out_dist || !out_count || !out_ticket) return fail(DR_E_ARG, "null output buffer");
     if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
     if (nq > DR_MAX_CHUNK) return fail(DR_E_UNSUPPORTED, "dr_search_submit takes at most %u queries per batch", DR_MAX_CHUNK);
+    if (k == 0) return fail(DR_E_ARG, "k must be positive");
     std::lock_guard<std::mutex> lk(ix->mu);
     HIPCHK(hipSetDevice(ix->device));
-    const int j = (int)(ix->next_ticket % DR_PIPE_DEPTH);
+    const int j = (int)(ix->next_ticket % DR_MAX_JOBS);
     PipeJob &jb = ix->jobs[j];
-    if (jb.active) { const int rc = finish_job_locked(ix, j); if (rc) return rc; }
-    QSlot &qs = ix->slots[DR_MAX_RESIDENT + j];
+    if (jb.active) { const int rc = finish_job_locked(ix, j); if (rc) return rc; }      // (the ticket DR_MAX_JOBS submits ago)
     // pinned source (dr_host_alloc / hipHostMalloc / hipHostRegister): the copy engine reads it in place; pageable: staged
     const float *src = queries;
     {
@@ -1217,64 +1364,59 @@ extern "C" int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq,
         }
     }
     const bool q_u8 = (ix->vec8_state == 1 || (ix->vec8_state == 0 && ix->D == 128)) && queries_are_u8(src, (size_t)nq * ix->D);
-    // From here on copies that read jb.pin_in / write jb.pin_out may be queued: a failure must not hand the slot back
-    // (jb.active stays false, the next submit would overwrite the staging buffers under a copy in flight) before those
-    // copies have drained.
-    const int rcq = [&]() -> int {
-    static const bool always_permute = getenv("DR_SUBMIT_PERMUTE") != nullptr;      // A/B: the round-2 upload (copy + permute kernel)
-    int rc = upload_slot_async(ix, qs, src, nq, ix->up_stream, ix->D > 256 || always_permute);
-    if (rc) return rc;
-    qs.q_u8 = q_u8;
-    if (mode == DR_MODE_M1 && ix->m) {
-        // the per-query ADC bounds travel with the upload, off the search stream
-        if (qs.pq_ub.reserve(nq)) return DR_E_NODEVICE;
-        { const int rcb = launch_pq_bound(ix, qs, nq, ix->up_stream); if (rcb) return rcb; }
-        qs.pq_ub_valid = true;
+    // ---- the group this job rides in: the open one if the parameters agree and it has room, else a new one
+    int g = ix->open_group;
+    if (g >= 0) {
+        const PipeGroup &og = ix->groups[g];
+        const bool same = og.k == k && og.L == L && og.bw == beam_width && og.mode == mode && og.policy == band_policy && og.flags == flags;
+        if (!same || og.nq + nq > og.cap) { (void)launch_group_locked(ix, g); g = -1; }     // (a failure stays with that group's jobs)
     }
-    HIPCHK(hipEventRecord(jb.up_done, ix->up_stream));
-    // a batch smaller than the chip's wavefront slots cannot fill it: consecutive small batches go to alternating search
-    // lanes (streams) and overlap
-    // -- measured SLOWER (profiles/r03/ab/ab_small_batches_two_search_lanes.json: 2500 queries per batch 4.03 -> 2.69 M QPS,
-    // 1250: 2.09 -> 1.58 M): off unless DR_TWO_LANES=1
-    static const bool two_lanes = getenv("DR_TWO_LANES") != nullptr;
-    const int lane = (two_lanes && (uint64_t)nq < (uint64_t)ix->num_cu * 16) ? (int)(ix->next_ticket & 1) : 0;
-    HIPCHK(hipStreamWaitEvent(lane ? ix->stream2 : ix->stream, jb.up_done, 0));
-    QSlot *const keep = ix->cs;
-    ix->cs = &qs;
-    ix->cur_lane = lane;
-    rc = run_locked(ix, k, L, beam_width, mode, band_policy, flags);
-    ix->cur_lane = 0;
-    ix->cs = keep;
-    if (rc) return rc;
-    const int set = ix->last_set;
-    dr_index::BatchSet &bs = ix->sets[set];
-    // download: behind the tie-order pass of this batch (which is behind its search kernel)
-    const size_t b_ids = (size_t)nq * k * 4, b_cnt = (size_t)nq * 4, b_st = (size_t)nq * sizeof(KStats);
-    rc = pin_reserve(&jb.pin_out, &jb.pin_out_bytes, 2 * b_ids + b_cnt + b_st + 4);
-    if (rc) return rc;
-    unsigned char *hp = static_cast<unsigned char *>(jb.pin_out);
-    HIPCHK(hipStreamWaitEvent(ix->down_stream, bs.fin_done, 0));
-    HIPCHK(hipMemcpyAsync(hp, bs.out_ids.p, b_ids, hipMemcpyDeviceToHost, ix->down_stream));
-    HIPCHK(hipMemcpyAsync(hp + b_ids, bs.out_dist.p, b_ids, hipMemcpyDeviceToHost, ix->down_stream));
-    HIPCHK(hipMemcpyAsync(hp + 2 * b_ids, bs.out_count.p, b_cnt, hipMemcpyDeviceToHost, ix->down_stream));
-    HIPCHK(hipMemcpyAsync(hp + 2 * b_ids + b_cnt, bs.stats.p, b_st, hipMemcpyDeviceToHost, ix->down_stream));
-    HIPCHK(hipMemcpyAsync(hp + 2 * b_ids + b_cnt + b_st, ix->fin_stat.p, 4, hipMemcpyDeviceToHost, ix->down_stream));
-    HIPCHK(hipEventRecord(jb.down_done, ix->down_stream));
-    return 0;
+    if (g < 0) {
+        g = (int)(ix->next_group % DR_PIPE_DEPTH);
+        PipeGroup &ng = ix->groups[g];
+        if (ng.state == 2) { const int rc = finish_group_locked(ix, g); if (rc) return rc; }   // (the launch DR_PIPE_DEPTH launches ago)
+        ix->next_group++;
+        ng.state = 1; ng.nq = 0; ng.njobs = 0; ng.live = 0; ng.set = -1;
+        ng.cap = std::max<uint32_t>(nq, std::min<uint32_t>(ix->coalesce_cap, DR_MAX_CHUNK));
+        ng.k = k; ng.L = L; ng.bw = beam_width; ng.mode = mode; ng.policy = band_policy; ng.flags = flags;
+        ng.q_u8 = true;
+        static const bool always_permute = getenv("DR_SUBMIT_PERMUTE") != nullptr;      // A/B: the round-2 upload (copy + permute kernel)
+        ng.with_qp = ix->D > 256 || always_permute;
+        ix->open_group = g;
+    }
+    PipeGroup &gr = ix->groups[g];
+    QSlot &qs = ix->slots[DR_MAX_RESIDENT + g];
+    // From here on copies that read jb.pin_in may be queued: a failure must not hand the ticket slot back (the next submit
+    // would overwrite the staging buffer under a copy in flight) before those copies have drained -- fail_group_locked drains.
+    const int rcq = [&]() -> int {
+        int rc = upload_slot_async(ix, qs, src, nq, ix->up_stream, gr.with_qp, gr.nq, gr.cap);
+        if (rc) return rc;
+        if (mode == DR_MODE_M1 && ix->m) {
+            // the per-query ADC bounds travel with the upload, off the search stream
+            rc = launch_pq_bound(ix, qs, nq, ix->up_stream, gr.nq, gr.cap);
+            if (rc) return rc;
+        }
+        return 0;
     }();
     if (rcq) {
-        const std::string keep_msg = g_err;       // (the drain below must not replace the message of the real failure)
-        for (hipStream_t st : { ix->up_stream, ix->stream, ix->stream2, ix->fstream, ix->down_stream }) (void)hipStreamSynchronize(st);
-        (void)hipGetLastError();
-        g_err = keep_msg;
+        // this job never joined; the jobs already in the group lose their launch with it (their uploads share the slot)
+        fail_group_locked(ix, g, rcq);
         return rcq;
     }
-    const int set = ix->last_set;
-    dr_index::BatchSet &bs = ix->sets[set];
-    jb.active = true; jb.ticket = ix->next_ticket++; jb.set = set; jb.nq = nq; jb.k = k;
+    jb.active = true; jb.ticket = ix->next_ticket++; jb.group = g; jb.q0 = gr.nq; jb.nq = nq; jb.k = k; jb.rc = 0;
     jb.out_ids = out_ids; jb.out_dist = out_dist; jb.out_count = out_count; jb.stats = stats;
-    bs.owner_job = j;
+    gr.nq += nq; gr.njobs++; gr.live++;
+    gr.q_u8 = gr.q_u8 && q_u8;
     *out_ticket = jb.ticket;
+    // full (a further job of this size would not fit), or the search stream is about to run dry: launch now; else it collects
+    const bool full = gr.nq + nq > gr.cap || gr.njobs >= DR_MAX_JOBS / 2;
+    const int rcl = kick_locked(ix, full);
+    if (rcl) {      // this job's launch failed: the submit fails and its ticket is void
+        const std::string msg = g_err;
+        (void)finish_job_locked(ix, j); ix->failed_tickets.erase(jb.ticket);
+        g_err = msg;
+        return rcl;
+    }
     return 0;
 }
 
@@ -1283,9 +1425,55 @@ extern "C" int dr_search_wait(dr_index *ix, uint64_t ticket)
     if (!ix) return fail(DR_E_ARG, "null index");
     std::lock_guard<std::mutex> lk(ix->mu);
     if (ticket == 0 || ticket >= ix->next_ticket) return fail(DR_E_ARG, "unknown ticket %llu", (unsigned long long)ticket);
-    for (int j = 0; j < DR_PIPE_DEPTH; j++)
-        if (ix->jobs[j].active && ix->jobs[j].ticket == ticket) return finish_job_locked(ix, j);
-    return 0;     // finished earlier (a later submit or a sync needed its slot)
+    for (int j = 0; j < DR_MAX_JOBS; j++)
+        if (ix->jobs[j].active && ix->jobs[j].ticket == ticket) { const int rc = finish_job_locked(ix, j); if (rc) return rc; break; }
+    auto it = ix->failed_tickets.find(ticket);
+    if (it != ix->failed_tickets.end()) {
+        const int rc = it->second.first; g_err = it->second.second;
+        ix->failed_tickets.erase(it);
+        return rc;
+    }
+    return 0;     // finished (now, or earlier: a later submit or a sync needed its slot)
+}
+
+// launches whatever dr_search_submit is still holding back (a caller that submits and then goes away for a while)
+extern "C" int dr_search_flush(dr_index *ix)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    HIPCHK(hipSetDevice(ix->device));
+    return kick_locked(ix, true);
+}
+
+// test hook: with `on`, held submits are launched only when their group is full, flushed or waited for (never by the
+// "search stream is running dry" rule, which depends on timing)
+extern "C" int dr_debug_hold(dr_index *ix, int on)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->hold_always = on != 0;
+    return 0;
+}
+
+// launches of the pipelined path since the handle was created: [0] launches, [1] tickets they carried, [2] most tickets in one
+// launch, [3] queries
+extern "C" int dr_pipeline_stats(dr_index *ix, uint64_t *out4)
+{
+    if (!ix || !out4) return fail(DR_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    out4[0] = ix->pipe_launches; out4[1] = ix->pipe_tickets; out4[2] = ix->pipe_max_tickets; out4[3] = ix->pipe_queries;
+    return 0;
+}
+
+extern "C" int dr_set_coalesce(dr_index *ix, uint32_t max_queries)
+{
+    if (!ix) return fail(DR_E_ARG, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (max_queries > DR_MAX_CHUNK) return fail(DR_E_ARG, "coalesced launches hold at most %u queries", DR_MAX_CHUNK);
+    HIPCHK(hipSetDevice(ix->device));
+    { const int rc = kick_locked(ix, true); if (rc) return rc; }
+    ix->coalesce_cap = max_queries;
+    return 0;
 }
 
 extern "C" int dr_batch_upload(dr_index *ix, const float *queries, uint32_t nq)

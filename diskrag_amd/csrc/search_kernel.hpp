@@ -1539,8 +1539,9 @@ template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0
 // (minimum wavefronts per SIMD: 2 for the one-wavefront workgroups at D <= 256, which are register-limited -- forcing 3 on
 // the exact traversals (168 VGPRs, 25 spilled) measured 0...+5 % slower at the c4 shape; the large dimensions hold a
 // 32-KiB table or the row pipeline's buffers: 1)
-// the register-table variant exists to run two wavefronts per SIMD: 256 registers each)
-__global__ __launch_bounds__(64 * NW, ((NW == 1 && D <= 256) || TREG > 0) ? 2 : 1) void search_kernel(const SearchParams p)
+// the register-table variant exists to run two wavefronts per SIMD: 256 registers each; the 4-wavefront workgroups of the
+// byte-row landing variants (16, 17) sit four to a CU like the 16 wavefronts of ONE workgroup of 11 / 13: 4 per SIMD, 128 registers)
+__global__ __launch_bounds__(64 * NW, ((NW == 1 && D <= 256) || TREG > 0) ? 2 : (NW == 4 && RB > 0 && U8) ? 4 : 1) void search_kernel(const SearchParams p)
 {
     search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB, U8, QB, TREG>(p);
 }

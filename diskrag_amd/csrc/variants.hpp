@@ -21,6 +21,9 @@
 //  15 = 2 with the table rows of the LAST 16 sub-quantisers held in VGPRs (64 registers, looked up with ds_bpermute) and
 //     only the first m - 16 rows in LDS: at m = 32 a table costs 16 KiB of LDS instead of 32, so 8 wavefronts fit a CU
 //     instead of 4 (two per SIMD: the traversal is bound by instruction latency, not by memory)  (m % 16 == 0, m >= 32)
+//  16 = 11, 17 = 13 in workgroups of FOUR wavefronts (same code, same 16 wavefronts per CU as four workgroups): a batch
+//     smaller than the chip's 4096 wavefront slots -- the 1250-query slice of an 8-GPU strong-scaling job, a coalesced
+//     handful of requests -- spreads over all 256 CUs instead of filling ceil(nq / 16) of them (round 4)
 // (tried in round 2 and removed: 16-wave forms of 3 and 5 for D <= 96 -- twice the queries in flight, 30 % slower than the
 //  per-query table at the c4 shape: that kernel is bound by its number of memory requests, not by latency)
 // sizeclass: result capacity <= 64 / 128 / 256 / 512 / 1024 (the last one: one-wavefront-per-workgroup variants only)
@@ -47,9 +50,11 @@ static const KindDesc DR_KINDS[] = {
     { 13, 16, false, 64, false, true, true, true, 0 },
     { 14, 16, false, 64, false, false, true, true, 0 },
     { 15, 1, false, 0, true, true, false, false, 16 },
+    { 16, 4, false, 64, false, true, true, false, 0 },
+    { 17, 4, false, 64, false, true, true, true, 0 },
 };
 #define DR_NUM_KINDS ((int)(sizeof(DR_KINDS) / sizeof(DR_KINDS[0])))
-#define DR_MAX_KIND_ID 15
+#define DR_MAX_KIND_ID 17
 #define DR_NUM_SIZECLASS 5
 #define DR_MAX_CAPACITY 1024u
 // position of variant `id` in DR_KINDS (= its row in DimKernels::search), or -1
@@ -58,6 +63,8 @@ static inline int dr_kind_pos(int id)
     for (int i = 0; i < DR_NUM_KINDS; i++) if (DR_KINDS[i].id == id) return i;
     return -1;
 }
+// the small-workgroup twin of a variant (same kernel in 4-wavefront workgroups), or -1
+static inline int dr_small_twin(int id) { return id == 11 ? 16 : id == 13 ? 17 : -1; }
 struct DimKernels {
     int D;
     const void *search[sizeof(DR_KINDS) / sizeof(DR_KINDS[0])][DR_NUM_SIZECLASS];     // [position in DR_KINDS][sizeclass]; nullptr: not built for this dimension

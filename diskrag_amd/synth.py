@@ -7,8 +7,9 @@ import numpy as np
 
 
 def sift_like(n, d=128, n_queries=10000, n_clusters=1024, seed=2024, latent=32, within=1.0, noise=0.2,
-              query_seed=None, rounded=True):
+              query_seed=None, rounded=True, queries_only=False):
     """Returns (vectors f32[n,d], queries f32[n_queries,d]); queries come from the same mixture, disjoint stream.
+    queries_only: (None, queries) -- the same queries without drawing the n vectors (their stream is their own).
 
     x = round(affine(B z + noise)), z ~ mixture of n_clusters Gaussians in a `latent`-dimensional space, B a fixed
     random latent x d map. Real SIFT descriptors have a local intrinsic dimension far below 128; an isotropic
@@ -32,7 +33,7 @@ def sift_like(n, d=128, n_queries=10000, n_clusters=1024, seed=2024, latent=32, 
             out[s:e] = np.clip(np.rint(v), 0, 218) if rounded else v       # rounded=False: SURVEY 8d's "un-rounded variant"
         return out
 
-    x = draw(n, rs)
+    x = None if queries_only else draw(n, rs)
     q = draw(n_queries, np.random.RandomState(seed + 1 if query_seed is None else query_seed))
     return x, q
 

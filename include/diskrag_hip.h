@@ -208,16 +208,31 @@ int dr_batch_select(dr_index *ix, uint32_t slot);
 
 /* Asynchronous, pipelined form of dr_search_batch (same arguments and results): dr_search_submit queues the upload
  * of the batch, its search, the tie-order pass and the download on separate HIP streams and returns a ticket;
- * dr_search_wait blocks until that batch's results are in the caller's output buffers. Up to 4 batches are in flight
- * per handle (a fifth submit first finishes the oldest), so the copies of batch i+1 / i-1 overlap the search kernel of
- * batch i and the throughput of a stream of host-resident batches approaches the HBM-resident rate. nq <= 32768 per
- * submit. The query buffer may be reused as soon as dr_search_submit returns when it is pageable memory (it is staged);
- * memory from dr_host_alloc (pinned: the copy engine reads it directly, no staging copy) must stay untouched until the
- * ticket has been waited for. The output buffers belong to the library until then. */
+ * dr_search_wait blocks until that batch's results are in the caller's output buffers. Up to DR_MAX_TICKETS tickets and
+ * 4 LAUNCHES are in flight per handle (a further submit first finishes the oldest), so the copies of batch i+1 / i-1 overlap
+ * the search kernel of batch i and the throughput of a stream of host-resident batches approaches the HBM-resident rate.
+ * nq <= 32768 per submit. The query buffer may be reused as soon as dr_search_submit returns when it is pageable memory
+ * (it is staged); memory from dr_host_alloc (pinned: the copy engine reads it directly, no staging copy) must stay
+ * untouched until the ticket has been waited for. The output buffers belong to the library until then.
+ *
+ * Small submits are COALESCED (round 4; one query per request is the shape of the reference's API routes, app.py:84-130, and
+ * nq/8 = 1250 queries is the per-GPU slice of SURVEY 8e's strong-scaling job): submits with equal (k, L, beam_width, mode,
+ * band_policy, flags) that arrive while the search stream is busy are held and ride in ONE launch -- one ticket space over
+ * their concatenated queries, one tie-order pass, one download; every ticket still gets exactly the bits a dr_search_batch
+ * call of its own would return (queries are independent). A submit that finds fewer than three searches queued is launched at
+ * once, so a lone request never waits; held submits are launched by the next submit that finds the stream running dry, by
+ * any dr_search_wait (which keeps feeding the stream while it waits), by dr_search_flush, or when the group reaches
+ * dr_set_coalesce's size (default 8192 queries; 0 = every submit is its own launch, the behaviour until round 3).
+ * If a launch fails, dr_search_wait of every ticket that rode in it answers the error. */
+#define DR_MAX_TICKETS 32u
 int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width,
                      uint32_t mode, uint32_t band_policy, uint32_t flags, uint32_t *out_ids, float *out_dist,
                      uint32_t *out_count, dr_stats *stats, uint64_t *out_ticket);
 int dr_search_wait(dr_index *ix, uint64_t ticket);
+int dr_search_flush(dr_index *ix);                       /* launches whatever dr_search_submit is holding back */
+int dr_set_coalesce(dr_index *ix, uint32_t max_queries); /* queries per coalesced launch (<= 32768); 0: no coalescing */
+int dr_pipeline_stats(dr_index *ix, uint64_t *out4);     /* [0] launches of the pipelined path, [1] tickets they carried, [2] most tickets in one launch, [3] queries */
+int dr_debug_hold(dr_index *ix, int on);                 /* test hook: held submits launch only when full / flushed / waited for */
 void *dr_host_alloc(uint64_t bytes); /* page-locked host memory (NULL on failure) */
 void dr_host_free(void *p);
 

@@ -7,6 +7,8 @@ run() { rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/$1 -- pyth
 run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"
 run sqa "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU"
+run tcca "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum"
+run tccb "TCC_REQ_sum TCC_READ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
 run sqb "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA"
 python3 - $S $N <<'PY'
 import csv, glob, json, sys
@@ -40,6 +42,13 @@ if fs is not None:
     out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / out.get("alg_bytes_per_launch", float("nan"))
 if cal: out["calibration"] = {"known_bytes": out.get("calib_bytes"), "corrected_bytes": cal * 1024 * 2}
 sq = {}
+tcc = {}
+for d in ("tcca", "tccb"):
+    rs = rows(d)
+    for c in sorted({r["Counter_Name"] for r in rs}):
+        v = mean_last(rs, c, sub)
+        if v is not None: tcc[c] = v
+out["tcc"] = tcc
 for d in ("sqa", "sqb"):
     rs = rows(d)
     for c in sorted({r["Counter_Name"] for r in rs}):
@@ -51,4 +60,4 @@ json.dump(out, open(f"gpurun_out/pmc_{S}/summary.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "sq"}, indent=1))
 PY
 # the raw counter CSVs (one row per dispatch, the builder launches hundreds of thousands) stay on the box: gpurun_out is capped at 64 MiB
-rm -rf $OUT/fetch $OUT/write $OUT/sqa $OUT/sqb
+rm -rf $OUT/fetch $OUT/write $OUT/sqa $OUT/sqb $OUT/tcca $OUT/tccb

@@ -98,3 +98,61 @@ def test_short_result_lists_argument_checks_and_close():
         rb.submit(np.zeros(2, np.float32))
     with pytest.raises(ValueError):
         RequestBatcher(eng, k_max=0)
+
+
+def test_a_cancelled_request_neither_kills_the_worker_nor_reaches_the_engine():
+    """a caller that cancels its pending Future (a handler's timeout, a client that went away) must not make the
+    worker thread die on InvalidStateError -- every later request would then block forever."""
+    eng = FakeEngine(delay=0.05)
+    with RequestBatcher(eng, k_max=4, L=50, max_batch=4, max_wait_ms=1) as rb:
+        first = rb.submit(np.array([1.0, 0, 0, 0], np.float32))            # occupies the worker for 50 ms
+        time.sleep(0.01)
+        gone = rb.submit(np.array([2.0, 0, 0, 0], np.float32))
+        assert gone.cancel()                                               # still pending: cancellable
+        kept = rb.submit(np.array([3.0, 0, 0, 0], np.float32))
+        assert [int(x) for _, x in first.result(5)[0]] == [1, 2, 3, 4]
+        assert [int(x) for _, x in kept.result(5)[0]] == [3, 4, 5, 6]
+        # the worker is alive and serves later requests
+        assert [int(x) for _, x in rb.search(np.array([9.0, 0, 0, 0], np.float32), timeout=5)[0]] == [9, 10, 11, 12]
+    assert sum(c[0] for c in eng.calls) == 3                               # the cancelled query never ran
+
+
+def test_a_future_resolved_behind_the_workers_back_is_survived():
+    eng = FakeEngine(delay=0.03)
+    with RequestBatcher(eng, k_max=2, L=50, max_batch=2, max_wait_ms=0) as rb:
+        f = rb.submit(np.array([5.0, 0, 0, 0], np.float32))
+        time.sleep(0.01)                          # the batch is running: not cancellable, but a caller can still break the Future
+        try:
+            f.set_exception(RuntimeError("caller gave up"))
+        except Exception:
+            pass
+        assert [int(x) for _, x in rb.search(np.array([7.0, 0, 0, 0], np.float32), timeout=5)[0]] == [7, 8]
+
+
+def test_a_malformed_request_fails_alone():
+    class Eng(FakeEngine):
+        dimension = 4
+    eng = Eng()
+    with RequestBatcher(eng, k_max=3, L=50, max_batch=8, max_wait_ms=20) as rb:
+        ok = rb.submit(np.zeros(4, np.float32))
+        with pytest.raises(ValueError):
+            rb.submit(np.zeros(5, np.float32))                             # refused in submit(): never stacked with the others
+        assert len(ok.result(5)[0]) == 3
+    eng2 = FakeEngine()                                                    # an engine that does not say its dimension: the first request sets it
+    with RequestBatcher(eng2, k_max=3, L=50, max_batch=8, max_wait_ms=20) as rb:
+        ok = rb.submit(np.zeros(4, np.float32))
+        with pytest.raises(ValueError):
+            rb.submit(np.zeros(6, np.float32))
+        assert len(ok.result(5)[0]) == 3
+
+
+def test_default_list_size_is_fixed_from_k_max():
+    """L=None: the batcher hands the engine max(2 * k_max, 20) explicitly, whatever k a request asks for"""
+    eng = FakeEngine()
+    with RequestBatcher(eng, k_max=16, max_batch=4, max_wait_ms=0) as rb:
+        rb.search(np.zeros(4, np.float32), k=2, timeout=5)
+    assert eng.calls[0][1:3] == (16, 32)
+    eng = FakeEngine()
+    with RequestBatcher(eng, k_max=5, max_batch=4, max_wait_ms=0) as rb:
+        rb.search(np.zeros(4, np.float32), timeout=5)
+    assert eng.calls[0][1:3] == (5, 20)

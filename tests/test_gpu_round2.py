@@ -59,7 +59,7 @@ def test_a_dropped_pipelined_job_does_not_lose_its_buffers():
         gc.collect()
         junk = [np.empty(len(g.queries) * 10, dtype=np.uint32) for _ in range(4)]              # churn the allocator
         del junk
-    assert len(ix.__dict__["_inflight"]) <= _ffi.PIPE_DEPTH
+    assert len(ix.__dict__["_inflight"]) <= _ffi.MAX_TICKETS
     j = ix.search_submit(g.queries, 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
     ids, dist, cnt, st = j.wait()
     assert np.array_equal(ids, want[0]) and np.array_equal(bits(dist), bits(want[1]))

@@ -5,6 +5,9 @@
 //   usage: gather_probe <table_MiB> <row_bytes> <waves_per_cu> <rows_in_flight_per_wave> [mode]
 //   mode 0: rows landed in LDS by global_load_lds (16 B per lane), mode 1: scattered 4-byte loads (one per lane),
 //   mode 2: scattered 4-byte load + store of the same word (read-modify-write without atomics), mode 3: atomicOr
+//   mode 4: scattered 32-byte rows, one per LANE (two 16-byte loads to registers: the code-word gather of the ADC traversals, m = 32)
+// Every run prints "REQS <requests per launch> BYTES <useful bytes per launch>", so that a rocprofv3 --pmc pass over the
+// probe calibrates FETCH_SIZE / TCC_EA0_RDREQ[_32B] for the access shape (profiles/r04/tcc_calibration.json).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +41,15 @@ __global__ __launch_bounds__(1024) void probe(const unsigned char *table, uint32
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             acc += *reinterpret_cast<const uint32_t *>(my + lane * 4);
+        } else if constexpr (MODE == 4) {
+            uint4 v[16];
+            for (uint32_t f = 0; f < inflight && f < 8; f++) {
+                seed = mix(seed + f + 1);
+                const uint64_t row = (uint64_t)mix(seed ^ (lane * 0x85ebca6bU)) % (nrows * (row_bytes / 32));
+                const uint4 *g = reinterpret_cast<const uint4 *>(table + row * 32);
+                v[2 * f] = g[0]; v[2 * f + 1] = g[1];
+            }
+            for (uint32_t f = 0; f < inflight && f < 8; f++) acc += v[2 * f].x + v[2 * f + 1].w;
         } else {
             uint32_t v[8];
             for (uint32_t f = 0; f < inflight && f < 8; f++) {
@@ -70,7 +82,7 @@ int main(int argc, char **argv)
     CHECK(hipMemset(table, 0, bytes));
     const uint32_t iters = 2000;
     const size_t lds = (size_t)wpc * inflight * 1024;
-    auto k = mode == 0 ? probe<0> : mode == 1 ? probe<1> : mode == 2 ? probe<2> : probe<3>;
+    auto k = mode == 0 ? probe<0> : mode == 1 ? probe<1> : mode == 2 ? probe<2> : mode == 4 ? probe<4> : probe<3>;
     CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     for (int rep = 0; rep < 3; rep++) {
@@ -80,7 +92,8 @@ int main(int argc, char **argv)
         float ms; CHECK(hipEventElapsedTime(&ms, a, b));
         const double instr = (double)cus * wpc * iters * inflight;
         const double reqs = mode == 0 ? instr * (64.0 / (row_bytes / 16)) : instr * 64.0;
-        const double gb = mode == 0 ? instr * 1024.0 / 1e9 : reqs * 4 / 1e9;
+        const double gb = mode == 0 ? instr * 1024.0 / 1e9 : reqs * (mode == 4 ? 32 : 4) / 1e9;
+        if (rep == 2) printf("REQS %.0f BYTES %.0f\n", reqs, gb * 1e9);
         if (rep == 2) printf("table %llu MiB row %u B waves/CU %u inflight %u mode %d: %.3f ms  %.2f G req/s  %.2f TB/s\n",
                              (unsigned long long)mib, row_bytes, wpc, inflight, mode, ms, reqs / ms / 1e6, gb / ms);
     }
