@@ -51,14 +51,14 @@ def parse_args(argv=None):
     ap.add_argument("--distinct-batches", dest="nb", type=int, default=8, help="distinct query batches rotated (<= 16)")
     ap.add_argument("--num-vectors", dest="n", type=int, default=1_000_000)
     ap.add_argument("--num-queries", dest="nq", type=int, default=10_000)
-    ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--R", type=int, default=64)
-    ap.add_argument("--L", type=int, default=100)
-    ap.add_argument("--bw", type=int, default=8, help="beam_width: 8 = the reference default of search()/the API routes (search_engine.py:530, app.py:96); 0 = None (no frontier trim)")
+    ap.add_argument("--dim", type=int, default=None, help="default 128 (c2), 1536 (c5)")
+    ap.add_argument("--R", type=int, default=None, help="default 64 (c2), 128 (c5)")
+    ap.add_argument("--L", type=int, default=None, help="default 100 (c2), 150 (c5)")
+    ap.add_argument("--bw", type=int, default=None, help="beam_width: default 8 (c2) = the reference default of search()/the API routes (search_engine.py:530, app.py:96), 16 (c5); 0 = None (no frontier trim)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (no trim, float rows, un-rounded data)")
     ap.add_argument("--m", type=int, default=32)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--L-build", type=int, default=100)
+    ap.add_argument("--L-build", type=int, default=None, help="default 100 (c2), 128 (c5)")
     ap.add_argument("--cpu-sample", type=int, default=2000, help="queries timed on the CPU oracle, all cores (rank 0, N=1 only)")
     ap.add_argument("--cpu-sample-1t", type=int, default=150, help="queries timed on ONE CPU thread")
     ap.add_argument("--no-cpu", action="store_true")
@@ -69,7 +69,13 @@ def parse_args(argv=None):
                          "--num-queries batches, every batch cut into contiguous slices of nq/N queries, one per rank")
     ap.add_argument("--blocking-calls", type=int, default=24, help="blocking dr_search_batch calls timed for config.qps_blocking_call (median)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    # the shape of the configuration (BASELINE.json configs[1] / configs[4]) unless given
+    dflt = {"c2": dict(dim=128, R=64, L=100, bw=8, L_build=100), "c5": dict(dim=1536, R=128, L=150, bw=16, L_build=128)}[args.config]
+    for name, v in dflt.items():
+        if getattr(args, name) is None:
+            setattr(args, name, v)
+    return args
 
 
 # ------------------------------------------------------------------------------------------------ ranks and barriers
@@ -436,8 +442,8 @@ def worker_c2(args, rk):
     ix.batch_select(0)
 
     def tickets_in_flight(n_q):
-        """submits a caller keeps in flight: PIPE_DEPTH launches' worth (a launch of small submits holds up to 8192 queries)"""
-        return _ffi.PIPE_DEPTH if n_q >= 8192 else min(_ffi.MAX_TICKETS - 2, _ffi.PIPE_DEPTH * max(1, 8192 // n_q))
+        """submits a caller keeps in flight: PIPE_DEPTH launches' worth (a launch of small submits holds up to 10240 queries)"""
+        return _ffi.PIPE_DEPTH if n_q > 5120 else min(_ffi.MAX_TICKETS - 2, _ffi.PIPE_DEPTH * max(1, 10240 // n_q))
 
     # ---------------------------------------------------------------- the headline: host memory -> host memory, pipelined
     def run_pipelined(n_launch, sources, depth=_ffi.PIPE_DEPTH):
@@ -737,64 +743,104 @@ def worker_c2(args, rk):
 
 # ------------------------------------------------------------------------------------------------ c5: graph-sharded
 def worker_c5(args, rk):
-    """BASELINE config c5 at bench scale: every rank owns ONE shard (its own vectors, sub-graph and PQ codes), every query
-    runs on every shard (the engine's PQ-only traversal, DR_MODE_PQ), the per-shard top-k lists are exchanged with one
-    RCCL all-gather per array and merged on the device (dr_sharded_search). Reports whole-job QPS and the recall of the
-    merged lists against the merged per-shard brute force."""
+    """BASELINE config c5 (1B x 1536, PQ-only, graph sharded 8 ways) at bench scale, through the pipeline of the full-size run
+    (scripts/c5_shard.py): every rank owns ONE shard of --num-vectors points of the 1536-d unit-mixture
+    stream -- generated chunk by chunk, encoded on the device (dr_pq_encode_rows) and forgotten: the vectors are never stored --,
+    builds its Vamana sub-graph from the code words alone (dr_build_vamana_pq, R = 128), and every query runs on every shard
+    (DR_MODE_PQ, L = 150, beam_width 16: the shard's operating point); the per-shard top-k lists travel as packed keys in ONE
+    RCCL all-gather and are merged on the device (dr_sharded_submit / dr_sharded_wait, two batches in flight). Recall is
+    against the brute-force ADC ranking of the union (dr_pq_scan_topk per shard, merged): the metric a PQ-only index can be
+    held to."""
     import diskrag_amd
     from diskrag_amd import HipIndex, _ffi
-    from diskrag_amd.synth import recall_at_k, sift_like
+    from diskrag_amd.parallel import merge_topk
+    from diskrag_amd.synth import UnitMixtureStream, recall_at_k
     ndev = diskrag_amd.device_count()
     if ndev < 1:
         raise RuntimeError("no HIP device: the engine has no CPU fallback")
     device = rk.local_rank % ndev
-    nq, k, D = args.nq, args.k, args.dim
-    x, q = sift_like(args.n, D, n_queries=nq, n_clusters=1024, seed=3000 + rk.rank, query_seed=77)   # same queries on every rank
-    ix = HipIndex.create_empty(x, R=args.R, device=device)
-    medoid, build_s = ix.build_vamana(L_build=args.L_build, alpha=1.2, passes=2, seed=7, pad_with_zero=False)
-    cb = ix.pq_train(args.m, n_sample=100_000, iters=8, seed=42)      # every shard trains on its own sample
-    ix.pq_encode(cb)
-    gt_local, gt_dist = ix.bruteforce_topk(q, k)
+    nq, k, D, m, R = args.nq, args.k, args.dim, args.m, args.R
+    n_s = args.n
+    blk = UnitMixtureStream.BLOCK
+    stride = -(-n_s // blk) * blk                       # every shard starts on a block of the stream
+    gen = UnitMixtureStream(d=D, n_clusters=4096, seed=11, latent=64, threads=min(32, os.cpu_count() or 1))
+    t0 = time.time()
+    # one codebook for the whole index: every rank trains on the SAME sample with the same seed (deterministic on the device)
+    sample = gen.draw(0, min(262144, stride))
+    tmp = HipIndex.create_empty(sample, R=R, device=device)
+    cb, _ = tmp.pq_train_ex(m, n_sample=50000, max_iter=15, n_init=1, seed=5)
+    tmp.close()
+    del sample
+    cb_s = time.time() - t0
+    q = gen.draw(0, nq, stream=1)                        # the same queries on every rank
+    sh = HipIndex.create_codes_empty(n_s, D, R, cb, device=device)
+    t0 = time.time()
+    ch = 8 * blk
+    for r0 in range(0, n_s, ch):
+        rows = min(ch, n_s - r0)
+        x = gen.draw(rk.rank * stride + r0, rows)
+        sh.encode_rows(x, r0)
+        del x
+    enc_s = time.time() - t0
+    medoid, build_s = sh.build_vamana_pq(L_build=args.L_build, alpha=1.2, passes=2, seed=7)
+    log(rk, f"shard of {n_s} x {D} encoded in {enc_s:.1f}s (codebook {cb_s:.1f}s), graph R={R} built from code words in {build_s:.1f}s")
+    base = rk.rank * n_s
+    # ground truth in the index's own metric: brute-force ADC top-k of every shard, merged over the ranks
+    ngt = min(nq, 1000)
+    g_ids, g_sq, _ = sh.pq_scan_topk(q[:ngt], k)
+    gts = rk.gather("gt", {"ids": (g_ids.astype(np.int64) + base).tolist(), "dist": g_sq.tolist()})
+    gt, _ = merge_topk([np.array(g["ids"], dtype=np.uint32) for g in gts], [np.array(g["dist"], dtype=np.float32) for g in gts], k)
     # communicator: rank 0 makes the id, the others read it from the scratch directory
     if rk.rank == 0:
         rk.put("rccl_id", _ffi.Comm.unique_id())
     uid = rk.get("rccl_id", 0, raw=True)
     comm = _ffi.Comm(uid, rk.world, rk.rank, device)
-    base = rk.rank * args.n
-    # exact ground truth of the union: the same exchange on the per-shard brute-force lists
-    gts = rk.gather("gt", {"ids": (gt_local.astype(np.int64) + base).tolist(), "dist": gt_dist.tolist()}) if rk.world > 1 else None
-    if gts is None:
-        gt = gt_local
-    else:
-        from diskrag_amd.parallel import merge_topk
-        gt, _ = merge_topk([np.array(g["ids"], dtype=np.uint32) for g in gts], [np.array(g["dist"], dtype=np.float32) for g in gts], k)
-    run = lambda: _ffi.sharded_search([ix], [base], q, k, L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQ, comm=comm)
-    for _ in range(max(1, args.warmup)):
-        run()
+    qp = _ffi.pinned_empty((nq, D), np.float32)
+    qp[:] = q
+
+    def stream(n_calls):
+        jobs, out, ms = [], None, np.zeros(3)
+        t1 = time.perf_counter()
+        for i in range(n_calls):
+            jobs.append(_ffi.sharded_submit([sh], [base], qp, k, L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQ, comm=comm))
+            if len(jobs) >= 2:
+                out = jobs.pop(0).wait(); ms += out[3]
+        for j in jobs:
+            out = j.wait(); ms += out[3]
+        return time.perf_counter() - t1, out, ms
+
+    stream(max(2, args.warmup))
     rk.barrier()
-    t0 = time.perf_counter()
-    ms = np.zeros(3)
-    for _ in range(args.steps):
-        ids, dist, status, m3 = run()
-        ms += m3
-    el = time.perf_counter() - t0
+    el, (ids, dist, status, _), ms = stream(args.steps)
     times = rk.gather("t_c5", el)
     if int(status.max()) != 0:
         raise RuntimeError("work-area overflow during the bench")
+    # one blocking call for the per-phase times (nothing overlapped) and the search kernel of the shard
+    _, _, _, ms1 = _ffi.sharded_search([sh], [base], qp, k, L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQ, comm=comm)
+    sh.batch_sync()                                     # (publishes the shard's kernel timings)
+    tm = sh.timing()
+    recall = recall_at_k(ids[:ngt], gt, k)
     out = {"metric": "QPS, graph-sharded PQ-only search (c5 layout at bench scale), batch=%d" % nq,
            "value": nq * args.steps / max(times), "unit": "queries/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": max(times) / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 (ADC sums over u8 codes)", "data": "synthetic",
-           "config": {"workload": "%d shards x %d points, d=%d, R=%d, PQ m=%d, DR_MODE_PQ L=%d beam_width=%s, k=%d; every query on "
-                                  "every shard; exchange = RCCL all-gather of nq*k*8 bytes per rank + device merge"
-                                  % (rk.world, args.n, D, args.R, args.m, args.L, args.bw or None, k),
-                      "recall_at_10_vs_exact": recall_at_k(ids, gt, k), "rccl_ranks": rk.world, "build_seconds": build_s,
-                      "ms_per_call": {"search": float(ms[0] / args.steps), "all_gather": float(ms[1] / args.steps),
-                                      "merge": float(ms[2] / args.steps)}}}
+           "config": {"workload": "c5 layout at bench scale: %d shards x %d points of the 1536-d unit-mixture stream (4096 clusters), vectors "
+                                  "encoded on the fly and never stored, PQ m=%d, graph built from code words (dr_build_vamana_pq R=%d, L_build=%d), "
+                                  "DR_MODE_PQ L=%d beam_width=%s, k=%d; every query on every shard; exchange = ONE RCCL all-gather of (nq*k + 1) "
+                                  "packed 64-bit words per rank + device merge; a step = one %d-query batch, two in flight (dr_sharded_submit/wait)"
+                                  % (rk.world, n_s, m, R, args.L_build, args.L, args.bw or None, k, nq),
+                      "recall_at_10_vs_bruteforce_adc": recall, "ground_truth_queries": ngt, "rccl_ranks": rk.world,
+                      "build_seconds": build_s, "encode_seconds": enc_s, "codebook_seconds": cb_s,
+                      "per_rank_seconds": times, "exchange_bytes_per_rank_per_batch": (nq * k + 1) * 8,
+                      "one_blocking_call_ms": {"search": float(ms1[0]), "all_gather": float(ms1[1]), "merge": float(ms1[2])},
+                      "search_kernel": {"variant": tm["variant"], "kernel_ms": tm["search_kernel_ms"], "table_kernel_ms": tm["lut_kernel_ms"],
+                                        "waves_per_cu": tm["waves_per_cu"]}}}
+    if recall < args.min_recall:
+        raise RuntimeError(f"c5: recall@{k} vs the brute-force ADC ranking = {recall:.4f} is below {args.min_recall}")
     if rk.rank == 0:
         print(json.dumps(out), flush=True)
     comm.close()
-    ix.close()
+    sh.close()
     return 0
 
 

@@ -21,7 +21,7 @@ TIER_HBM, TIER_HOST = 0, 1       # where the full-precision rows live (dr_index_
 MAX_RESIDENT = 16
 COMM_ID_BYTES = 128
 
-E_ARG, E_NODEVICE, E_IO, E_NOPQ, E_OVERFLOW, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+E_ARG, E_NODEVICE, E_IO, E_NOPQ, E_OVERFLOW, E_UNSUPPORTED, E_REMOTE = -1, -2, -3, -4, -5, -6, -7
 
 
 class DrStats(C.Structure):
@@ -47,7 +47,7 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_debug_force_kind", "dr_search_batch_f64",
            "dr_index_create_codes", "dr_index_drop_vectors", "dr_pq_scan_best",
            "dr_batch_select", "dr_search_submit", "dr_search_wait", "dr_search_flush", "dr_set_coalesce", "dr_pipeline_stats", "dr_debug_hold", "dr_host_alloc", "dr_host_free",
-           "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_merge_topk",
+           "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_sharded_submit", "dr_sharded_wait", "dr_merge_topk",
            "dr_debug_prune", "dr_debug_prune_pq", "dr_pq_train_ex", "dr_index_create_codes_empty", "dr_pq_encode_rows", "dr_build_vamana_pq",
            "dr_scalar_kernels", "dr_index_inline_codes", "dr_pq_scan_topk", "dr_index_copy_codes"]
 
@@ -182,6 +182,11 @@ def load_library():
     L.dr_sharded_search.restype = C.c_int
     L.dr_sharded_search.argtypes = [C.POINTER(vp), u32p, C.c_uint32, vp, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p, fp]
+    L.dr_sharded_submit.restype = C.c_int
+    L.dr_sharded_submit.argtypes = [C.POINTER(vp), u32p, C.c_uint32, vp, fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p, fp, C.POINTER(C.c_uint64)]
+    L.dr_sharded_wait.restype = C.c_int
+    L.dr_sharded_wait.argtypes = [vp, C.c_uint64]
     L.dr_debug_prune.restype = C.c_int
     L.dr_debug_prune.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_float, C.c_uint32, u32p, u32p]
     L.dr_merge_topk.restype = C.c_int
@@ -681,6 +686,48 @@ def sharded_search(shards, id_bases, queries, k, L=100, beam_width=8, mode=MODE_
                                             int(band_policy), int(flags), _p(ids, C.c_uint32), _p(dist, C.c_float),
                                             _p(status, C.c_uint32), _p(ms, C.c_float)))
     return ids, dist, status, ms
+
+
+class PendingSharded:
+    """A sharded search in flight (sharded_submit): wait() gives (global ids, distances, status per query, ms[3])."""
+
+    def __init__(self, first_shard, q, nq, k):
+        self._first, self._q, self.ticket = first_shard, q, 0
+        self.ids = np.empty((nq, k), dtype=np.uint32)
+        self.dist = np.empty((nq, k), dtype=np.float32)
+        self.status = np.empty(nq, dtype=np.uint32)
+        self.ms = np.zeros(3, dtype=np.float32)
+
+    def wait(self):
+        _check(load_library().dr_sharded_wait(self._first._h, self.ticket))
+        self._q = None
+        self._first.__dict__.get("_sharded_inflight", {}).pop(self.ticket, None)
+        return self.ids, self.dist, self.status, self.ms
+
+
+def sharded_submit(shards, id_bases, queries, k, L=100, beam_width=8, mode=MODE_PQ, band_policy=0, flags=0, comm=None):
+    """dr_sharded_submit: the first half of sharded_search; two calls may be in flight per first shard (batch i+1 is searched
+    while batch i is exchanged and merged). Every rank must submit in the same order."""
+    n = len(shards)
+    D = shards[0].D
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    if q.ndim != 2 or q.shape[1] != D:
+        raise ValueError(f"queries must be [nq, {D}], got {q.shape}")
+    nq = q.shape[0]
+    hs = (C.c_void_p * n)(*[s._h for s in shards])
+    bases = np.ascontiguousarray(id_bases, dtype=np.uint32)
+    job = PendingSharded(shards[0], q, nq, int(k))
+    t = C.c_uint64(0)
+    _check(load_library().dr_sharded_submit(hs, _p(bases, C.c_uint32), n, comm._h if comm is not None else None,
+                                            _p(q, C.c_float), nq, int(k), int(L), int(beam_width or 0), int(mode),
+                                            int(band_policy), int(flags), _p(job.ids, C.c_uint32), _p(job.dist, C.c_float),
+                                            _p(job.status, C.c_uint32), _p(job.ms, C.c_float), C.byref(t)))
+    job.ticket = int(t.value)
+    live = shards[0].__dict__.setdefault("_sharded_inflight", {})      # (the library writes into the job's arrays until it is finished)
+    live[job.ticket] = job
+    for tk in [tk for tk in live if tk + 2 <= job.ticket]:
+        del live[tk]
+    return job
 
 
 def merge_topk_device(ids, dist, k_out, device=0):

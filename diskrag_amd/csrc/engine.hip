@@ -149,23 +149,40 @@ struct PipeGroup {
     hipEvent_t up_done = nullptr, down_done = nullptr;
 };
 
-// Persistent work area of dr_sharded_search (comm.inc), owned by the first shard of the call: staging arrays, events, the
-// exchange stream and a page-locked slab for the results live across calls (a call used to hipMalloc nine arrays and
-// create three events).
-struct ShardScratch {
-    std::mutex mu;
-    DevBuf<uint32_t> loc_ids, send_ids, all_ids, fin_ids, status;
-    DevBuf<float> loc_dist, send_dist, all_dist, fin_dist, q;
-    hipEvent_t e[4] = {};                 // start, local lists ready, exchange done, final merge done
-    std::vector<hipEvent_t> shard_done;   // one per local shard
-    hipStream_t xs = nullptr;             // merge / exchange / download stream (without a communicator)
+// Persistent work areas of dr_sharded_submit (comm.inc), owned by the first shard of the call: staging arrays, events, the
+// exchange stream and a page-locked slab for the results live across calls. Two of them: batch i+1 is searched while batch i
+// is exchanged, merged and downloaded.
+#define DR_SHARD_DEPTH 2
+struct ShardWork {
+    DevBuf<uint32_t> loc_ids, fin_ids, status;
+    DevBuf<float> loc_dist, fin_dist, q;
+    DevBuf<u64> send_keys, all_keys, words;     // my list + status word; every rank's; the ranks' status words
+    hipEvent_t e[5] = {};                       // start, local lists ready, exchange done, final merge done, download done
+    hipEvent_t up = nullptr;                    // batch on the device
     void *pin = nullptr; size_t pin_bytes = 0;
-    ~ShardScratch()
+    bool active = false;
+    uint64_t ticket = 0;
+    uint32_t nq = 0, k = 0; int nranks = 1;
+    int local_rc = 0; std::string local_msg;
+    uint32_t *out_ids = nullptr; float *out_dist = nullptr; uint32_t *out_status = nullptr; float *out_ms = nullptr;
+    ~ShardWork()
     {
         for (auto &x : e) if (x) (void)hipEventDestroy(x);
+        if (up) (void)hipEventDestroy(up);
+        if (pin) (void)hipHostFree(pin);
+    }
+};
+struct ShardScratch {
+    std::mutex mu;
+    ShardWork w[DR_SHARD_DEPTH];
+    uint64_t next_ticket = 1;
+    std::map<uint64_t, std::pair<int, std::string>> failed;   // tickets finished by a later submit with an error
+    std::vector<hipEvent_t> shard_done;   // one per local shard
+    hipStream_t xs = nullptr;             // merge / exchange / download stream (without a communicator)
+    ~ShardScratch()
+    {
         for (auto &x : shard_done) if (x) (void)hipEventDestroy(x);
         if (xs) (void)hipStreamDestroy(xs);
-        if (pin) (void)hipHostFree(pin);
     }
 };
 
@@ -194,7 +211,8 @@ struct dr_index {
     DevBuf<uint8_t> nbcodes;      // [N][R][m] inline neighbour codes (dr_index_inline_codes), rebuilt before the next search when stale
     bool inline_codes = false, nbcodes_valid = false;
     DevBuf<float> codebook;
-    DevBuf<float> sdc;            // centroid-pair table [m][256][256] (PQ-only builder), built on first use
+    DevBuf<float> sdc;            // centroid-pair table [m][256][256] (PQ-only builder), built on first use FOR THE CODEBOOK IN PLACE:
+    uint64_t codebook_gen = 0, sdc_gen = ~0ull;   // every codebook / m change bumps codebook_gen; ensure_sdc rebuilds a table of another generation
     DevBuf<uint32_t> perm;
     std::vector<uint32_t> h_perm;
     // bit order of the visited bitmaps (build_bit_order): rank[id] = bit position, adjr = rank of every adjacency slot
@@ -215,7 +233,7 @@ struct dr_index {
     uint64_t next_ticket = 1, next_group = 0;
     int open_group = -1;          // the group that is collecting jobs (state 1), or -1
     std::map<uint64_t, std::pair<int, std::string>> failed_tickets;   // tickets whose launch failed, until their dr_search_wait collects the error
-    uint32_t coalesce_cap = 8192; // queries a group of small submits may grow to (dr_set_coalesce; 0: every submit is its own launch)
+    uint32_t coalesce_cap = 10240; // queries a group of small submits may grow to (dr_set_coalesce; 0: every submit is its own launch)
     bool hold_always = false;     // dr_debug_hold: submits are only launched when full / flushed / waited for (tests)
     uint64_t pipe_launches = 0, pipe_tickets = 0, pipe_max_tickets = 0, pipe_queries = 0;   // dr_pipeline_stats
     hipStream_t up_stream = nullptr, down_stream = nullptr;
@@ -433,7 +451,7 @@ extern "C" int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_
     if (ix->codebook.reserve((size_t)256 * ix->D)) return DR_E_NODEVICE;
     HIPCHK(hipMemcpy(ix->codes.p, codes, (size_t)ix->N * m, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ix->codebook.p, codebook, (size_t)256 * ix->D * 4, hipMemcpyHostToDevice));
-    ix->m = m; ix->sd = ix->D / m;
+    ix->m = m; ix->sd = ix->D / m; ix->codebook_gen++;
     for (auto &qs : ix->slots) qs.pq_ub_valid = false;
     ix->adc_live = -1; ix->nbcodes_valid = false;
     return 0;
@@ -919,7 +937,11 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // visited set: per wavefront slot one word per 24 bit positions (+ an 8-bit query stamp: nothing is cleared
     // between queries, search_kernel.hpp) and the slot's stamp counter
     const uint32_t vis_words = (uint32_t)(((ix->N + 23) / 24 + 3) & ~3ull);
-    if ((size_t)slots * vis_words > vis.n || slots > vis_epoch.n) {
+    // The engine's own ADC traversals (DR_MODE_PQ, the PQ-only builder's searches) keep NO visited set (SearchParams::novis):
+    // no visited words (20 MB per wavefront slot on a 1.25e8-point shard), no bit-position twin of the adjacency.
+    static const bool keep_vis = getenv("DR_PQ_VISITED_SET") != nullptr;       // A/B: round 3's form
+    const bool novis = !keep_vis && (mode == DR_MODE_PQ || (ov && ov->sdc));
+    if (!novis && ((size_t)slots * vis_words > vis.n || slots > vis_epoch.n)) {
         // (re)allocation: fresh words and stamps -- queued launches still use the old buffers
         if (vis.p) HIPCHK(hipStreamSynchronize(st));
         if (vis.reserve((size_t)slots * vis_words) || vis_epoch.reserve(slots)) return DR_E_NODEVICE;
@@ -944,10 +966,11 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
 
     SearchParams p;
     memset(&p, 0, sizeof p);
-    if (!ov && !ix->adjr_valid) { const int rcb = build_bit_order(ix); if (rcb) return rcb; }
+    if (!ov && !novis && !ix->adjr_valid) { const int rcb = build_bit_order(ix); if (rcb) return rcb; }
     if (!ov && ix->inline_codes && !ix->nbcodes_valid && ix->codes.p && (mode == DR_MODE_M1 || pq_only)) { const int rci = build_inline_codes(ix); if (rci) return rci; }
     p.vecp = ix->vecp.p; p.adj = ix->adj.p; p.first = ix->first.p; p.codes = ix->codes.p; p.codebook = ix->codebook.p;
-    p.adjr = (!ov && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
+    p.adjr = (!ov && !novis && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
+    p.novis = novis ? 1u : 0u;
     p.nbcodes = (!ov && ix->inline_codes && ix->nbcodes_valid) ? ix->nbcodes.p : nullptr;
     p.vec8 = ix->vec8_state == 1 ? ix->vec8.p : nullptr;
     // chain-major copy of the batch: the builder hands nothing else; a batch uploaded without it (dr_search_submit, D <= 256)
@@ -1271,14 +1294,17 @@ static int launch_group_locked(dr_index *ix, int g)
     return 0;
 }
 
-// Launch policy for the open group: at once while fewer than three search kernels of the pipeline are queued or running (the
-// search stream would run dry: a lone request never waits), otherwise the group keeps collecting until it is full. Called
-// by every submit and, while it waits, by dr_search_wait.
+// Launch policy for the open group: at once while fewer than TWO search kernels of the pipeline are queued or running (one
+// running + one queued behind it keeps the search stream fed; a lone request finds none and never waits), otherwise the
+// group keeps collecting until it is full -- so under load a launch carries what arrived during one kernel. (A threshold
+// of three launched nearly every submit alone: the host, blocked on the oldest launch's download, came back to find the
+// stream nearly dry -- gpurun_out r04 call 2: 1.06 submits per launch.) Called by every submit and, while it waits, by
+// dr_search_wait.
 static int kick_locked(dr_index *ix, bool force = false)
 {
     const int g = ix->open_group;
     if (g < 0) return 0;
-    if (!force && (ix->hold_always || searches_in_flight(ix) >= 3)) return 0;
+    if (!force && (ix->hold_always || searches_in_flight(ix) >= 2)) return 0;
     return launch_group_locked(ix, g);
 }
 
@@ -1903,8 +1929,12 @@ static uint32_t prune_multi_enabled(uint32_t D)
 // centroid-pair table S[m][256][256] (8 MB at m = 32): every distance of the PQ-only builder is a sum of its entries
 static int ensure_sdc(dr_index *ix)
 {
-    if (ix->sdc.p) return 0;
+    // (the table used to outlive its codebook -- dr_index_set_pq / dr_pq_encode / a codes-empty upload replaced the
+    // codebook or m and a later dr_build_vamana_pq / dr_debug_prune_pq scored with the OLD table, out of bounds if m grew)
+    if (ix->sdc.p && ix->sdc_gen == ix->codebook_gen) return 0;
+    ix->sdc.release();
     if (ix->sdc.reserve((size_t)ix->m * 65536)) return DR_E_NODEVICE;
+    ix->sdc_gen = ix->codebook_gen;
     hipLaunchKernelGGL(sdc_table_kernel, dim3(ix->m * 256), dim3(256), 0, ix->stream, ix->codebook.p, ix->m, ix->sd, ix->sdc.p);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2177,7 +2207,7 @@ extern "C" int dr_index_create_codes_empty(dr_index **out, uint64_t N, uint32_t 
     if (!rc && hipMemset(ix->adj.p, 0xFF, (size_t)N * R * 4) != hipSuccess) rc = fail(DR_E_NODEVICE, "memset failed");
     if (!rc && hipMemset(ix->first.p, 0, (size_t)N * ((R + 63) / 64) * 8) != hipSuccess) rc = fail(DR_E_NODEVICE, "memset failed");
     if (rc) { dr_index_close(ix); return rc; }
-    ix->m = m; ix->sd = D / m;
+    ix->m = m; ix->sd = D / m; ix->codebook_gen++;
     *out = ix;
     return 0;
 }
@@ -2197,7 +2227,7 @@ extern "C" int dr_index_copy_codes(dr_index *dst, dr_index *src)
     if (dst->codes.reserve((size_t)src->N * src->m) || dst->codebook.reserve((size_t)256 * src->D)) return DR_E_NODEVICE;
     HIPCHK(hipMemcpy(dst->codes.p, src->codes.p, (size_t)src->N * src->m, hipMemcpyDeviceToDevice));
     HIPCHK(hipMemcpy(dst->codebook.p, src->codebook.p, (size_t)256 * src->D * 4, hipMemcpyDeviceToDevice));
-    dst->m = src->m; dst->sd = src->sd;
+    dst->m = src->m; dst->sd = src->sd; dst->codebook_gen++;
     dst->sdc.release();
     for (auto &qs : dst->slots) qs.pq_ub_valid = false;
     dst->adc_live = -1; dst->nbcodes_valid = false;
@@ -2452,7 +2482,7 @@ extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uin
     if (rc) return rc;
     if (out_codes) HIPCHK(hipMemcpyAsync(out_codes, ix->codes.p, (size_t)ix->N * m, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
-    ix->m = m; ix->sd = ix->D / m;
+    ix->m = m; ix->sd = ix->D / m; ix->codebook_gen++;
     for (auto &qs : ix->slots) qs.pq_ub_valid = false;
     ix->adc_live = -1; ix->nbcodes_valid = false;
     return 0;

@@ -95,6 +95,15 @@ struct SearchParams {
     // word only, and its table T[j][c] = |C_j[c] - C_j[code_j]|^2 is m rows of the centroid-pair table sdc[m][256][256]
     const float *sdc;
     const u32 *build_pts;
+    // 1: no visited set (round 4; the engine's own ADC traversals -- DR_MODE_PQ and the PQ-only builder's searches). Every
+    // first-occurrence neighbour of an expansion is scored; one that would enter the list is looked up IN the list (same id
+    // => same ADC distance => same 64-bit key) and dropped if it is there. That is exact: a node scored before and not in the
+    // list now was rejected or evicted at a worst distance W' >= W(now) and can never be accepted again, and while the list
+    // is filling every scored node is in it -- so ids, distances and the accepted-insert sequence are those of the
+    // visited-set form, while the visited words (a load per test, a store per new node, 20 MB per wavefront slot on a
+    // 1.25e8-point shard), their bit-position twin of the adjacency and the grouping passes are gone. stats.visited / stats.pq
+    // then count EVALUATIONS (a node met again after it fell out of the list is scored again). vis / adjr may be null.
+    u32 novis;
 };
 
 DEV u32 lane_id() { return threadIdx.x & 63; }
@@ -581,6 +590,7 @@ DEV void search_body(const SearchParams &p)
     const bool has_out = FILTER ? true : (p.out_ids != nullptr);
     const bool has_ties = FILTER ? true : (p.tie_list != nullptr);
     const bool kcos = !FILTER && KIND == DIST_EXACT && p.vnorm2 != nullptr;      // traversal metric: cosine distance (M3)
+    const bool novis = !FILTER && KIND == DIST_ADC_SQ && p.novis != 0u;          // no visited set (SearchParams::novis)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
@@ -661,7 +671,7 @@ DEV void search_body(const SearchParams &p)
     // queries (the clears and the log they needed were a quarter of the kernel's memory requests); the stamp counts
     // 1..255 per slot and the slot's words are wiped once per 255 queries.
     u32 *vbm = p.vis + (size_t)slot_id * p.vis_words;
-    u32 vstamp = (u32)__builtin_amdgcn_readfirstlane((int)p.vis_epoch[slot_id]);
+    u32 vstamp = novis ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)p.vis_epoch[slot_id]);
     const int cap = (int)p.cap;
     const u32 nwords = (p.R + 63) / 64;
 
@@ -782,7 +792,7 @@ DEV void search_body(const SearchParams &p)
         u32 trn = 0;
 #endif
         // next stamp; after 255 queries the slot's words are wiped and the count restarts
-        if (vstamp >= 255u) {
+        if (!novis && vstamp >= 255u) {
             uint4 *vb4 = reinterpret_cast<uint4 *>(vbm);
             for (u32 i = lane; i < p.vis_words / 4; i += 64) vb4[i] = make_uint4(0, 0, 0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -803,7 +813,7 @@ DEV void search_body(const SearchParams &p)
         // ---- start node (search_engine.py:416-426)
         {
             const u32 start = p.medoid;
-            if (lane == 0) {
+            if (lane == 0 && !novis) {
                 const u32 sp = p.adjr ? p.medoid_pos : start;
                 const u32 sw = __umulhi(sp, 0xAAAAAAABu) >> 4;            // sp / 24
                 vbm[sw] = vtag | (1u << (sp - sw * 24u));                // first word of this query: whatever was there is stale
@@ -886,7 +896,7 @@ DEV void search_body(const SearchParams &p)
                     nbid_l = pre_buf[lane]; nbpos_l = pre_buf[64 + lane];
                     aux_w = *reinterpret_cast<const u64 *>(pre_buf + 128);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // read before the next prefetch reuses the area
-                } else { nbid_l = idrow[sl]; nbpos_l = posrow[sl]; aux_w = auxp[0]; }
+                } else { nbid_l = idrow[sl]; nbpos_l = novis ? 0u : posrow[sl]; aux_w = auxp[0]; }
                 // Predict the next pop -- the best frontier entry that is left now (this expansion's neighbours may still
                 // beat it) -- and land ITS adjacency row in LDS: no VGPR destination, nobody waits for it, and when the
                 // prediction holds the next expansion starts without its first global round trip.
@@ -949,8 +959,8 @@ DEV void search_body(const SearchParams &p)
                 u32 vraw = 0u;
                 const u32 hsh = vw * 0x9E3779B1u;
                 const u32 bh = hsh >> 20;                                // filter bit of this word
-                bool vneed = active;
-                if constexpr (VB_BITS > 0) vneed = active && ((blm[bh >> 5] >> (bh & 31)) & 1u) != 0u;
+                bool vneed = active && !novis;
+                if constexpr (VB_BITS > 0) vneed = vneed && ((blm[bh >> 5] >> (bh & 31)) & 1u) != 0u;
                 if (vneed) vraw = __hip_atomic_load(&vbm[vw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // Code words of the row's neighbours fetched BESIDE the visited test instead of after it (one dependent
                 // round trip less per expansion) whenever their ADC may be needed: always for the ADC traversals; for M1
@@ -973,7 +983,8 @@ DEV void search_body(const SearchParams &p)
                     }
                     if (spec && active) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m);
                 }
-                {
+                if (novis) isnew = active;      // every neighbour is scored; the list itself says which are already in it (decisions)
+                else {
                     u32 vldr = (u32)lane;
                     u32 *vacc = reinterpret_cast<u32 *>(nb_e);         // idle until the distances are written
                     u64 *vtab = reinterpret_cast<u64 *>(mk);           // idle until the rows land / the merge
@@ -1282,6 +1293,7 @@ DEV void search_body(const SearchParams &p)
                         }
                         const bool iscand = ((cm >> lane) & 1ull) != 0ull;
                         int lb_lo = 0, lb_hi = rn, ut_lo = 0, ut_hi = rn, ux_lo = 0, ux_hi = rn;
+                        bool isdup = false;
                         const u64 key_ut = ((u64)tbits << 32) | 0xFFFFFFFFull, key_ux = ((u64)xbits << 32) | 0xFFFFFFFFull;
                         if (iscand && !by_ballot) {
                             constexpr int ITER = (NCHR == 1) ? 7 : (NCHR == 2) ? 8 : (NCHR == 4) ? 9 : (NCHR == 8) ? 10 : 11;
@@ -1297,6 +1309,8 @@ DEV void search_body(const SearchParams &p)
                                     if (ux_lo < ux_hi) { if (v3 <= key_ux) ux_lo = m3 + 1; else ux_hi = m3; }
                                 }
                             }
+                            // no visited set: is this key in the list already? (lb_lo = list keys below it)
+                            if (novis) isdup = lb_lo < rn && mk[min(lb_lo, rn - 1)] == mykey;
                         }
                         // (the candidate masks are built as two 32-bit halves -- candidates in lanes 0..31, then 32..63 -- so
                         // that every update is one select and one OR instead of two of each on a 64-bit register pair)
@@ -1331,6 +1345,12 @@ DEV void search_body(const SearchParams &p)
                                             c_ut += __popcll(__ballot(rk.v[ch] <= kut));
                                             if (count_pass) c_ux += __popcll(__ballot(rk.v[ch] <= kux));
                                         }
+                                        if (novis) {      // (unused list slots hold ~0, never a candidate's key)
+                                            u64 eqm = 0ull;
+#pragma unroll
+                                            for (int ch = 0; ch < NCHR; ch++) eqm |= __ballot(rk.v[ch] == kf);
+                                            isdup = (lane == f) ? (eqm != 0ull) : isdup;
+                                        }
                                         lb_lo = (lane == f) ? c_lb : lb_lo;
                                         ut_lo = (lane == f) ? c_ut : ut_lo;
                                         if (count_pass) ux_lo = (lane == f) ? c_ux : ux_lo;
@@ -1342,7 +1362,7 @@ DEV void search_body(const SearchParams &p)
                             for (int ch = 0; ch < NCHR; ch++) oldm[ch] |= (u64)om[ch] << (32 * half);
                         }
                         // a lane can be accepted only if its own exact distance beats the current worst (when full)
-                        const bool canacc = iscand && (!full0 || tbits < W0b);
+                        const bool canacc = iscand && !isdup && (!full0 || tbits < W0b);
                         accmask = __ballot(canacc);
                         for (int round = 0; round < 66; round++) {
                             const u64 nxt = __ballot(canacc && (u32)ut_lo + (u32)__popcll(Mt & accmask) < (u32)cap);
@@ -1532,7 +1552,7 @@ DEV void search_body(const SearchParams &p)
             qi = (u32)__builtin_amdgcn_readfirstlane((int)t) - p.ticket_base + nslots;
         }
     }
-    if (lane == 0) p.vis_epoch[slot_id] = vstamp;
+    if (lane == 0 && !novis) p.vis_epoch[slot_id] = vstamp;
 }
 
 template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false, int TREG = 0>

@@ -10,7 +10,11 @@ Two layouts:
     (`gather_rows` when one rank needs them all).
   * graph-sharded (c5): every rank holds a disjoint id range [base, base + n_local) with its own sub-graph; every
     query runs on every shard; the per-shard top-k lists (local ids + shard base) are exchanged with ONE
-    all-gather of nq*k*(4+4) bytes per rank and merged in canonical (distance, id) order (`allgather_merge_topk`).
+    all-gather of (nq*k + 1) 64-bit words per rank -- packed (distance, id) keys and the rank's status word -- and merged
+    in canonical (distance, id) order (`allgather_merge_topk`). A rank whose local phase failed still joins the collective,
+    with an empty list and a non-zero status word: the call then fails on EVERY rank (`ShardExchangeError`) instead of
+    leaving the others blocked in the collective (dr_sharded_submit, csrc/comm.inc, is the device statement of the same
+    protocol).
 """
 import numpy as np
 
@@ -46,23 +50,69 @@ def merge_topk(ids_list, dist_list, k):
     return out_ids, out_dist
 
 
-def allgather_merge_topk(local_ids, local_dist, shard_base, k, group=None, device=None):
-    """Graph-sharded merge: local ids are shard-local; adds `shard_base`, all-gathers every rank's (ids, dist) with
-    one collective each and merges. Needs an initialised torch.distributed process group."""
+class ShardExchangeError(RuntimeError):
+    """Another rank of a graph-sharded search failed its local phase: the call fails on every rank (DR_E_REMOTE)."""
+
+    def __init__(self, statuses):
+        bad = {r: int(s) for r, s in enumerate(statuses) if int(s) != 0}
+        super().__init__("sharded search: rank(s) %s failed their local phase (status %s); every rank fails this call"
+                         % (sorted(bad), bad))
+        self.statuses = [int(s) for s in statuses]
+
+
+def pack_keys(ids, dist):
+    """(ids u32, dist f32) -> uint64 keys that order like (distance ascending, id ascending): an order-preserving map of
+    the distance's bits << 32 | id; empty slots (PAD), NaN and +inf -> ~0 (sort last). -0.0 packs as +0.0. This is the
+    form the lists travel in (csrc/comm.inc merge_topk_kernel, key_ord)."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    d = np.ascontiguousarray(dist, dtype=np.float32)
+    b = np.where(d == 0, np.float32(0.0), d).view(np.uint32).astype(np.uint64)
+    o = np.where(b >> np.uint64(31) != 0, b ^ np.uint64(0xFFFFFFFF), b ^ np.uint64(0x80000000))
+    keys = (o << np.uint64(32)) | ids.astype(np.uint64)
+    invalid = (ids == PAD) | np.isnan(d) | (d == np.float32(np.inf))
+    return np.where(invalid, np.uint64(0xFFFFFFFFFFFFFFFF), keys)
+
+
+def unpack_keys(keys):
+    """inverse of pack_keys: (ids, dist); ~0 -> (PAD, NaN)"""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    o = (keys >> np.uint64(32)).astype(np.uint32)
+    b = np.where(o >> np.uint32(31) != 0, o ^ np.uint32(0x80000000), o ^ np.uint32(0xFFFFFFFF)).astype(np.uint32)
+    ids = (keys & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    d = b.view(np.float32).copy()
+    empty = keys == np.uint64(0xFFFFFFFFFFFFFFFF)
+    ids[empty] = PAD
+    d[empty] = np.nan
+    return ids, d
+
+
+def allgather_merge_topk(local_ids, local_dist, shard_base, k, group=None, device=None, local_status=0):
+    """Graph-sharded merge: local ids are shard-local; adds `shard_base`, packs the list into 64-bit keys, puts this rank's
+    status word behind it and all-gathers the nq*k + 1 words of every rank with ONE collective, then merges. A rank calls
+    this even when its local phase failed (`local_status` != 0, any lists): if any rank's status is non-zero every rank
+    raises ShardExchangeError after the collective. Needs an initialised torch.distributed process group."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
+    local_ids = np.asarray(local_ids, dtype=np.uint32)
     gids = np.where(local_ids == PAD, PAD, (local_ids.astype(np.uint64) + np.uint64(shard_base)).astype(np.uint32))
-    t_ids = torch.from_numpy(gids.astype(np.int64))
-    t_dist = torch.from_numpy(np.ascontiguousarray(local_dist, dtype=np.float32))
+    keys = pack_keys(gids, local_dist)
+    if local_status:
+        keys = np.full_like(keys, np.uint64(0xFFFFFFFFFFFFFFFF))
+    nq, kk = keys.shape
+    words = np.concatenate([keys.reshape(-1), np.array([local_status], dtype=np.uint64)])
+    t = torch.from_numpy(words.view(np.int64).copy())      # (collectives have no unsigned 64-bit type: ship the bits)
     if device is not None:
-        t_ids, t_dist = t_ids.to(device), t_dist.to(device)
-    all_ids = [torch.empty_like(t_ids) for _ in range(world)]
-    all_dist = [torch.empty_like(t_dist) for _ in range(world)]
-    dist.all_gather(all_ids, t_ids, group=group)
-    dist.all_gather(all_dist, t_dist, group=group)
-    return merge_topk([a.cpu().numpy().astype(np.uint32) for a in all_ids], [a.cpu().numpy() for a in all_dist], k)
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    got = [o.cpu().numpy().view(np.uint64) for o in out]
+    statuses = [int(g[-1]) for g in got]
+    if any(statuses):
+        raise ShardExchangeError(statuses)
+    lists = [unpack_keys(g[:-1].reshape(nq, kk)) for g in got]
+    return merge_topk([a for a, _ in lists], [b for _, b in lists], k)
 
 
 def gather_rows(local_rows, group=None, device=None):

@@ -3,10 +3,12 @@ Vamana sub-graph and PQ codes on one GPU, every query runs on every shard, and t
 in canonical (distance, id) order.
 
 The GPU path is the C ABI's dr_sharded_search (include/diskrag_hip.h): lists of the shards of one process are merged by a
-device kernel, lists of different processes (one per GPU) travel in ONE RCCL all-gather per array over xGMI, issued on
-the device-resident results, and are merged on the device again -- no host staging, no PyTorch. `comm` is an
-`_ffi.Comm` (RCCL communicator; None for a single process). 1 process x 8 shards and 8 processes x 1 shard give the
-same answer.
+device kernel, lists of different processes (one per GPU) travel in ONE RCCL all-gather over xGMI -- packed 64-bit
+(distance, id) keys plus the rank's status word, issued on the device-resident merged list -- and are merged on the
+device again: no host staging, no PyTorch. `comm` is an `_ffi.Comm` (RCCL communicator; None for a single process).
+1 process x 8 shards and 8 processes x 1 shard give the same answer. A rank whose shards fail still joins the exchange
+and the call then fails on every rank (DR_E_REMOTE / ShardExchangeError) instead of hanging the others.
+`search_submit` is the pipelined form (two batches in flight: batch i+1 searches while batch i is exchanged).
 
 A host-logic twin (per-shard `search_batch` calls merged with numpy, optionally exchanged through a torch.distributed
 group that the caller passes in) is kept for objects that are not device indexes: it is what the 2-rank gloo test on
@@ -55,24 +57,55 @@ class ShardedSearch:
         """Every local shard searches all queries; returns (global ids [nq,k] PAD-padded, distances [nq,k] NaN-padded,
         info). Raises if any shard reports a non-zero status (nothing is dropped silently)."""
         if self._on_device():
-            ids, dist, status, ms = _ffi.sharded_search([sh.index for sh in self.shards], [sh.base for sh in self.shards],
-                                                        queries, k, L=L, beam_width=beam_width, mode=mode,
-                                                        band_policy=band_policy, flags=flags, comm=self.comm)
-            if int(status.max(initial=0)) != 0:
-                raise _ffi.DiskragHipError(-5, f"sharded search: status {int(status.max())}")
-            return ids, dist, {"status": status, "ms": {"search": float(ms[0]), "all_gather": float(ms[1]), "merge": float(ms[2])}}
-        ids_l, dist_l, stats_l = [], [], []
-        for sh in self.shards:
-            ids, dist, cnt, st = sh.index.search_batch(queries, k, L=L, beam_width=beam_width, mode=mode,
-                                                       band_policy=band_policy, flags=flags)
-            if int(st["status"].max(initial=0)) != 0:
-                raise _ffi.DiskragHipError(-5, f"shard at base {sh.base}: search status {int(st['status'].max())}")
-            ids_l.append(globalize(ids, sh.base))
-            dist_l.append(dist)
-            stats_l.append(st)
-        ids, dist = merge_topk(ids_l, dist_l, k)
+            return self.search_submit(queries, k, L=L, beam_width=beam_width, mode=mode, band_policy=band_policy, flags=flags).wait()
+        # ---- host-logic twin. The local phase may fail (a shard raises, a work area overflows): with a group the rank still
+        # joins the one collective -- empty list, non-zero status word -- so that nobody is left waiting in it, and every
+        # rank raises afterwards (the failing rank its own error, the others ShardExchangeError).
+        ids_l, dist_l, stats_l, err = [], [], [], None
+        try:
+            for sh in self.shards:
+                ids, dist, cnt, st = sh.index.search_batch(queries, k, L=L, beam_width=beam_width, mode=mode,
+                                                           band_policy=band_policy, flags=flags)
+                if int(st["status"].max(initial=0)) != 0:
+                    raise _ffi.DiskragHipError(-5, f"shard at base {sh.base}: search status {int(st['status'].max())}")
+                ids_l.append(globalize(ids, sh.base))
+                dist_l.append(dist)
+                stats_l.append(st)
+            ids, dist = merge_topk(ids_l, dist_l, k)
+        except Exception as e:           # noqa: BLE001 -- whatever it was, the other ranks must not hang on it
+            if self.group is None:
+                raise
+            err = e
+            nq = len(queries)
+            ids, dist = np.full((nq, k), PAD, dtype=np.uint32), np.full((nq, k), np.nan, dtype=np.float32)
         if self.group is not None:
-            from .parallel import allgather_merge_topk
-            # ids are already global: shard_base 0 in the exchange
-            ids, dist = allgather_merge_topk(ids, dist, 0, k, group=self.group, device=self.collective_device)
+            from .parallel import ShardExchangeError, allgather_merge_topk
+            try:
+                # ids are already global: shard_base 0 in the exchange
+                ids, dist = allgather_merge_topk(ids, dist, 0, k, group=self.group, device=self.collective_device,
+                                                 local_status=0 if err is None else 1)
+            except ShardExchangeError:
+                if err is not None:
+                    raise err
+                raise
         return ids, dist, stats_l
+
+    def search_submit(self, queries, k, L=100, beam_width=8, mode=_ffi.MODE_M3, band_policy=0, flags=_ffi.F_USE_PQ):
+        """Pipelined form for device shards (dr_sharded_submit): returns an object whose wait() gives what search_batch
+        returns. Two may be in flight; every rank must submit in the same order."""
+        if not self._on_device():
+            raise TypeError("search_submit needs device indexes")
+        job = _ffi.sharded_submit([sh.index for sh in self.shards], [sh.base for sh in self.shards], queries, k, L=L,
+                                  beam_width=beam_width, mode=mode, band_policy=band_policy, flags=flags, comm=self.comm)
+        return _PendingShardedSearch(job)
+
+
+class _PendingShardedSearch:
+    def __init__(self, job):
+        self._job = job
+
+    def wait(self):
+        ids, dist, status, ms = self._job.wait()
+        if int(status.max(initial=0)) != 0:
+            raise _ffi.DiskragHipError(-5, f"sharded search: status {int(status.max())}")
+        return ids, dist, {"status": status, "ms": {"search": float(ms[0]), "all_gather": float(ms[1]), "merge": float(ms[2])}}

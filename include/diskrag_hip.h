@@ -54,6 +54,7 @@ extern "C" {
 #define DR_E_NOPQ (-4)       /* mode needs PQ data but dr_index_set_pq was not called */
 #define DR_E_OVERFLOW (-5)   /* a per-query work area overflowed (see dr_stats.status) */
 #define DR_E_UNSUPPORTED (-6)
+#define DR_E_REMOTE (-7)      /* dr_sharded_search: another rank of the exchange failed its local phase (every rank fails the call) */
 
 typedef struct dr_index dr_index;
 
@@ -139,8 +140,13 @@ int dr_index_set_adjacency(dr_index *ix, const uint32_t *adj);
  * The id space is cut into disjoint ranges; every range is an index of its own (its own Vamana sub-graph, PQ codes)
  * on one GPU; every query runs on every shard; the per-shard top-k lists (shard-local ids + the shard's base) are
  * merged in canonical (distance ascending, id ascending) order. Across processes the lists travel in ONE RCCL
- * all-gather of nq*k*(4+4) bytes per rank (over xGMI inside a node), issued on the engine's stream on the
- * device-resident result arrays, and are merged by a device kernel -- no host staging, no PyTorch.
+ * all-gather of (nq*k + 1) * 8 bytes per rank (over xGMI inside a node) -- every entry one packed 64-bit key
+ * (order-preserving map of the distance's bits << 32 | id), plus the rank's status word -- issued on the exchange stream
+ * on the device-resident merged list, and are merged by a device kernel -- no host staging, no PyTorch.
+ * Failure protocol: every rank reaches the collective whatever happened to its own shards; a rank whose local phase failed
+ * sends an empty list and its error code in the status word, and the call then fails on EVERY rank (the local DR_E_* on the
+ * rank it belongs to, DR_E_REMOTE on the others) instead of leaving the others blocked in the collective. Only a failure to
+ * allocate the exchange buffers themselves cannot be told: the communicator is aborted (ncclCommAbort).
  *
  * dr_comm_unique_id: rank 0 creates the 128-byte RCCL id and hands it to the other ranks by whatever side channel the
  * host has (a file, a pipe, MPI); dr_comm_init is collective over the nranks processes (one process per GPU);
@@ -148,7 +154,10 @@ int dr_index_set_adjacency(dr_index *ix, const uint32_t *adj);
  * dr_sharded_search: runs (mode, flags) on each of this rank's `nshards` indexes (all on `comm`'s device; without a
  * comm: on the first shard's device, one process), merges them on the device, all-gathers and merges across ranks;
  * every rank receives the full result. id_base[s] is added to shard s's local ids. Output as dr_search_batch
- * (DR_PAD / NaN padded); out_status[nq] (may be NULL) receives the OR of the shards' dr_stats.status per query. */
+ * (DR_PAD / NaN padded); out_status[nq] (may be NULL) receives the OR of THIS rank's shards' dr_stats.status per query.
+ * dr_sharded_submit / dr_sharded_wait: the same call in two halves, two in flight (per first shard): batch i+1 is uploaded
+ * and searched while batch i is exchanged, merged and downloaded; the output buffers belong to the library until the
+ * ticket has been waited for (dr_sharded_wait takes shards[0] of the submit). All ranks must submit in the same order. */
 typedef struct dr_comm dr_comm;
 #define DR_COMM_ID_BYTES 128
 int dr_comm_unique_id(void *out_id /*[DR_COMM_ID_BYTES]*/);
@@ -159,6 +168,11 @@ int dr_sharded_search(dr_index *const *shards, const uint32_t *id_base, uint32_t
                       const float *queries, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width, uint32_t mode,
                       uint32_t band_policy, uint32_t flags, uint32_t *out_ids, float *out_dist, uint32_t *out_status,
                       float *out_ms /*[3] search, all-gather, merge (may be NULL)*/);
+int dr_sharded_submit(dr_index *const *shards, const uint32_t *id_base, uint32_t nshards, dr_comm *comm,
+                      const float *queries, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width, uint32_t mode,
+                      uint32_t band_policy, uint32_t flags, uint32_t *out_ids, float *out_dist, uint32_t *out_status,
+                      float *out_ms, uint64_t *out_ticket);
+int dr_sharded_wait(dr_index *first_shard, uint64_t ticket);
 /* The merge kernel alone, on host arrays (test seam): ids[S][nq][k] GLOBAL ids (DR_PAD = empty), dist[S][nq][k];
  * empty and NaN entries sort last and come out as DR_PAD / NaN. */
 int dr_merge_topk(int device, const uint32_t *ids, const float *dist, uint32_t S, uint32_t nq, uint32_t k,
@@ -219,10 +233,10 @@ int dr_batch_select(dr_index *ix, uint32_t slot);
  * nq/8 = 1250 queries is the per-GPU slice of SURVEY 8e's strong-scaling job): submits with equal (k, L, beam_width, mode,
  * band_policy, flags) that arrive while the search stream is busy are held and ride in ONE launch -- one ticket space over
  * their concatenated queries, one tie-order pass, one download; every ticket still gets exactly the bits a dr_search_batch
- * call of its own would return (queries are independent). A submit that finds fewer than three searches queued is launched at
+ * call of its own would return (queries are independent). A submit that finds fewer than two searches queued is launched at
  * once, so a lone request never waits; held submits are launched by the next submit that finds the stream running dry, by
  * any dr_search_wait (which keeps feeding the stream while it waits), by dr_search_flush, or when the group reaches
- * dr_set_coalesce's size (default 8192 queries; 0 = every submit is its own launch, the behaviour until round 3).
+ * dr_set_coalesce's size (default 10240 queries; 0 = every submit is its own launch, the behaviour until round 3).
  * If a launch fails, dr_search_wait of every ticket that rode in it answers the error. */
 #define DR_MAX_TICKETS 32u
 int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width,

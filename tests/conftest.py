@@ -20,6 +20,8 @@ INDEX_FIXTURES = {
     "sift128_R64_m32": "sift128", "sift128_R16_m32": "sift128",
     "unit1536_R16_m32": "unit1536", "unit1536_R16_m64": "unit1536",
     "faq32_R16_nopq": "faq32", "deep96_R32_m16": "deep96",
+    # round 4: the edges of the reference's legal PQ shapes (adaptive_pq.py:29,80-91): m = 96 (sub_dim 8), m = 128 (sub_dim 2), m = 4 (sub_dim 64)
+    "unit768_R16_m96": "unit768", "unit256_R16_m128": "unit256", "unit256_R16_m4": "unit256",
 }
 
 

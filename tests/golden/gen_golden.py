@@ -397,6 +397,28 @@ def main():
             dict(mode="M4", L=100, k=10),
         ])
 
+    # ---- round 4: the edges of the reference's legal PQ shapes (pydiskann/pq/adaptive_pq.py:29,80-91: m in {4 ... 128},
+    # sub_dim 2 ... 64; "high_accuracy" indexes of <= 50k points carry m = 96 / 128). New names only: the fixtures above are
+    # never regenerated by these (their graphs are time-seeded, Q15).
+    if want("unit768"):
+        x, q = ds_unit(778, 500, 768, 12, ncl=3, noise=1.0)
+        np.savez_compressed(HERE / "data_unit768.npz", vectors=x, queries=q)
+        build_index_fixture(work, "unit768_R16_m96", x, q, R=16, Lb=32, alpha=1.2, m=96, seed=61, cases=[
+            m1(100, 0, pol=0), m1(100, 0, pol=1), m1(20, 8, pol=0), m1(20, 8, pol=1),
+            dict(mode="M3", bw=8, k=5, use_pq=True),
+        ])
+    if want("unit256"):
+        x, q = ds_unit(779, 600, 256, 12, ncl=4, noise=1.0)
+        np.savez_compressed(HERE / "data_unit256.npz", vectors=x, queries=q)
+        build_index_fixture(work, "unit256_R16_m128", x, q, R=16, Lb=32, alpha=1.2, m=128, seed=62, cases=[
+            m1(100, 0, pol=0), m1(100, 0, pol=1), m1(20, 8, pol=1),
+            dict(mode="M3", bw=8, k=5, use_pq=True),
+        ])
+        build_index_fixture(work, "unit256_R16_m4", x, q, R=16, Lb=32, alpha=1.2, m=4, seed=63, cases=[
+            m1(100, 0, pol=0), m1(100, 0, pol=1), m1(20, 8, pol=0),
+            dict(mode="M3", bw=8, k=5, use_pq=True),
+        ])
+
 
 if __name__ == "__main__":
     main()

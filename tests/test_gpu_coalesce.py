@@ -45,7 +45,7 @@ def test_held_submits_ride_in_one_launch_and_return_their_own_bits(name, params)
         got[order[0]] = jobs[order[0]].wait()                                 # the first wait launches the whole group
         after = ix.pipeline_stats()
         assert after["launches"] == before["launches"] + 1 and after["tickets"] == before["tickets"] + len(jobs)
-        assert after["max_tickets_per_launch"] >= len(jobs) and after["queries"] == before["queries"] + sum(sizes)
+        assert after["max_tickets_per_launch"] >= len(jobs) and after["queries"] == before["queries"] + sum(len(b) for b in batches)
         for i in order[1:]:
             got[i] = jobs[i].wait()
         for i, w in enumerate(want):
@@ -89,7 +89,7 @@ def test_groups_split_on_parameters_capacity_and_flush():
         for j in jobs:
             assert _same(j.wait(), wa)
     finally:
-        ix.set_coalesce(8192)
+        ix.set_coalesce(10240)
         ix.debug_hold(False)
     ix.batch_sync()
 

@@ -79,7 +79,7 @@ def test_regime_probe_on_sift_scale_data():
         ids, dist, cnt, st = ix.search_batch(q, 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
         assert ix.debug_force_kind(-1) == 0                      # Q1: the policy is provably true, ADC skipped
         assert st["pq_evaluated"].sum() < 0.1 * st["pq"].sum()
-        assert ix.timing()["block"] == 1024                      # byte rows landed in LDS, 16 waves per workgroup
+        assert ix.timing()["variant"] == 17 and ix.timing()["block"] == 256    # byte rows landed in LDS; 96 queries < 4096 slots: the 4-wavefront workgroups
         ix.set_pq(cb, codes)                                     # a PQ change resets the probe
         assert ix.debug_force_kind(-1) == -1
     finally:
@@ -99,7 +99,7 @@ def test_byte_rows_are_lossless_and_only_for_integer_data():
     try:
         want = orc.search_batch(x, adj, q, medoid, orc.M1, 10, L=100, bw=8, codes=codes, codebook=cb, nthreads=8)
         blocks = {}
-        for kind in (9, 11, 13, -1):
+        for kind in (9, 11, 13, 16, 17, -1):
             ix.debug_force_kind(kind)
             for (L, bw) in ((100, 8), (100, 0), (300, 16), (20, 8)):
                 ids, dist, cnt, st = ix.search_batch(q, 10, L=L, beam_width=bw, mode=_ffi.MODE_M1)
@@ -108,9 +108,11 @@ def test_byte_rows_are_lossless_and_only_for_integer_data():
                 assert np.array_equal(ids, w[0]) and np.array_equal(dist.view(np.uint32), w[1].astype(np.float32).view(np.uint32))
                 assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), w[3])
             blocks[kind] = (ix.timing()["block"], ix.timing()["lds_bytes"])
-            assert ix.timing()["variant"] == (kind if kind >= 0 else 13)   # integer data AND integer queries: 13
+            # integer data AND integer queries: 13 -- as 17 (4-wavefront workgroups) for a batch below the chip's 4096 wavefront slots
+            assert ix.timing()["variant"] == (kind if kind >= 0 else 17)
         assert blocks[9][0] == 768 and blocks[11][0] == 1024 and blocks[11][1] < blocks[9][1] + 4 * 8192
-        assert blocks[-1] == blocks[13] and blocks[13][0] == blocks[11][0] and blocks[13][1] == blocks[11][1] + 16 * 528   # + adjacency landing areas
+        assert blocks[13][0] == blocks[11][0] and blocks[13][1] == blocks[11][1] + 16 * 528   # + adjacency landing areas
+        assert blocks[-1] == blocks[17] and blocks[17] == (256, blocks[13][1] // 4) and blocks[16] == (256, blocks[11][1] // 4)
         # byte queries (13 / 14: v_dot4_u32_u8 distances) are taken only when EVERY component of the batch is an integer
         # in [0, 255]; one fractional, negative or too-large component and the batch runs on the float-query variants.
         # Extreme integer queries (all 0 / all 255 against rows up to 218) stay exact as well.

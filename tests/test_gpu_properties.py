@@ -52,7 +52,7 @@ def test_counters_are_consistent(big):
     assert (st["exact"] <= st["visited"]).all() and (st["pq_evaluated"] <= st["pq"]).all()
     assert (st["steps"] <= 1000).all() and (st["inserts"] <= st["exact"]).all()
     # byte-row variant, R = 64, bit order on: the adjacency row of the predicted next node is prefetched into LDS
-    assert ix.timing()["variant"] == 13
+    assert ix.timing()["variant"] in (13, 17)      # (17: the same kernel in 4-wavefront workgroups, batches below 4096 queries)
     assert (st["adj_prefetch_hits"] < st["steps"]).all() and st["adj_prefetch_hits"].sum() > 0.5 * st["steps"].sum()
     ix.debug_force_kind(9)
     try:

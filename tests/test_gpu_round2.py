@@ -372,6 +372,37 @@ def test_pq_prune_kernel_equals_its_restatement(D, m):
         sh.close()
 
 
+def test_centroid_pair_table_follows_the_codebook():
+    """the centroid-pair table of the PQ-only builder is cached on the handle; replacing the codebook (set_pq with
+    another m, pq_encode) must rebuild it -- dr_debug_prune_pq right after each change against the restatement on the NEW
+    codebook (a stale table scores with the old centroids; with a larger m it was read out of bounds)."""
+    from diskrag_amd import HipIndex
+    from diskrag_amd.synth import unit_mixture
+    from oracle import pybuild
+    rs = np.random.RandomState(3)
+    x, _ = unit_mixture(2500, 128, n_queries=4, n_clusters=16, seed=8, latent=10)
+    ix = HipIndex.create_empty(x, R=16)
+    try:
+        books = {}
+        for m in (16, 32, 8, 32):
+            cb = ix.pq_train(m, n_sample=2500, iters=3, seed=100 + len(books) + m)     # (the second m = 32 book differs from the first)
+            codes = ix.pq_encode(cb, want_codes=True)          # replaces codebook and m on the handle
+            books[(m, len(books))] = (cb, codes)
+            for trial in range(6):
+                p = int(rs.randint(len(x)))
+                cands = rs.choice(len(x), size=int(rs.choice([17, 64, 130])), replace=False).astype(np.uint32)
+                got = ix.debug_prune_pq(p, cands, 1.2, 16)
+                want = pybuild.robust_prune_pq(cb, codes, p, cands, 1.2, 16)
+                assert got.tolist() == want.tolist(), (m, trial)
+        # set_pq (host-side codes + codebook) invalidates it too
+        (cb, codes) = books[(16, 0)]
+        ix.set_pq(cb, codes)
+        p, cands = 7, rs.choice(len(x), size=90, replace=False).astype(np.uint32)
+        assert ix.debug_prune_pq(p, cands, 1.2, 16).tolist() == pybuild.robust_prune_pq(cb, codes, p, cands, 1.2, 16).tolist()
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("name,m", [("sift128", 32), ("deep96", 16)])
 def test_pq_trainer_reaches_the_reference_quantisation_error(name, m):
     """N2: k-means++ / n_init / Lloyd on the device vs DiskANNPQ.fit (sklearn) on the same vectors: the summed inertia is

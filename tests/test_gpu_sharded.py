@@ -92,3 +92,59 @@ def test_pq_only_shard_without_vectors():
     with pytest.raises(DiskragHipError):
         ix.search_batch(q, 10, L=50, mode=_ffi.MODE_M1)
     ix.close()
+
+
+def test_pipelined_sharded_submits_and_the_failure_protocol():
+    """Round 4: dr_sharded_submit / dr_sharded_wait -- two batches in flight, any wait order, more submits
+    than work areas -- return the bits of the blocking call; the lists travel as packed keys + a status word in ONE
+    all-gather (a real one-rank RCCL communicator here); a rank whose shard cannot run the mode reports the error through
+    the exchange instead of leaving it, and the handles keep working."""
+    import pytest
+    from diskrag_amd import HipIndex, _ffi
+    from diskrag_amd.parallel import shard_slice
+    from diskrag_amd.synth import sift_like
+    n, nshard, k = 12000, 3, 10
+    x, q = sift_like(n, 128, n_queries=120, n_clusters=32, seed=31, query_seed=32)
+    shards, bases, cb = [], [], None
+    for s in range(nshard):
+        sl = shard_slice(n, nshard, s)
+        ix = HipIndex.create_empty(x[sl], R=32)
+        ix.build_vamana(L_build=50, alpha=1.2, passes=2, seed=9 + s, pad_with_zero=False)
+        if cb is None:
+            cb = ix.pq_train(16, n_sample=4000, iters=4)
+        ix.pq_encode(cb)
+        shards.append(ix); bases.append(sl.start)
+    nopq = HipIndex.create_empty(x[:4000], R=32)           # a shard that was never encoded: DR_MODE_PQ fails on it (DR_E_NOPQ)
+    nopq.build_vamana(L_build=50, alpha=1.2, passes=2, seed=3, pad_with_zero=False)
+    comm = _ffi.Comm(_ffi.Comm.unique_id(), 1, 0, 0)
+    try:
+        batches = [np.ascontiguousarray(q[a:b]) for a, b in ((0, 120), (0, 7), (7, 60), (60, 61), (30, 120))]
+        for c in (comm, None):
+            want = [_ffi.sharded_search(shards, bases, b, k, L=60, beam_width=8, mode=_ffi.MODE_PQ, comm=c) for b in batches]
+            jobs = [_ffi.sharded_submit(shards, bases, b, k, L=60, beam_width=8, mode=_ffi.MODE_PQ, comm=c) for b in batches]
+            for i in (4, 0, 2, 1, 3):
+                ids, dist, status, ms = jobs[i].wait()
+                assert np.array_equal(ids, want[i][0]) and np.array_equal(dist.view(np.uint32), want[i][1].view(np.uint32))
+                assert np.array_equal(status, want[i][2])
+            # the local phase fails on the second shard: the call comes back with THAT error (the exchange still ran) ...
+            with pytest.raises(_ffi.DiskragHipError) as ei:
+                _ffi.sharded_search([shards[0], nopq, shards[2]], [0, 4000, 8000], batches[0], k, L=60, beam_width=8, mode=_ffi.MODE_PQ, comm=c)
+            assert ei.value.code == _ffi.E_NOPQ
+            # ... a failing submit between two good ones does not disturb them ...
+            j0 = _ffi.sharded_submit(shards, bases, batches[2], k, L=60, beam_width=8, mode=_ffi.MODE_PQ, comm=c)
+            jbad = _ffi.sharded_submit([nopq] + shards[1:], bases, batches[2], k, L=60, beam_width=8, mode=_ffi.MODE_PQ, comm=c)
+            j1 = _ffi.sharded_submit(shards, bases, batches[4], k, L=60, beam_width=8, mode=_ffi.MODE_PQ, comm=c)
+            assert np.array_equal(j1.wait()[0], want[4][0])
+            assert np.array_equal(j0.wait()[0], want[2][0])
+            with pytest.raises(_ffi.DiskragHipError):
+                jbad.wait()
+            # ... and everything still answers afterwards, the shard that had work queued when the call failed included
+            ids, dist, _, _ = _ffi.sharded_search(shards, bases, batches[0], k, L=60, beam_width=8, mode=_ffi.MODE_PQ, comm=c)
+            assert np.array_equal(ids, want[0][0]) and np.array_equal(dist.view(np.uint32), want[0][1].view(np.uint32))
+            one = shards[0].search_batch(batches[1], k, L=60, beam_width=8, mode=_ffi.MODE_PQ)
+            assert (one[3]["status"] == 0).all()
+    finally:
+        comm.close()
+        nopq.close()
+        for ix in shards:
+            ix.close()

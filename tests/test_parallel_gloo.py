@@ -126,3 +126,88 @@ def test_strong_scaling_slices_tile_any_batch():
             sl = [bench.slice_of(nq, world, r) for r in range(world)]
             assert sl[0][0] == 0 and sl[-1][1] == nq and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
             assert max(h - l for l, h in sl) - min(h - l for l, h in sl) <= 1
+
+
+def test_packed_keys_order_and_round_trip():
+    """the form the lists travel in (ONE all-gather of 64-bit words): order = (distance, id), distances survive bit for bit"""
+    from diskrag_amd.parallel import PAD, merge_topk, pack_keys, unpack_keys
+    rs = np.random.RandomState(4)
+    d = np.abs(rs.randn(6, 9)).astype(np.float32)
+    d[0, 0] = np.nan; d[1, 1] = np.inf; d[2, 2] = 0.0; d[3, 3] = d[3, 4]            # a tie on distance: id decides
+    ids = rs.randint(0, 2 ** 32 - 2, size=(6, 9)).astype(np.uint32)
+    ids[4, 4] = PAD
+    keys = pack_keys(ids, d)
+    i2, d2 = unpack_keys(keys)
+    valid = ~np.isnan(d) & (d != np.inf) & (ids != PAD)
+    assert np.array_equal(i2[valid], ids[valid]) and np.array_equal(d2[valid].view(np.uint32), d[valid].view(np.uint32))
+    assert (i2[~valid] == PAD).all() and np.isnan(d2[~valid]).all()
+    # sorting the keys IS the canonical merge
+    want_ids, want_d = merge_topk([ids], [d], 9)
+    si, sd = unpack_keys(np.sort(keys, axis=1))
+    assert np.array_equal(si, want_ids) and np.array_equal(sd.view(np.uint32), want_d.view(np.uint32))
+    assert pack_keys(np.array([[3]], np.uint32), np.array([[-0.0]], np.float32)) == pack_keys(np.array([[3]], np.uint32), np.array([[0.0]], np.float32))
+
+
+def _failing_worker(rank, world, port, ret):
+    """rank 1's shard raises in its local phase: BOTH ranks must come back (with an error), nobody blocks in the collective;
+    the next call, with healthy shards, works -- the protocol left nothing behind"""
+    import torch.distributed as dist
+    from diskrag_amd import parallel
+    from diskrag_amd.sharded import GraphShard, ShardedSearch
+    from oracle import pyoracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = load_golden("sift128_R64_m32")
+        n, k = len(g.vectors), 5
+        own = parallel.shard_slice(n, world, rank)
+
+        class Shard:
+            def __init__(self, vecs, broken):
+                self.v, self.broken = vecs, broken
+
+            def search_batch(self, queries, k, L=100, beam_width=0, mode=0, band_policy=0, flags=0):
+                if self.broken:
+                    raise RuntimeError("shard without PQ data")
+                li = orc.bruteforce_topk(self.v, queries, k)
+                ld = np.array([[orc.sqdist(self.v[i], q) for i in row] for row, q in zip(li, queries)], dtype=np.float32)
+                return li, ld, np.full(len(queries), k, dtype=np.uint32), np.zeros(len(queries), dtype=[("status", np.uint32)])
+
+        q = g.queries[:8]
+        outcome = []
+        for broken in (rank == 1, False, rank == 0):
+            eng = ShardedSearch([GraphShard(Shard(g.vectors[own], broken), own.start)], group=dist.group.WORLD)
+            try:
+                ids, d, _ = eng.search_batch(q, k)
+                outcome.append(("ok", ids))
+            except parallel.ShardExchangeError as e:
+                outcome.append(("remote", e.statuses))
+            except RuntimeError as e:
+                outcome.append(("local", str(e)))
+        ret[rank] = outcome
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_fails_the_call_on_every_rank_and_hangs_nobody():
+    import torch.multiprocessing as mp
+    from oracle import pyoracle as orc
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0, "a rank hung or died"
+    g = load_golden("sift128_R64_m32")
+    gt = orc.bruteforce_topk(g.vectors, g.queries[:8], 5)
+    r0, r1 = ret[0], ret[1]
+    assert r0[0] == ("remote", [0, 1]) and r1[0] == ("local", "shard without PQ data")      # call 1: rank 1 failed
+    assert r0[1][0] == "ok" and r1[1][0] == "ok"                                            # call 2: healthy
+    assert np.array_equal(r0[1][1], r1[1][1])
+    assert all(set(a.tolist()) == set(b.tolist()) for a, b in zip(r0[1][1], gt))            # (sets: ties may order differently from the brute force)
+    assert r0[2] == ("local", "shard without PQ data") and r1[2] == ("remote", [1, 0])      # call 3: rank 0 failed
