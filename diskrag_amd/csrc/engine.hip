@@ -939,7 +939,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     const uint32_t vis_words = (uint32_t)(((ix->N + 23) / 24 + 3) & ~3ull);
     // The engine's own ADC traversals (DR_MODE_PQ, the PQ-only builder's searches) keep NO visited set (SearchParams::novis):
     // no visited words (20 MB per wavefront slot on a 1.25e8-point shard), no bit-position twin of the adjacency.
-    static const bool keep_vis = getenv("DR_PQ_VISITED_SET") != nullptr;       // A/B: round 3's form
+    const bool keep_vis = getenv("DR_PQ_VISITED_SET") != nullptr;       // A/B: round 3's form (read per launch: a script flips it between runs)
     const bool novis = !keep_vis && (mode == DR_MODE_PQ || (ov && ov->sdc));
     if (!novis && ((size_t)slots * vis_words > vis.n || slots > vis_epoch.n)) {
         // (re)allocation: fresh words and stamps -- queued launches still use the old buffers

@@ -891,12 +891,19 @@ DEV void search_body(const SearchParams &p)
                 const u32 sl = min(slot, p.R - 1);
                 u32 nbid_l, nbpos_l;
                 u64 aux_w;
+                uint4 cw0 = make_uint4(0, 0, 0, 0), cw1 = cw0, cw2 = cw0, cw3 = cw0;
+                // No visited set AND inline neighbour codes: where a slot's code word lives depends on the popped node alone, so
+                // the row's code words leave WITH its ids and mask -- ONE memory round trip per expansion instead of two (ids, then
+                // the code words of those ids), R*m contiguous bytes instead of R scattered gathers. (A slot that turns out to be a
+                // pad or a repeat costs its 32 bytes of a line that is read anyway.)
+                const bool codes_with_row = SPEC_CODES && novis && p.nbcodes != nullptr;
                 if (ADJPRE && pre_hit) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     nbid_l = pre_buf[lane]; nbpos_l = pre_buf[64 + lane];
                     aux_w = *reinterpret_cast<const u64 *>(pre_buf + 128);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // read before the next prefetch reuses the area
                 } else { nbid_l = idrow[sl]; nbpos_l = novis ? 0u : posrow[sl]; aux_w = auxp[0]; }
+                if constexpr (SPEC_CODES) { if (codes_with_row) adc_load_codes(cw0, cw1, cw2, cw3, p.nbcodes + ((size_t)cur * p.R + sl) * p.m, p.m); }
                 // Predict the next pop -- the best frontier entry that is left now (this expansion's neighbours may still
                 // beat it) -- and land ITS adjacency row in LDS: no VGPR destination, nobody waits for it, and when the
                 // prediction holds the next expansion starts without its first global round trip.
@@ -967,7 +974,6 @@ DEV void search_body(const SearchParams &p)
                 // unless the bound that lets the expansion skip the ADC already holds with every active lane counted as
                 // new (a superset of the final need_adc below, so the registers are loaded whenever they are used). The
                 // few code words of neighbours that turn out to be visited are wasted requests (~15 %).
-                uint4 cw0 = make_uint4(0, 0, 0, 0), cw1 = cw0, cw2 = cw0, cw3 = cw0;
                 // (inline neighbour codes: the slot's code word sits in the block beside the adjacency row -- one coalesced
                 // read of R*m bytes per expansion instead of a scattered m-byte gather per neighbour)
                 const u8 *mycode = p.nbcodes ? p.nbcodes + ((size_t)cur * p.R + min(slot, p.R - 1)) * p.m : p.codes + (size_t)nbid * p.m;
@@ -981,7 +987,7 @@ DEV void search_body(const SearchParams &p)
                             if (pq_ub < f_mul(Wlow, 0.8f)) spec = false;
                         }
                     }
-                    if (spec && active) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m);
+                    if (spec && active && !codes_with_row) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m);
                 }
                 if (novis) isnew = active;      // every neighbour is scored; the list itself says which are already in it (decisions)
                 else {

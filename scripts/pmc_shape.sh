@@ -9,6 +9,7 @@ run write "WRITE_SIZE"
 run sqa "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU"
 run tcca "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum"
 run tccb "TCC_REQ_sum TCC_READ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
+run tccc "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum TCC_WRITE_sum"
 run sqb "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA"
 python3 - $S $N <<'PY'
 import csv, glob, json, sys
@@ -43,12 +44,22 @@ if fs is not None:
 if cal: out["calibration"] = {"known_bytes": out.get("calib_bytes"), "corrected_bytes": cal * 1024 * 2}
 sq = {}
 tcc = {}
-for d in ("tcca", "tccb"):
+for d in ("tcca", "tccb", "tccc"):
     rs = rows(d)
     for c in sorted({r["Counter_Name"] for r in rs}):
         v = mean_last(rs, c, sub)
         if v is not None: tcc[c] = v
 out["tcc"] = tcc
+# byte-exact read traffic from the request-size split (profiles/r04/tcc_calibration.json: FETCH_SIZE counts 64 B per request whatever its size)
+if "TCC_EA0_RDREQ_sum" in tcc and "TCC_EA0_RDREQ_128B_sum" in tcc:
+    n128, n64 = tcc["TCC_EA0_RDREQ_128B_sum"], tcc.get("TCC_EA0_RDREQ_64B_sum", 0.0)
+    n32 = tcc.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+    rest = max(0.0, tcc["TCC_EA0_RDREQ_sum"] - n128 - n64 - n32)
+    out["read_bytes_by_request_size"] = {"requests": tcc["TCC_EA0_RDREQ_sum"], "128B": n128, "64B": n64, "32B": n32, "unsized_counted_as_64B": rest,
+                                         "bytes": 128 * n128 + 64 * (n64 + rest) + 32 * n32}
+    if "write_bytes_per_launch" in out:
+        out["hbm_bytes_per_launch_by_request_size"] = out["read_bytes_by_request_size"]["bytes"] + out["write_bytes_per_launch"]
+        out["traffic_over_algorithmic_by_request_size"] = out["hbm_bytes_per_launch_by_request_size"] / out.get("alg_bytes_per_launch", float("nan"))
 for d in ("sqa", "sqb"):
     rs = rows(d)
     for c in sorted({r["Counter_Name"] for r in rs}):
@@ -60,4 +71,4 @@ json.dump(out, open(f"gpurun_out/pmc_{S}/summary.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "sq"}, indent=1))
 PY
 # the raw counter CSVs (one row per dispatch, the builder launches hundreds of thousands) stay on the box: gpurun_out is capped at 64 MiB
-rm -rf $OUT/fetch $OUT/write $OUT/sqa $OUT/sqb $OUT/tcca $OUT/tccb
+rm -rf $OUT/fetch $OUT/write $OUT/sqa $OUT/sqb $OUT/tcca $OUT/tccb $OUT/tccc

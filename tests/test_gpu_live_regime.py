@@ -125,7 +125,9 @@ def test_byte_rows_are_lossless_and_only_for_integer_data():
             for kind in (13, -1):
                 ix.debug_force_kind(kind)
                 ids, dist, cnt, st = ix.search_batch(qq, 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
-                assert ix.timing()["variant"] == (13 if name == "extreme" else 11), name
+                # (16 / 17: the 4-wavefront workgroups of 11 / 13 -- these batches are far below the chip's 4096 wavefront slots; a forced
+                # variant that applies is kept as forced)
+                assert ix.timing()["variant"] == ((13 if kind == 13 else 17) if name == "extreme" else 16), name
                 assert np.array_equal(ids, w[0]) and np.array_equal(dist.view(np.uint32), w[1].astype(np.float32).view(np.uint32)), name
                 assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), w[3]), name
         # the exact traversals: float rows (8) == byte rows (12) == byte rows and queries (14) == oracle
