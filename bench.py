@@ -533,7 +533,8 @@ def worker_c2(args, rk):
     recall = sum(r * n for r, n in recalls) / sum(n for _, n in recalls) if strong else recall_local
     if recall < args.min_recall:
         raise RuntimeError(f"recall@{k} = {recall:.4f} is below the metric's bar {args.min_recall}")
-    variant = ix.timing()["variant"]
+    variant_launched = ix.timing()["variant"]
+    variant = {16: 11, 17: 13}.get(variant_launched, variant_launched)      # (16 / 17: the same kernels in 4-wavefront workgroups, batches below 4096 queries)
     a_all, per_q = alg_bytes(st, D, args.R, args.m, k)
     alg_launch = (a_all - 4 * 256 * D) / nb + 4 * 256 * D      # per 10k-query launch
     k_ms = float(tm_head["search_kernel_ms"])                    # mean launch duration over the timed pipelined region
@@ -561,13 +562,13 @@ def worker_c2(args, rk):
     # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 read
     # correction applied): collected offline on this same workload by scripts/profile_run.sh, committed under profiles/
     traffic, traffic_src = None, None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         pmc = ROOT / "profiles" / rnd / "pmc_traffic.json"
         if traffic is None and pmc.exists() and (args.n, nq, D, args.R, args.L, args.m) == (1_000_000, 10_000, 128, 64, 100, 32):
             rec = json.loads(pmc.read_text()).get("beam_width_%d" % args.bw)
             if rec and (rnd != "r01" or variant == 13):
                 traffic = rec["hbm_bytes_per_launch"]
-                traffic_src = ("profiles/%s/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes over scripts/pmc_target.py "
+                traffic_src = ("profiles/%s/pmc_traffic.json: rocprofv3 --pmc read requests by size (TCC_EA0_RDREQ_32B/64B/128B; FETCH_SIZE x2 before round 4) + WRITE_SIZE, separate passes over scripts/pmc_target.py "
                                "-- the same workload and build, collected by scripts/profile_run.sh in ANOTHER run on another box of the pool (a PMC pass "
                                "cannot share a process with the timed region); hbm_frac divides it by THIS run's kernel time") % rnd
 
@@ -664,7 +665,7 @@ def worker_c2(args, rk):
                                      if variant == 13 else "f32"),
                    "float32_rows": float_rows, "byte_rows_float32_queries": float_queries,
                    "small_batches_on_one_gpu": small_batch, "strong_scaling": strong_cfg, "pq_scan": pq_scan},
-        "roofline": {"bound": "hbm", "kernel": "search_kernel<128,M1> variant %d" % variant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+        "roofline": {"bound": "hbm", "kernel": "search_kernel<128,M1> variant %d" % variant_launched, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "hbm_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_kernel,

@@ -16,7 +16,7 @@ MODE_M1, MODE_M2, MODE_M3, MODE_M4 = 1, 2, 3, 4
 PIPE_DEPTH = 4          # DR_PIPE_DEPTH (csrc/engine.hip): LAUNCHES of the pipelined path in flight per handle
 MAX_TICKETS = 32        # DR_MAX_TICKETS (include/diskrag_hip.h): dr_search_submit tickets in flight (small submits share launches)
 MODE_PQ = 5      # engine mode without a reference counterpart: M1's loop on squared ADC distances only (diskrag_hip.h)
-F_USE_PQ, F_SQDIST, F_RERANK, F_COSINE = 1, 2, 4, 8
+F_USE_PQ, F_SQDIST, F_RERANK, F_COSINE, F_NO_VISITED_SET = 1, 2, 4, 8, 16
 TIER_HBM, TIER_HOST = 0, 1       # where the full-precision rows live (dr_index_*_tiered)
 MAX_RESIDENT = 16
 COMM_ID_BYTES = 128
@@ -40,7 +40,7 @@ STATS_DTYPE = np.dtype([("steps", "<u4"), ("visited", "<u4"), ("exact", "<u4"), 
 
 # every symbol include/diskrag_hip.h declares
 EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create", "dr_index_set_pq",
-           "dr_index_set_adjacency", "dr_index_open_tiered", "dr_index_create_tiered", "dr_index_create_empty_tiered", "dr_search_batch", "dr_batch_upload", "dr_batch_run", "dr_batch_download",
+           "dr_index_set_adjacency", "dr_index_open_tiered", "dr_index_create_tiered", "dr_index_create_empty_tiered", "dr_index_write_rows", "dr_search_batch", "dr_batch_upload", "dr_batch_run", "dr_batch_download",
            "dr_get_timing", "dr_exact_distances", "dr_distance_table", "dr_adc", "dr_pq_scan",
            "dr_bruteforce_topk", "dr_get_node", "dr_index_close", "dr_index_create_empty", "dr_build_vamana",
            "dr_get_adjacency", "dr_pq_train", "dr_pq_encode", "dr_debug_phase_cycles", "dr_batch_sync",
@@ -84,6 +84,8 @@ def load_library():
     L.dr_index_create_tiered.argtypes = [C.POINTER(vp), fp, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
     L.dr_index_create_empty_tiered.restype = C.c_int
     L.dr_index_create_empty_tiered.argtypes = [C.POINTER(vp), fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
+    L.dr_index_write_rows.restype = C.c_int
+    L.dr_index_write_rows.argtypes = [vp, fp, C.c_uint64, C.c_uint64]
     L.dr_pq_scan_best.restype = C.c_int
     L.dr_pq_scan_best.argtypes = [vp, fp, C.c_uint32, fp, u32p, fp, fp]
     L.dr_index_create_codes.restype = C.c_int
@@ -244,6 +246,20 @@ class HipIndex:
         h = C.c_void_p()
         _check(L.dr_index_create_empty_tiered(C.byref(h), _p(vectors, C.c_float), N, D, int(R), int(device), int(vector_tier)))
         return cls(h, N, D, R, 0)
+
+    @classmethod
+    def create_rows_empty(cls, N, D, R, device=0, vector_tier=TIER_HBM):
+        """An index of N x D rows that arrive later through write_rows() (a stream: generated, or read chunk by chunk); the
+        graph is then built on the device. With TIER_HOST the rows live in pinned host memory."""
+        h = C.c_void_p()
+        _check(load_library().dr_index_create_empty_tiered(C.byref(h), None, int(N), int(D), int(R), int(device), int(vector_tier)))
+        return cls(h, int(N), int(D), int(R), 0)
+
+    def write_rows(self, rows, row0):
+        v = np.ascontiguousarray(rows, dtype=np.float32)
+        if v.ndim != 2 or v.shape[1] != self.D:
+            raise ValueError(f"rows must be [n, {self.D}]")
+        _check(load_library().dr_index_write_rows(self._h, _p(v, C.c_float), int(row0), v.shape[0]))
 
     @classmethod
     def create_codes(cls, adj, medoid, D, codebook, codes, device=0):

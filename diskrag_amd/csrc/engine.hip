@@ -937,10 +937,10 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // visited set: per wavefront slot one word per 24 bit positions (+ an 8-bit query stamp: nothing is cleared
     // between queries, search_kernel.hpp) and the slot's stamp counter
     const uint32_t vis_words = (uint32_t)(((ix->N + 23) / 24 + 3) & ~3ull);
-    // The engine's own ADC traversals (DR_MODE_PQ, the PQ-only builder's searches) keep NO visited set (SearchParams::novis):
-    // no visited words (20 MB per wavefront slot on a 1.25e8-point shard), no bit-position twin of the adjacency.
-    const bool keep_vis = getenv("DR_PQ_VISITED_SET") != nullptr;       // A/B: round 3's form (read per launch: a script flips it between runs)
-    const bool novis = !keep_vis && (mode == DR_MODE_PQ || (ov && ov->sdc));
+    // DR_F_NO_VISITED_SET (DR_MODE_PQ): the traversal keeps NO visited set (SearchParams::novis) -- no visited words (20 MB per
+    // wavefront slot on a 1.25e8-point shard), no bit-position twin of the adjacency; same results, more evaluations.
+    if ((flags & DR_F_NO_VISITED_SET) && mode != DR_MODE_PQ) return fail(DR_E_ARG, "DR_F_NO_VISITED_SET goes with DR_MODE_PQ");
+    const bool novis = !ov && mode == DR_MODE_PQ && (flags & DR_F_NO_VISITED_SET) != 0;
     if (!novis && ((size_t)slots * vis_words > vis.n || slots > vis_epoch.n)) {
         // (re)allocation: fresh words and stamps -- queued launches still use the old buffers
         if (vis.p) HIPCHK(hipStreamSynchronize(st));
@@ -970,7 +970,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (!ov && ix->inline_codes && !ix->nbcodes_valid && ix->codes.p && (mode == DR_MODE_M1 || pq_only)) { const int rci = build_inline_codes(ix); if (rci) return rci; }
     p.vecp = ix->vecp.p; p.adj = ix->adj.p; p.first = ix->first.p; p.codes = ix->codes.p; p.codebook = ix->codebook.p;
     p.adjr = (!ov && !novis && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
-    p.novis = novis ? 1u : 0u;
+    const bool rowpre = getenv("DR_PQ_ROW_PREFETCH") != nullptr;      // A/B (round 4): ids of the predicted next pop's row landed in LDS
+    p.novis = novis ? (1u | (rowpre && !(ov && ov->sdc) ? 2u : 0u)) : 0u;
     p.nbcodes = (!ov && ix->inline_codes && ix->nbcodes_valid) ? ix->nbcodes.p : nullptr;
     p.vec8 = ix->vec8_state == 1 ? ix->vec8.p : nullptr;
     // chain-major copy of the batch: the builder hands nothing else; a batch uploaded without it (dr_search_submit, D <= 256)
@@ -1449,10 +1450,30 @@ extern "C" int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq,
 extern "C" int dr_search_wait(dr_index *ix, uint64_t ticket)
 {
     if (!ix) return fail(DR_E_ARG, "null index");
-    std::lock_guard<std::mutex> lk(ix->mu);
+    std::unique_lock<std::mutex> lk(ix->mu);
     if (ticket == 0 || ticket >= ix->next_ticket) return fail(DR_E_ARG, "unknown ticket %llu", (unsigned long long)ticket);
-    for (int j = 0; j < DR_MAX_JOBS; j++)
-        if (ix->jobs[j].active && ix->jobs[j].ticket == ticket) { const int rc = finish_job_locked(ix, j); if (rc) return rc; break; }
+    HIPCHK(hipSetDevice(ix->device));
+    // The handle is NOT held while the ticket's results are on their way: other threads submit meanwhile (their requests ride
+    // in the launch this one may still be waiting for -- a pool of request handlers, one query each, app.py:84-130), and the
+    // waiting thread is the one that keeps the launch policy running.
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        int j = -1;
+        for (int i = 0; i < DR_MAX_JOBS; i++) if (ix->jobs[i].active && ix->jobs[i].ticket == ticket) j = i;
+        if (j < 0) break;                 // finished meanwhile (a submit or a sync needed its slot)
+        PipeJob &jb = ix->jobs[j];
+        PipeGroup &gr = ix->groups[jb.group];
+        // still collecting: launched by the policy once fewer than two searches are queued (at once under the test hook)
+        if (!jb.rc && gr.state == 1) (void)kick_locked(ix, ix->hold_always);
+        else (void)kick_locked(ix);       // (another group may be collecting: keep the search stream fed)
+        bool ready = jb.rc != 0;
+        if (!ready && gr.state == 2) { ready = hipEventQuery(gr.down_done) != hipErrorNotReady; (void)hipGetLastError(); }
+        if (ready) { const int rc = finish_job_locked(ix, j); if (rc) return rc; break; }
+        lk.unlock();
+        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(300)) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        lk.lock();
+    }
     auto it = ix->failed_tickets.find(ticket);
     if (it != ix->failed_tickets.end()) {
         const int rc = it->second.first; g_err = it->second.second;
@@ -1883,13 +1904,15 @@ extern "C" int dr_index_create_empty(dr_index **out, const float *vectors, uint6
 extern "C" int dr_index_create_empty_tiered(dr_index **out, const float *vectors, uint64_t N, uint32_t D, uint32_t R, int device,
                                             uint32_t vector_tier)
 {
-    if (!out || !vectors) return fail(DR_E_ARG, "null argument");
+    if (!out) return fail(DR_E_ARG, "null argument");
     dr_index *ix = new dr_index();
     int rc = index_alloc_common(ix, N, D, R, 0, device, true, vector_tier);
     if (rc) { dr_index_close(ix); return rc; }
     DevBuf<uint32_t> staging;
     const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / (D * 4));
-    for (uint64_t r0 = 0; r0 < N && !rc; r0 += chunk) {
+    // (vectors == NULL: the rows arrive later, chunk by chunk, through dr_index_write_rows -- an index whose rows do not fit in
+    // host memory twice, or are generated / read as a stream)
+    for (uint64_t r0 = 0; vectors && r0 < N && !rc; r0 += chunk) {
         const uint64_t rows = std::min(chunk, N - r0);
         rc = ingest_chunk(ix, vectors + (size_t)r0 * D, r0, rows, D, false, staging);
     }
@@ -1899,6 +1922,26 @@ extern "C" int dr_index_create_empty_tiered(dr_index **out, const float *vectors
     if (rc) { dr_index_close(ix); return rc; }
     *out = ix;
     return 0;
+}
+
+// rows [row0, row0 + n) of the stored vectors, from host memory (any tier): the streaming form of dr_index_create_empty's upload
+extern "C" int dr_index_write_rows(dr_index *ix, const float *rows, uint64_t row0, uint64_t n)
+{
+    if (!ix || !rows) return fail(DR_E_ARG, "null argument");
+    if (row0 > ix->N || n > ix->N - row0) return fail(DR_E_ARG, "rows [%llu, %llu) outside the index (N=%llu)", (unsigned long long)row0, (unsigned long long)(row0 + n), (unsigned long long)ix->N);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    { const int rcv = need_vectors(ix, "dr_index_write_rows"); if (rcv) return rcv; }
+    HIPCHK(hipSetDevice(ix->device));
+    { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }
+    DevBuf<uint32_t> staging;
+    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / (ix->D * 4));
+    int rc = 0;
+    for (uint64_t r0 = 0; r0 < n && !rc; r0 += chunk)
+        rc = ingest_chunk(ix, rows + (size_t)r0 * ix->D, row0 + r0, std::min(chunk, n - r0), ix->D, false, staging);
+    // what was derived from the old rows is stale
+    ix->rank_valid = false; ix->adjr_valid = false; ix->vec8_state = (ix->vec8_state == -1 && ix->D != 128) ? -1 : 0; ix->vec8.release();
+    ix->vnorm2.release(); ix->adc_live = -1;
+    return rc;
 }
 
 extern "C" int dr_get_adjacency(dr_index *ix, uint32_t *out)

@@ -103,6 +103,8 @@ struct SearchParams {
     // visited-set form, while the visited words (a load per test, a store per new node, 20 MB per wavefront slot on a
     // 1.25e8-point shard), their bit-position twin of the adjacency and the grouping passes are gone. stats.visited / stats.pq
     // then count EVALUATIONS (a node met again after it fell out of the list is scored again). vis / adjr may be null.
+    // bit 1 (with bit 0): the ids of the predicted next pop's adjacency row are landed in LDS during the running expansion
+    // (R <= 128), so that on a hit the expansion starts with its code-word gathers instead of waiting for the row first.
     u32 novis;
 };
 
@@ -590,7 +592,8 @@ DEV void search_body(const SearchParams &p)
     const bool has_out = FILTER ? true : (p.out_ids != nullptr);
     const bool has_ties = FILTER ? true : (p.tie_list != nullptr);
     const bool kcos = !FILTER && KIND == DIST_EXACT && p.vnorm2 != nullptr;      // traversal metric: cosine distance (M3)
-    const bool novis = !FILTER && KIND == DIST_ADC_SQ && p.novis != 0u;          // no visited set (SearchParams::novis)
+    const bool novis = !FILTER && KIND == DIST_ADC_SQ && (p.novis & 1u) != 0u;   // no visited set (SearchParams::novis)
+    const bool rowpre = novis && (p.novis & 2u) != 0u && p.R <= 128u;             // ... and the next row's ids prefetched into LDS
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
@@ -876,6 +879,36 @@ DEV void search_body(const SearchParams &p)
             }
             PH(1);
 
+            // (no visited set) the ids of this node's row, landed in LDS by the previous expansion if it predicted this pop; then the
+            // same for the next pop: the best frontier entry that is left now (this expansion's neighbours may still beat it). The
+            // landing area is the 512-byte id / distance staging of the exact traversals, idle in an ADC-only kernel. Static
+            // graph data: valid whatever happens to the lists meanwhile.
+            u32 *rowpre_buf = nb_id;
+            bool rowpre_hit = false;
+            u32 hit_ids0 = 0u, hit_ids1 = 0u;
+            if (rowpre) {
+                rowpre_hit = cur == pre_id;
+                if (rowpre_hit) {
+                    npre_hit++;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    hit_ids0 = rowpre_buf[lane]; hit_ids1 = rowpre_buf[64 + lane];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // read before the next prefetch reuses the area
+                }
+                pre_id = 0xFFFFFFFFu;
+                const int ia2 = frontier_first<NCHR>(rk, fl, rn);
+                const u64 ka2 = (ia2 >= 0) ? fkey(list_get<NCHR>(rk, ia2)) : ~0ull;
+                const u64 kb2 = (tn > 0) ? readlane64(tl.v[0], 0) : ~0ull;
+                const u64 kn = ka2 <= kb2 ? ka2 : kb2;
+                if (kn != ~0ull) {
+                    pre_id = (u32)kn;
+                    const u32 *gi = p.adj + (size_t)pre_id * p.R;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gi + min((u32)lane, p.R - 1)),
+                        (__attribute__((address_space(3))) void *)rowpre_buf, 4, 0, 0);
+                    if (p.R > 64u)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gi + min(64u + (u32)lane, p.R - 1)),
+                            (__attribute__((address_space(3))) void *)(rowpre_buf + 64), 4, 0, 0);
+                }
+            }
             for (u32 cbase = 0; cbase < p.R; cbase += 64) {
                 const u32 slot = cbase + lane;
                 // One memory round trip for the whole row: ids, bit positions and the mask/degree word are loaded
@@ -902,7 +935,8 @@ DEV void search_body(const SearchParams &p)
                     nbid_l = pre_buf[lane]; nbpos_l = pre_buf[64 + lane];
                     aux_w = *reinterpret_cast<const u64 *>(pre_buf + 128);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // read before the next prefetch reuses the area
-                } else { nbid_l = idrow[sl]; nbpos_l = novis ? 0u : posrow[sl]; aux_w = auxp[0]; }
+                } else if (rowpre_hit) { nbid_l = cbase ? hit_ids1 : hit_ids0; nbpos_l = 0u; aux_w = auxp[0]; }
+                else { nbid_l = idrow[sl]; nbpos_l = novis ? 0u : posrow[sl]; aux_w = auxp[0]; }
                 if constexpr (SPEC_CODES) { if (codes_with_row) adc_load_codes(cw0, cw1, cw2, cw3, p.nbcodes + ((size_t)cur * p.R + sl) * p.m, p.m); }
                 // Predict the next pop -- the best frontier entry that is left now (this expansion's neighbours may still
                 // beat it) -- and land ITS adjacency row in LDS: no VGPR destination, nobody waits for it, and when the
@@ -987,7 +1021,10 @@ DEV void search_body(const SearchParams &p)
                             if (pq_ub < f_mul(Wlow, 0.8f)) spec = false;
                         }
                     }
-                    if (spec && active && !codes_with_row) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m);
+                    // (no visited set: the gather only needs a real id, not the first-occurrence mask -- on a prefetch hit the mask
+                    // word is still on its way while the code words are requested)
+                    const bool codelane = novis ? (slot < p.R && nbid < (u32)p.N) : active;
+                    if (spec && codelane && !codes_with_row) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m);
                 }
                 if (novis) isnew = active;      // every neighbour is scored; the list itself says which are already in it (decisions)
                 else {

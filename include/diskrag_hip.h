@@ -41,6 +41,12 @@ extern "C" {
 #define DR_F_RERANK 4u /* DR_MODE_PQ: score the final result list with exact squared L2 (A1, search_engine.py:374-379) and
                           return the k best in (distance, id) order; needs the stored vectors */
 
+#define DR_F_NO_VISITED_SET 16u /* DR_MODE_PQ only (round 4): no visited set. Every first-occurrence neighbour of an expansion is scored; one
+                                 * that would enter the list is looked up in the list and dropped if it is there. Same ids, distances and
+                                 * order as without the flag (a node scored before and not in the list now can never be accepted again),
+                                 * no visited words (N/6 bytes per wavefront slot: 42 GB on a 1.25e8-point shard) and a third of the HBM
+                                 * traffic, but nodes that left the list are scored again: stats.visited / stats.pq count EVALUATIONS
+                                 * (1.7x with beam_width 8, 3x without trim -- measured slower there, profiles/r04/ab/). Off by default. */
 #define DR_F_COSINE 8u /* M3 without DR_F_USE_PQ: the in-memory graph's distance_metric='cosine' -- compute_query_distance ->
                           cosine_similarity_cython (vamana_graph.py:324-329, cython_utils.pyx:53-70): 1 - cos, 0 when a norm is
                           0; out_dist = sqrt of it (vamana_graph.py:598). The reference sums in float32 under -ffast-math
@@ -115,8 +121,11 @@ int dr_index_open_tiered(dr_index **out, const char *index_dat, uint64_t N, uint
                          int device, uint32_t vector_tier);
 int dr_index_create_tiered(dr_index **out, const float *vectors, const uint32_t *adj, uint64_t N, uint32_t D,
                            uint32_t R, uint32_t medoid, int device, uint32_t vector_tier);
-int dr_index_create_empty_tiered(dr_index **out, const float *vectors, uint64_t N, uint32_t D, uint32_t R, int device,
-                                 uint32_t vector_tier);
+int dr_index_create_empty_tiered(dr_index **out, const float *vectors /* NULL: filled by dr_index_write_rows */, uint64_t N,
+                                 uint32_t D, uint32_t R, int device, uint32_t vector_tier);
+/* Rows [row0, row0 + n) of the stored vectors from host memory: the streaming form of the upload (an index whose rows are
+ * generated or read chunk by chunk and would not fit in host memory beside their own copy in the host tier). */
+int dr_index_write_rows(dr_index *ix, const float *rows, uint64_t row0, uint64_t n);
 
 /* Attaches PQ data: codebook[m][256][D/m] (kmeans_list[j].cluster_centers_, T3) and codes[N][m]
  * (pq_codes.bin, T2, diskann_persist.py:30-31,205-206). Replaces load_pq_codebook/load_pq_codes in

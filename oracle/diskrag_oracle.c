@@ -43,7 +43,7 @@
 #define ORC_F_CYTHON 2u   /* M4: greedy_search_cython twin (squared L2 via l2_distance_fast_cython) */
 #define ORC_F_QUERY_F64 4u
 #define ORC_F_RERANK 16u  /* ORC_PQ: exact squared L2 (A1) of the final list, (distance, id) order */
-#define ORC_F_PQ_VISITED_SET 64u /* ORC_PQ, tests only: round 3's statement with an explicit visited set (same ids and distances; counters differ) */
+#define ORC_F_NO_VISITED_SET 64u /* ORC_PQ: the statement without a visited set (engine flag DR_F_NO_VISITED_SET): same ids and distances; the counters count evaluations */
 #define ORC_F_COSINE 32u  /* M3 without PQ: distance_metric='cosine' (cosine_similarity_cython, cython_utils.pyx:53-70) */
 #define ORC_F_PAIRWISE 8u  /* squared-L2 modes: use the numpy pairwise order (what the device computes) instead of the
                              sequential Cython loop, whose -ffast-math order is unpinned anyway */

@@ -15,7 +15,7 @@ PAD = 0xFFFFFFFF
 M1, M2, M3, M4 = 1, 2, 3, 4
 PQ = 5    # engine mode DR_MODE_PQ (no reference counterpart): M1's loop on squared ADC distances only
 F_USE_PQ, F_CYTHON, F_QUERY_F64, F_PAIRWISE, F_RERANK, F_COSINE = 1, 2, 4, 8, 16, 32
-F_PQ_VISITED_SET = 64     # PQ mode, tests only: the visited-set statement of round 3 (same ids / distances, other counters)
+F_NO_VISITED_SET = 64     # PQ mode: the statement without a visited set (engine flag DR_F_NO_VISITED_SET): same ids / distances, evaluation counters
 
 _lib = None
 

@@ -1,4 +1,4 @@
-"""A/B (GPU box): the engine's ADC traversals with and without a visited set (round 4; DR_PQ_VISITED_SET=1 = round 3's form),
+"""A/B (GPU box): the engine's ADC traversals with and without a visited set (round 4: DR_F_NO_VISITED_SET; + DR_PQ_ROW_PREFETCH=1: the next row's ids landed in LDS),
 interleaved in ONE process on ONE index, each with and without inline neighbour codes (dr_index_inline_codes). usage: ab_novis.py c5s|c3|c4 N  -> prints one JSON line per run, checksums must agree"""
 import hashlib
 import json
@@ -22,10 +22,11 @@ runs = [("PQ L=100 bw=8", dict(L=100, beam_width=8, mode=_ffi.MODE_PQ)), ("PQ L=
         ("PQ+rerank L=250 no trim", dict(L=250, beam_width=0, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)),
         ("PQ L=400 no trim", dict(L=400, beam_width=0, mode=_ffi.MODE_PQ))]
 for rep in range(2):
-    for tag, kw in runs:
-        for vis, inline in ((1, 0), (0, 0), (1, 1), (0, 1)):
-            if vis: os.environ["DR_PQ_VISITED_SET"] = "1"
-            else: os.environ.pop("DR_PQ_VISITED_SET", None)
+    for tag, kw0 in runs:
+        for vis, inline, pre in ((1, 0, 0), (0, 0, 0), (0, 0, 1), (1, 1, 0), (0, 1, 0)):
+            kw = dict(kw0, flags=kw0.get("flags", 0) | (0 if vis else _ffi.F_NO_VISITED_SET))
+            if pre: os.environ["DR_PQ_ROW_PREFETCH"] = "1"
+            else: os.environ.pop("DR_PQ_ROW_PREFETCH", None)
             ix.inline_codes(bool(inline))
             ix.batch_run(10, **kw); ix.batch_sync()
             t0 = time.perf_counter()
@@ -35,6 +36,6 @@ for rep in range(2):
             ids, dist, cnt, st = ix.batch_download()
             t = ix.timing()
             rec = float(np.mean([len(set(a) & set(b)) / 10 for a, b in zip(ids[:1000], gt)]))
-            print(json.dumps({"shape": shape, "N": n, "run": tag, "visited_set": bool(vis), "inline_codes": bool(inline), "kernel_ms": t["search_kernel_ms"], "table_kernel_ms": t["lut_kernel_ms"],
+            print(json.dumps({"shape": shape, "N": n, "run": tag, "visited_set": bool(vis), "inline_codes": bool(inline), "next_row_prefetch": bool(pre), "prefetch_hits": float(st["adj_prefetch_hits"].mean()), "kernel_ms": t["search_kernel_ms"], "table_kernel_ms": t["lut_kernel_ms"],
                               "qps": 10000 / dt, "variant": t["variant"], "waves_per_cu": t["waves_per_cu"], "recall_vs_exact": rec, "steps": float(st["steps"].mean()),
                               "pq": float(st["pq"].mean()), "results_sha1": hashlib.sha1(ids.tobytes() + dist.tobytes()).hexdigest()[:12]}), flush=True)

@@ -192,3 +192,33 @@ def test_small_workgroup_variants_return_the_same_bits(bw):
     o = orc.search_batch(x, adj, qf, medoid, orc.M1, 10, L=100, bw=bw, codes=codes, codebook=cb)
     assert np.array_equal(got[0], o[0]) and np.array_equal(bits(got[1]), bits(o[1].astype(np.float32)))
     ix.close()
+
+
+def test_request_threads_share_launches():
+    """a pool of request handlers, one query per request (app.py:84-130), each calling submit + wait: dr_search_wait does not
+    hold the handle while it waits, so the other threads' submits ride in the same launches -- and every request still gets
+    the bits of a call of its own"""
+    import threading
+    from diskrag_amd import _ffi
+    g = load_golden("sift128_R64_m32")
+    ix = get_index("sift128_R64_m32")
+    params = dict(L=100, beam_width=8, mode=_ffi.MODE_M1)
+    want = ix.search_batch(g.queries, 10, **params)
+    s0 = ix.pipeline_stats()
+    bad, nthreads, per = [], 16, 40
+
+    def client(t):
+        for i in range(per):
+            qi = (t * 7 + i) % len(g.queries)
+            ids, dist, cnt, st = ix.search_submit(g.queries[qi:qi + 1], 10, **params).wait()
+            if not (np.array_equal(ids[0], want[0][qi]) and np.array_equal(bits(dist[0]), bits(want[1][qi])) and cnt[0] == want[2][qi]):
+                bad.append((t, i))
+
+    th = [threading.Thread(target=client, args=(t,)) for t in range(nthreads)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not bad
+    s1 = ix.pipeline_stats()
+    assert s1["tickets"] - s0["tickets"] == nthreads * per
+    assert s1["launches"] - s0["launches"] <= nthreads * per          # (how many share a launch depends on timing; the bits do not)
+    ix.batch_sync()

@@ -123,6 +123,45 @@ def test_pq_mode_matches_its_oracle_restatement(name):
         shard.close()
 
 
+@pytest.mark.parametrize("name", ["randn128_R16_m32", "sift128_R64_m32", "unit1536_R16_m32", "unit1536_R16_m64", "deep96_R32_m16", "unit768_R16_m96"])
+def test_pq_mode_without_a_visited_set(name, monkeypatch):
+    """DR_F_NO_VISITED_SET (round 4): the engine's PQ traversal with no visited words -- every neighbour scored, one that would
+    enter the list looked up in the list. Bit-exact against the oracle's statement of the same rule (ids, distance bits, counts,
+    evaluation counters), and the same ids / distances as the traversal WITH a visited set; with and without inline neighbour
+    codes (their code words then leave with the adjacency row), the exact rerank, and the next row's ids prefetched into LDS."""
+    from diskrag_amd import HipIndex, _ffi
+    from oracle import pyoracle as orc
+    g = load_golden(name)
+    ix = get_index(name)
+    shard = HipIndex.create_codes(g.adj, g.medoid, g.vectors.shape[1], g.codebook, g.codes)
+    try:
+        for (L, bw, k) in ((100, 8, 10), (40, 0, 10), (10, 3, 10), (200, 16, 25), (64, 8, 64), (1, 1, 1)):
+            w = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, flags=orc.F_NO_VISITED_SET, codes=g.codes, codebook=g.codebook)
+            base = ix.search_batch(g.queries, k, L=L, beam_width=bw, mode=_ffi.MODE_PQ)
+            for eng, inline, pre in ((ix, False, False), (shard, False, False), (shard, True, False), (ix, True, True), (shard, False, True)):
+                eng.inline_codes(inline)
+                if pre: monkeypatch.setenv("DR_PQ_ROW_PREFETCH", "1")
+                else: monkeypatch.delenv("DR_PQ_ROW_PREFETCH", raising=False)
+                ids, dist, cnt, st = eng.search_batch(g.queries, k, L=L, beam_width=bw, mode=_ffi.MODE_PQ, flags=_ffi.F_NO_VISITED_SET)
+                assert int(st["status"].max()) == 0
+                assert np.array_equal(ids, w[0]) and np.array_equal(cnt, w[2]), (name, L, bw, inline, pre)
+                valid = w[0] != 0xFFFFFFFF
+                assert np.array_equal(bits(dist)[valid], bits(w[1].astype(np.float32))[valid])
+                assert np.array_equal(_stats4(st), w[3]), (name, L, bw, inline, pre)
+                assert np.array_equal(ids, base[0]) and np.array_equal(bits(dist)[valid], bits(base[1])[valid])      # == with a visited set
+                if pre and bw != 1: assert st["adj_prefetch_hits"].sum() > 0
+            monkeypatch.delenv("DR_PQ_ROW_PREFETCH", raising=False)
+            ix.inline_codes(False); shard.inline_codes(False)
+            wr = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, flags=orc.F_RERANK | orc.F_NO_VISITED_SET,
+                                  codes=g.codes, codebook=g.codebook)
+            ids, dist, cnt, st = ix.search_batch(g.queries, k, L=L, beam_width=bw, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK | _ffi.F_NO_VISITED_SET)
+            assert np.array_equal(ids, wr[0]) and np.array_equal(cnt, wr[2]) and np.array_equal(_stats4(st), wr[3])
+        with pytest.raises(_ffi.DiskragHipError):        # the flag belongs to DR_MODE_PQ
+            ix.search_batch(g.queries, 10, L=50, beam_width=8, mode=_ffi.MODE_M1, flags=_ffi.F_NO_VISITED_SET)
+    finally:
+        shard.close()
+
+
 @pytest.mark.parametrize("name", ["unit1536_R16_m32", "unit1536_R16_m64"])
 def test_split_table_variant_returns_the_same_bits(name):
     """Variant 15 (round 3): the table rows of the last 16 sub-quantisers in registers (ds_bpermute lookups), the rest in LDS

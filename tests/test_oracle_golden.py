@@ -195,17 +195,16 @@ def test_m3_cosine_against_the_reference(name):
 
 @pytest.mark.parametrize("name", PQ_FIXTURES)
 def test_pq_mode_without_a_visited_set_equals_the_visited_set_statement(name):
-    """Round 4: the engine's PQ traversal (mode 5, no reference counterpart) keeps no visited set -- every neighbour is
-    scored and one that would enter the list is looked up in the list. Same ids, distances, hit counts and expansions as the
-    statement with an explicit visited set (round 3's, ORC_F_PQ_VISITED_SET), on every PQ fixture, trimmed and not, short and
-    long lists, with the exact rerank; only the evaluation counters grow (a node met again after it left the list is scored
-    again)."""
+    """Round 4: DR_F_NO_VISITED_SET -- the engine's PQ traversal (mode 5, no reference counterpart) without a visited set: every
+    neighbour is scored and one that would enter the list is looked up in the list. Same ids, distances, hit counts and
+    expansions as the statement with an explicit visited set, on every PQ fixture, trimmed and not, short and long lists, with
+    the exact rerank; only the evaluation counters grow (a node met again after it left the list is scored again)."""
     from oracle import pyoracle as orc
     g = load_golden(name)
     for (L, bw, k) in ((100, 8, 10), (40, 0, 10), (10, 3, 10), (200, 16, 25), (64, 8, 64), (5, 0, 5), (1, 1, 1)):
         for fl in (0, orc.F_RERANK):
-            a = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, flags=fl, codes=g.codes, codebook=g.codebook)
-            b = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, flags=fl | orc.F_PQ_VISITED_SET,
+            a = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, flags=fl | orc.F_NO_VISITED_SET, codes=g.codes, codebook=g.codebook)
+            b = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, flags=fl,
                                  codes=g.codes, codebook=g.codebook)
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]), (name, L, bw, k, fl)
             va = a[0] != 0xFFFFFFFF
@@ -213,7 +212,6 @@ def test_pq_mode_without_a_visited_set_equals_the_visited_set_statement(name):
             assert np.array_equal(a[3][:, 0], b[3][:, 0])                                  # expansions
             assert (a[3][:, 3] >= b[3][:, 3]).all()                                        # evaluations >= distinct nodes scored
         # the same on the in-memory adjacency (no 0-padding: no repeated ids in a row)
-        a = orc.search_batch(g.vectors, g.mem_adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, codes=g.codes, codebook=g.codebook)
-        b = orc.search_batch(g.vectors, g.mem_adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, flags=orc.F_PQ_VISITED_SET, codes=g.codes,
-                             codebook=g.codebook)
+        a = orc.search_batch(g.vectors, g.mem_adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, flags=orc.F_NO_VISITED_SET, codes=g.codes, codebook=g.codebook)
+        b = orc.search_batch(g.vectors, g.mem_adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, codes=g.codes, codebook=g.codebook)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[3][:, 0], b[3][:, 0])
