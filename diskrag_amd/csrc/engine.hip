@@ -525,25 +525,10 @@ extern "C" void dr_index_close(dr_index *ix)
 
 // ------------------------------------------------------------------------------------------------ batches
 
-// every component an integer in [0, 255]? (byte-query variants; non-integer data leaves at the first block)
-static bool queries_are_u8(const float *queries, size_t n)
-{
-    bool ok = true;
-    for (size_t b = 0; b < n && ok; b += 4096) {
-        const size_t e = std::min(n, b + 4096);
-        unsigned bad = 0;     // branch-free so that it vectorises (out-of-range and NaN are clamped before the conversion)
-        for (size_t i = b; i < e; i++) {
-            const float v = queries[i];
-            const float c = (v >= 0.0f && v <= 255.0f) ? v : -1.0f;
-            const int iv = (int)c;
-            bad |= (unsigned)(iv < 0) | (unsigned)((float)iv != v);
-        }
-        ok = !bad;
-    }
-    return ok;
-}
+// every component an integer in [0, 255]? (byte-query variants) -- host_simd.cpp: AVX2 where the CPU has it
+extern "C" bool dr_host_all_u8(const float *q, size_t n);
+static bool queries_are_u8(const float *queries, size_t n) { return dr_host_all_u8(queries, n); }
 
-// queues the copy of a batch into a slot and its chain-major twin on `st`
 // (q0, room: a job of a coalesced group lands behind the jobs before it in a slot sized for the whole group)
 static int upload_slot_async(dr_index *ix, QSlot &qs, const float *src, uint32_t nq, hipStream_t st, bool with_qp = true, uint32_t q0 = 0, uint32_t room = 0)
 {
@@ -890,7 +875,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     static const int PREF_BUILD_PQ[] = { 15, 2 }, PREF_BUILD_PQ_NOTREG[] = { 2, 2 };
     const int *pref = k_m1 ? PREF_M1 : (ov && ov->sdc) ? (no_treg ? PREF_BUILD_PQ_NOTREG : PREF_BUILD_PQ) : k_adc ? (no_treg ? PREF_ADC_NOTREG : PREF_ADC) : ov ? PREF_BUILD : PREF_EX;
     const int npref = k_m1 ? 5 : (ov && ov->sdc) ? 2 : k_adc ? 3 : ov ? 2 : 4;
-    if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 8 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
+    // (round 4: the per-query table wins with as few as five or six wavefronts per CU -- c4 shape, lists of 300-500 entries: 1.38x over
+    // the shared codebook at eight, profiles/r04/ab/ab_c4_long_lists_table_vs_codebook.jsonl; it used to need eight to be preferred)
+    if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 5 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
     int kind = -1;
     for (int i = 0; i < npref && kind < 0; i++) if (usable(pref[i])) kind = pref[i];
     {

@@ -571,6 +571,50 @@ DEV u32 a4_threshold_bits(float pq, float thr, bool &ok) {
     return cb;
 }
 
+// ---- a finished query: result keys, the k best (ids, distances), tie detection for the tie-order pass, counters
+template <int NCHR>
+DEV void write_results(const SearchParams &p, u32 qi, int cap, u32 kmode, bool has_out, bool has_ties, const RegList<NCHR> &rk, int rn,
+                       u32 steps, u32 nvisited, u32 nexact, u32 npq, u32 status, u32 ninserts, u32 npq_eval, u32 npre_hit)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int c = 0; c < NCHR; c++) {
+        const int i = c * 64 + lane;
+        if (i < rn) p.res_keys[(size_t)qi * cap + i] = rk.v[c];
+    }
+    const int kout = min((int)p.k, rn);
+    bool t = false;
+#pragma unroll
+    for (int c = 0; c < NCHR; c++) {
+        const int i = c * 64 + lane;
+        // tie detection on the sort key of the final stable sort (distance; sqrt(distance) for M3)
+        const u64 nextk = wave_shl1(rk.v[c], (c + 1 < NCHR) ? readlane64(rk.v[c + 1 < NCHR ? c + 1 : c], 0) : ~0ull);
+        float a = key_dist(rk.v[c]), b = key_dist(nextk);
+        if (kmode == 3u) { a = f_sqrt(a); b = f_sqrt(b); }
+        if (i < kout && i + 1 < rn && a == b) t = true;
+        if (has_out) {
+            if (i < (int)p.k) {
+                p.out_ids[(size_t)qi * p.k + i] = (i < kout) ? ~(u32)rk.v[c] : 0xFFFFFFFFu;
+                p.out_dist[(size_t)qi * p.k + i] = (i < kout) ? a : __uint_as_float(0x7FC00000u);
+            }
+        }
+    }
+    if (has_out) for (int i = NCHR * 64 + lane; i < (int)p.k; i += 64) {
+        p.out_ids[(size_t)qi * p.k + i] = 0xFFFFFFFFu;
+        p.out_dist[(size_t)qi * p.k + i] = __uint_as_float(0x7FC00000u);
+    }
+    const bool anyt = __ballot(t) != 0ull;
+    if (lane == 0) {
+        p.res_n[qi] = (u32)rn;
+        if (p.out_count) p.out_count[qi] = (u32)kout;
+        if (anyt && has_ties) p.tie_list[atomicAdd(p.tie_count, 1u)] = qi;
+        KStats st;
+        st.steps = steps; st.visited = nvisited; st.exact = nexact; st.pq = npq; st.status = status;
+        st.inserts = ninserts; st.pq_evaluated = npq_eval; st.adj_prefetch_hits = npre_hit;
+        p.stats[qi] = st;
+    }
+}
+
 template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false, int TREG = 0>
 DEV void search_body(const SearchParams &p)
 {
@@ -1551,42 +1595,7 @@ DEV void search_body(const SearchParams &p)
         }
 
         // ---- write results
-#pragma unroll
-        for (int c = 0; c < NCHR; c++) {
-            const int i = c * 64 + lane;
-            if (i < rn) p.res_keys[(size_t)qi * cap + i] = rk.v[c];
-        }
-        const int kout = min((int)p.k, rn);
-        bool t = false;
-#pragma unroll
-        for (int c = 0; c < NCHR; c++) {
-            const int i = c * 64 + lane;
-            // tie detection on the sort key of the final stable sort (distance; sqrt(distance) for M3)
-            const u64 nextk = wave_shl1(rk.v[c], (c + 1 < NCHR) ? readlane64(rk.v[c + 1 < NCHR ? c + 1 : c], 0) : ~0ull);
-            float a = key_dist(rk.v[c]), b = key_dist(nextk);
-            if (kmode == 3u) { a = f_sqrt(a); b = f_sqrt(b); }
-            if (i < kout && i + 1 < rn && a == b) t = true;
-            if (has_out) {
-                if (i < (int)p.k) {
-                    p.out_ids[(size_t)qi * p.k + i] = (i < kout) ? ~(u32)rk.v[c] : 0xFFFFFFFFu;
-                    p.out_dist[(size_t)qi * p.k + i] = (i < kout) ? a : __uint_as_float(0x7FC00000u);
-                }
-            }
-        }
-        if (has_out) for (int i = NCHR * 64 + lane; i < (int)p.k; i += 64) {
-            p.out_ids[(size_t)qi * p.k + i] = 0xFFFFFFFFu;
-            p.out_dist[(size_t)qi * p.k + i] = __uint_as_float(0x7FC00000u);
-        }
-        const bool anyt = __ballot(t) != 0ull;
-        if (lane == 0) {
-            p.res_n[qi] = (u32)rn;
-            if (p.out_count) p.out_count[qi] = (u32)kout;
-            if (anyt && has_ties) p.tie_list[atomicAdd(p.tie_count, 1u)] = qi;
-            KStats st;
-            st.steps = steps; st.visited = nvisited; st.exact = nexact; st.pq = npq; st.status = status;
-            st.inserts = ninserts; st.pq_evaluated = npq_eval; st.adj_prefetch_hits = npre_hit;
-            p.stats[qi] = st;
-        }
+        write_results<NCHR>(p, qi, cap, kmode, has_out, has_ties, rk, rn, steps, nvisited, nexact, npq, status, ninserts, npq_eval, npre_hit);
         PH(7);
         PH_END(qi);
         {

@@ -107,3 +107,34 @@ def test_python_constants_match_the_header():
             "DR_MAX_TICKETS": _ffi.MAX_TICKETS, "DR_E_REMOTE": _ffi.E_REMOTE}
     for name, val in want.items():
         assert defs[name] == val, name
+
+
+def test_host_byte_query_check_agrees_with_numpy():
+    """dr_host_all_u8 (csrc/host_simd.cpp; the check that routes a batch to the byte-query kernel variants): every component an
+    integer in [0, 255] -- the AVX2 path against the plain statement, offending values in the vector body and in the tail."""
+    import ctypes as C
+    import diskrag_amd
+    lib = diskrag_amd.load_library()
+    lib.dr_host_all_u8.restype = C.c_bool
+    lib.dr_host_all_u8.argtypes = [C.POINTER(C.c_float), C.c_size_t]
+    rs = np.random.RandomState(0)
+
+    def ask(a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        return bool(lib.dr_host_all_u8(a.ctypes.data_as(C.POINTER(C.c_float)), a.size))
+
+    def plain(a):
+        a = np.asarray(a, dtype=np.float32)
+        with np.errstate(invalid="ignore"):
+            return bool(np.all((a >= 0) & (a <= 255) & (np.trunc(a) == a)))
+
+    for n in (0, 1, 7, 31, 32, 33, 64, 100, 4096, 4097, 1250 * 128 + 5):
+        base = rs.randint(0, 256, size=n).astype(np.float32)
+        assert ask(base) and plain(base)
+        if n:
+            for bad in (0.5, -1.0, 256.0, np.nan, np.inf, -np.inf, 1e30, 254.99998):
+                for pos in {0, n // 2, n - 1}:
+                    a = base.copy(); a[pos] = bad
+                    assert ask(a) == plain(a) == False, (n, bad, pos)
+            a = base.copy(); a[n // 2] = -0.0          # converts to the byte 0
+            assert ask(a) and plain(a)
