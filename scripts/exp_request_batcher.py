@@ -1,6 +1,8 @@
 """Measurement (GPU box): T client threads asking ONE query per request (the /search route's shape) on the bench index --
-directly (every request its own dr_search_batch call; the handle serialises them) and through RequestBatcher.
-usage: exp_request_batcher.py  -> gpurun_out/r03/request_batcher.json"""
+directly (every request its own dr_search_batch call; the handle serialises them), through RequestBatcher, and (round 4) as
+submit + wait per request: dr_search_wait does not hold the handle, so concurrent requests are coalesced into shared launches
+by the library itself.
+usage: exp_request_batcher.py  -> gpurun_out/r04/request_batcher.json"""
 import json
 import sys
 import threading
@@ -40,7 +42,11 @@ out = {"index": "1M x 128, R 64, m 32 (the bench index)", "request": "M1, k 10, 
 direct = lambda v: ix.search_batch(v, 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
 for v in q[:64]: direct(v)
 for T in (1, 16, 64, 256):
-    rec = {"direct": run(T, max(20, 2000 // T), direct)}
+    s0 = ix.pipeline_stats()
+    rec = {"direct": run(T, max(20, 2000 // T), direct),
+           "submit_wait_per_request": run(T, max(20, 4000 // T), lambda v: ix.search_submit(v.reshape(1, -1), 10, L=100, beam_width=8, mode=_ffi.MODE_M1).wait())}
+    s1 = ix.pipeline_stats()
+    rec["submit_wait_per_request"]["requests_per_launch"] = (s1["tickets"] - s0["tickets"]) / max(1, s1["launches"] - s0["launches"])
     for wait in (0.0, 0.2, 1.0):
         with RequestBatcher(Eng(), k_max=10, L=100, beam_width=8, max_batch=4096, max_wait_ms=wait) as rb:
             r = run(T, max(20, 4000 // T), lambda v: rb.search(v))
@@ -48,4 +54,6 @@ for T in (1, 16, 64, 256):
         rec[f"batcher_wait_{wait}ms"] = r
     out["runs"][f"{T}_threads"] = rec
     print(T, rec, flush=True)
-json.dump(out, open("gpurun_out/r03/request_batcher.json", "w"), indent=1)
+import os
+os.makedirs("gpurun_out/r04", exist_ok=True)
+json.dump(out, open("gpurun_out/r04/request_batcher.json", "w"), indent=1)

@@ -88,6 +88,21 @@ if spec == "extra":
     extra_pass()
     ix.close()
     sys.exit(0)
+if spec == "m1fine":
+    # round 4: the reference-faithful M1 around its recall-0.95 point (long lists: the per-query table is now preferred down to
+    # five wavefronts per CU), with and without a frontier trim, next to the shape's other operating points
+    for L in ((400, 450, 500) if shape == "c4" else (200, 300, 400)):
+        for bw in (0, 64, 32):
+            run(f"M1_L{L}_bw{bw or 'None'}_policy0", L=L, beam_width=bw, mode=_ffi.MODE_M1, band_policy=0)
+    ix.debug_force_kind(3)
+    run("M1_L500_bwNone_policy0_forced_variant3_shared_codebook" if shape == "c4" else "M1_L400_bwNone_policy0_forced_variant3", L=500 if shape == "c4" else 400,
+        beam_width=0, mode=_ffi.MODE_M1, band_policy=0)
+    ix.debug_force_kind(-1)
+    for L in ((300, 350) if shape == "c4" else (250, 300)):
+        run(f"PQ_rerank_L{L}_bwNone", L=L, beam_width=0, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)
+    run("M2_bw128", L=100, beam_width=128, mode=_ffi.MODE_M2)
+    ix.close()
+    sys.exit(0)
 Ls = (100, 200, 400) if quick else (100, 200, 400, 800)
 for L in Ls:
     for bw in (8, 0):
