@@ -489,6 +489,7 @@ def worker_c2(args, rk):
         n_s = shi - slo
         q_s = np.ascontiguousarray(q_job.reshape(nb, nq_job, D)[:, slo:shi].reshape(nb * n_s, D))
         del q_job
+        ix.batch_select(15)             # (brute force and blocking calls use the selected resident batch as scratch: keep them off the bench's)
         gt_s, _ = ix.bruteforce_topk(q_s, k)
         src_s = []
         for b in range(nb):
@@ -505,6 +506,9 @@ def worker_c2(args, rk):
         sp1 = ix.pipeline_stats()
         t_s = rk.gather("t_strong", el_s)
         ids_s = np.concatenate([ix.search_batch(a, k, L=args.L, beam_width=args.bw, mode=mode)[0] for a in src_s])
+        if nb == 16:
+            ix.batch_upload(qb[15])
+        ix.batch_select(0)
         rec_s = rk.gather("recall_strong", [recall_at_k(ids_s, gt_s, k), n_s])
         strong_cfg = {"value": nq_job * launches / max(t_s), "unit": "queries/s", "scaling": "strong",
                       "what": "ONE stream of %d-query batches, every batch cut into %d contiguous slices, one per GPU; value = the stream's "

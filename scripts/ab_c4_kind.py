@@ -34,3 +34,20 @@ for rep in range(2):
                               "table_kernel_ms": t["lut_kernel_ms"], "qps": 10000 / dt, "recall": rec, "exact": float(st["exact"].mean()), "pq_eval": float(st["pq_evaluated"].mean()),
                               "steps": float(st["steps"].mean())}), flush=True)
 ix.debug_force_kind(-1)
+# the engine's PQ traversal + rerank at the same shape: shared codebook (variant 5, the engine's pick at D <= 128) against the per-query table (variant 2)
+for rep in range(2):
+    for (L, bw) in ((400, 32), (350, 0), (100, 8)):
+        for kind in (5, 2, -1):
+            ix.debug_force_kind(kind)
+            kw = dict(L=L, beam_width=bw, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)
+            ix.batch_run(10, **kw); ix.batch_sync()
+            t0 = time.perf_counter()
+            for _ in range(3): ix.batch_run(10, **kw)
+            ix.batch_sync()
+            dt = (time.perf_counter() - t0) / 3
+            ids, dist, cnt, st = ix.batch_download()
+            t = ix.timing()
+            rec = float(np.mean([len(set(a) & set(b)) / 10 for a, b in zip(ids[:1000], gt)]))
+            print(json.dumps({"N": n, "mode": "PQ+rerank", "L": L, "bw": bw, "forced": kind, "variant": t["variant"], "waves_per_cu": t["waves_per_cu"], "kernel_ms": t["search_kernel_ms"],
+                              "table_kernel_ms": t["lut_kernel_ms"], "qps": 10000 / dt, "recall": rec, "pq_eval": float(st["pq_evaluated"].mean()), "steps": float(st["steps"].mean())}), flush=True)
+ix.debug_force_kind(-1)

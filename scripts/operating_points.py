@@ -88,6 +88,20 @@ if spec == "extra":
     extra_pass()
     ix.close()
     sys.exit(0)
+if spec == "bwsweep":
+    # round 4: intermediate frontier trims (beam_width is a parameter of the reference's search, search_engine.py:477-479; rounds 1-3
+    # swept 8 and None only): at equal recall a trim of 32-128 halves the expansions of the no-trim operating points
+    for L in ((350, 400, 500) if shape == "c4" else (250, 300, 400)):
+        for bw in ((128, 64, 32) if shape == "c4" else (0, 128, 64, 32)):
+            run(f"PQ_rerank_L{L}_bw{bw or 'None'}", L=L, beam_width=bw, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)
+    if shape != "c4":
+        for L in (200, 400):
+            for bw in (0, 64, 32):
+                run(f"M1_L{L}_bw{bw or 'None'}_policy0", L=L, beam_width=bw, mode=_ffi.MODE_M1, band_policy=0)
+        for bwx in (64, 128):
+            run(f"M2_bw{bwx}", L=100, beam_width=bwx, mode=_ffi.MODE_M2)
+    ix.close()
+    sys.exit(0)
 if spec == "m1fine":
     # round 4: the reference-faithful M1 around its recall-0.95 point (long lists: the per-query table is now preferred down to
     # five wavefronts per CU), with and without a frontier trim, next to the shape's other operating points
