@@ -1204,311 +1204,7 @@ extern "C" void *dr_host_alloc(uint64_t bytes)
 
 extern "C" void dr_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
-// ---- pipelined batches: upload | search | tie order | download on four streams ------------------------------------
-static int pin_reserve(void **p, size_t *have, size_t need)
-{
-    if (*have >= need) return 0;
-    if (*p) (void)hipHostFree(*p);
-    *p = nullptr; *have = 0;
-    if (hipHostMalloc(p, need, hipHostMallocDefault) != hipSuccess) return fail(DR_E_NODEVICE, "hipHostMalloc(%zu) failed", need);
-    *have = need;
-    return 0;
-}
-
-// ---- coalesced launches (round 4) -------------------------------------------------------------------------------------
-// search kernels of the pipelined path that are queued or running (their BatchSet's search_done has not fired)
-static int searches_in_flight(dr_index *ix)
-{
-    int n = 0;
-    for (const PipeGroup &gr : ix->groups)
-        if (gr.state == 2 && gr.set >= 0 && hipEventQuery(ix->sets[gr.set].search_done) == hipErrorNotReady) n++;
-    (void)hipGetLastError();
-    return n;
-}
-
-// every job of a group answers `rc` from now on (its launch failed: nothing was or will be written to their buffers)
-static void fail_group_locked(dr_index *ix, int g, int rc)
-{
-    PipeGroup &gr = ix->groups[g];
-    const std::string msg = g_err;
-    // copies that read the jobs' staging buffers / kernels that use the group's slot may be queued: drain before anything is reused
-    for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) (void)hipStreamSynchronize(st);
-    (void)hipGetLastError();
-    for (PipeJob &jb : ix->jobs) if (jb.active && jb.group == g) { jb.rc = rc; jb.err = msg; }
-    if (gr.set >= 0 && ix->sets[gr.set].owner_group == g) ix->sets[gr.set].owner_group = -1;
-    gr.state = 2; gr.set = -1;        // "launched": its jobs only have to be collected
-    if (ix->open_group == g) ix->open_group = -1;
-    g_err = msg;
-}
-
-// queues the search, the tie-order pass and the download of an open group: ONE launch for all its jobs
-static int launch_group_locked(dr_index *ix, int g)
-{
-    PipeGroup &gr = ix->groups[g];
-    if (gr.state != 1) return 0;
-    if (ix->open_group == g) ix->open_group = -1;
-    QSlot &qs = ix->slots[DR_MAX_RESIDENT + g];
-    const int rc = [&]() -> int {
-        HIPCHK(hipEventRecord(gr.up_done, ix->up_stream));       // behind the upload (and bound kernels) of its last job
-        HIPCHK(hipStreamWaitEvent(ix->stream, gr.up_done, 0));
-        qs.nq = gr.nq; qs.q_u8 = gr.q_u8; qs.qp_valid = gr.with_qp;
-        qs.pq_ub_valid = (gr.mode == DR_MODE_M1 && ix->m != 0);   // (every job computed the bounds of its run on the upload stream)
-        QSlot *const keep = ix->cs;
-        ix->cs = &qs;
-        int r = run_locked(ix, gr.k, gr.L, gr.bw, gr.mode, gr.policy, gr.flags);
-        ix->cs = keep;
-        if (r) return r;
-        gr.set = ix->last_set;
-        dr_index::BatchSet &bs = ix->sets[gr.set];
-        bs.owner_group = g;
-        // download: behind the tie-order pass of this launch (which is behind its search kernel); jobs copy their rows out of the slab
-        const size_t b_ids = (size_t)gr.nq * gr.k * 4, b_cnt = (size_t)gr.nq * 4, b_st = (size_t)gr.nq * sizeof(KStats);
-        r = pin_reserve(&gr.pin_out, &gr.pin_out_bytes, 2 * b_ids + b_cnt + b_st + 4);
-        if (r) return r;
-        unsigned char *hp = static_cast<unsigned char *>(gr.pin_out);
-        HIPCHK(hipStreamWaitEvent(ix->down_stream, bs.fin_done, 0));
-        HIPCHK(hipMemcpyAsync(hp, bs.out_ids.p, b_ids, hipMemcpyDeviceToHost, ix->down_stream));
-        HIPCHK(hipMemcpyAsync(hp + b_ids, bs.out_dist.p, b_ids, hipMemcpyDeviceToHost, ix->down_stream));
-        HIPCHK(hipMemcpyAsync(hp + 2 * b_ids, bs.out_count.p, b_cnt, hipMemcpyDeviceToHost, ix->down_stream));
-        HIPCHK(hipMemcpyAsync(hp + 2 * b_ids + b_cnt, bs.stats.p, b_st, hipMemcpyDeviceToHost, ix->down_stream));
-        HIPCHK(hipMemcpyAsync(hp + 2 * b_ids + b_cnt + b_st, ix->fin_stat.p, 4, hipMemcpyDeviceToHost, ix->down_stream));
-        HIPCHK(hipEventRecord(gr.down_done, ix->down_stream));
-        return 0;
-    }();
-    if (rc) { fail_group_locked(ix, g, rc); return rc; }
-    gr.state = 2;
-    ix->pipe_launches++; ix->pipe_tickets += gr.njobs; ix->pipe_queries += gr.nq;
-    ix->pipe_max_tickets = std::max<uint64_t>(ix->pipe_max_tickets, gr.njobs);
-    return 0;
-}
-
-// Launch policy for the open group: at once while fewer than TWO search kernels of the pipeline are queued or running (one
-// running + one queued behind it keeps the search stream fed; a lone request finds none and never waits), otherwise the
-// group keeps collecting until it is full -- so under load a launch carries what arrived during one kernel. (A threshold
-// of three launched nearly every submit alone: the host, blocked on the oldest launch's download, came back to find the
-// stream nearly dry -- gpurun_out r04 call 2: 1.06 submits per launch.) Called by every submit and, while it waits, by
-// dr_search_wait.
-static int kick_locked(dr_index *ix, bool force = false)
-{
-    const int g = ix->open_group;
-    if (g < 0) return 0;
-    if (!force && (ix->hold_always || searches_in_flight(ix) >= 2)) return 0;
-    return launch_group_locked(ix, g);
-}
-
-static int finish_job_locked(dr_index *ix, int j)
-{
-    PipeJob &jb = ix->jobs[j];
-    if (!jb.active) return 0;
-    HIPCHK(hipSetDevice(ix->device));
-    PipeGroup &gr = ix->groups[jb.group];
-    if (gr.state == 1) (void)launch_group_locked(ix, jb.group);     // (a failure is recorded in the group's jobs, this one included)
-    auto retire = [&]() {
-        jb.active = false;
-        if (gr.live > 0 && --gr.live == 0) {
-            if (gr.set >= 0 && ix->sets[gr.set].owner_group == jb.group) ix->sets[gr.set].owner_group = -1;
-            gr.state = 0; gr.set = -1;
-        }
-    };
-    if (jb.rc) {
-        // its launch failed: the error belongs to the ticket (dr_search_wait answers it), not to whoever needs the slot now
-        if (ix->failed_tickets.size() >= 1024) ix->failed_tickets.erase(ix->failed_tickets.begin());
-        ix->failed_tickets[jb.ticket] = std::make_pair(jb.rc, jb.err);
-        jb.rc = 0; retire();
-        return 0;
-    }
-    // another group is still collecting: while this job's results are on their way the waiting thread keeps the search stream fed
-    while (ix->open_group >= 0 && hipEventQuery(gr.down_done) == hipErrorNotReady) {
-        (void)hipGetLastError();
-        (void)kick_locked(ix);            // (a failure stays with that group's jobs)
-        if (ix->open_group >= 0) std::this_thread::sleep_for(std::chrono::microseconds(20));
-    }
-    (void)hipGetLastError();
-    HIPCHK(hipEventSynchronize(gr.down_done));
-    const size_t g_ids = (size_t)gr.nq * gr.k * 4, g_cnt = (size_t)gr.nq * 4, g_st = (size_t)gr.nq * sizeof(KStats);
-    const unsigned char *hp = static_cast<const unsigned char *>(gr.pin_out);
-    memcpy(jb.out_ids, hp + (size_t)jb.q0 * jb.k * 4, (size_t)jb.nq * jb.k * 4);
-    memcpy(jb.out_dist, hp + g_ids + (size_t)jb.q0 * jb.k * 4, (size_t)jb.nq * jb.k * 4);
-    memcpy(jb.out_count, hp + 2 * g_ids + (size_t)jb.q0 * 4, (size_t)jb.nq * 4);
-    if (jb.stats) memcpy(jb.stats, hp + 2 * g_ids + g_cnt + (size_t)jb.q0 * sizeof(KStats), (size_t)jb.nq * sizeof(KStats));
-    uint32_t ties = 0;
-    memcpy(&ties, hp + 2 * g_ids + g_cnt + g_st, 4);
-    if (gr.nq >= 1024) ix->fin_hint = std::max<uint32_t>(ties, 16);
-    harvest_kernel_times(ix, false);
-    retire();
-    return 0;
-}
-
-// the results of every job of a launched group reach their callers' buffers (its BatchSet or its slot is needed)
-static int finish_group_locked(dr_index *ix, int g)
-{
-    int rc_first = 0; std::string msg;
-    for (int j = 0; j < DR_MAX_JOBS; j++)
-        if (ix->jobs[j].active && ix->jobs[j].group == g) { const int rc = finish_job_locked(ix, j); if (rc && !rc_first) { rc_first = rc; msg = g_err; } }
-    if (rc_first) g_err = msg;
-    return rc_first;
-}
-
-extern "C" int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width,
-                                uint32_t mode, uint32_t band_policy, uint32_t flags, uint32_t *out_ids, float *out_dist,
-                                uint32_t *out_count, dr_stats *stats, uint64_t *out_ticket)
-{
-    if (!ix) return fail(DR_E_ARG, "null index");
-    if (!out_ids || !out_dist || !out_count || !out_ticket) return fail(DR_E_ARG, "null output buffer");
-    if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
-    if (nq > DR_MAX_CHUNK) return fail(DR_E_UNSUPPORTED, "dr_search_submit takes at most %u queries per batch", DR_MAX_CHUNK);
-    if (k == 0) return fail(DR_E_ARG, "k must be positive");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    HIPCHK(hipSetDevice(ix->device));
-    const int j = (int)(ix->next_ticket % DR_MAX_JOBS);
-    PipeJob &jb = ix->jobs[j];
-    if (jb.active) { const int rc = finish_job_locked(ix, j); if (rc) return rc; }      // (the ticket DR_MAX_JOBS submits ago)
-    // pinned source (dr_host_alloc / hipHostMalloc / hipHostRegister): the copy engine reads it in place; pageable: staged
-    const float *src = queries;
-    {
-        hipPointerAttribute_t at;
-        const bool pinned = hipPointerGetAttributes(&at, queries) == hipSuccess && at.type == hipMemoryTypeHost;
-        (void)hipGetLastError();
-        if (!pinned) {
-            const size_t bytes = (size_t)nq * ix->D * 4;
-            const int rc = pin_reserve(&jb.pin_in, &jb.pin_in_bytes, bytes);
-            if (rc) return rc;
-            memcpy(jb.pin_in, queries, bytes);
-            src = static_cast<const float *>(jb.pin_in);
-        }
-    }
-    const bool q_u8 = (ix->vec8_state == 1 || (ix->vec8_state == 0 && ix->D == 128)) && queries_are_u8(src, (size_t)nq * ix->D);
-    // ---- the group this job rides in: the open one if the parameters agree and it has room, else a new one
-    int g = ix->open_group;
-    if (g >= 0) {
-        const PipeGroup &og = ix->groups[g];
-        const bool same = og.k == k && og.L == L && og.bw == beam_width && og.mode == mode && og.policy == band_policy && og.flags == flags;
-        if (!same || og.nq + nq > og.cap) { (void)launch_group_locked(ix, g); g = -1; }     // (a failure stays with that group's jobs)
-    }
-    if (g < 0) {
-        g = (int)(ix->next_group % DR_PIPE_DEPTH);
-        PipeGroup &ng = ix->groups[g];
-        if (ng.state == 2) { const int rc = finish_group_locked(ix, g); if (rc) return rc; }   // (the launch DR_PIPE_DEPTH launches ago)
-        ix->next_group++;
-        ng.state = 1; ng.nq = 0; ng.njobs = 0; ng.live = 0; ng.set = -1;
-        ng.cap = std::max<uint32_t>(nq, std::min<uint32_t>(ix->coalesce_cap, DR_MAX_CHUNK));
-        ng.k = k; ng.L = L; ng.bw = beam_width; ng.mode = mode; ng.policy = band_policy; ng.flags = flags;
-        ng.q_u8 = true;
-        static const bool always_permute = getenv("DR_SUBMIT_PERMUTE") != nullptr;      // A/B: the round-2 upload (copy + permute kernel)
-        ng.with_qp = ix->D > 256 || always_permute;
-        ix->open_group = g;
-    }
-    PipeGroup &gr = ix->groups[g];
-    QSlot &qs = ix->slots[DR_MAX_RESIDENT + g];
-    // From here on copies that read jb.pin_in may be queued: a failure must not hand the ticket slot back (the next submit
-    // would overwrite the staging buffer under a copy in flight) before those copies have drained -- fail_group_locked drains.
-    const int rcq = [&]() -> int {
-        int rc = upload_slot_async(ix, qs, src, nq, ix->up_stream, gr.with_qp, gr.nq, gr.cap);
-        if (rc) return rc;
-        if (mode == DR_MODE_M1 && ix->m) {
-            // the per-query ADC bounds travel with the upload, off the search stream
-            rc = launch_pq_bound(ix, qs, nq, ix->up_stream, gr.nq, gr.cap);
-            if (rc) return rc;
-        }
-        return 0;
-    }();
-    if (rcq) {
-        // this job never joined; the jobs already in the group lose their launch with it (their uploads share the slot)
-        fail_group_locked(ix, g, rcq);
-        return rcq;
-    }
-    jb.active = true; jb.ticket = ix->next_ticket++; jb.group = g; jb.q0 = gr.nq; jb.nq = nq; jb.k = k; jb.rc = 0;
-    jb.out_ids = out_ids; jb.out_dist = out_dist; jb.out_count = out_count; jb.stats = stats;
-    gr.nq += nq; gr.njobs++; gr.live++;
-    gr.q_u8 = gr.q_u8 && q_u8;
-    *out_ticket = jb.ticket;
-    // full (a further job of this size would not fit), or the search stream is about to run dry: launch now; else it collects
-    const bool full = gr.nq + nq > gr.cap || gr.njobs >= DR_MAX_JOBS / 2;
-    const int rcl = kick_locked(ix, full);
-    if (rcl) {      // this job's launch failed: the submit fails and its ticket is void
-        const std::string msg = g_err;
-        (void)finish_job_locked(ix, j); ix->failed_tickets.erase(jb.ticket);
-        g_err = msg;
-        return rcl;
-    }
-    return 0;
-}
-
-extern "C" int dr_search_wait(dr_index *ix, uint64_t ticket)
-{
-    if (!ix) return fail(DR_E_ARG, "null index");
-    std::unique_lock<std::mutex> lk(ix->mu);
-    if (ticket == 0 || ticket >= ix->next_ticket) return fail(DR_E_ARG, "unknown ticket %llu", (unsigned long long)ticket);
-    HIPCHK(hipSetDevice(ix->device));
-    // The handle is NOT held while the ticket's results are on their way: other threads submit meanwhile (their requests ride
-    // in the launch this one may still be waiting for -- a pool of request handlers, one query each, app.py:84-130), and the
-    // waiting thread is the one that keeps the launch policy running.
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        int j = -1;
-        for (int i = 0; i < DR_MAX_JOBS; i++) if (ix->jobs[i].active && ix->jobs[i].ticket == ticket) j = i;
-        if (j < 0) break;                 // finished meanwhile (a submit or a sync needed its slot)
-        PipeJob &jb = ix->jobs[j];
-        PipeGroup &gr = ix->groups[jb.group];
-        // still collecting: launched by the policy once fewer than two searches are queued (at once under the test hook)
-        if (!jb.rc && gr.state == 1) (void)kick_locked(ix, ix->hold_always);
-        else (void)kick_locked(ix);       // (another group may be collecting: keep the search stream fed)
-        bool ready = jb.rc != 0;
-        if (!ready && gr.state == 2) { ready = hipEventQuery(gr.down_done) != hipErrorNotReady; (void)hipGetLastError(); }
-        if (ready) { const int rc = finish_job_locked(ix, j); if (rc) return rc; break; }
-        lk.unlock();
-        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(300)) std::this_thread::yield();
-        else std::this_thread::sleep_for(std::chrono::microseconds(20));
-        lk.lock();
-    }
-    auto it = ix->failed_tickets.find(ticket);
-    if (it != ix->failed_tickets.end()) {
-        const int rc = it->second.first; g_err = it->second.second;
-        ix->failed_tickets.erase(it);
-        return rc;
-    }
-    return 0;     // finished (now, or earlier: a later submit or a sync needed its slot)
-}
-
-// launches whatever dr_search_submit is still holding back (a caller that submits and then goes away for a while)
-extern "C" int dr_search_flush(dr_index *ix)
-{
-    if (!ix) return fail(DR_E_ARG, "null index");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    HIPCHK(hipSetDevice(ix->device));
-    return kick_locked(ix, true);
-}
-
-// test hook: with `on`, held submits are launched only when their group is full, flushed or waited for (never by the
-// "search stream is running dry" rule, which depends on timing)
-extern "C" int dr_debug_hold(dr_index *ix, int on)
-{
-    if (!ix) return fail(DR_E_ARG, "null index");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    ix->hold_always = on != 0;
-    return 0;
-}
-
-// launches of the pipelined path since the handle was created: [0] launches, [1] tickets they carried, [2] most tickets in one
-// launch, [3] queries
-extern "C" int dr_pipeline_stats(dr_index *ix, uint64_t *out4)
-{
-    if (!ix || !out4) return fail(DR_E_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    out4[0] = ix->pipe_launches; out4[1] = ix->pipe_tickets; out4[2] = ix->pipe_max_tickets; out4[3] = ix->pipe_queries;
-    return 0;
-}
-
-extern "C" int dr_set_coalesce(dr_index *ix, uint32_t max_queries)
-{
-    if (!ix) return fail(DR_E_ARG, "null index");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    if (max_queries > DR_MAX_CHUNK) return fail(DR_E_ARG, "coalesced launches hold at most %u queries", DR_MAX_CHUNK);
-    HIPCHK(hipSetDevice(ix->device));
-    { const int rc = kick_locked(ix, true); if (rc) return rc; }
-    ix->coalesce_cap = max_queries;
-    return 0;
-}
+#include "pipeline.inc"
 
 extern "C" int dr_batch_upload(dr_index *ix, const float *queries, uint32_t nq)
 {
@@ -1638,885 +1334,11 @@ extern "C" int dr_search_batch_f64(dr_index *ix, const double *queries, uint32_t
     return rc;
 }
 
-// --------------------------------------------------------------------------------- kernel-level entry points
+#include "entry_points.inc"
 
-extern "C" int dr_exact_distances(dr_index *ix, const float *queries, uint32_t nq, const uint32_t *node_ids, uint32_t n,
-                                  float *out)
-{
-    if (!ix || !queries || !node_ids || !out || nq == 0 || n == 0) return fail(DR_E_ARG, "bad argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    { const int rcv = need_vectors(ix, "dr_exact_distances"); if (rcv) return rcv; }
-    for (uint32_t i = 0; i < n; i++) if (node_ids[i] >= ix->N) return fail(DR_E_ARG, "node id %u out of range", node_ids[i]);
-    int rc = upload_queries_locked(ix, queries, nq);
-    if (rc) return rc;
-    DevBuf<uint32_t> ids; DevBuf<float> o;
-    if (ids.reserve(n) || o.reserve((size_t)nq * n)) return DR_E_NODEVICE;
-    HIPCHK(hipMemcpyAsync(ids.p, node_ids, (size_t)n * 4, hipMemcpyHostToDevice, ix->stream));
-    const float *vecp = ix->vecp.p; const float *qp = ix->cs->qp.p; const uint32_t *idp = ids.p; float *op = o.p;
-    void *args[] = { &vecp, &qp, &nq, &idp, &n, &op };
-    const unsigned gx = std::min<unsigned>((n + 7) / 8, 1024);
-    HIPCHK(hipLaunchKernel(ix->kern->exact, dim3(gx, nq), dim3(64), args, (size_t)ix->D * 4, ix->stream));
-    HIPCHK(hipMemcpyAsync(out, o.p, (size_t)nq * n * 4, hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    ids.release(); o.release();
-    return 0;
-}
+#include "builder.inc"
 
-extern "C" int dr_distance_table(dr_index *ix, const float *queries, uint32_t nq, float *out)
-{
-    if (!ix || !queries || !out || nq == 0) return fail(DR_E_ARG, "bad argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    if (ix->m == 0) return fail(DR_E_NOPQ, "no PQ data");
-    int rc = upload_queries_locked(ix, queries, nq);
-    if (rc) return rc;
-    DevBuf<float> o;
-    if (o.reserve((size_t)nq * ix->m * 256)) return DR_E_NODEVICE;
-    { const int rcl = launch_lut_build(ix, ix->cs->q.p, nq, o.p); if (rcl) return rcl; }      // the kernel the searches use
-    HIPCHK(hipMemcpyAsync(out, o.p, (size_t)nq * ix->m * 256 * 4, hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    o.release();
-    return 0;
-}
-
-static int adc_common(dr_index *ix, const float *queries, uint32_t nq, const uint32_t *node_ids, uint64_t n,
-                      float *out_sq, float *out_sqrt, float *kernel_ms)
-{
-    if (ix->m == 0) return fail(DR_E_NOPQ, "no PQ data");
-    int rc = upload_queries_locked(ix, queries, nq);
-    if (rc) return rc;
-    DevBuf<uint32_t> ids; DevBuf<float> o1, o2;
-    if (node_ids) {
-        for (uint64_t i = 0; i < n; i++) if (node_ids[i] >= ix->N) return fail(DR_E_ARG, "node id out of range");
-        if (ids.reserve(n)) return DR_E_NODEVICE;
-        HIPCHK(hipMemcpyAsync(ids.p, node_ids, n * 4, hipMemcpyHostToDevice, ix->stream));
-    }
-    if (out_sq && o1.reserve((size_t)nq * n)) return DR_E_NODEVICE;
-    if (out_sqrt && o2.reserve((size_t)nq * n)) return DR_E_NODEVICE;
-    const size_t lds = (size_t)ix->D * 4 + (size_t)ix->m * 256 * 4;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&adc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned gx = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ix->num_cu * 8);
-    HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
-    hipLaunchKernelGGL(adc_kernel, dim3(gx, nq), dim3(256), lds, ix->stream, ix->codebook.p, ix->cs->q.p, ix->codes.p,
-                       node_ids ? ids.p : nullptr, n, ix->D, ix->m, ix->sd, out_sq ? o1.p : nullptr, out_sqrt ? o2.p : nullptr);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
-    if (out_sq) HIPCHK(hipMemcpyAsync(out_sq, o1.p, (size_t)nq * n * 4, hipMemcpyDeviceToHost, ix->stream));
-    if (out_sqrt) HIPCHK(hipMemcpyAsync(out_sqrt, o2.p, (size_t)nq * n * 4, hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ix->ev[2], ix->ev[3]);
-    ids.release(); o1.release(); o2.release();
-    return 0;
-}
-
-extern "C" int dr_adc(dr_index *ix, const float *queries, uint32_t nq, const uint32_t *node_ids, uint32_t n,
-                      float *out_sq, float *out_sqrt)
-{
-    if (!ix || !queries || !node_ids || nq == 0 || n == 0) return fail(DR_E_ARG, "bad argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    return adc_common(ix, queries, nq, node_ids, n, out_sq, out_sqrt, nullptr);
-}
-
-extern "C" int dr_pq_scan(dr_index *ix, const float *queries, uint32_t nq, float *out_sq, float *kernel_ms)
-{
-    return dr_pq_scan_best(ix, queries, nq, out_sq, nullptr, nullptr, kernel_ms);
-}
-
-// Flat scan of all N code words per query (pq_scan_kernel): out_sq (optional) gets every squared ADC distance,
-// out_best_id / out_best_sq (optional) the nearest code word per query (smallest id among equal sums).
-static int pq_scan_best_locked(dr_index *ix, const float *queries, uint32_t nq, float *out_sq, uint32_t *out_best_id,
-                               float *out_best_sq, float *kernel_ms);
-extern "C" int dr_pq_scan_best(dr_index *ix, const float *queries, uint32_t nq, float *out_sq, uint32_t *out_best_id,
-                               float *out_best_sq, float *kernel_ms)
-{
-    if (!ix || !queries || nq == 0) return fail(DR_E_ARG, "bad argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    return pq_scan_best_locked(ix, queries, nq, out_sq, out_best_id, out_best_sq, kernel_ms);
-}
-// (the caller holds ix->mu: the PQ-only builder scans for its medoid in the middle of a build)
-static int pq_scan_best_locked(dr_index *ix, const float *queries, uint32_t nq, float *out_sq, uint32_t *out_best_id,
-                               float *out_best_sq, float *kernel_ms)
-{
-    if (ix->m == 0) return fail(DR_E_NOPQ, "no PQ data");
-    const uint32_t m = ix->m;
-    if ((m & 15u) != 0 || m > 64) {
-        // generic form (any m): all distances through adc_kernel, the nearest code word picked on the host
-        std::vector<float> tmp;
-        float *all = out_sq;
-        if (!all && (out_best_id || out_best_sq)) { tmp.resize((size_t)nq * ix->N); all = tmp.data(); }
-        int rcg = adc_common(ix, queries, nq, nullptr, ix->N, all, nullptr, kernel_ms);
-        if (rcg || !all) return rcg;
-        for (uint32_t qi = 0; qi < nq; qi++) {
-            const float *row = all + (size_t)qi * ix->N;
-            uint64_t bi = 0;
-            for (uint64_t i = 1; i < ix->N; i++) if (row[i] < row[bi]) bi = i;
-            if (out_best_id) out_best_id[qi] = (uint32_t)bi;
-            if (out_best_sq) out_best_sq[qi] = row[bi];
-        }
-        return 0;
-    }
-    int rc = upload_queries_locked(ix, queries, nq);
-    if (rc) return rc;
-    const uint64_t n = ix->N;
-    DevBuf<float> o1; DevBuf<u64> best;
-    if (out_sq && o1.reserve((size_t)nq * n)) return DR_E_NODEVICE;
-    if (best.reserve(nq)) return DR_E_NODEVICE;
-    HIPCHK(hipMemsetAsync(best.p, 0xFF, (size_t)nq * 8, ix->stream));
-    const size_t lds = (size_t)ix->D * 4 + (size_t)m * 256 * 4;
-    const void *kfn = m == 16 ? reinterpret_cast<const void *>(&pq_scan_kernel<1>) : m == 32 ? reinterpret_cast<const void *>(&pq_scan_kernel<2>)
-                    : m == 48 ? reinterpret_cast<const void *>(&pq_scan_kernel<3>) : reinterpret_cast<const void *>(&pq_scan_kernel<4>);
-    HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int occ = 1;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds));
-    if (occ < 1) occ = 1;
-    // persistent blocks: the table is built once per block; with several queries in flight the rows share the chip
-    const unsigned per_q = (unsigned)std::max<uint64_t>(1, (uint64_t)occ * ix->num_cu / std::min<uint32_t>(nq, (uint32_t)occ * ix->num_cu));
-    const unsigned gx = (unsigned)std::min<uint64_t>((n + 255) / 256, per_q);
-    const float *cbp = ix->codebook.p; const float *qp = ix->cs->q.p; const uint8_t *cdp = ix->codes.p; uint64_t nn = n;
-    uint32_t D = ix->D, sd = ix->sd; float *op = out_sq ? o1.p : nullptr; u64 *bp = best.p;
-    void *args[] = { &cbp, &qp, &cdp, &nn, &D, &sd, &op, &bp };
-    HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
-    HIPCHK(hipLaunchKernel(kfn, dim3(gx, nq), dim3(256), args, lds, ix->stream));
-    HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
-    std::vector<u64> hb(nq);
-    if (out_sq) HIPCHK(hipMemcpyAsync(out_sq, o1.p, (size_t)nq * n * 4, hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipMemcpyAsync(hb.data(), best.p, (size_t)nq * 8, hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ix->ev[2], ix->ev[3]);
-    for (uint32_t i = 0; i < nq; i++) {
-        if (out_best_id) out_best_id[i] = (uint32_t)hb[i];
-        if (out_best_sq) { const uint32_t b = (uint32_t)(hb[i] >> 32); memcpy(&out_best_sq[i], &b, 4); }
-    }
-    o1.release(); best.release();
-    return 0;
-}
-
-// Brute-force ADC search: the k nearest code words per query by a flat scan (pq_scan_topk_kernel + topk_merge_kernel).
-extern "C" int dr_pq_scan_topk(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t *out_ids, float *out_sq,
-                               float *kernel_ms)
-{
-    if (!ix || !queries || !out_ids || nq == 0 || k == 0 || k > 64) return fail(DR_E_ARG, "bad argument (k <= 64)");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    if (ix->m == 0) return fail(DR_E_NOPQ, "no PQ data");
-    const uint32_t m = ix->m;
-    if ((m & 15u) != 0 || m > 64) return fail(DR_E_UNSUPPORTED, "dr_pq_scan_topk needs n_subvectors in {16, 32, 48, 64}");
-    HIPCHK(hipSetDevice(ix->device));
-    const size_t lds = (size_t)m * 1024 + 4 * 64 * 8;
-    const void *kfn = m == 16 ? reinterpret_cast<const void *>(&pq_scan_topk_kernel<1>) : m == 32 ? reinterpret_cast<const void *>(&pq_scan_topk_kernel<2>)
-                    : m == 48 ? reinterpret_cast<const void *>(&pq_scan_topk_kernel<3>) : reinterpret_cast<const void *>(&pq_scan_topk_kernel<4>);
-    HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int occ = 1;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 256, lds));
-    if (occ < 1) occ = 1;
-    // queries are scanned in groups that fill the chip once: `per_q` blocks per query, `group` queries per launch
-    const uint64_t n = ix->N;
-    const uint32_t slots = (uint32_t)occ * ix->num_cu;
-    const uint32_t per_q = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 16383) / 16384, std::min<uint32_t>(slots, 256)));
-    const uint32_t group = std::max<uint32_t>(1, std::min<uint32_t>(nq, 4 * slots / per_q));
-    DevBuf<float> lut, osq; DevBuf<u64> part; DevBuf<uint32_t> oid;
-    if (lut.reserve((size_t)group * m * 256) || part.reserve((size_t)group * per_q * 4 * k) || oid.reserve((size_t)nq * k) || osq.reserve((size_t)nq * k))
-        return DR_E_NODEVICE;
-    float ms_sum = 0;
-    for (uint32_t q0 = 0; q0 < nq; q0 += group) {
-        const uint32_t g = std::min(group, nq - q0);
-        int rc = upload_queries_locked(ix, queries + (size_t)q0 * ix->D, g);
-        if (rc) return rc;
-        rc = launch_lut_build(ix, ix->cs->q.p, g, lut.p);
-        if (rc) return rc;
-        const float *lp = lut.p; const uint8_t *cdp = ix->codes.p; uint64_t nn = n; uint32_t kk = k; u64 *pp = part.p;
-        void *args[] = { &lp, &cdp, &nn, &kk, &pp };
-        HIPCHK(hipEventRecord(ix->ev[2], ix->stream));
-        HIPCHK(hipLaunchKernel(kfn, dim3(per_q, g), dim3(256), args, lds, ix->stream));
-        HIPCHK(hipEventRecord(ix->ev[3], ix->stream));
-        hipLaunchKernelGGL(topk_merge_kernel, dim3(g), dim3(64), 0, ix->stream, part.p, per_q * 4, k, oid.p + (size_t)q0 * k, osq.p + (size_t)q0 * k);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(ix->stream));
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, ix->ev[2], ix->ev[3]);
-        ms_sum += ms;
-    }
-    HIPCHK(hipMemcpy(out_ids, oid.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-    if (out_sq) HIPCHK(hipMemcpy(out_sq, osq.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
-    if (kernel_ms) *kernel_ms = ms_sum;
-    return 0;
-}
-
-extern "C" int dr_bruteforce_topk(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t *out_ids,
-                                  float *out_dist)
-{
-    if (!ix || !queries || !out_ids || nq == 0 || k == 0 || k > 64) return fail(DR_E_ARG, "bad argument (k <= 64)");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    { const int rcv = need_vectors(ix, "dr_bruteforce_topk"); if (rcv) return rcv; }
-    int rc = upload_queries_locked(ix, queries, nq);
-    if (rc) return rc;
-    DevBuf<uint32_t> oi; DevBuf<float> od;
-    if (oi.reserve((size_t)nq * k) || od.reserve((size_t)nq * k)) return DR_E_NODEVICE;
-    const float *vecp = ix->vecp.p; const float *qp = ix->cs->qp.p; uint64_t N = ix->N; uint32_t *oip = oi.p; float *odp = od.p;
-    // small batches: the rows are cut into S slices per query so that the launch still has a few thousand wavefronts
-    const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(64, N / 4096 + 1), ((uint64_t)ix->num_cu * 16) / nq));
-    DevBuf<u64> part;
-    if (S > 1 && part.reserve((size_t)nq * S * k)) return DR_E_NODEVICE;
-    u64 *pp = S > 1 ? part.p : nullptr;
-    void *args[] = { &vecp, &N, &qp, &nq, &k, &oip, &odp, &pp };
-    const size_t lds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + 64 * 8;
-    HIPCHK(hipLaunchKernel(ix->kern->bruteforce, dim3(nq, S), dim3(64), args, lds, ix->stream));
-    if (S > 1) { hipLaunchKernelGGL(topk_merge_kernel, dim3(nq), dim3(64), 0, ix->stream, part.p, S, k, oi.p, od.p); HIPCHK(hipGetLastError()); }
-    HIPCHK(hipMemcpyAsync(out_ids, oi.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
-    if (out_dist) HIPCHK(hipMemcpyAsync(out_dist, od.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    oi.release(); od.release();
-    return 0;
-}
-
-extern "C" int dr_get_node(dr_index *ix, uint64_t node_id, float *out_vec, uint32_t *out_nbrs)
-{
-    if (!ix || !out_vec || !out_nbrs) return fail(DR_E_ARG, "null argument");
-    if (node_id >= ix->N) return fail(DR_E_ARG, "node id out of range");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    { const int rcv = need_vectors(ix, "dr_get_node"); if (rcv) return rcv; }
-    HIPCHK(hipSetDevice(ix->device));
-    std::vector<float> tmp(ix->D);
-    HIPCHK(hipMemcpy(tmp.data(), ix->vecp.p + node_id * ix->D, (size_t)ix->D * 4, hipMemcpyDefault));     // (HBM or the host tier)
-    for (uint32_t e = 0; e < ix->D; e++) out_vec[e] = tmp[ix->h_perm[e]];
-    HIPCHK(hipMemcpy(out_nbrs, ix->adj.p + node_id * ix->R, (size_t)ix->R * 4, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------ builder
-
-extern "C" int dr_index_create_empty(dr_index **out, const float *vectors, uint64_t N, uint32_t D, uint32_t R, int device)
-{
-    return dr_index_create_empty_tiered(out, vectors, N, D, R, device, DR_TIER_HBM);
-}
-
-extern "C" int dr_index_create_empty_tiered(dr_index **out, const float *vectors, uint64_t N, uint32_t D, uint32_t R, int device,
-                                            uint32_t vector_tier)
-{
-    if (!out) return fail(DR_E_ARG, "null argument");
-    dr_index *ix = new dr_index();
-    int rc = index_alloc_common(ix, N, D, R, 0, device, true, vector_tier);
-    if (rc) { dr_index_close(ix); return rc; }
-    DevBuf<uint32_t> staging;
-    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / (D * 4));
-    // (vectors == NULL: the rows arrive later, chunk by chunk, through dr_index_write_rows -- an index whose rows do not fit in
-    // host memory twice, or are generated / read as a stream)
-    for (uint64_t r0 = 0; vectors && r0 < N && !rc; r0 += chunk) {
-        const uint64_t rows = std::min(chunk, N - r0);
-        rc = ingest_chunk(ix, vectors + (size_t)r0 * D, r0, rows, D, false, staging);
-    }
-    staging.release();
-    if (!rc && hipMemset(ix->adj.p, 0xFF, (size_t)N * R * 4) != hipSuccess) rc = fail(DR_E_NODEVICE, "memset failed");
-    if (!rc && hipMemset(ix->first.p, 0, (size_t)N * ((R + 63) / 64) * 8) != hipSuccess) rc = fail(DR_E_NODEVICE, "memset failed");
-    if (rc) { dr_index_close(ix); return rc; }
-    *out = ix;
-    return 0;
-}
-
-// rows [row0, row0 + n) of the stored vectors, from host memory (any tier): the streaming form of dr_index_create_empty's upload
-extern "C" int dr_index_write_rows(dr_index *ix, const float *rows, uint64_t row0, uint64_t n)
-{
-    if (!ix || !rows) return fail(DR_E_ARG, "null argument");
-    if (row0 > ix->N || n > ix->N - row0) return fail(DR_E_ARG, "rows [%llu, %llu) outside the index (N=%llu)", (unsigned long long)row0, (unsigned long long)(row0 + n), (unsigned long long)ix->N);
-    std::lock_guard<std::mutex> lk(ix->mu);
-    { const int rcv = need_vectors(ix, "dr_index_write_rows"); if (rcv) return rcv; }
-    HIPCHK(hipSetDevice(ix->device));
-    { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }
-    DevBuf<uint32_t> staging;
-    const uint64_t chunk = std::max<uint64_t>(1, (256ull << 20) / (ix->D * 4));
-    int rc = 0;
-    for (uint64_t r0 = 0; r0 < n && !rc; r0 += chunk)
-        rc = ingest_chunk(ix, rows + (size_t)r0 * ix->D, row0 + r0, std::min(chunk, n - r0), ix->D, false, staging);
-    // what was derived from the old rows is stale
-    ix->rank_valid = false; ix->adjr_valid = false; ix->vec8_state = (ix->vec8_state == -1 && ix->D != 128) ? -1 : 0; ix->vec8.release();
-    ix->vnorm2.release(); ix->adc_live = -1;
-    return rc;
-}
-
-extern "C" int dr_get_adjacency(dr_index *ix, uint32_t *out)
-{
-    if (!ix || !out) return fail(DR_E_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    HIPCHK(hipSetDevice(ix->device));
-    HIPCHK(hipMemcpy(out, ix->adj.p, (size_t)ix->N * ix->R * 4, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-static uint64_t splitmix64(uint64_t &x)
-{
-    uint64_t z = (x += 0x9E3779B97F4A7C15ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
-// the exact prune's multi-pick form (build_kernels.hpp): dimensions with the split row form only
-static uint32_t prune_multi_enabled(uint32_t D)
-{
-    static const bool off = getenv("DR_PRUNE_PLAIN") != nullptr;      // (A/B: one pass over the candidates' rows per pick)
-    const DimKernels *k = dr_dim_kernels((int)D);
-    return (!off && k && k->prune_multi) ? 1u : 0u;
-}
-
-// centroid-pair table S[m][256][256] (8 MB at m = 32): every distance of the PQ-only builder is a sum of its entries
-static int ensure_sdc(dr_index *ix)
-{
-    // (the table used to outlive its codebook -- dr_index_set_pq / dr_pq_encode / a codes-empty upload replaced the
-    // codebook or m and a later dr_build_vamana_pq / dr_debug_prune_pq scored with the OLD table, out of bounds if m grew)
-    if (ix->sdc.p && ix->sdc_gen == ix->codebook_gen) return 0;
-    ix->sdc.release();
-    if (ix->sdc.reserve((size_t)ix->m * 65536)) return DR_E_NODEVICE;
-    ix->sdc_gen = ix->codebook_gen;
-    hipLaunchKernelGGL(sdc_table_kernel, dim3(ix->m * 256), dim3(256), 0, ix->stream, ix->codebook.p, ix->m, ix->sd, ix->sdc.p);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-// prune_pq_kernel for q.npoints points: rows in registers (8 wavefronts per CU) when m is 16 or 32, in LDS otherwise
-// (DR_PQ_PRUNE_LDS=1 forces the LDS form: A/B, and the check that both build the same graph).
-static int launch_prune_pq(dr_index *ix, const PrunePQParams &q)
-{
-    static const bool force_lds = getenv("DR_PQ_PRUNE_LDS") != nullptr;
-    const int m16 = (!force_lds && (ix->m == 16 || ix->m == 32)) ? (int)(ix->m / 16) : 0;
-    const size_t lds = (m16 ? 0 : (size_t)ix->m * 1024) + (size_t)DR_PRUNE_PQ_MAXC * 24 + 1024 + (size_t)DR_PRUNE_PQ_MAXC * ix->m;
-    const dim3 grid(std::min<unsigned>(q.npoints, (unsigned)ix->num_cu * (m16 ? 8 : 4)));
-    if (m16 == 2) hipLaunchKernelGGL(prune_pq_kernel<2>, grid, dim3(64), lds, ix->stream, q);
-    else if (m16 == 1) hipLaunchKernelGGL(prune_pq_kernel<1>, grid, dim3(64), lds, ix->stream, q);
-    else {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&prune_pq_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(prune_pq_kernel<0>, grid, dim3(64), lds, ix->stream, q);
-    }
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-static int build_vamana_common(dr_index *ix, uint32_t L_build, float alpha, uint32_t passes, uint64_t seed,
-                               uint32_t pad_with_zero, uint32_t max_batch, uint32_t *out_medoid, float *out_seconds, bool pq)
-{
-    if (!ix) return fail(DR_E_ARG, "null index");
-    if (L_build == 0 || L_build > 256) return fail(DR_E_ARG, "L_build must be in 1..256");
-    if (ix->R > 128) return fail(DR_E_UNSUPPORTED, "builder supports R <= 128");
-    // (the PQ-only prune holds its candidates' code words in LDS: the construction list plus a full row with its slack slots)
-    if (pq && L_build + ix->R + 64 > DR_PRUNE_PQ_MAXC)
-        return fail(DR_E_ARG, "dr_build_vamana_pq: L_build + R + 64 = %u exceeds the prune's %d candidates", L_build + ix->R + 64, DR_PRUNE_PQ_MAXC);
-    if (passes == 0) passes = 2;
-    std::lock_guard<std::mutex> lk(ix->mu);
-    if (!pq) { const int rcv = need_vectors(ix, "dr_build_vamana"); if (rcv) return rcv; }
-    if (pq && ix->m == 0) return fail(DR_E_NOPQ, "dr_build_vamana_pq needs the code words (dr_index_create_codes_empty + dr_pq_encode_rows)");
-    HIPCHK(hipSetDevice(ix->device));
-    { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }
-    const uint64_t N = ix->N;
-    const uint32_t D = ix->D, R = ix->R;
-    const uint32_t RX = R + 64;                       // slack slots for reverse edges inside one batch
-    if (max_batch == 0) max_batch = 32768;
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    struct EvPair { hipEvent_t &a, &b; ~EvPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evp{ t0, t1 };   // every early return frees them
-    HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1));
-    HIPCHK(hipEventRecord(t0, ix->stream));
-
-    // ---- medoid: stored vector nearest to the centroid (the reference samples, cython_utils.pyx:210-263)
-    if (!pq) {
-        DevBuf<double> acc;
-        if (acc.reserve(D, true)) return DR_E_NODEVICE;
-        hipLaunchKernelGGL(column_sum_kernel, dim3(1024), dim3(128), 0, ix->stream, ix->vecp.p, N, D, acc.p);
-        HIPCHK(hipGetLastError());
-        std::vector<double> hacc(D);
-        HIPCHK(hipMemcpyAsync(hacc.data(), acc.p, D * sizeof(double), hipMemcpyDeviceToHost, ix->stream));
-        HIPCHK(hipStreamSynchronize(ix->stream));
-        acc.release();
-        // acc is in chain-major positions: upload as an already-permuted query
-        std::vector<float> cq(D);
-        for (uint32_t e = 0; e < D; e++) cq[e] = (float)(hacc[e] / (double)N);
-        if (ix->cs->q.reserve(D) || ix->cs->qp.reserve(D)) return DR_E_NODEVICE;
-        HIPCHK(hipMemcpyAsync(ix->cs->qp.p, cq.data(), D * 4, hipMemcpyHostToDevice, ix->stream));
-        DevBuf<uint32_t> oi; DevBuf<float> od;
-        if (oi.reserve(1) || od.reserve(1)) return DR_E_NODEVICE;
-        const float *vecp = ix->vecp.p; const float *qp = ix->cs->qp.p; uint64_t NN = N; uint32_t one = 1; uint32_t *oip = oi.p; float *odp = od.p;
-        // (one query: the rows are cut into slices, one wavefront each, folded by topk_merge_kernel -- same winner as one
-        // wavefront over all rows: smallest distance, then smallest id)
-        const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(1024, N / 4096));
-        DevBuf<u64> part;
-        if (S > 1 && part.reserve(S)) return DR_E_NODEVICE;
-        u64 *pp = S > 1 ? part.p : nullptr;
-        void *args[] = { &vecp, &NN, &qp, &one, &one, &oip, &odp, &pp };
-        const size_t lds = (D > 256 ? (size_t)D * 4 : 0) + 64 * 8;
-        HIPCHK(hipLaunchKernel(ix->kern->bruteforce, dim3(1, S), dim3(64), args, lds, ix->stream));
-        if (S > 1) { hipLaunchKernelGGL(topk_merge_kernel, dim3(1), dim3(64), 0, ix->stream, part.p, S, 1u, oi.p, od.p); HIPCHK(hipGetLastError()); }
-        uint32_t med = 0;
-        HIPCHK(hipMemcpyAsync(&med, oi.p, 4, hipMemcpyDeviceToHost, ix->stream));
-        HIPCHK(hipStreamSynchronize(ix->stream));
-        oi.release(); od.release();
-        ix->medoid = med;
-    } else {
-        // PQ-only: the mean of the decoded vectors follows from the per-sub-quantiser histogram of the code words; the
-        // medoid is the code word nearest to it (flat ADC scan)
-        DevBuf<uint32_t> hist;
-        if (hist.reserve((size_t)ix->m * 256, true)) return DR_E_NODEVICE;
-        hipLaunchKernelGGL(code_histogram_kernel, dim3(4096), dim3(256), 0, ix->stream, ix->codes.p, N, ix->m, hist.p);
-        HIPCHK(hipGetLastError());
-        std::vector<uint32_t> hh((size_t)ix->m * 256);
-        std::vector<float> hcb((size_t)256 * D), mean(D, 0.0f);
-        HIPCHK(hipMemcpyAsync(hh.data(), hist.p, hh.size() * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIPCHK(hipMemcpyAsync(hcb.data(), ix->codebook.p, hcb.size() * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIPCHK(hipStreamSynchronize(ix->stream));
-        for (uint32_t jq = 0; jq < ix->m; jq++)
-            for (uint32_t t = 0; t < ix->sd; t++) {
-                double a = 0;
-                for (uint32_t c = 0; c < 256; c++) a += (double)hh[jq * 256 + c] * hcb[((size_t)jq * 256 + c) * ix->sd + t];
-                mean[jq * ix->sd + t] = (float)(a / (double)N);
-            }
-        // flat scan for the nearest code word (pq_scan_kernel through the regular entry point's machinery)
-        uint32_t best = 0; float bsq = 0, kms = 0;
-        const int rcs = pq_scan_best_locked(ix, mean.data(), 1, nullptr, &best, &bsq, &kms);
-        if (rcs) return rcs;
-        ix->medoid = best;
-    }
-    DevBuf<uint32_t> adjb, deg, order, fwd, fwd_n, ovf_list, ovf_count;
-    if (adjb.reserve((size_t)N * RX) || deg.reserve(N + 2, true) || order.reserve(N) || fwd.reserve((size_t)max_batch * R) ||
-        fwd_n.reserve(max_batch) || ovf_list.reserve(N) || ovf_count.reserve(1))
-        return DR_E_NODEVICE;
-    HIPCHK(hipMemsetAsync(adjb.p, 0xFF, (size_t)N * RX * 4, ix->stream));
-    if (!pq && (ix->cs->q.reserve((size_t)max_batch * D) || ix->cs->qp.reserve((size_t)max_batch * D))) return DR_E_NODEVICE;
-    // reverse-edge pass: sorted pairs (deterministic; DR_BUILD_ATOMIC_REV=1 selects the atomic append it replaced, for A/B)
-    static const bool rev_atomic = getenv("DR_BUILD_ATOMIC_REV") != nullptr;
-    DevBuf<u64> rkeys_a, rkeys_b;
-    DevBuf<unsigned char> rtemp;
-    if (!rev_atomic) {
-        const size_t np = (size_t)max_batch * R;
-        if (rkeys_a.reserve(np) || rkeys_b.reserve(np)) return DR_E_NODEVICE;
-        size_t tb = 0;
-        HIPCHK(rocprim::radix_sort_keys(nullptr, tb, rkeys_a.p, rkeys_b.p, (unsigned int)np, 0u, 64u, ix->stream));
-        if (rtemp.reserve(tb + 16)) return DR_E_NODEVICE;
-    }
-    if (pq) { const int rcs = ensure_sdc(ix); if (rcs) return rcs; }
-
-    // DR_PQ_BUILD_SLACK (diagnosis): how far a row of the PQ-only builder may exceed R before it is re-pruned (default: a quarter of the slack slots: 4x fewer re-prunes at 2 points of recall, profiles/r02/scale_c5_small_4M.json)
-    static const char *slack_env = getenv("DR_PQ_BUILD_SLACK");
-    const uint32_t pq_slack = slack_env ? std::min<uint32_t>((uint32_t)atoi(slack_env), RX - R - 1) : (RX - R) / 4;
-    // the exact prune scores the next few likely picks in one pass over the candidates' rows (D <= 256; DR_PRUNE_PLAIN=1: one pass per pick)
-    const uint32_t prune_multi = prune_multi_enabled(D);
-    const size_t prune_lds = (D > 256 ? (size_t)D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024 + (prune_multi ? (size_t)4 * DR_PRUNE_MAXC * 4 : 0);
-    std::vector<uint32_t> horder(N);
-    uint64_t rng = seed ? seed : 1;
-    int rc = 0;
-    for (uint32_t pass = 0; pass < passes && !rc; pass++) {
-        for (uint64_t i = 0; i < N; i++) horder[i] = (uint32_t)i;
-        for (uint64_t i = N - 1; i > 0; i--) { uint64_t jx = splitmix64(rng) % (i + 1); std::swap(horder[i], horder[jx]); }
-        HIPCHK(hipMemcpyAsync(order.p, horder.data(), N * 4, hipMemcpyHostToDevice, ix->stream));
-        HIPCHK(hipStreamSynchronize(ix->stream));
-        const float a = (pass == 0 && passes > 1) ? 1.0f : alpha;      // cython_utils.pyx:312
-        uint64_t done = 0;
-        uint32_t bsz = 1;
-        while (done < N && !rc) {
-            // batch sizes double while the graph is small (pass 0); later passes run at the cap
-            uint32_t b = (pass == 0) ? std::min<uint64_t>(bsz, std::max<uint64_t>(1, done / 16 + 1)) : max_batch;
-            b = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(b, max_batch), N - done);
-            const uint32_t *pts = order.p + done;
-            // 1. queries = the batch points' own vectors (already chain-major); PQ-only: their code words
-            if (!pq) hipLaunchKernelGGL(gather_rows_kernel, dim3(b), dim3(64), 0, ix->stream, ix->vecp.p, pts, b, D, ix->cs->qp.p);
-            BuildOverride ov = { adjb.p, deg.p, RX, b };
-            if (pq) { ov.sdc = ix->sdc.p; ov.pts = pts; }
-            rc = run_locked(ix, 1, L_build, 0, DR_MODE_M4, 0, DR_F_SQDIST, &ov);
-            if (rc) break;
-            // 2. prune -> forward rows
-            PruneParams pp;
-            pp.vecp = ix->vecp.p; pp.adjb = adjb.p; pp.deg = deg.p; pp.RX = RX; pp.R = R; pp.alpha = a;
-            pp.points = pts; pp.npoints = b; pp.res_keys = ix->sets[0].res_keys.p; pp.res_n = ix->sets[0].res_n.p; pp.cap = L_build;
-            pp.fwd = fwd.p; pp.fwd_n = fwd_n.p; pp.multi = prune_multi;
-            PrunePQParams pq_pp;
-            pq_pp.codes = ix->codes.p; pq_pp.sdc = ix->sdc.p; pq_pp.m = ix->m; pq_pp.adjb = adjb.p; pq_pp.deg = deg.p; pq_pp.RX = RX; pq_pp.R = R;
-            pq_pp.alpha = a; pq_pp.points = pts; pq_pp.npoints = b; pq_pp.res_keys = pp.res_keys; pq_pp.res_n = pp.res_n; pq_pp.cap = L_build;
-            pq_pp.fwd = fwd.p; pq_pp.fwd_n = fwd_n.p;
-            if (pq) {
-                const int rcp = launch_prune_pq(ix, pq_pp);
-                if (rcp) return rcp;
-            } else {
-                void *args[] = { &pp };
-                const unsigned g = std::min<unsigned>(b, (unsigned)ix->num_cu * 16);
-                HIPCHK(hipLaunchKernel(prune_multi ? ix->kern->prune_multi : ix->kern->prune, dim3(g), dim3(64), args, prune_lds, ix->stream));
-            }
-            // 3. reverse edges
-            HIPCHK(hipMemsetAsync(ovf_count.p, 0, 4, ix->stream));
-            {
-                const uint64_t threads = (uint64_t)b * R;
-                // (PQ-only builder: rows run half-way into their slack before they are re-pruned, see reverse_edges_kernel)
-                if (rev_atomic) {
-                    hipLaunchKernelGGL(reverse_edges_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ix->stream,
-                                       adjb.p, deg.p, RX, R, pts, b, fwd.p, fwd_n.p, ovf_list.p, ovf_count.p, (uint32_t)N, pq ? R + pq_slack : R);
-                    HIPCHK(hipGetLastError());
-                } else {
-                    // sorted (target, source) pairs, one thread per target's run: deterministic (engine_kernels.hpp)
-                    hipLaunchKernelGGL(rev_pairs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ix->stream, pts, b, R, fwd.p, fwd_n.p, rkeys_a.p);
-                    HIPCHK(hipGetLastError());
-                    size_t tb = rtemp.n;
-                    HIPCHK(rocprim::radix_sort_keys((void *)rtemp.p, tb, rkeys_a.p, rkeys_b.p, (unsigned int)threads, 0u, 64u, ix->stream));
-                    hipLaunchKernelGGL(rev_apply_sorted_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ix->stream, rkeys_b.p, (uint32_t)threads,
-                                       adjb.p, deg.p, RX, ovf_list.p, ovf_count.p, (uint32_t)N, pq ? R + pq_slack : R);
-                    HIPCHK(hipGetLastError());
-                }
-            }
-            uint32_t novf = 0;
-            HIPCHK(hipMemcpyAsync(&novf, ovf_count.p, 4, hipMemcpyDeviceToHost, ix->stream));
-            HIPCHK(hipStreamSynchronize(ix->stream));
-            // 4. re-prune rows that grew past R
-            if (novf) {
-                novf = (uint32_t)std::min<uint64_t>(novf, N);
-                PruneParams po = pp;
-                po.points = ovf_list.p; po.npoints = novf; po.res_keys = nullptr; po.res_n = nullptr; po.cap = 0;
-                po.fwd = nullptr; po.fwd_n = nullptr;
-                if (pq) {
-                    PrunePQParams qo = pq_pp;
-                    qo.points = ovf_list.p; qo.npoints = novf; qo.res_keys = nullptr; qo.res_n = nullptr; qo.cap = 0; qo.fwd = nullptr; qo.fwd_n = nullptr;
-                    const int rcp = launch_prune_pq(ix, qo);
-                    if (rcp) return rcp;
-                } else {
-                void *args[] = { &po };
-                const unsigned g = std::min<unsigned>(novf, (unsigned)ix->num_cu * 16);
-                HIPCHK(hipLaunchKernel(prune_multi ? ix->kern->prune_multi : ix->kern->prune, dim3(g), dim3(64), args, prune_lds, ix->stream));
-                }
-            }
-            done += b;
-            if (bsz < max_batch) bsz *= 2;
-        }
-    }
-    if (!rc && pq) {
-        // what is still over R after the last batch is pruned now
-        HIPCHK(hipMemsetAsync(ovf_count.p, 0, 4, ix->stream));
-        hipLaunchKernelGGL(collect_over_kernel, dim3(4096), dim3(256), 0, ix->stream, deg.p, N, R, ovf_list.p, ovf_count.p);
-        HIPCHK(hipGetLastError());
-        uint32_t novf = 0;
-        HIPCHK(hipMemcpyAsync(&novf, ovf_count.p, 4, hipMemcpyDeviceToHost, ix->stream));
-        HIPCHK(hipStreamSynchronize(ix->stream));
-        if (novf) {
-            PrunePQParams qo;
-            qo.codes = ix->codes.p; qo.sdc = ix->sdc.p; qo.m = ix->m; qo.adjb = adjb.p; qo.deg = deg.p; qo.RX = RX; qo.R = R; qo.alpha = alpha;
-            qo.points = ovf_list.p; qo.npoints = novf; qo.res_keys = nullptr; qo.res_n = nullptr; qo.cap = 0; qo.fwd = nullptr; qo.fwd_n = nullptr;
-            const int rcp = launch_prune_pq(ix, qo);
-            if (rcp) return rcp;
-        }
-    }
-    if (!rc) {
-        const uint64_t total = N * R;
-        if (R <= 128) {     // rows in a canonical order: a device-built graph is reproducible bit for bit (engine_kernels.hpp)
-            const int rcr = build_rank(ix);      // (locality order of the visited bits: neighbours that share a bitmap line sit in adjacent lanes)
-            if (rcr) return rcr;
-            hipLaunchKernelGGL(compact_adj_sorted_kernel, dim3((unsigned)std::min<uint64_t>((N + 3) / 4, (uint64_t)ix->num_cu * 32)), dim3(256), 0, ix->stream, adjb.p,
-                               deg.p, N, RX, R, pad_with_zero ? 0u : 0xFFFFFFFFu, ix->rank_valid ? ix->rank.p : nullptr, ix->adj.p);
-        }
-        else
-            hipLaunchKernelGGL(compact_adj_kernel, dim3((unsigned)std::min<uint64_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, ix->stream, adjb.p,
-                               deg.p, N, RX, R, pad_with_zero ? 0u : 0xFFFFFFFFu, ix->adj.p);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(ix->stream));
-        rc = build_first_masks(ix);
-    }
-    HIPCHK(hipEventRecord(t1, ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, t0, t1);
-    adjb.release(); deg.release(); order.release(); fwd.release(); fwd_n.release(); ovf_list.release(); ovf_count.release();
-    ix->cs->nq = 0;
-    if (out_medoid) *out_medoid = ix->medoid;
-    if (out_seconds) *out_seconds = ms / 1000.0f;
-    return rc;
-}
-
-extern "C" int dr_build_vamana(dr_index *ix, uint32_t L_build, float alpha, uint32_t passes, uint64_t seed,
-                               uint32_t pad_with_zero, uint32_t max_batch, uint32_t *out_medoid, float *out_seconds)
-{
-    return build_vamana_common(ix, L_build, alpha, passes, seed, pad_with_zero, max_batch, out_medoid, out_seconds, false);
-}
-
-// ---- PQ-only shards built on the device (BASELINE config c5): code words streamed in, graph built from code words ------
-extern "C" int dr_index_create_codes_empty(dr_index **out, uint64_t N, uint32_t D, uint32_t R, const float *codebook, uint32_t m, int device)
-{
-    if (!out || !codebook) return fail(DR_E_ARG, "null argument");
-    if (m == 0 || D % m || D / m > 128) return fail(DR_E_ARG, "bad n_subvectors %u for D=%u", m, D);
-    dr_index *ix = new dr_index();
-    int rc = index_alloc_common(ix, N, D, R, 0, device, false);
-    if (!rc && (ix->codes.reserve((size_t)N * m, true) || ix->codebook.reserve((size_t)256 * D))) rc = DR_E_NODEVICE;
-    if (!rc && hipMemcpy(ix->codebook.p, codebook, (size_t)256 * D * 4, hipMemcpyHostToDevice) != hipSuccess) rc = fail(DR_E_NODEVICE, "codebook upload failed");
-    if (!rc && hipMemset(ix->adj.p, 0xFF, (size_t)N * R * 4) != hipSuccess) rc = fail(DR_E_NODEVICE, "memset failed");
-    if (!rc && hipMemset(ix->first.p, 0, (size_t)N * ((R + 63) / 64) * 8) != hipSuccess) rc = fail(DR_E_NODEVICE, "memset failed");
-    if (rc) { dr_index_close(ix); return rc; }
-    ix->m = m; ix->sd = D / m; ix->codebook_gen++;
-    *out = ix;
-    return 0;
-}
-
-// the code table (and codebook) of `src` copied into `dst` on the device: a second shard handle over the same points with
-// another degree R -- the streamed vectors are gone, only the code words can be reused
-extern "C" int dr_index_copy_codes(dr_index *dst, dr_index *src)
-{
-    if (!dst || !src || dst == src) return fail(DR_E_ARG, "bad argument");
-    std::lock(dst->mu, src->mu);
-    std::lock_guard<std::mutex> l1(dst->mu, std::adopt_lock), l2(src->mu, std::adopt_lock);
-    if (dst->N != src->N || dst->D != src->D || dst->device != src->device) return fail(DR_E_ARG, "the two handles differ in N, D or device");
-    if (src->m == 0 || !src->codes.p) return fail(DR_E_NOPQ, "the source holds no code words");
-    HIPCHK(hipSetDevice(dst->device));
-    { const int rcq = quiesce_locked(dst); if (rcq) return rcq; }
-    { const int rcq = quiesce_locked(src); if (rcq) return rcq; }
-    if (dst->codes.reserve((size_t)src->N * src->m) || dst->codebook.reserve((size_t)256 * src->D)) return DR_E_NODEVICE;
-    HIPCHK(hipMemcpy(dst->codes.p, src->codes.p, (size_t)src->N * src->m, hipMemcpyDeviceToDevice));
-    HIPCHK(hipMemcpy(dst->codebook.p, src->codebook.p, (size_t)256 * src->D * 4, hipMemcpyDeviceToDevice));
-    dst->m = src->m; dst->sd = src->sd; dst->codebook_gen++;
-    dst->sdc.release();
-    for (auto &qs : dst->slots) qs.pq_ub_valid = false;
-    dst->adc_live = -1; dst->nbcodes_valid = false;
-    return 0;
-}
-
-extern "C" int dr_pq_encode_rows(dr_index *ix, const float *vectors, uint64_t row0, uint64_t rows)
-{
-    if (!ix || !vectors) return fail(DR_E_ARG, "null argument");
-    if (ix->m == 0) return fail(DR_E_NOPQ, "no codebook attached");
-    if (rows == 0 || row0 + rows > ix->N) return fail(DR_E_ARG, "rows [%llu, %llu) outside the index", (unsigned long long)row0, (unsigned long long)(row0 + rows));
-    std::lock_guard<std::mutex> lk(ix->mu);
-    HIPCHK(hipSetDevice(ix->device));
-    const uint32_t D = ix->D, m = ix->m, sd = ix->sd;
-    const uint64_t chunk = std::max<uint64_t>(1, (1ull << 30) / (D * 4));
-    DevBuf<float> tmp;
-    if (tmp.reserve((size_t)std::min(chunk, rows) * D)) return DR_E_NODEVICE;
-    const size_t lds = (size_t)256 * sd * 4;
-    const void *afn = nullptr;
-#define DR_PICK(SDV) afn = reinterpret_cast<const void *>(&pq_assign_rows_kernel<SDV>)
-    DR_ASSIGN_SD_CASES(DR_PICK)
-#undef DR_PICK
-    HIPCHK(hipFuncSetAttribute(afn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (uint64_t r0 = 0; r0 < rows; r0 += chunk) {
-        const uint64_t n = std::min(chunk, rows - r0);
-        HIPCHK(hipMemcpyAsync(tmp.p, vectors + (size_t)r0 * D, (size_t)n * D * 4, hipMemcpyHostToDevice, ix->stream));
-        const unsigned gx = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ix->num_cu * 4);
-        const float *xin = tmp.p; uint64_t nn = n; uint32_t Dv = D, mv = m, sdv = sd; const float *cbk = ix->codebook.p;
-        u8 *outp = ix->codes.p + (size_t)(row0 + r0) * m;
-        void *args[] = { &xin, &nn, &Dv, &mv, &sdv, &cbk, &outp };
-        HIPCHK(hipLaunchKernel(afn, dim3(gx, m), dim3(256), args, lds, ix->stream));
-        HIPCHK(hipStreamSynchronize(ix->stream));
-    }
-    ix->adc_live = -1; ix->nbcodes_valid = false;
-    return 0;
-}
-
-extern "C" int dr_build_vamana_pq(dr_index *ix, uint32_t L_build, float alpha, uint32_t passes, uint64_t seed, uint32_t max_batch,
-                                  uint32_t *out_medoid, float *out_seconds)
-{
-    return build_vamana_common(ix, L_build, alpha, passes, seed, 0, max_batch, out_medoid, out_seconds, true);
-}
-
-// Test seam for the builder: the robust prune of ONE point over an explicit candidate list, run by the
-// same prune_kernel the builder launches. The tests compare it with the CPU restatement of the reference's
-// robust_prune_fast_cython (cython_utils.pyx:435-492) without that function's stale vector reads.
-extern "C" int dr_debug_prune(dr_index *ix, uint32_t point, const uint32_t *candidates, uint32_t n, float alpha, uint32_t R,
-                              uint32_t *out_selected, uint32_t *out_count)
-{
-    if (!ix || !candidates || !out_selected || !out_count) return fail(DR_E_ARG, "null argument");
-    if (point >= ix->N || n == 0 || n > DR_PRUNE_MAXC || R == 0 || R > 192) return fail(DR_E_ARG, "bad prune arguments (n <= %d, R <= 192)", DR_PRUNE_MAXC);
-    for (uint32_t i = 0; i < n; i++) if (candidates[i] >= ix->N) return fail(DR_E_ARG, "candidate id %u out of range", candidates[i]);
-    std::lock_guard<std::mutex> lk(ix->mu);
-    { const int rcv = need_vectors(ix, "dr_debug_prune"); if (rcv) return rcv; }
-    HIPCHK(hipSetDevice(ix->device));
-    // the candidates travel as a one-query "search result" (the kernel recomputes their distances); the row itself is empty
-    DevBuf<u64> keys; DevBuf<uint32_t> resn, adjb, deg, pts, fwd, fwdn;
-    if (keys.reserve(n) || resn.reserve(1) || adjb.reserve((size_t)ix->N * R) || deg.reserve(ix->N + 2, true) || pts.reserve(1) ||
-        fwd.reserve(R) || fwdn.reserve(1)) return DR_E_NODEVICE;
-    std::vector<u64> hk(n);
-    for (uint32_t i = 0; i < n; i++) hk[i] = (u64)(uint32_t)(~candidates[i]);
-    HIPCHK(hipMemcpyAsync(keys.p, hk.data(), (size_t)n * 8, hipMemcpyHostToDevice, ix->stream));
-    HIPCHK(hipMemcpyAsync(resn.p, &n, 4, hipMemcpyHostToDevice, ix->stream));
-    HIPCHK(hipMemcpyAsync(pts.p, &point, 4, hipMemcpyHostToDevice, ix->stream));
-    PruneParams pp;
-    pp.vecp = ix->vecp.p; pp.adjb = adjb.p; pp.deg = deg.p; pp.RX = R; pp.R = R; pp.alpha = alpha;
-    pp.points = pts.p; pp.npoints = 1; pp.res_keys = keys.p; pp.res_n = resn.p; pp.cap = n; pp.fwd = fwd.p; pp.fwd_n = fwdn.p;
-    pp.multi = prune_multi_enabled(ix->D);
-    void *args[] = { &pp };
-    const size_t prune_lds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)DR_PRUNE_MAXC * 24 + 1024 + (pp.multi ? (size_t)4 * DR_PRUNE_MAXC * 4 : 0);
-    HIPCHK(hipLaunchKernel(pp.multi ? ix->kern->prune_multi : ix->kern->prune, dim3(1), dim3(64), args, prune_lds, ix->stream));
-    HIPCHK(hipMemcpyAsync(out_selected, fwd.p, (size_t)R * 4, hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipMemcpyAsync(out_count, fwdn.p, 4, hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    return 0;
-}
-
-// The same seam for the PQ-only builder's prune (prune_pq_kernel, whichever form serves this m): candidates scored by sums of
-// centroid-pair table entries (A3's order), sorted by (distance, id), greedy picks, alpha * d(p*, c) <= d(p, c) drops c.
-extern "C" int dr_debug_prune_pq(dr_index *ix, uint32_t point, const uint32_t *candidates, uint32_t n, float alpha, uint32_t R,
-                                 uint32_t *out_selected, uint32_t *out_count)
-{
-    if (!ix || !candidates || !out_selected || !out_count) return fail(DR_E_ARG, "null argument");
-    if (point >= ix->N || n == 0 || n > DR_PRUNE_PQ_MAXC || R == 0 || R > 128)
-        return fail(DR_E_ARG, "bad prune arguments (n <= %d, R <= 128)", DR_PRUNE_PQ_MAXC);
-    for (uint32_t i = 0; i < n; i++) if (candidates[i] >= ix->N) return fail(DR_E_ARG, "candidate id %u out of range", candidates[i]);
-    std::lock_guard<std::mutex> lk(ix->mu);
-    if (ix->m == 0) return fail(DR_E_NOPQ, "dr_debug_prune_pq needs the code words");
-    HIPCHK(hipSetDevice(ix->device));
-    { const int rcs = ensure_sdc(ix); if (rcs) return rcs; }
-    DevBuf<u64> keys; DevBuf<uint32_t> resn, adjb, deg, pts, fwd, fwdn;
-    if (keys.reserve(n) || resn.reserve(1) || adjb.reserve((size_t)ix->N * R) || deg.reserve(ix->N + 2, true) || pts.reserve(1) ||
-        fwd.reserve(R) || fwdn.reserve(1)) return DR_E_NODEVICE;
-    std::vector<u64> hk(n);
-    for (uint32_t i = 0; i < n; i++) hk[i] = (u64)(uint32_t)(~candidates[i]);
-    HIPCHK(hipMemcpyAsync(keys.p, hk.data(), (size_t)n * 8, hipMemcpyHostToDevice, ix->stream));
-    HIPCHK(hipMemcpyAsync(resn.p, &n, 4, hipMemcpyHostToDevice, ix->stream));
-    HIPCHK(hipMemcpyAsync(pts.p, &point, 4, hipMemcpyHostToDevice, ix->stream));
-    PrunePQParams q;
-    q.codes = ix->codes.p; q.sdc = ix->sdc.p; q.m = ix->m; q.adjb = adjb.p; q.deg = deg.p; q.RX = R; q.R = R; q.alpha = alpha;
-    q.points = pts.p; q.npoints = 1; q.res_keys = keys.p; q.res_n = resn.p; q.cap = n; q.fwd = fwd.p; q.fwd_n = fwdn.p;
-    { const int rcp = launch_prune_pq(ix, q); if (rcp) return rcp; }
-    HIPCHK(hipMemcpyAsync(out_selected, fwd.p, (size_t)R * 4, hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipMemcpyAsync(out_count, fwdn.p, 4, hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------ PQ build
-
-static int pq_assign(dr_index *ix, const uint32_t *d_ids, uint64_t n, uint32_t m, const float *d_codebook, uint8_t *d_out)
-{
-    const uint32_t sd = ix->D / m;
-    const size_t lds = (size_t)256 * sd * 4;
-    const void *afn = nullptr;
-#define DR_PICK(SDV) afn = reinterpret_cast<const void *>(&pq_assign_kernel<SDV>)
-    DR_ASSIGN_SD_CASES(DR_PICK)
-#undef DR_PICK
-    HIPCHK(hipFuncSetAttribute(afn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned gx = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ix->num_cu * 4);
-    const float *vp = ix->vecp.p; const u32 *pm = ix->perm.p; uint64_t nn = n; uint32_t Dv = ix->D, mv = m, sdv = sd;
-    void *args[] = { &vp, &pm, &d_ids, &nn, &Dv, &mv, &sdv, &d_codebook, &d_out };
-    HIPCHK(hipLaunchKernel(afn, dim3(gx, m), dim3(256), args, lds, ix->stream));
-    return 0;
-}
-
-// DiskANNPQ.fit (pq/fast_pq.py:188-243) runs m independent sklearn KMeans(256, init='k-means++', n_init, max_iter, tol).
-// Everything runs on the device (engine_kernels.hpp, "k-means on the device"): greedy k-means++ seeding with sklearn's
-// 2 + log k local trials (one workgroup per sub-quantiser, uniform numbers from the host's splitmix64 stream), Lloyd
-// iterations = nearest-centre assignment + fixed-point centre sums + centre update, sklearn's stopping rule (total squared
-// centre shift <= tol * mean per-feature variance), n_init restarts keeping the lowest inertia per sub-quantiser. The host
-// only reads m shifts per iteration and m inertias per restart. Deterministic for a given seed.
-extern "C" int dr_pq_train_ex(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t max_iter, uint32_t n_init, float tol, uint64_t seed,
-                              float *out_codebook, double *out_inertia)
-{
-    if (!ix || !out_codebook) return fail(DR_E_ARG, "null argument");
-    if (m == 0 || ix->D % m || ix->D / m > 128) return fail(DR_E_ARG, "bad n_subvectors %u for D=%u", m, ix->D);
-    if (ix->N < 256) return fail(DR_E_ARG, "need at least 256 vectors (fast_pq.py:212-213)");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    { const int rcv = need_vectors(ix, "dr_pq_train"); if (rcv) return rcv; }
-    HIPCHK(hipSetDevice(ix->device));
-    const uint32_t D = ix->D, sd = D / m;
-    const uint32_t ns = (uint32_t)std::min<uint64_t>(n_sample ? n_sample : 100000, ix->N);
-    if (max_iter == 0) max_iter = 10;
-    if (n_init == 0) n_init = 1;
-    // sample without replacement (partial Fisher-Yates over ids)
-    std::vector<uint32_t> ids(ns);
-    {
-        uint64_t rng = seed ? seed : 42;
-        if (ns == ix->N) { for (uint32_t i = 0; i < ns; i++) ids[i] = i; }
-        else {
-            std::vector<uint32_t> all(ix->N);
-            for (uint64_t i = 0; i < ix->N; i++) all[i] = (uint32_t)i;
-            for (uint32_t i = 0; i < ns; i++) { uint64_t jx = i + splitmix64(rng) % (ix->N - i); std::swap(all[i], all[jx]); ids[i] = all[i]; }
-        }
-    }
-    DevBuf<uint32_t> d_ids, d_counts; DevBuf<float> d_x, d_xt, d_cb, d_d2, d_maxabs; DevBuf<uint8_t> d_assign;
-    DevBuf<double> d_var, d_unif, d_shift, d_inertia; DevBuf<int> d_fix; DevBuf<unsigned long long> d_sums;
-    if (d_ids.reserve(ns) || d_x.reserve((size_t)ns * D) || d_xt.reserve((size_t)ns * D) || d_cb.reserve((size_t)256 * D) || d_assign.reserve((size_t)ns * m) ||
-        d_d2.reserve((size_t)ns * m) || d_maxabs.reserve(m) || d_var.reserve(m) || d_unif.reserve((size_t)m * 256 * 8) || d_shift.reserve(m) ||
-        d_inertia.reserve(m) || d_fix.reserve(m) || d_sums.reserve((size_t)256 * D, true) || d_counts.reserve((size_t)m * 256, true))
-        return DR_E_NODEVICE;
-    HIPCHK(hipMemcpyAsync(d_ids.p, ids.data(), (size_t)ns * 4, hipMemcpyHostToDevice, ix->stream));
-    hipLaunchKernelGGL(gather_subvectors_kernel, dim3(ns), dim3(64), 0, ix->stream, ix->vecp.p, ix->perm.p, d_ids.p, ns, D, d_x.p);
-    HIPCHK(hipGetLastError());
-    // the seeding kernel reads the sample by columns (km_transpose_kernel)
-    hipLaunchKernelGGL(km_transpose_kernel, dim3((ns + 31) / 32, (D + 31) / 32), dim3(256), 0, ix->stream, d_x.p, ns, D, d_xt.p);
-    HIPCHK(hipGetLastError());
-    // sklearn's stopping rule: total squared centre shift <= tol * mean per-feature variance (KMeans tol, default 1e-4);
-    // the fixed-point scale of the centre sums: the largest exponent that cannot overflow 63 bits over ns terms
-    hipLaunchKernelGGL(km_stats_kernel, dim3(m), dim3(DR_KM_THREADS), 0, ix->stream, d_x.p, ns, D, sd, d_var.p, d_maxabs.p);
-    HIPCHK(hipGetLastError());
-    std::vector<double> var_mean(m);
-    std::vector<float> max_abs(m);
-    HIPCHK(hipMemcpyAsync(var_mean.data(), d_var.p, (size_t)m * 8, hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipMemcpyAsync(max_abs.data(), d_maxabs.p, (size_t)m * 4, hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    std::vector<double> tol_j(m);
-    std::vector<int> fix(m);
-    for (uint32_t jq = 0; jq < m; jq++) {
-        tol_j[jq] = (double)tol * var_mean[jq];
-        int e = 0;
-        (void)std::frexp((double)max_abs[jq] * (double)ns + 1.0, &e);      // value < 2^e
-        fix[jq] = 61 - e;
-    }
-    HIPCHK(hipMemcpyAsync(d_fix.p, fix.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, ix->stream));
-    const size_t acc_lds_full = (size_t)256 * sd * 8 + 1024;
-    const int use_lds = acc_lds_full <= 128 * 1024 ? 1 : 0;
-    const size_t acc_lds = use_lds ? acc_lds_full : 1024;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&km_accumulate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)acc_lds));
-    const unsigned acc_gx = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>((ns + 255) / 256, std::max<uint32_t>(1, (uint32_t)ix->num_cu / m)));
-
-    std::vector<float> cb((size_t)m * 256 * sd), best_cb((size_t)m * 256 * sd);
-    std::vector<double> best_inertia(m, -1.0), inertia(m), shift(m), unif((size_t)m * 256 * 8);
-    for (uint32_t r = 0; r < n_init; r++) {
-        // the restart's random numbers: per sub-quantiser its own splitmix64 stream (seed, restart, jq)
-        for (uint32_t jq = 0; jq < m; jq++) {
-            uint64_t rng = (seed ? seed : 42) * 0x9E3779B97F4A7C15ull + ((uint64_t)r << 32) + jq + 1;
-            for (uint32_t e = 0; e < 256 * 8; e++) unif[(size_t)jq * 2048 + e] = (double)(splitmix64(rng) >> 11) * (1.0 / 9007199254740992.0);
-        }
-        HIPCHK(hipMemcpyAsync(d_unif.p, unif.data(), unif.size() * 8, hipMemcpyHostToDevice, ix->stream));
-        hipLaunchKernelGGL(kmeanspp_kernel, dim3(m), dim3(DR_KM_THREADS), 0, ix->stream, d_xt.p, ns, D, sd, d_unif.p, d_d2.p, d_cb.p);
-        HIPCHK(hipGetLastError());
-        for (uint32_t it = 0; it < max_iter; it++) {
-            int rc = pq_assign(ix, d_ids.p, ns, m, d_cb.p, d_assign.p);
-            if (rc) return rc;
-            hipLaunchKernelGGL(km_accumulate_kernel, dim3(acc_gx, m), dim3(256), acc_lds, ix->stream, d_x.p, d_assign.p, ns, D, m, sd, d_fix.p,
-                               d_sums.p, d_counts.p, use_lds);
-            hipLaunchKernelGGL(km_finalize_kernel, dim3(m), dim3(256), 0, ix->stream, d_cb.p, sd, d_fix.p, d_sums.p, d_counts.p, d_shift.p);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(shift.data(), d_shift.p, (size_t)m * 8, hipMemcpyDeviceToHost, ix->stream));
-            HIPCHK(hipStreamSynchronize(ix->stream));
-            bool done = true;
-            for (uint32_t jq = 0; jq < m; jq++) done = done && shift[jq] <= tol_j[jq];
-            if (done) break;
-        }
-        // labels and inertia of the final centres
-        const int rc = pq_assign(ix, d_ids.p, ns, m, d_cb.p, d_assign.p);
-        if (rc) return rc;
-        hipLaunchKernelGGL(km_inertia_kernel, dim3(m), dim3(DR_KM_THREADS), 0, ix->stream, d_x.p, d_assign.p, ns, D, m, sd, d_cb.p, d_inertia.p);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(inertia.data(), d_inertia.p, (size_t)m * 8, hipMemcpyDeviceToHost, ix->stream));
-        HIPCHK(hipMemcpyAsync(cb.data(), d_cb.p, cb.size() * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIPCHK(hipStreamSynchronize(ix->stream));
-        for (uint32_t jq = 0; jq < m; jq++)
-            if (best_inertia[jq] < 0 || inertia[jq] < best_inertia[jq]) {
-                best_inertia[jq] = inertia[jq];
-                memcpy(&best_cb[(size_t)jq * 256 * sd], &cb[(size_t)jq * 256 * sd], (size_t)256 * sd * 4);
-            }
-    }
-    memcpy(out_codebook, best_cb.data(), best_cb.size() * 4);
-    if (out_inertia) { double tot = 0; for (double v : best_inertia) tot += v; *out_inertia = tot; }
-    return 0;
-}
-
-extern "C" int dr_pq_train(dr_index *ix, uint32_t m, uint32_t n_sample, uint32_t iters, uint64_t seed, float *out_codebook)
-{
-    return dr_pq_train_ex(ix, m, n_sample, iters ? iters : 10, 1, 1e-4f, seed, out_codebook, nullptr);
-}
-
-extern "C" int dr_pq_encode(dr_index *ix, const float *codebook, uint32_t m, uint8_t *out_codes)
-{
-    if (!ix || !codebook) return fail(DR_E_ARG, "null argument");
-    if (m == 0 || ix->D % m || ix->D / m > 128) return fail(DR_E_ARG, "bad n_subvectors %u for D=%u", m, ix->D);
-    std::lock_guard<std::mutex> lk(ix->mu);
-    { const int rcv = need_vectors(ix, "dr_pq_encode"); if (rcv) return rcv; }
-    HIPCHK(hipSetDevice(ix->device));
-    { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }
-    if (ix->codes.reserve((size_t)ix->N * m) || ix->codebook.reserve((size_t)256 * ix->D)) return DR_E_NODEVICE;
-    HIPCHK(hipMemcpyAsync(ix->codebook.p, codebook, (size_t)256 * ix->D * 4, hipMemcpyHostToDevice, ix->stream));
-    int rc = pq_assign(ix, nullptr, ix->N, m, ix->codebook.p, ix->codes.p);
-    if (rc) return rc;
-    if (out_codes) HIPCHK(hipMemcpyAsync(out_codes, ix->codes.p, (size_t)ix->N * m, hipMemcpyDeviceToHost, ix->stream));
-    HIPCHK(hipStreamSynchronize(ix->stream));
-    ix->m = m; ix->sd = ix->D / m; ix->codebook_gen++;
-    for (auto &qs : ix->slots) qs.pq_ub_valid = false;
-    ix->adc_live = -1; ix->nbcodes_valid = false;
-    return 0;
-}
+#include "pq_build.inc"
 
 // C8: the reference's scalar distance kernels on row pairs (no index needed).
 extern "C" int dr_scalar_kernels(int device, const float *x, const float *y, uint32_t n, uint32_t D, float *out_l2, float *out_cos)
