@@ -873,7 +873,14 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // MEASURED on the first M1 batch an index state serves (its counters are read once that launch has finished, see
     // the end of this function); until then the SIFT-scale preference applies. Results never depend on the variant.
     static const int PREF_BUILD_PQ[] = { 15, 2 }, PREF_BUILD_PQ_NOTREG[] = { 2, 2 };
-    const int *pref = k_m1 ? PREF_M1 : (ov && ov->sdc) ? (no_treg ? PREF_BUILD_PQ_NOTREG : PREF_BUILD_PQ) : k_adc ? (no_treg ? PREF_ADC_NOTREG : PREF_ADC) : ov ? PREF_BUILD : PREF_EX;
+    // ADC-only traversals at D <= 128 (round 4): the per-query table (2; built for the batch by lut_build_kernel since round 3) beats the
+    // shared codebook (5) whenever six tables fit a CU -- c4 shape (D = 96, m = 16): L = 100 beam_width 8 3.99 -> 2.08 ms, L = 350 no trim
+    // 21.1 -> 15.0 ms, same results (profiles/r04/ab/ab_c4_adc_table_vs_codebook_10M.jsonl); the codebook form stays for tables that
+    // leave fewer than six wavefronts per CU (D = 128, m = 32)
+    static const int PREF_ADC_TABLE[] = { 15, 2, 5 }, PREF_ADC_TABLE_NOTREG[] = { 2, 5, 5 };
+    const bool adc_table_first = k_adc && !(ov && ov->sdc) && lds_of(2) * 6 <= 160 * 1024;
+    const int *pref = k_m1 ? PREF_M1 : (ov && ov->sdc) ? (no_treg ? PREF_BUILD_PQ_NOTREG : PREF_BUILD_PQ)
+                    : k_adc ? (adc_table_first ? (no_treg ? PREF_ADC_TABLE_NOTREG : PREF_ADC_TABLE) : (no_treg ? PREF_ADC_NOTREG : PREF_ADC)) : ov ? PREF_BUILD : PREF_EX;
     const int npref = k_m1 ? 5 : (ov && ov->sdc) ? 2 : k_adc ? 3 : ov ? 2 : 4;
     // (round 4: the per-query table wins with as few as five or six wavefronts per CU -- c4 shape, lists of 300-500 entries: 1.38x over
     // the shared codebook at eight, profiles/r04/ab/ab_c4_long_lists_table_vs_codebook.jsonl; it used to need eight to be preferred)

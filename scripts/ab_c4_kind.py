@@ -1,6 +1,6 @@
 """A/B (GPU box): the rerank-policy-live M1 at the c4 shape with LONG lists (the recall >= 0.95 operating points need L = 400-500):
 per-query table in LDS (variant 0, 6 wavefronts per CU at this list size) against the shared codebook (variant 3, 8 wavefronts per CU,
-table entries recomputed per neighbour), which the engine picks today because 8 tables do not fit. usage: ab_c4_kind.py N"""
+table entries recomputed per neighbour), which the engine picks today because 8 tables do not fit. usage: ab_c4_kind.py N [D m]"""
 import json
 import sys
 import time
@@ -10,6 +10,8 @@ from diskrag_amd import HipIndex, _ffi
 from diskrag_amd.synth import unit_mixture, unit_mixture_parallel
 n = int(sys.argv[1])
 D, m, ncl, latent, R = 96, 16, 4096, 32, 64
+if len(sys.argv) > 3:      # another unit-norm shape: D m   (e.g. 128 32: does the table at FOUR wavefronts per CU beat the codebook at eight?)
+    D, m = int(sys.argv[2]), int(sys.argv[3])
 gen = unit_mixture_parallel if n * D >= (1 << 32) else unit_mixture
 x, q = gen(n, D, n_queries=10000, n_clusters=ncl, seed=11, latent=latent)
 ix = HipIndex.create_empty(x, R=R)
