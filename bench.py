@@ -67,6 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every rank its own batches of --num-queries; strong (SURVEY.md 8e): ONE stream of "
                          "--num-queries batches, every batch cut into contiguous slices of nq/N queries, one per rank")
+    ap.add_argument("--pq-scan-codes", type=int, default=64_000_000, help="code words of the isolated PQ-scan measurement (config.pq_scan)")
     ap.add_argument("--blocking-calls", type=int, default=24, help="blocking dr_search_batch calls timed for config.qps_blocking_call (median)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
@@ -483,7 +484,7 @@ def worker_c2(args, rk):
     # (SURVEY.md 8e / BASELINE metric "batch=10k; 1/2/4/8": ONE stream of nq-query batches, every batch cut into N contiguous
     # slices, one per GPU -- the same job batches on every rank, generated from the common seed)
     strong_cfg = None
-    if rk.world > 1 and not strong and not args.no_secondary:
+    if rk.world > 1 and not strong:
         slo, shi = slice_of(nq_job, rk.world, rk.rank)
         _, q_job = sift_like(args.n, D, n_queries=nq_job * nb, n_clusters=1024, seed=2024, query_seed=9000, queries_only=True)
         n_s = shi - slo
@@ -629,7 +630,7 @@ def worker_c2(args, rk):
                 "submits_per_launch": (s1["tickets"] - s0["tickets"]) / max(1, s1["launches"] - s0["launches"]),
                 "queries_per_launch": (s1["queries"] - s0["queries"]) / max(1, s1["launches"] - s0["launches"]),
                 "kernel_ms_per_launch": ix.timing()["search_kernel_ms"], "variant": ix.timing()["variant"]}
-        pq_scan = isolated_pq_scan(device)
+        pq_scan = isolated_pq_scan(device, n_codes=args.pq_scan_codes)
 
     out = {
         "metric": "QPS @ recall@10>=0.95, SIFT1M-shaped d=128 L2, batch=10k",
@@ -842,10 +843,12 @@ def worker_c5(args, rk):
                                         "waves_per_cu": tm["waves_per_cu"]}}}
     if recall < args.min_recall:
         raise RuntimeError(f"c5: recall@{k} vs the brute-force ADC ranking = {recall:.4f} is below {args.min_recall}")
-    if rk.rank == 0:
-        print(json.dumps(out), flush=True)
     comm.close()
     sh.close()
+    if rk.rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)       # (librccl prints a version banner through the C stdout: out before the one JSON line)
+        print(json.dumps(out), flush=True)
     return 0
 
 

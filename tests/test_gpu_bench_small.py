@@ -1,0 +1,54 @@
+"""bench.py itself on a GPU box, at toy size: the N = 1 line and the N = 2 job (two ranks sharing the one GPU) with the real
+engine -- the weak-scaling line must carry the strong-scaling figure (`config.strong_scaling`), the explicit
+`--scaling strong` mode must tile the batches, and the c5 pipeline must run on one rank. (Round 4: the strong-scaling block once
+clobbered a resident batch of the weak-scaling measurement; nothing but a real run sees that.)"""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+TOY = ["--num-vectors", "30000", "--num-queries", "600", "--steps", "2", "--warmup", "1", "--batches-per-step", "3", "--distinct-batches", "4",
+       "--no-cpu", "--min-recall", "0.5", "--blocking-calls", "3", "--pq-scan-codes", "1000000"]
+
+
+def _json_line(stdout):
+    """the bench's one JSON line (librccl prints its banner to the C stdout, which is flushed after Python's)"""
+    return json.loads([l for l in stdout.strip().splitlines() if l.startswith("{")][-1])
+
+
+def _run(extra):
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py")] + TOY + extra, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return _json_line(r.stdout)
+
+
+def test_one_rank_line_has_roofline_and_small_batches():
+    d = _run([])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and d["config"]["recall_at_10"] >= 0.5
+    sb = d["config"]["small_batches_on_one_gpu"]
+    assert len(sb) == 3 and all(v["qps"] > 0 and v["submits_per_launch"] >= 1 for v in sb.values())
+
+
+def test_two_ranks_on_one_gpu_weak_line_carries_the_strong_figure():
+    d = _run(["--gpus", "2", "--no-secondary"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and len(d["config"]["per_rank_seconds"]) == 2
+    s = d["config"]["strong_scaling"]
+    assert s["value"] > 0 and s["queries_per_batch_per_gpu"] == 300 and len(s["per_rank_seconds"]) == 2 and s["recall_at_10"] >= 0.5
+
+
+def test_two_ranks_strong_mode_tiles_every_batch():
+    d = _run(["--gpus", "2", "--scaling", "strong", "--no-secondary"])
+    assert d["scaling"] == "strong" and d["config"]["per_rank_slice"] == [[0, 300], [300, 600]] and d["config"]["recall_at_10"] >= 0.5
+
+
+def test_c5_pipeline_on_one_rank():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", "c5", "--num-vectors", "65536", "--num-queries", "500", "--steps", "3", "--warmup", "1",
+                        "--min-recall", "0.5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["value"] > 0 and d["config"]["rccl_ranks"] == 1 and d["config"]["recall_at_10_vs_bruteforce_adc"] >= 0.5
