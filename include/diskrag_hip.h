@@ -165,8 +165,9 @@ int dr_index_set_adjacency(dr_index *ix, const uint32_t *adj);
  * every rank receives the full result. id_base[s] is added to shard s's local ids. Output as dr_search_batch
  * (DR_PAD / NaN padded); out_status[nq] (may be NULL) receives the OR of THIS rank's shards' dr_stats.status per query.
  * dr_sharded_submit / dr_sharded_wait: the same call in two halves, two in flight (per first shard): batch i+1 is uploaded
- * and searched while batch i is exchanged, merged and downloaded; the output buffers belong to the library until the
- * ticket has been waited for (dr_sharded_wait takes shards[0] of the submit). All ranks must submit in the same order. */
+ * and searched while batch i is exchanged, merged and downloaded; the output buffers -- and a page-locked query buffer,
+ * which the copy engine reads in place -- belong to the library until the ticket has been waited for (dr_sharded_wait takes
+ * shards[0] of the submit). All ranks must submit in the same order. */
 typedef struct dr_comm dr_comm;
 #define DR_COMM_ID_BYTES 128
 int dr_comm_unique_id(void *out_id /*[DR_COMM_ID_BYTES]*/);
