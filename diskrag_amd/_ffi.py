@@ -455,8 +455,8 @@ class HipIndex:
         # job until the library can no longer touch it (its ticket slot has been reused: ticket <= newest - MAX_TICKETS).
         live = self.__dict__.setdefault("_inflight", {})
         live[job.ticket] = job
-        for tk in [tk for tk in live if tk + MAX_TICKETS <= job.ticket]:
-            del live[tk]
+        for tk in [tk for tk in list(live) if tk + MAX_TICKETS <= job.ticket]:
+            live.pop(tk, None)          # (request threads share the index: another thread may have dropped it already)
         return job
 
     def search_flush(self):

@@ -169,12 +169,20 @@ class SearchEngineCorrect:
         kernel and get np.float64 distances back."""
         return np.asarray(query_vector).dtype == np.float64
 
+    def _one(self, query_vector, k, **kw):
+        """One float32 query through the pipelined path (submit + wait): the handle is not held while the request is in flight,
+        so concurrent request handlers (the reference serves one query per request from a thread pool, app.py:84-130) share
+        launches -- 5x the requests/s of serialised blocking calls at 16+ threads, the same bits (tests/test_gpu_coalesce.py); a
+        lone request is launched at once."""
+        q = np.ascontiguousarray(query_vector, dtype=np.float32).reshape(1, -1)
+        return self.index.search_submit(q, k, **kw).wait()
+
     def _pq_accelerated_graph_search(self, query_vector: np.ndarray, k: int = 10, L: int = 100,
                                      beam_width: Optional[int] = None, band_policy: int = 0
                                      ) -> Tuple[List[Tuple[float, int]], Dict]:
         t0 = time.time()
         f64 = self._is_f64(query_vector)
-        run = self.index.search_batch_f64 if f64 else self.index.search_batch
+        run = self.index.search_batch_f64 if f64 else self._one
         ids, dist, cnt, st = run(query_vector, k, L=L, beam_width=beam_width or 0, mode=_ffi.MODE_M1,
                                  band_policy=band_policy)
         self._check_status(st)
@@ -193,7 +201,7 @@ class SearchEngineCorrect:
                             ) -> Tuple[List[Tuple[float, int]], Dict]:
         t0 = time.time()
         f64 = self._is_f64(query_vector)
-        run = self.index.search_batch_f64 if f64 else self.index.search_batch
+        run = self.index.search_batch_f64 if f64 else self._one
         # the reference hard-codes beam_width=8 here and ignores L (search_engine.py:513-519, Q6)
         ids, dist, cnt, st = run(query_vector, k, L=L, beam_width=8, mode=_ffi.MODE_M2)
         self._check_status(st)

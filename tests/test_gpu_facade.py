@@ -275,3 +275,47 @@ def test_request_batcher_returns_the_bits_of_direct_calls(tmp_path):
         assert [stats["search_steps"], stats["nodes_visited"], stats["exact_distance_computations"],
                 stats["pq_distance_computations"]] == c["stats"][qi].tolist()
     eng.close()
+
+
+def test_facade_request_threads_share_launches_and_keep_the_goldens(tmp_path):
+    """Round 4: the facade's one-query searches go through the pipelined path (submit + wait), so the handler threads of a
+    server (one query per request, app.py:84-130) share launches instead of queueing on the handle -- every request still gets
+    the reference's golden answer (ids, distance bits, the four counters), whichever requests it rode with; mixed with blocking
+    batched calls and M2 requests on the same engine."""
+    import threading
+    from diskrag_amd.search_engine import SearchEngineCorrect
+    g = load_golden("sift128_R64_m32")
+    write_collection(tmp_path, "c", g)
+    eng = SearchEngineCorrect("c", base_dir=tmp_path)
+    c = g.case(1)            # M1, L=100, beam_width=8, k=10
+    m2 = eng._exact_graph_search(g.queries[3], k=8)
+    errors = []
+
+    def handler(t):
+        try:
+            for i in range(30):
+                qi = (5 * t + i) % len(g.queries)
+                res, stats = eng._pq_accelerated_graph_search(g.queries[qi], k=10, L=100, beam_width=8)
+                n = int(c["count"][qi])
+                ok = ([int(x) for _, x in res] == [int(x) for x in c["ids"][qi][:n]] and
+                      np.array_equal(np.array([d for d, _ in res], dtype=np.float32).view(np.uint32), c["dist"][qi][:n].view(np.uint32)) and
+                      [stats["search_steps"], stats["nodes_visited"], stats["exact_distance_computations"], stats["pq_distance_computations"]] == c["stats"][qi].tolist())
+                if not ok:
+                    errors.append((t, i, qi))
+                if i % 10 == t % 10:
+                    ids, _, _, _ = eng.search_batch(g.queries, k=10, L=100, beam_width=8)
+                    if not np.array_equal(ids, c["ids"]):
+                        errors.append((t, i, "batch"))
+                    r2, _ = eng._exact_graph_search(g.queries[3], k=8)
+                    if [int(x) for _, x in r2] != [int(x) for _, x in m2[0]]:
+                        errors.append((t, i, "m2"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=handler, args=(t,)) for t in range(12)]
+    for t in th: t.start()
+    for t in th: t.join(timeout=300)
+    assert not errors, errors[:3]
+    s = eng.index.pipeline_stats()
+    assert s["tickets"] >= 12 * 30 and s["launches"] <= s["tickets"]
+    eng.close()
