@@ -232,6 +232,7 @@ struct dr_index {
     PipeGroup groups[DR_PIPE_DEPTH];
     uint64_t next_ticket = 1, next_group = 0;
     int open_group = -1;          // the group that is collecting jobs (state 1), or -1
+    int waiters = 0;              // threads inside dr_search_wait's polling loop
     std::map<uint64_t, std::pair<int, std::string>> failed_tickets;   // tickets whose launch failed, until their dr_search_wait collects the error
     uint32_t coalesce_cap = 10240; // queries a group of small submits may grow to (dr_set_coalesce; 0: every submit is its own launch)
     bool hold_always = false;     // dr_debug_hold: submits are only launched when full / flushed / waited for (tests)

@@ -127,8 +127,12 @@ for gi, (R, LB) in enumerate(CFG):
     sh.batch_upload(q)
     grid = os.environ.get("C5_GRID")        # "L:bw,L:bw,...": a finer sweep around an operating point instead of the standard grid
     if grid:
-        for L, bw in (tuple(int(v) for v in g.split(":")) for g in grid.split(",")):
-            run(f"{G}/PQ_L{L}_bw{bw or 'None'}", L=L, beam_width=bw, mode=_ffi.MODE_PQ)
+        for g in grid.split(","):
+            parts = g.split(":")
+            L, bw = int(parts[0]), int(parts[1])
+            nv = len(parts) > 2 and parts[2] == "nv"          # "L:bw:nv": the same run without a visited set (DR_F_NO_VISITED_SET, round 4)
+            run(f"{G}/PQ_L{L}_bw{bw or 'None'}" + ("_no_visited_set" if nv else ""), L=L, beam_width=bw, mode=_ffi.MODE_PQ,
+                flags=_ffi.F_NO_VISITED_SET if nv else 0)
         continue
     for L in (100, 200, 400, 800):
         for bw in (8, 0):
