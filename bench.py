@@ -53,8 +53,8 @@ def parse_args(argv=None):
     ap.add_argument("--num-queries", dest="nq", type=int, default=10_000)
     ap.add_argument("--dim", type=int, default=None, help="default 128 (c2), 1536 (c5)")
     ap.add_argument("--R", type=int, default=None, help="default 64 (c2), 128 (c5)")
-    ap.add_argument("--L", type=int, default=None, help="default 100 (c2), 150 (c5)")
-    ap.add_argument("--bw", type=int, default=None, help="beam_width: default 8 (c2) = the reference default of search()/the API routes (search_engine.py:530, app.py:96), 16 (c5); 0 = None (no frontier trim)")
+    ap.add_argument("--L", type=int, default=None, help="default 100 (c2 and c5)")
+    ap.add_argument("--bw", type=int, default=None, help="beam_width: default 8 (c2) = the reference default of search()/the API routes (search_engine.py:530, app.py:96), 32 (c5); 0 = None (no frontier trim)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (no trim, float rows, un-rounded data)")
     ap.add_argument("--m", type=int, default=32)
     ap.add_argument("--k", type=int, default=10)
@@ -72,7 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
     # the shape of the configuration (BASELINE.json configs[1] / configs[4]) unless given
-    dflt = {"c2": dict(dim=128, R=64, L=100, bw=8, L_build=100), "c5": dict(dim=1536, R=128, L=150, bw=16, L_build=128)}[args.config]
+    dflt = {"c2": dict(dim=128, R=64, L=100, bw=8, L_build=100), "c5": dict(dim=1536, R=128, L=100, bw=32, L_build=128)}[args.config]
     for name, v in dflt.items():
         if getattr(args, name) is None:
             setattr(args, name, v)
@@ -753,7 +753,8 @@ def worker_c5(args, rk):
     (scripts/c5_shard.py): every rank owns ONE shard of --num-vectors points of the 1536-d unit-mixture
     stream -- generated chunk by chunk, encoded on the device (dr_pq_encode_rows) and forgotten: the vectors are never stored --,
     builds its Vamana sub-graph from the code words alone (dr_build_vamana_pq, R = 128), and every query runs on every shard
-    (DR_MODE_PQ, L = 150, beam_width 16: the shard's operating point); the per-shard top-k lists travel as packed keys in ONE
+    (DR_MODE_PQ | DR_F_NO_VISITED_SET, L = 100, beam_width 32: the full-size shard's operating point, 1.46 M QPS at recall 0.961 vs the
+    ADC ranking, profiles/r04/scale_c5_shard_R128_no_visited_set.json); the per-shard top-k lists travel as packed keys in ONE
     RCCL all-gather and are merged on the device (dr_sharded_submit / dr_sharded_wait, two batches in flight). Recall is
     against the brute-force ADC ranking of the union (dr_pq_scan_topk per shard, merged): the metric a PQ-only index can be
     held to."""
@@ -804,11 +805,13 @@ def worker_c5(args, rk):
     qp = _ffi.pinned_empty((nq, D), np.float32)
     qp[:] = q
 
+    c5_flags = _ffi.F_NO_VISITED_SET        # (same results as with a visited set; 24-33 % faster at the full shard size, neutral at bench scale)
+
     def stream(n_calls):
         jobs, out, ms = [], None, np.zeros(3)
         t1 = time.perf_counter()
         for i in range(n_calls):
-            jobs.append(_ffi.sharded_submit([sh], [base], qp, k, L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQ, comm=comm))
+            jobs.append(_ffi.sharded_submit([sh], [base], qp, k, L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQ, flags=c5_flags, comm=comm))
             if len(jobs) >= 2:
                 out = jobs.pop(0).wait(); ms += out[3]
         for j in jobs:
@@ -822,7 +825,7 @@ def worker_c5(args, rk):
     if int(status.max()) != 0:
         raise RuntimeError("work-area overflow during the bench")
     # one blocking call for the per-phase times (nothing overlapped) and the search kernel of the shard
-    _, _, _, ms1 = _ffi.sharded_search([sh], [base], qp, k, L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQ, comm=comm)
+    _, _, _, ms1 = _ffi.sharded_search([sh], [base], qp, k, L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQ, flags=c5_flags, comm=comm)
     sh.batch_sync()                                     # (publishes the shard's kernel timings)
     tm = sh.timing()
     recall = recall_at_k(ids[:ngt], gt, k)
@@ -832,7 +835,7 @@ def worker_c5(args, rk):
            "dtype": "f32 (ADC sums over u8 codes)", "data": "synthetic",
            "config": {"workload": "c5 layout at bench scale: %d shards x %d points of the 1536-d unit-mixture stream (4096 clusters), vectors "
                                   "encoded on the fly and never stored, PQ m=%d, graph built from code words (dr_build_vamana_pq R=%d, L_build=%d), "
-                                  "DR_MODE_PQ L=%d beam_width=%s, k=%d; every query on every shard; exchange = ONE RCCL all-gather of (nq*k + 1) "
+                                  "DR_MODE_PQ | DR_F_NO_VISITED_SET L=%d beam_width=%s, k=%d; every query on every shard; exchange = ONE RCCL all-gather of (nq*k + 1) "
                                   "packed 64-bit words per rank + device merge; a step = one %d-query batch, two in flight (dr_sharded_submit/wait)"
                                   % (rk.world, n_s, m, R, args.L_build, args.L, args.bw or None, k, nq),
                       "recall_at_10_vs_bruteforce_adc": recall, "ground_truth_queries": ngt, "rccl_ranks": rk.world,

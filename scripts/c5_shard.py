@@ -131,8 +131,11 @@ for gi, (R, LB) in enumerate(CFG):
             parts = g.split(":")
             L, bw = int(parts[0]), int(parts[1])
             nv = len(parts) > 2 and parts[2] == "nv"          # "L:bw:nv": the same run without a visited set (DR_F_NO_VISITED_SET, round 4)
-            run(f"{G}/PQ_L{L}_bw{bw or 'None'}" + ("_no_visited_set" if nv else ""), L=L, beam_width=bw, mode=_ffi.MODE_PQ,
-                flags=_ffi.F_NO_VISITED_SET if nv else 0)
+            pre = len(parts) > 3 and parts[3] == "pre"        # "L:bw:nv:pre": ... with the next row's ids prefetched into LDS (DR_PQ_ROW_PREFETCH)
+            if pre: os.environ["DR_PQ_ROW_PREFETCH"] = "1"
+            else: os.environ.pop("DR_PQ_ROW_PREFETCH", None)
+            run(f"{G}/PQ_L{L}_bw{bw or 'None'}" + ("_no_visited_set" if nv else "") + ("_next_row_prefetch" if pre else ""), L=L, beam_width=bw,
+                mode=_ffi.MODE_PQ, flags=_ffi.F_NO_VISITED_SET if nv else 0)
         continue
     for L in (100, 200, 400, 800):
         for bw in (8, 0):

@@ -88,6 +88,14 @@ if spec == "extra":
     extra_pass()
     ix.close()
     sys.exit(0)
+if spec == "nvsweep":
+    # round 4: DR_F_NO_VISITED_SET at full size (on the 1.25e8-point c5 shard it is 9-33 % FASTER, at 1M-10M points it was slower)
+    for L, bw in (((400, 32), (350, 64), (350, 0)) if shape == "c4" else ((250, 0), (250, 128), (300, 64))):
+        for nv in (0, 1):
+            run(f"PQ_rerank_L{L}_bw{bw or 'None'}" + ("_no_visited_set" if nv else ""), L=L, beam_width=bw, mode=_ffi.MODE_PQ,
+                flags=_ffi.F_RERANK | (_ffi.F_NO_VISITED_SET if nv else 0))
+    ix.close()
+    sys.exit(0)
 if spec == "bwsweep":
     # round 4: intermediate frontier trims (beam_width is a parameter of the reference's search, search_engine.py:477-479; rounds 1-3
     # swept 8 and None only): at equal recall a trim of 32-128 halves the expansions of the no-trim operating points
