@@ -935,7 +935,12 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // DR_F_NO_VISITED_SET (DR_MODE_PQ): the traversal keeps NO visited set (SearchParams::novis) -- no visited words (20 MB per
     // wavefront slot on a 1.25e8-point shard), no bit-position twin of the adjacency; same results, more evaluations.
     if ((flags & DR_F_NO_VISITED_SET) && mode != DR_MODE_PQ) return fail(DR_E_ARG, "DR_F_NO_VISITED_SET goes with DR_MODE_PQ");
-    const bool novis = !ov && mode == DR_MODE_PQ && (flags & DR_F_NO_VISITED_SET) != 0;
+    // The PQ-only builder's searches run the same way on LARGE shards -- same lists, hence the same graph bit for bit (tests/test_gpu_round2.py),
+    // and at the c5 shard's size 15 % off the whole build (1.25e8 points, R = 128: 420 -> 356 s, profiles/r04/scale_c5_shard_R128_build_no_visited_set.json):
+    // there the visited words are tens of GB of random-access footprint. DR_BUILD_PQ_NO_VISITED_SET=0 / 1 overrides the size rule.
+    bool build_novis = ix->N >= (1ull << 25);
+    { const char *e = getenv("DR_BUILD_PQ_NO_VISITED_SET"); if (e) build_novis = e[0] == '1'; }
+    const bool novis = (!ov && mode == DR_MODE_PQ && (flags & DR_F_NO_VISITED_SET) != 0) || (ov && ov->sdc && build_novis);
     if (!novis && ((size_t)slots * vis_words > vis.n || slots > vis_epoch.n)) {
         // (re)allocation: fresh words and stamps -- queued launches still use the old buffers
         if (vis.p) HIPCHK(hipStreamSynchronize(st));

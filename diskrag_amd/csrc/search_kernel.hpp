@@ -52,6 +52,12 @@
 
 enum DistKind { DIST_EXACT = 0, DIST_ADC_SQ = 2 };
 
+// A/B switch (round 4): score the rows of a byte-row burst instruction by instruction as they land instead of after the whole burst
+#ifndef DR_BURST_PIPE
+#define DR_BURST_PIPE 0
+#endif
+template <int K> DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K) : "memory"); }
+
 struct KStats { u32 steps, visited, exact, pq, status, inserts, pq_evaluated, adj_prefetch_hits; };
 
 struct SearchParams {
@@ -1187,14 +1193,16 @@ DEV void search_body(const SearchParams &p)
                             for (int r = 0; r < RB; r += 8) rid[r / 8] = nb_id[min(b0 + r + (lane >> 3), nrow - 1)];
 #pragma unroll
                             for (int r = 0; r < RB; r += 8) {
-                                if (r < nb) {
+                                // (DR_BURST_PIPE: every instruction of the burst is issued -- the ones past the last row re-read it, an L2
+                                // hit -- so that the waits below are compile-time counts)
+                                if (DR_BURST_PIPE || r < nb) {
                                     const u8 *g = p.vec8 + (size_t)rid[r / 8] * D + (lane & 7) * 16;
                                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                         (__attribute__((address_space(3))) void *)(const_cast<unsigned char *>(rowbuf8) + (size_t)r * D), 16, 0, 0);
                                 }
                             }
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            for (int r8 = 0; r8 < nb; r8 += 8) {
+                            if (!DR_BURST_PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            auto pass = [&](const int r8) {
                                 const int row = min(r8 + oct, nb - 1);
                                 const uint4 w = *reinterpret_cast<const uint4 *>(rowbuf8 + (size_t)row * D + j * 16);
                                 const u32 words[4] = { w.x, w.y, w.z, w.w };
@@ -1223,6 +1231,17 @@ DEV void search_body(const SearchParams &p)
                                 }
                                 if (knorm) ev = f_sqrt(ev);
                                 if (j == 0 && r8 + oct < nb) nb_e[b0 + r8 + oct] = ev;
+                            };
+                            if constexpr (DR_BURST_PIPE != 0) {
+                                // pass i scores rows 8i .. 8i + 7 as soon as THEIR instruction has landed (loads return in order: at most
+                                // RB/8 - 1 - i newer ones may still be in flight), while the rest of the burst is still arriving
+                                static_assert(RB == 64, "eight instructions per burst");
+#define DR_BURST_PASS(I) if ((I) * 8 < nb) { wait_vmcnt<7 - (I)>(); pass((I) * 8); }
+                                DR_BURST_PASS(0) DR_BURST_PASS(1) DR_BURST_PASS(2) DR_BURST_PASS(3) DR_BURST_PASS(4) DR_BURST_PASS(5) DR_BURST_PASS(6) DR_BURST_PASS(7)
+#undef DR_BURST_PASS
+                                wait_vmcnt<0>();      // (the instructions past the last row)
+                            } else {
+                                for (int r8 = 0; r8 < nb; r8 += 8) pass(r8);
                             }
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         }

@@ -614,6 +614,29 @@ print("GRAPH", hashlib.sha1(ix.get_adjacency().tobytes()).hexdigest())
 """
 
 
+def test_pq_builder_searches_without_a_visited_set_build_the_same_graph(monkeypatch):
+    """Round 4: on large shards the PQ-only builder's greedy searches keep no visited set (DR_BUILD_PQ_NO_VISITED_SET; automatic from
+    2^25 points): the lists they return are the same, so the graph must be the same bit for bit -- forced on and off here."""
+    import hashlib
+    from diskrag_amd import HipIndex
+    from diskrag_amd.synth import unit_mixture
+    x, _ = unit_mixture(20000, 128, n_queries=4, n_clusters=32, seed=13, latent=12)
+    full = HipIndex.create_empty(x, R=16)
+    cb = full.pq_train(32, n_sample=8000, iters=3)
+    full.close()
+    shas = {}
+    for env in ("0", "1"):
+        monkeypatch.setenv("DR_BUILD_PQ_NO_VISITED_SET", env)
+        sh = HipIndex.create_codes_empty(len(x), 128, 64, cb)
+        try:
+            sh.encode_rows(x, 0)
+            medoid, _ = sh.build_vamana_pq(L_build=80, alpha=1.2, passes=2, seed=5)
+            shas[env] = (medoid, hashlib.sha1(sh.get_adjacency().tobytes()).hexdigest())
+        finally:
+            sh.close()
+    assert shas["0"] == shas["1"]
+
+
 @pytest.mark.parametrize("D", [96, 128, 256])
 def test_exact_prune_forms_build_the_same_graph(D, tmp_path):
     """prune_kernel<D, true> (the next <= 4 likely picks scored in one pass over the candidates' rows; the default at D <= 256)
