@@ -62,6 +62,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=2000, help="queries timed on the CPU oracle, all cores (rank 0, N=1 only)")
     ap.add_argument("--cpu-sample-1t", type=int, default=150, help="queries timed on ONE CPU thread")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed region (+ the 8 launches the recall is computed from): what scripts/profile_run.sh runs under "
+                         "rocprofv3 --kernel-trace --stats, so that the search kernel's average duration in the stats is the timed region's")
     ap.add_argument("--min-recall", type=float, default=0.95, help="the metric's recall bar: the bench fails below it")
     ap.add_argument("--config", default="c2", choices=["c2", "c5"], help="c2: the headline (query-sharded replicas); c5: graph-sharded PQ-only search with the RCCL top-k exchange")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -389,6 +392,8 @@ def worker_c2(args, rk):
     medoid, build_s = ix.build_vamana(L_build=args.L_build, alpha=1.2, passes=2, seed=7, pad_with_zero=True)
     log(rk, f"vamana graph built on device {device} in {build_s:.1f}s (upload+build {time.time() - t0:.1f}s), medoid {medoid}")
     t0 = time.time()
+    if args.headline_only:
+        args.no_cpu = args.no_secondary = True
     want_cpu = rk.rank == 0 and rk.world == 1 and not args.no_cpu
     cb = ix.pq_train(args.m, n_sample=100_000, iters=8)
     codes = ix.pq_encode(cb, want_codes=want_cpu)
@@ -443,13 +448,14 @@ def worker_c2(args, rk):
     ix.batch_select(0)
 
     def tickets_in_flight(n_q):
-        """submits a caller keeps in flight: PIPE_DEPTH launches' worth (a launch of small submits holds up to 10240 queries)"""
-        return _ffi.PIPE_DEPTH if n_q > 5120 else min(_ffi.MAX_TICKETS - 2, _ffi.PIPE_DEPTH * max(1, 10240 // n_q))
+        """submits a caller keeps in flight: PIPE_DEPTH launches' worth (a launch coalesces submits up to 32768 queries) + 2"""
+        return min(_ffi.MAX_TICKETS - 2, _ffi.PIPE_DEPTH * max(1, 32768 // n_q) + 2)
 
     # ---------------------------------------------------------------- the headline: host memory -> host memory, pipelined
     def run_pipelined(n_launch, sources, depth=_ffi.PIPE_DEPTH):
-        """a stream of n_launch submits, `depth` tickets in flight (10k-query batches: one launch each, PIPE_DEPTH in flight;
-        small batches: the library coalesces the submits that find the search stream busy into one launch)"""
+        """a stream of n_launch submits, `depth` tickets in flight; the library coalesces the submits that find the search stream
+        busy into one launch of up to 32768 queries (10k-query batches: 2-3 per launch -- a 10k-query launch is 2.4 queries per
+        wavefront slot and ends in a tail of idle slots; small batches: up to PIPE_DEPTH launches' worth of submits)"""
         jobs, done = [], 0
         t1 = time.perf_counter()
         for i in range(n_launch):
@@ -464,12 +470,18 @@ def worker_c2(args, rk):
         el = time.perf_counter() - t1
         return el, last
 
-    run_pipelined(max(3, args.warmup * args.bps), qb)          # warm-up (also sizes every buffer of the pipeline)
+    depth_head = tickets_in_flight(nq)
+    run_pipelined(max(3 * depth_head, args.warmup * args.bps), qb, depth_head)     # warm-up (also sizes every buffer of the pipeline)
     ix.batch_sync()
     rk.barrier()
-    elapsed, last = run_pipelined(launches, qb)
+    ps0 = ix.pipeline_stats()
+    elapsed, last = run_pipelined(launches, qb, depth_head)
     ix.batch_sync()                                            # everything is waited for inside the clock (it already is)
     tm_head = ix.timing()
+    ps1 = ix.pipeline_stats()
+    n_kernel_launches = max(1, ps1["launches"] - ps0["launches"])
+    q_per_launch = (ps1["queries"] - ps0["queries"]) / n_kernel_launches       # queries one search-kernel launch of the timed region held
+    submits_per_launch = (ps1["tickets"] - ps0["tickets"]) / n_kernel_launches
     times = rk.gather("t_head", elapsed)
     elapsed_job = max(times)
     slices = rk.gather("slice", [lo, hi])
@@ -520,9 +532,12 @@ def worker_c2(args, rk):
 
     # ---------------------------------------------------------------- the same rotation, batches resident in HBM
     rk.barrier()
-    el_res, tm_res = run_resident(args.bw, launches)
-    res_times = rk.gather("t_res", el_res)
-    qps_resident = total_q / max(res_times)
+    if args.headline_only:
+        res_times, tm_res, qps_resident = None, {"search_kernel_ms": None}, None
+    else:
+        el_res, tm_res = run_resident(args.bw, launches)
+        res_times = rk.gather("t_res", el_res)
+        qps_resident = total_q / max(res_times)
 
     # results of every distinct batch: recall, counters, algorithmic bytes
     ids, dist_out, st = collect(args.bw)
@@ -541,19 +556,23 @@ def worker_c2(args, rk):
     variant_launched = ix.timing()["variant"]
     variant = {16: 11, 17: 13}.get(variant_launched, variant_launched)      # (16 / 17: the same kernels in 4-wavefront workgroups, batches below 4096 queries)
     a_all, per_q = alg_bytes(st, D, args.R, args.m, k)
-    alg_launch = (a_all - 4 * 256 * D) / nb + 4 * 256 * D      # per 10k-query launch
+    per_launch = q_per_launch / nq                               # the timed region's launches hold this many batches on average
+    alg_launch = ((a_all - 4 * 256 * D) / nb) * per_launch + 4 * 256 * D      # per launch of the timed region (q_per_launch queries)
+    alg_launch_1 = (a_all - 4 * 256 * D) / nb + 4 * 256 * D                   # per one-batch launch (the resident legs below)
     k_ms = float(tm_head["search_kernel_ms"])                    # mean launch duration over the timed pipelined region
     achieved_ref = alg_launch / (k_ms * 1e-3) / 1e9
 
     # PCIe-inclusive rate from PAGEABLE caller memory (the library stages it), for reference
     qb_pageable = [np.array(a) for a in qb[:min(nb, 4)]]
-    el_pg, _ = run_pipelined(max(8, launches // 8), qb_pageable)
-    qps_pageable = nq * max(8, launches // 8) / el_pg
+    qps_pageable = None
+    if not args.headline_only:
+        el_pg, _ = run_pipelined(max(8, launches // 8), qb_pageable, depth_head)
+        qps_pageable = nq * max(8, launches // 8) / el_pg
     # ... and SURVEY.md 8d's literal metric: nq / wall time of ONE blocking dr_search_batch call (upload, search, tie order,
     # download, nothing overlapped), median over --blocking-calls calls rotating the distinct batches (pageable sources)
     ix.batch_select(15)             # (a blocking call uploads into the selected resident batch: keep it off the bench's)
     call_s = []
-    for i in range(max(3, args.blocking_calls) + 2):
+    for i in range(3 if args.headline_only else max(3, args.blocking_calls) + 2):
         src = qb_pageable[i % len(qb_pageable)]
         t1 = time.perf_counter()
         ix.search_batch(src, k, L=args.L, beam_width=args.bw, mode=mode)
@@ -575,13 +594,28 @@ def worker_c2(args, rk):
                 traffic = rec["hbm_bytes_per_launch"]
                 traffic_src = ("profiles/%s/pmc_traffic.json: rocprofv3 --pmc read requests by size (TCC_EA0_RDREQ_32B/64B/128B; FETCH_SIZE x2 before round 4) + WRITE_SIZE, separate passes over scripts/pmc_target.py "
                                "-- the same workload and build, collected by scripts/profile_run.sh in ANOTHER run on another box of the pool (a PMC pass "
-                               "cannot share a process with the timed region); hbm_frac divides it by THIS run's kernel time") % rnd
+                               "cannot share a process with the timed region), one batch per launch there: scaled by this run's batches per launch "
+                               "(the counters are linear in the queries of a launch); hbm_frac divides it by THIS run's kernel time") % rnd
 
     byte_rows = variant in (11, 13)
     # the kernel's own necessary bytes: a scored vector is D bytes for the byte-row variants, 4D for float rows
     a_k, _ = alg_bytes(st, D, args.R, args.m, k, row_bytes=D if byte_rows else 4 * D)
-    alg_kernel = (a_k - 4 * 256 * D) / nb + 4 * 256 * D
+    alg_kernel = ((a_k - 4 * 256 * D) / nb) * per_launch + 4 * 256 * D
+    alg_kernel_1 = (a_k - 4 * 256 * D) / nb + 4 * 256 * D
     achieved = alg_kernel / (k_ms * 1e-3) / 1e9
+    if traffic is not None:
+        traffic = traffic * per_launch      # the PMC passes run one batch per launch; the counters are linear in the queries of a launch
+    # one launch per batch, PIPE_DEPTH in flight (how rounds 2-3 ran the headline): the same stream without coalescing
+    one_per_launch = None
+    if not args.headline_only:
+        ix.set_coalesce(nq)
+        run_pipelined(3 * _ffi.PIPE_DEPTH, qb)
+        ix.batch_sync()
+        el_1, _ = run_pipelined(max(40, launches // 2), qb)
+        ix.batch_sync()
+        one_per_launch = {"qps": nq * max(40, launches // 2) / el_1, "kernel_ms": float(ix.timing()["search_kernel_ms"]),
+                          "tickets_in_flight": _ffi.PIPE_DEPTH}
+        ix.set_coalesce(32768)
     secondary = float_rows = float_queries = unrounded = None
     if not args.no_secondary and rk.world == 1:
         n_sec = max(40, launches // 4)
@@ -597,7 +631,7 @@ def worker_c2(args, rk):
         def forced(kind):
             el3, tm3 = run_resident(args.bw, n_sec, kind=kind)
             return {"variant": tm3["variant"], "qps_resident": nq * n_sec / el3, "kernel_ms": tm3["search_kernel_ms"],
-                    "roofline_frac": (alg_launch if tm3["variant"] not in (11, 13) else alg_kernel) / (tm3["search_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                    "roofline_frac": (alg_launch_1 if tm3["variant"] not in (11, 13) else alg_kernel_1) / (tm3["search_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
         if byte_rows:
             float_rows = forced(9)          # float32 rows: what data that is not integer-valued gets
@@ -641,15 +675,19 @@ def worker_c2(args, rk):
         "data": "synthetic",
         "config": {"workload": "SIFT1M-shaped synthetic (configs[1]): N=%d d=%d L2, R=%d, L_search=%d, PQ m=%d, beam_width=%s, "
                                "k=%d, batch=%d queries, mode=M1 reference-faithful; a step = %d consecutive batches, %d distinct "
-                               "batches per GPU rotating; value = host memory -> host memory (dr_search_submit/wait, %d launches in flight)"
-                               % (args.n, D, args.R, args.L, args.m, args.bw or None, k, nq_job, args.bps, nb, _ffi.PIPE_DEPTH)
+                               "batches per GPU rotating; value = host memory -> host memory (dr_search_submit/wait, one submit per batch, %d batches in flight; "
+                               "the library runs the batches that wait for the search stream as one launch: %.2f batches = %.0f queries per launch)"
+                               % (args.n, D, args.R, args.L, args.m, args.bw or None, k, nq_job, args.bps, nb, depth_head, submits_per_launch, q_per_launch)
                                + ("; STRONG scaling: every batch is cut into %d contiguous slices, one per GPU (slice of rank 0: %d queries)" % (rk.world, nq) if strong else ""),
                    "recall_at_10": recall, "build_seconds": build_s,
                    "parallelism": ("query-sharded replicas x%d, one batch split over the ranks" if strong else "query-sharded replicas x%d") % rk.world,
                    "per_rank_slice": slices if strong else None,
+                   "tickets_in_flight": depth_head, "queries_per_launch": q_per_launch, "submits_per_launch": submits_per_launch,
+                   "kernel_launches_in_timed_region": n_kernel_launches, "kernel_ms_per_batch": k_ms / per_launch,
+                   "one_launch_per_batch": one_per_launch,
                    "ms_per_batch": elapsed_job / launches * 1e3, "timed_region_s": elapsed_job, "per_rank_seconds": times,
                    "per_rank_qps": [(sl[1] - sl[0]) * launches / t for sl, t in zip(slices, times)],
-                   "qps_resident": qps_resident, "ms_per_batch_resident": max(res_times) / launches * 1e3,
+                   "qps_resident": qps_resident, "ms_per_batch_resident": (max(res_times) / launches * 1e3) if res_times else None,
                    "kernel_ms_resident": tm_res["search_kernel_ms"],
                    "qps_pcie_inclusive_pageable_source": qps_pageable,
                    "qps_blocking_call": {"median": qps_one_call, "calls": len(call_s), "best": nq / call_s[0], "worst": nq / call_s[-1],
@@ -673,7 +711,7 @@ def worker_c2(args, rk):
         "roofline": {"bound": "hbm", "kernel": "search_kernel<128,M1> variant %d" % variant_launched, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "hbm_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_kernel,
+                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_kernel, "queries_per_launch": q_per_launch,
                      "row_bytes": D if byte_rows else 4 * D,
                      "reference_accounting": {"algorithmic_bytes_per_launch": alg_launch, "achieved": achieved_ref,
                                               "frac": achieved_ref / HBM_PEAK_GBPS,

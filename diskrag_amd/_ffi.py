@@ -14,7 +14,7 @@ LIB_PATH = Path(_os.environ["DR_LIB"]) if _os.environ.get("DR_LIB") else PKG_DIR
 PAD = 0xFFFFFFFF
 MODE_M1, MODE_M2, MODE_M3, MODE_M4 = 1, 2, 3, 4
 PIPE_DEPTH = 4          # DR_PIPE_DEPTH (csrc/engine.hip): LAUNCHES of the pipelined path in flight per handle
-MAX_TICKETS = 32        # DR_MAX_TICKETS (include/diskrag_hip.h): dr_search_submit tickets in flight (small submits share launches)
+MAX_TICKETS = 128        # DR_MAX_TICKETS (include/diskrag_hip.h): dr_search_submit tickets in flight (small submits share launches)
 MODE_PQ = 5      # engine mode without a reference counterpart: M1's loop on squared ADC distances only (diskrag_hip.h)
 F_USE_PQ, F_SQDIST, F_RERANK, F_COSINE, F_NO_VISITED_SET = 1, 2, 4, 8, 16
 TIER_HBM, TIER_HOST = 0, 1       # where the full-precision rows live (dr_index_*_tiered)

@@ -115,8 +115,8 @@ struct QSlot {
 };
 #define DR_PIPE_DEPTH 4     // LAUNCHES of the pipelined path in flight (3 until round 3: a launch is finished only after its tie-order pass, which finds
                             // room in the TAIL of the next search kernel -- its latency, not its work, starved a 3-deep pipeline: profiles/r03/ab/ab_c2_companions_v3.log)
-static_assert(DR_MAX_TICKETS == 32u, "header and engine agree on the tickets in flight");
-#define DR_MAX_JOBS 32      // dr_search_submit tickets in flight (round 4: small submits are coalesced, several jobs ride in one launch)
+static_assert(DR_MAX_TICKETS == 128u, "header and engine agree on the tickets in flight");
+#define DR_MAX_JOBS 128      // dr_search_submit tickets in flight (round 4: small submits are coalesced, several jobs ride in one launch)
 #define DR_NUM_SETS (DR_PIPE_DEPTH + 1)
 
 // One dr_search_submit ticket. Round 4: a job no longer owns a launch -- it is a run of q0 .. q0 + nq - 1 inside the launch of
@@ -234,7 +234,7 @@ struct dr_index {
     int open_group = -1;          // the group that is collecting jobs (state 1), or -1
     int waiters = 0;              // threads inside dr_search_wait's polling loop
     std::map<uint64_t, std::pair<int, std::string>> failed_tickets;   // tickets whose launch failed, until their dr_search_wait collects the error
-    uint32_t coalesce_cap = 10240; // queries a group of small submits may grow to (dr_set_coalesce; 0: every submit is its own launch)
+    uint32_t coalesce_cap = 32768; // queries a group of small submits may grow to (dr_set_coalesce; 0: every submit is its own launch)
     bool hold_always = false;     // dr_debug_hold: submits are only launched when full / flushed / waited for (tests)
     uint64_t pipe_launches = 0, pipe_tickets = 0, pipe_max_tickets = 0, pipe_queries = 0;   // dr_pipeline_stats
     hipStream_t up_stream = nullptr, down_stream = nullptr;

@@ -40,6 +40,12 @@
 #define PH_BEGIN() u64 ph_acc[8] = {0,0,0,0,0,0,0,0}; u64 ph_t0, ph_t1; PH_STAMP(ph_t0)
 #define PH(i) do { PH_STAMP(ph_t1); ph_acc[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; } while (0)
 #define PH_END(qi) do { if (lane == 0 && p.phase) for (int i_ = 0; i_ < 8; i_++) p.phase[(size_t)(qi) * 8 + i_] = ph_acc[i_]; } while (0)
+#elif defined(DR_PHASE_MARK)
+// (-DDR_PHASE_MARK: the phase boundaries as comments in the otherwise unchanged ISA -- scripts/phase_budget.py counts the
+// instructions between them)
+#define PH_BEGIN() asm volatile("; DR_PHASE_BEGIN")
+#define PH(i) asm volatile("; DR_PHASE_END " #i)
+#define PH_END(qi) do {} while (0)
 #else
 #define PH_BEGIN() do {} while (0)
 #define PH(i) do {} while (0)

@@ -2,7 +2,7 @@
 # rocprofv3 evidence for the bench kernel (run on the GPU box through gpurun). Output: gpurun_out/prof/
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 1 --headline-only > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 for bw in 8 0; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_bw$bw -- python3 scripts/pmc_target.py $bw > $OUT/pmc_fetch_bw$bw.out 2> $OUT/pmc_fetch_bw$bw.err
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_bw$bw -- python3 scripts/pmc_target.py $bw > $OUT/pmc_write_bw$bw.out 2> $OUT/pmc_write_bw$bw.err

@@ -89,7 +89,7 @@ def test_groups_split_on_parameters_capacity_and_flush():
         for j in jobs:
             assert _same(j.wait(), wa)
     finally:
-        ix.set_coalesce(10240)
+        ix.set_coalesce(32768)
         ix.debug_hold(False)
     ix.batch_sync()
 
