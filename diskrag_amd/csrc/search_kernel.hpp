@@ -117,6 +117,8 @@ struct SearchParams {
     // then count EVALUATIONS (a node met again after it fell out of the list is scored again). vis / adjr may be null.
     // bit 1 (with bit 0): the ids of the predicted next pop's adjacency row are landed in LDS during the running expansion
     // (R <= 128), so that on a hit the expansion starts with its code-word gathers instead of waiting for the row first.
+    // bit 2: the adjacency prefetch of the byte-query variants WITH a second chance (A/B switch DR_REPREFETCH=1; measured: hits 58 -> 97 %,
+    // kernel 1 % slower -- profiles/r04/ab/ab_c2_second_chance_prefetch.jsonl).
     u32 novis;
 };
 
@@ -845,6 +847,7 @@ DEV void search_body(const SearchParams &p)
         u32 npq_eval = 0;
         u32 steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0, ninserts = 0;
         u32 pre_id = 0xFFFFFFFFu;   // node whose adjacency row is (being) landed in pre_buf; none at query start
+        u32 pre_db = 0xFFFFFFFFu;   // distance bits of that node (the prediction a better new neighbour replaces)
         u32 npre_hit = 0;
         const bool pre_on = ADJPRE && has_first && p.adjr != nullptr && p.R == 64u;
 #ifdef DR_TRACE_VIS
@@ -998,14 +1001,14 @@ DEV void search_body(const SearchParams &p)
                 // beat it) -- and land ITS adjacency row in LDS: no VGPR destination, nobody waits for it, and when the
                 // prediction holds the next expansion starts without its first global round trip.
                 if constexpr (ADJPRE) {
-                    pre_id = 0xFFFFFFFFu;
+                    pre_id = 0xFFFFFFFFu; pre_db = 0xFFFFFFFFu;
                     if (pre_on) {
                         const int ia2 = frontier_first<NCHR>(rk, fl, rn);
                         const u64 ka2 = (ia2 >= 0) ? fkey(list_get<NCHR>(rk, ia2)) : ~0ull;
                         const u64 kb2 = (tn > 0) ? readlane64(tl.v[0], 0) : ~0ull;
                         const u64 kn = ka2 <= kb2 ? ka2 : kb2;
                         if (kn != ~0ull) {
-                            pre_id = (u32)kn;
+                            pre_id = (u32)kn; pre_db = (u32)(kn >> 32);
                             const u32 *gi = p.adj + (size_t)pre_id * 64 + lane, *gp = p.adjr + (size_t)pre_id * 64 + lane;
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gi,
                                 (__attribute__((address_space(3))) void *)pre_buf, 4, 0, 0);
@@ -1342,6 +1345,32 @@ DEV void search_body(const SearchParams &p)
                     if constexpr (FILTER) {
                         npq += nnew;            // the reference counts one PQ distance per new neighbour
                         if (need_adc) npq_eval += nnew;
+                    }
+                    if constexpr (ADJPRE) {
+                        // Second chance for the prediction (round 4, A/B switch, OFF by default): the row landed above belongs to the best
+                        // frontier entry that was left when this expansion began -- 42 % of the time one of THIS expansion's neighbours is
+                        // closer and is popped instead. Its distance is known now: land ITS row over the stale one (same area; a
+                        // wavefront's loads return in order, so the later one wins) and let the decision pass hide the round trip.
+                        // Measured: hits 58 -> 97 % of the expansions and the kernel 1 % SLOWER -- the length of an expansion's chain of
+                        // round trips is not what bounds this kernel.
+                        if (pre_on && (p.novis & 4u) != 0u) {
+                            const u32 eb = rowlane ? __float_as_uint(e) : 0xFFFFFFFFu;      // (distances are >= 0: the bits order like the values)
+                            const u32 mb = wave_min_u32(eb);
+                            if (mb < pre_db) {
+                                const int fb = __ffsll((long long)__ballot(eb == mb)) - 1;
+                                pre_id = readlane32(myid, fb); pre_db = mb;
+                                const u32 *gi = p.adj + (size_t)pre_id * 64 + lane, *gp = p.adjr + (size_t)pre_id * 64 + lane;
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gi,
+                                    (__attribute__((address_space(3))) void *)pre_buf, 4, 0, 0);
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
+                                    (__attribute__((address_space(3))) void *)(pre_buf + 64), 4, 0, 0);
+                                if (lane < 2) {
+                                    const u32 *gm = reinterpret_cast<const u32 *>(p.first + (size_t)pre_id) + lane;
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gm,
+                                        (__attribute__((address_space(3))) void *)(pre_buf + 128), 4, 0, 0);
+                                }
+                            }
+                        }
                     }
                 } else {
                     if constexpr (!SPEC_CODES) { if (isnew) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m); }
