@@ -84,6 +84,52 @@ def extra_pass():
     for L in ((300, 350) if shape == "c4" else (250, 300, 350)):
         run(f"PQ_rerank_L{L}_bwNone", L=L, beam_width=0, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)
 
+def run_stream(tag, cap, depth, n_sub=48, **kw):
+    """host memory -> host memory: a stream of nq-query submits (dr_search_submit / dr_search_wait), `depth` in flight; the library runs the
+    submits that wait for the search stream as one launch of up to `cap` queries"""
+    try:
+        ix.set_coalesce(cap)
+        src = _ffi.pinned_empty(q.shape, np.float32); src[:] = q
+
+        def go(n):
+            jobs, done, last = [], 0, None
+            t1 = time.perf_counter()
+            for i in range(n):
+                jobs.append(ix.search_submit(src, 10, reuse_outputs=True, **kw))
+                if len(jobs) - done >= depth:
+                    last = jobs[done].wait(); jobs[done] = None; done += 1
+            for j in range(done, len(jobs)):
+                last = jobs[j].wait()
+            return time.perf_counter() - t1, last
+        go(2 * depth); ix.batch_sync()
+        s0 = ix.pipeline_stats()
+        dt, last = go(n_sub)
+        ix.batch_sync()
+        s1 = ix.pipeline_stats()
+        t = ix.timing()
+        nl = max(1, s1["launches"] - s0["launches"])
+        emit({"run": tag, "args": {k: int(v) for k, v in kw.items()}, "path": "dr_search_submit/wait, host -> host", "coalesce_cap": cap, "tickets_in_flight": depth,
+              "qps": nq * n_sub / dt, "recall_at_10": recall_at_k(last[0], gt, 10), "queries_per_launch": (s1["queries"] - s0["queries"]) / nl,
+              "kernel_ms_per_launch": t["search_kernel_ms"], "kernel_ms_per_10k_queries": t["search_kernel_ms"] * 10000.0 / ((s1["queries"] - s0["queries"]) / nl),
+              "variant": t["variant"], "status_max": int(last[3]["status"].max())})
+    except Exception as e:
+        emit({"run": tag, "error": str(e)})
+    finally:
+        ix.set_coalesce(32768)
+
+
+if spec == "stream":
+    # end of round 4: the shape's operating points at recall >= 0.95 as a host -> host stream of nq-query submits, one launch per submit
+    # against shared launches (the tail of a launch: 10 000 queries are 2.4-4.9 queries per wavefront slot)
+    pts = ((("M1_L500_bw64", dict(L=500, beam_width=64, mode=_ffi.MODE_M1)), ("PQ_rerank_L400_bw32", dict(L=400, beam_width=32, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)),
+            ("M2_bw128", dict(L=100, beam_width=128, mode=_ffi.MODE_M2))) if shape == "c4" else
+           (("PQ_rerank_L250_bwNone", dict(L=250, beam_width=0, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)), ("M1_L200_bw64", dict(L=200, beam_width=64, mode=_ffi.MODE_M1))))
+    for tag, kw in pts:
+        run(tag + "_resident", **kw)
+        run_stream(tag + "_stream_one_launch_per_submit", nq, 4, **kw)
+        run_stream(tag + "_stream_shared_launches", 32768, 14, **kw)
+    ix.close()
+    sys.exit(0)
 if spec == "extra":
     extra_pass()
     ix.close()
