@@ -222,3 +222,44 @@ def test_request_threads_share_launches():
     assert s1["tickets"] - s0["tickets"] == nthreads * per
     assert s1["launches"] - s0["launches"] <= nthreads * per          # (how many share a launch depends on timing; the bits do not)
     ix.batch_sync()
+
+
+@pytest.mark.parametrize("name,params", [
+    ("sift128_R64_m32", dict(L=100, beam_width=8, mode=1)),
+    ("unit1536_R16_m32", dict(L=60, beam_width=8, mode=5)),
+])
+def test_large_groups_full_batches_share_a_launch(name, params):
+    """end of round 4: launches hold up to 32768 queries (10240 before) and 64 tickets (16): three 6000-query submits ride in ONE launch of
+    18000 queries -- the per-query ADC bounds of M1 are computed once for the whole launch -- and a fourth that would overflow the
+    capacity opens the next; 70 small tickets in one launch; every ticket the bits of a blocking call of its own"""
+    g = load_golden(name)
+    ix = get_index(name)
+    rs = np.random.RandomState(5)
+    nq = len(g.queries)
+    big = [np.ascontiguousarray(g.queries[rs.randint(0, nq, size=n)]) for n in (6000, 6000, 6000, 15000)]
+    want = [ix.search_batch(b, 10, **params) for b in big]
+    ix.debug_hold(True)
+    try:
+        s0 = ix.pipeline_stats()
+        jobs = [ix.search_submit(b, 10, **params) for b in big[:3]]
+        assert ix.pipeline_stats()["launches"] == s0["launches"]                   # 18000 queries held in one group
+        jobs.append(ix.search_submit(big[3], 10, **params))                        # 18000 + 15000 > 32768: launches the first group
+        s1 = ix.pipeline_stats()
+        assert s1["launches"] == s0["launches"] + 1 and s1["queries"] == s0["queries"] + 18000 and s1["tickets"] == s0["tickets"] + 3
+        got = [j.wait() for j in jobs]
+        for i, w in enumerate(want):
+            assert _same(got[i], w), (name, i)
+        # many tickets in one launch
+        small = [np.ascontiguousarray(g.queries[rs.randint(0, nq, size=1 + (i % 5))]) for i in range(70)]
+        want_s = [ix.search_batch(b, 10, **params) for b in small]
+        s2 = ix.pipeline_stats()
+        jobs = [ix.search_submit(b, 10, **params) for b in small]
+        s3 = ix.pipeline_stats()
+        assert s3["launches"] - s2["launches"] == 1 and s3["tickets"] - s2["tickets"] == 64     # the 64th ticket filled (and launched) the first group
+        got = [j.wait() for j in jobs]
+        assert ix.pipeline_stats()["launches"] == s2["launches"] + 2
+        for i, w in enumerate(want_s):
+            assert _same(got[i], w), (name, "small", i)
+    finally:
+        ix.debug_hold(False)
+    ix.batch_sync()
