@@ -5,9 +5,12 @@ N = 1,000,000 x d = 128 L2, R = 64 slots, PQ m = 32, L_search = 100, batch = 10,
 
 What is measured:
   * `value`: queries per second of a stream of 10k-query batches that start in HOST memory and end as results in HOST
-    memory -- dr_search_submit / dr_search_wait (include/diskrag_hip.h): upload, search, tie-order pass and download
-    of consecutive batches overlap on separate HIP streams, four batches in flight. Distinct batches rotate
-    (--distinct-batches, default 8), so no step replays the previous step's queries.
+    memory -- dr_search_submit / dr_search_wait (include/diskrag_hip.h): one submit per batch, 14 batches in flight; upload,
+    search, tie-order pass and download overlap on separate HIP streams, and the library runs the batches that wait for the
+    search stream as ONE launch (2-3 batches per launch: `config.queries_per_launch`; a lone 10k-query launch ends in a tail
+    of idle wavefront slots). Distinct batches rotate (--distinct-batches, default 8), so no step replays the previous
+    step's queries. `roofline` is per launch of the timed region; `config.one_launch_per_batch` is the same stream with
+    one launch per batch and four in flight (how rounds 2-3 ran it).
   * `config.qps_resident`: the same rotation with every batch already resident in HBM (dr_batch_select / dr_batch_run).
   * a "step" is --batches-per-step (default 40) consecutive 10k-query batches, so that the timed region of the
     driver's 20 steps lasts about a second; `ms_per_step` is per step, `config.ms_per_batch` per 10k-query batch.
