@@ -246,7 +246,7 @@ int dr_batch_select(dr_index *ix, uint32_t slot);
  * call of its own would return (queries are independent). A submit that finds fewer than two searches queued is launched at
  * once, so a lone request never waits; held submits are launched by the next submit that finds the stream running dry, by
  * any dr_search_wait (which keeps feeding the stream while it waits), by dr_search_flush, or when the group reaches
- * dr_set_coalesce's size (default 32768 queries; 0 = every submit is its own launch, the behaviour until round 3). FULL batches
+ * dr_set_coalesce's size or DR_MAX_TICKETS / 2 tickets (default 32768 queries; 0 = every submit is its own launch, the behaviour until round 3). FULL batches
  * are coalesced too: a 10 000-query launch is 2.4 queries per wavefront slot and ends in a tail of idle slots that the next batch's
  * kernel (same stream) cannot fill; launches of 20-25 k queries take 1.05 ms per 10 000 queries instead of 1.24.
  * If a launch fails, dr_search_wait of every ticket that rode in it answers the error. */

@@ -97,6 +97,36 @@ def run(tag, **kw):
     print(tag, out["runs"][tag], flush=True)
 
 
+def run_stream(tag, depth=14, n_sub=48, **kw):
+    """the same operating point as a host -> host stream of nq-query submits (dr_search_submit / dr_search_wait): the library runs the submits
+    that wait for the search stream as one launch (end of round 4: a 10 000-query launch is 4.9 queries per wavefront slot on this kernel)"""
+    src = _ffi.pinned_empty(q.shape, np.float32); src[:] = q
+
+    def go(n):
+        jobs, done, last = [], 0, None
+        t1 = time.perf_counter()
+        for i in range(n):
+            jobs.append(sh.search_submit(src, 10, reuse_outputs=True, **kw))
+            if len(jobs) - done >= depth:
+                last = jobs[done].wait(); jobs[done] = None; done += 1
+        for j in range(done, len(jobs)):
+            last = jobs[j].wait()
+        return time.perf_counter() - t1, last
+    go(2 * depth); sh.batch_sync()
+    s0 = sh.pipeline_stats()
+    dt, last = go(n_sub)
+    sh.batch_sync()
+    s1 = sh.pipeline_stats()
+    t = sh.timing()
+    qpl = (s1["queries"] - s0["queries"]) / max(1, s1["launches"] - s0["launches"])
+    out["runs"][tag] = {"path": "dr_search_submit / dr_search_wait, host -> host, %d submits in flight" % depth, "qps": nq * n_sub / dt, "queries_per_launch": qpl,
+                        "kernel_ms_per_launch": t["search_kernel_ms"], "kernel_ms_per_10k_queries": t["search_kernel_ms"] * 10000.0 / qpl,
+                        "table_build_kernel_ms_per_launch": t["lut_kernel_ms"], "variant": t["variant"],
+                        "recall_at_10_vs_bruteforce_adc": recall_at_k(last[0][:NGT], gt_adc, 10), "status_max": int(last[3]["status"].max())}
+    save()
+    print(tag, out["runs"][tag], flush=True)
+
+
 # ground truth in the shard's own metric: brute-force ADC top-10 (flat scan of all code words, top-k kept on the device)
 t0 = time.perf_counter()
 gt_adc, gt_adc_sq, scan_ms = sh.pq_scan_topk(q[:max(NGT, 1)], 10)
@@ -136,6 +166,9 @@ for gi, (R, LB) in enumerate(CFG):
             else: os.environ.pop("DR_PQ_ROW_PREFETCH", None)
             run(f"{G}/PQ_L{L}_bw{bw or 'None'}" + ("_no_visited_set" if nv else "") + ("_next_row_prefetch" if pre else ""), L=L, beam_width=bw,
                 mode=_ffi.MODE_PQ, flags=_ffi.F_NO_VISITED_SET if nv else 0)
+            if parts[-1] == "stream":                         # "...:stream": the same point again as a host -> host stream with shared launches
+                run_stream(f"{G}/PQ_L{L}_bw{bw or 'None'}" + ("_no_visited_set" if nv else "") + "_stream_shared_launches", L=L, beam_width=bw,
+                           mode=_ffi.MODE_PQ, flags=_ffi.F_NO_VISITED_SET if nv else 0)
         continue
     for L in (100, 200, 400, 800):
         for bw in (8, 0):
