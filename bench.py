@@ -543,7 +543,16 @@ def worker_c2(args, rk):
         qps_resident = total_q / max(res_times)
 
     # results of every distinct batch: recall, counters, algorithmic bytes
-    ids, dist_out, st = collect(args.bw)
+    if args.headline_only:
+        # (under rocprofv3: every launch of the process is then one of the pipelined path's, so that the kernel's average duration in
+        # the --stats summary is the timed region's)
+        jobs_c = [ix.search_submit(qb[b], k, L=args.L, beam_width=args.bw, mode=mode) for b in range(nb)]
+        outs_c = [j.wait() for j in jobs_c]
+        ids = np.concatenate([o[0] for o in outs_c]); dist_out = np.concatenate([o[1] for o in outs_c]); st = np.concatenate([o[3] for o in outs_c])
+        if (st["status"] != 0).any():
+            raise RuntimeError("work-area overflow during the bench")
+    else:
+        ids, dist_out, st = collect(args.bw)
     # the pipelined path (what `value` times) must have produced the same answers as the resident path the recall is
     # computed from: its last waited batch against the same batch of collect()
     lb = (launches - 1) % nb
@@ -575,12 +584,12 @@ def worker_c2(args, rk):
     # download, nothing overlapped), median over --blocking-calls calls rotating the distinct batches (pageable sources)
     ix.batch_select(15)             # (a blocking call uploads into the selected resident batch: keep it off the bench's)
     call_s = []
-    for i in range(3 if args.headline_only else max(3, args.blocking_calls) + 2):
+    for i in range(0 if args.headline_only else max(3, args.blocking_calls) + 2):
         src = qb_pageable[i % len(qb_pageable)]
         t1 = time.perf_counter()
         ix.search_batch(src, k, L=args.L, beam_width=args.bw, mode=mode)
         call_s.append(time.perf_counter() - t1)
-    call_s = sorted(call_s[2:])     # (the first two calls size the slot's buffers)
+    call_s = sorted(call_s[2:]) or [float("inf")]     # (the first two calls size the slot's buffers)
     qps_one_call = nq / call_s[len(call_s) // 2]
     if nb == 16:
         ix.batch_upload(qb[15])
@@ -693,7 +702,7 @@ def worker_c2(args, rk):
                    "qps_resident": qps_resident, "ms_per_batch_resident": (max(res_times) / launches * 1e3) if res_times else None,
                    "kernel_ms_resident": tm_res["search_kernel_ms"],
                    "qps_pcie_inclusive_pageable_source": qps_pageable,
-                   "qps_blocking_call": {"median": qps_one_call, "calls": len(call_s), "best": nq / call_s[0], "worst": nq / call_s[-1],
+                   "qps_blocking_call": None if args.headline_only else {"median": qps_one_call, "calls": len(call_s), "best": nq / call_s[0], "worst": nq / call_s[-1],
                                          "note": "SURVEY.md 8d's literal metric: nq / wall time of one blocking dr_search_batch call "
                                                  "(pageable source; upload + search + tie order + download, nothing overlapped)"},
                    "per_query": {"expansions": float(st["steps"].mean()), "pq_distances": float(st["pq"].mean()),
