@@ -69,6 +69,8 @@ def parse_args(argv=None):
                     help="only the timed region (+ the 8 launches the recall is computed from): what scripts/profile_run.sh runs under "
                          "rocprofv3 --kernel-trace --stats, so that the search kernel's average duration in the stats is the timed region's")
     ap.add_argument("--min-recall", type=float, default=0.95, help="the metric's recall bar: the bench fails below it")
+    ap.add_argument("--c5-group", type=int, default=3, help="c5: submits per exchange (dr_sharded_set_group): one launch per shard and one all-gather for that many "
+                                                            "consecutive 10k-query submits; 1 = every submit its own exchange")
     ap.add_argument("--config", default="c2", choices=["c2", "c5"], help="c2: the headline (query-sharded replicas); c5: graph-sharded PQ-only search with the RCCL top-k exchange")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every rank its own batches of --num-queries; strong (SURVEY.md 8e): ONE stream of "
@@ -857,20 +859,28 @@ def worker_c5(args, rk):
 
     c5_flags = _ffi.F_NO_VISITED_SET        # (same results as with a visited set; 24-33 % faster at the full shard size, neutral at bench scale)
 
+    # Exchanges of --c5-group submits (a count, never a timing: every rank forms the same exchanges), three exchanges' worth of submits in
+    # flight: a 10k-query launch of this kernel is 4.9 queries per wavefront slot and ends in a tail of idle slots
+    # (profiles/r04/scale_c5_shard_R128_stream.json: 1.44 -> 1.76 M QPS on the full-size shard with 26.7 k queries per launch)
+    grp = max(1, min(16, args.c5_group, 32768 // max(1, nq)))
+    _ffi.sharded_set_group(sh, grp)
+    depth_c5 = 2 if grp == 1 else 3 * grp
+
     def stream(n_calls):
         jobs, out, ms = [], None, np.zeros(3)
         t1 = time.perf_counter()
         for i in range(n_calls):
             jobs.append(_ffi.sharded_submit([sh], [base], qp, k, L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQ, flags=c5_flags, comm=comm))
-            if len(jobs) >= 2:
+            if len(jobs) >= depth_c5:
                 out = jobs.pop(0).wait(); ms += out[3]
         for j in jobs:
             out = j.wait(); ms += out[3]
         return time.perf_counter() - t1, out, ms
 
-    stream(max(2, args.warmup))
+    stream(max(2 * depth_c5, args.warmup))
     rk.barrier()
     el, (ids, dist, status, _), ms = stream(args.steps)
+    _ffi.sharded_set_group(sh, 1)
     times = rk.gather("t_c5", el)
     if int(status.max()) != 0:
         raise RuntimeError("work-area overflow during the bench")
@@ -886,11 +896,12 @@ def worker_c5(args, rk):
            "config": {"workload": "c5 layout at bench scale: %d shards x %d points of the 1536-d unit-mixture stream (4096 clusters), vectors "
                                   "encoded on the fly and never stored, PQ m=%d, graph built from code words (dr_build_vamana_pq R=%d, L_build=%d), "
                                   "DR_MODE_PQ | DR_F_NO_VISITED_SET L=%d beam_width=%s, k=%d; every query on every shard; exchange = ONE RCCL all-gather of (nq*k + 1) "
-                                  "packed 64-bit words per rank + device merge; a step = one %d-query batch, two in flight (dr_sharded_submit/wait)"
-                                  % (rk.world, n_s, m, R, args.L_build, args.L, args.bw or None, k, nq),
+                                  "packed 64-bit words per rank + device merge; a step = one %d-query batch (dr_sharded_submit/wait), %d submits per exchange "
+                                  "(one launch per shard, one all-gather: dr_sharded_set_group), %d submits in flight"
+                                  % (rk.world, n_s, m, R, args.L_build, args.L, args.bw or None, k, nq, grp, depth_c5),
                       "recall_at_10_vs_bruteforce_adc": recall, "ground_truth_queries": ngt, "rccl_ranks": rk.world,
                       "build_seconds": build_s, "encode_seconds": enc_s, "codebook_seconds": cb_s,
-                      "per_rank_seconds": times, "exchange_bytes_per_rank_per_batch": (nq * k + 1) * 8,
+                      "per_rank_seconds": times, "exchange_bytes_per_rank_per_batch": (nq * k + 1) * 8, "submits_per_exchange": grp, "submits_in_flight": depth_c5,
                       "one_blocking_call_ms": {"search": float(ms1[0]), "all_gather": float(ms1[1]), "merge": float(ms1[2])},
                       "search_kernel": {"variant": tm["variant"], "kernel_ms": tm["search_kernel_ms"], "table_kernel_ms": tm["lut_kernel_ms"],
                                         "waves_per_cu": tm["waves_per_cu"]}}}

@@ -47,7 +47,7 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_debug_force_kind", "dr_search_batch_f64",
            "dr_index_create_codes", "dr_index_drop_vectors", "dr_pq_scan_best",
            "dr_batch_select", "dr_search_submit", "dr_search_wait", "dr_search_flush", "dr_set_coalesce", "dr_pipeline_stats", "dr_debug_hold", "dr_host_alloc", "dr_host_free",
-           "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_sharded_submit", "dr_sharded_wait", "dr_merge_topk",
+           "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_sharded_submit", "dr_sharded_wait", "dr_sharded_set_group", "dr_sharded_flush", "dr_merge_topk",
            "dr_debug_prune", "dr_debug_prune_pq", "dr_pq_train_ex", "dr_index_create_codes_empty", "dr_pq_encode_rows", "dr_build_vamana_pq",
            "dr_scalar_kernels", "dr_index_inline_codes", "dr_pq_scan_topk", "dr_index_copy_codes"]
 
@@ -189,6 +189,10 @@ def load_library():
                                     C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp, u32p, fp, C.POINTER(C.c_uint64)]
     L.dr_sharded_wait.restype = C.c_int
     L.dr_sharded_wait.argtypes = [vp, C.c_uint64]
+    L.dr_sharded_set_group.restype = C.c_int
+    L.dr_sharded_set_group.argtypes = [vp, C.c_uint32]
+    L.dr_sharded_flush.restype = C.c_int
+    L.dr_sharded_flush.argtypes = [vp]
     L.dr_debug_prune.restype = C.c_int
     L.dr_debug_prune.argtypes = [vp, C.c_uint32, u32p, C.c_uint32, C.c_float, C.c_uint32, u32p, u32p]
     L.dr_merge_topk.restype = C.c_int
@@ -722,7 +726,7 @@ class PendingSharded:
 
 
 def sharded_submit(shards, id_bases, queries, k, L=100, beam_width=8, mode=MODE_PQ, band_policy=0, flags=0, comm=None):
-    """dr_sharded_submit: the first half of sharded_search; two calls may be in flight per first shard (batch i+1 is searched
+    """dr_sharded_submit: the first half of sharded_search; four exchanges may be in flight per first shard (batch i+1 is searched
     while batch i is exchanged and merged). Every rank must submit in the same order."""
     n = len(shards)
     D = shards[0].D
@@ -741,9 +745,21 @@ def sharded_submit(shards, id_bases, queries, k, L=100, beam_width=8, mode=MODE_
     job.ticket = int(t.value)
     live = shards[0].__dict__.setdefault("_sharded_inflight", {})      # (the library writes into the job's arrays until it is finished)
     live[job.ticket] = job
-    for tk in [tk for tk in live if tk + 2 <= job.ticket]:
-        del live[tk]
+    # (four exchanges of at most 16 submits are in flight: a ticket 64 submits old has been finished by the library)
+    for tk in [tk for tk in list(live) if tk + 64 <= job.ticket]:
+        live.pop(tk, None)
     return job
+
+
+def sharded_set_group(first_shard, n):
+    """dr_sharded_set_group: n consecutive sharded_submit calls share ONE exchange (one launch per shard, one all-gather); a count, not a
+    timing, so that every rank forms the same exchanges. An exchange is launched when full, when one of its jobs is waited for, or by
+    sharded_flush."""
+    _check(load_library().dr_sharded_set_group(first_shard._h, int(n)))
+
+
+def sharded_flush(first_shard):
+    _check(load_library().dr_sharded_flush(first_shard._h))
 
 
 def merge_topk_device(ids, dist, k_out, device=0):

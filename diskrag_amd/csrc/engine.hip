@@ -152,7 +152,11 @@ struct PipeGroup {
 // Persistent work areas of dr_sharded_submit (comm.inc), owned by the first shard of the call: staging arrays, events, the
 // exchange stream and a page-locked slab for the results live across calls. Two of them: batch i+1 is searched while batch i
 // is exchanged, merged and downloaded.
-#define DR_SHARD_DEPTH 2
+#define DR_SHARD_DEPTH 4
+// one dr_sharded_submit riding in an exchange: its run of the exchange's queries and where its results go
+struct ShardPart { uint64_t ticket; uint32_t q0, nq; uint32_t *out_ids; float *out_dist; uint32_t *out_status; float *out_ms; };
+// ONE exchange: the submits it carries (dr_sharded_set_group: a fixed number per exchange, so that every rank forms the same
+// exchanges whatever its timing), their queries concatenated on the device, the local lists, the packed keys, the results
 struct ShardWork {
     DevBuf<uint32_t> loc_ids, fin_ids, status;
     DevBuf<float> loc_dist, fin_dist, q;
@@ -160,11 +164,13 @@ struct ShardWork {
     hipEvent_t e[5] = {};                       // start, local lists ready, exchange done, final merge done, download done
     hipEvent_t up = nullptr;                    // batch on the device
     void *pin = nullptr; size_t pin_bytes = 0;
-    bool active = false;
-    uint64_t ticket = 0;
-    uint32_t nq = 0, k = 0; int nranks = 1;
-    int local_rc = 0; std::string local_msg;
-    uint32_t *out_ids = nullptr; float *out_dist = nullptr; uint32_t *out_status = nullptr; float *out_ms = nullptr;
+    int state = 0;                              // 0 free, 1 collecting submits, 2 launched (its tickets only have to be collected)
+    std::vector<ShardPart> parts;
+    uint32_t nq = 0, cap = 0, k = 0, L = 0, bw = 0, mode = 0, policy = 0, flags = 0; int nranks = 1;
+    bool q_u8 = true;
+    std::vector<dr_index *> shards; std::vector<uint32_t> id_base; dr_comm *comm = nullptr;
+    int local_rc = 0; std::string local_msg;    // this rank's local phase failed: travels as the status word, answered at the wait
+    int launch_rc = 0; std::string launch_msg;  // the exchange could not be queued at all: every ticket answers this
     ~ShardWork()
     {
         for (auto &x : e) if (x) (void)hipEventDestroy(x);
@@ -175,7 +181,9 @@ struct ShardWork {
 struct ShardScratch {
     std::mutex mu;
     ShardWork w[DR_SHARD_DEPTH];
-    uint64_t next_ticket = 1;
+    uint64_t next_ticket = 1, next_work = 0;
+    int open = -1;                        // the work that is collecting submits, if any
+    uint32_t group = 1;                   // submits per exchange (dr_sharded_set_group)
     std::map<uint64_t, std::pair<int, std::string>> failed;   // tickets finished by a later submit with an error
     std::vector<hipEvent_t> shard_done;   // one per local shard
     hipStream_t xs = nullptr;             // merge / exchange / download stream (without a communicator)

@@ -92,12 +92,24 @@ class ShardedSearch:
 
     def search_submit(self, queries, k, L=100, beam_width=8, mode=_ffi.MODE_M3, band_policy=0, flags=_ffi.F_USE_PQ):
         """Pipelined form for device shards (dr_sharded_submit): returns an object whose wait() gives what search_batch
-        returns. Two may be in flight; every rank must submit in the same order."""
+        returns. Four exchanges may be in flight; every rank must submit (and, with set_group, wait) in the same order."""
         if not self._on_device():
             raise TypeError("search_submit needs device indexes")
         job = _ffi.sharded_submit([sh.index for sh in self.shards], [sh.base for sh in self.shards], queries, k, L=L,
                                   beam_width=beam_width, mode=mode, band_policy=band_policy, flags=flags, comm=self.comm)
         return _PendingShardedSearch(job)
+
+
+    def set_group(self, n):
+        """n consecutive search_submit calls share ONE exchange (dr_sharded_set_group: one launch per shard, one all-gather; a count,
+        never a timing, so that every rank forms the same exchanges); launched when full, when one of its jobs is waited for, or by flush()."""
+        if not self._on_device():
+            raise TypeError("set_group needs device indexes")
+        _ffi.sharded_set_group(self.shards[0].index, n)
+
+    def flush(self):
+        if self._on_device():
+            _ffi.sharded_flush(self.shards[0].index)
 
 
 class _PendingShardedSearch:

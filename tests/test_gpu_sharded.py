@@ -148,3 +148,75 @@ def test_pipelined_sharded_submits_and_the_failure_protocol():
         nopq.close()
         for ix in shards:
             ix.close()
+
+
+def test_grouped_exchanges_carry_several_submits():
+    """End of round 4: dr_sharded_set_group(n) -- n consecutive submits ride in ONE exchange (one launch per shard over their
+    concatenated queries, one all-gather); the rule is a count, a wait or a flush, never a timing. Every ticket gets the bits of a
+    blocking call of its own; parameters that differ split an exchange; a failing local phase fails every ticket of its exchange
+    and nothing else."""
+    from diskrag_amd import HipIndex, _ffi
+    from diskrag_amd.parallel import shard_slice
+    from diskrag_amd.synth import sift_like
+    n, nshard, k = 12000, 3, 10
+    x, q = sift_like(n, 128, n_queries=120, n_clusters=32, seed=41, query_seed=42)
+    shards, bases, cb = [], [], None
+    for s in range(nshard):
+        sl = shard_slice(n, nshard, s)
+        ix = HipIndex.create_empty(x[sl], R=32)
+        ix.build_vamana(L_build=50, alpha=1.2, passes=2, seed=19 + s, pad_with_zero=False)
+        if cb is None:
+            cb = ix.pq_train(16, n_sample=4000, iters=4)
+        ix.pq_encode(cb)
+        shards.append(ix); bases.append(sl.start)
+    nopq = HipIndex.create_empty(x[:4000], R=32)
+    nopq.build_vamana(L_build=50, alpha=1.2, passes=2, seed=3, pad_with_zero=False)
+    comm = _ffi.Comm(_ffi.Comm.unique_id(), 1, 0, 0)
+    kw = dict(L=60, beam_width=8, mode=_ffi.MODE_PQ)
+
+    def same(got, want):
+        return (np.array_equal(got[0], want[0]) and np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32)) and np.array_equal(got[2], want[2]))
+    try:
+        batches = [np.ascontiguousarray(q[a:b]) for a, b in ((0, 120), (0, 7), (7, 60), (60, 61), (30, 120))]
+        for c in (comm, None):
+            want = [_ffi.sharded_search(shards, bases, b, k, comm=c, **kw) for b in batches]
+            want40 = _ffi.sharded_search(shards, bases, batches[2], k, L=40, beam_width=8, mode=_ffi.MODE_PQ, comm=c)
+            _ffi.sharded_set_group(shards[0], 3)
+            # a blocking call under a group size of 3: its wait launches the exchange it rides in alone
+            assert same(_ffi.sharded_search(shards, bases, batches[0], k, comm=c, **kw), want[0])
+            # five submits: three fill the first exchange, the wait for the fifth launches the second (two submits)
+            jobs = [_ffi.sharded_submit(shards, bases, b, k, comm=c, **kw) for b in batches]
+            got = {}
+            for i in (4, 0, 3, 2, 1):
+                got[i] = jobs[i].wait()
+                assert same(got[i], want[i]), i
+            assert np.array_equal(got[0][3], got[1][3]) and np.array_equal(got[0][3], got[2][3])        # one exchange: the same three phase times
+            assert np.array_equal(got[3][3], got[4][3]) and not np.array_equal(got[0][3], got[3][3])
+            # other parameters close the collecting exchange; a flush launches what is held
+            ja = _ffi.sharded_submit(shards, bases, batches[2], k, comm=c, **kw)
+            jb = _ffi.sharded_submit(shards, bases, batches[2], k, L=40, beam_width=8, mode=_ffi.MODE_PQ, comm=c)
+            _ffi.sharded_flush(shards[0])
+            assert same(jb.wait(), want40) and same(ja.wait(), want[2])
+            # more submits than exchanges in flight (4 x 3 tickets): the oldest are finished by the library, every wait still answers
+            many = [_ffi.sharded_submit(shards, bases, batches[i % 5], k, comm=c, **kw) for i in range(17)]
+            for i in reversed(range(17)):
+                assert same(many[i].wait(), want[i % 5]), i
+            # a local phase that fails (a shard without PQ data): every ticket of THAT exchange answers the error, the next exchange is fine
+            bad = [shards[0], nopq, shards[2]]
+            j0 = _ffi.sharded_submit(bad, [0, 4000, 8000], batches[1], k, comm=c, **kw)
+            j1 = _ffi.sharded_submit(bad, [0, 4000, 8000], batches[3], k, comm=c, **kw)
+            j2 = _ffi.sharded_submit(shards, bases, batches[4], k, comm=c, **kw)        # (other shards: closes the failing exchange, opens its own)
+            assert same(j2.wait(), want[4])
+            for j in (j1, j0):
+                with pytest.raises(_ffi.DiskragHipError) as ei:
+                    j.wait()
+                assert ei.value.code == _ffi.E_NOPQ
+            _ffi.sharded_set_group(shards[0], 1)
+            assert same(_ffi.sharded_submit(shards, bases, batches[0], k, comm=c, **kw).wait(), want[0])
+        with pytest.raises(_ffi.DiskragHipError):
+            _ffi.sharded_set_group(shards[0], 17)
+    finally:
+        comm.close()
+        nopq.close()
+        for ix in shards:
+            ix.close()
