@@ -127,6 +127,37 @@ def run_stream(tag, depth=14, n_sub=48, **kw):
     print(tag, out["runs"][tag], flush=True)
 
 
+def run_exchange(tag, group=3, n_sub=48, **kw):
+    """the same operating point through the graph-sharded path (dr_sharded_submit / dr_sharded_wait, one-rank RCCL communicator): `group`
+    consecutive submits per exchange (dr_sharded_set_group: one launch per shard, one all-gather), 3 exchanges' worth of submits in flight"""
+    comm = _ffi.Comm(_ffi.Comm.unique_id(), 1, 0, 0)
+    try:
+        src = _ffi.pinned_empty(q.shape, np.float32); src[:] = q
+        _ffi.sharded_set_group(sh, group)
+        depth = 2 if group == 1 else 3 * group
+
+        def go(n):
+            jobs, last = [], None
+            t1 = time.perf_counter()
+            for i in range(n):
+                jobs.append(_ffi.sharded_submit([sh], [0], src, 10, comm=comm, **kw))
+                if len(jobs) >= depth:
+                    last = jobs.pop(0).wait()
+            for j in jobs:
+                last = j.wait()
+            return time.perf_counter() - t1, last
+        go(2 * depth)
+        dt, last = go(n_sub)
+        _ffi.sharded_set_group(sh, 1)
+        out["runs"][tag] = {"path": "dr_sharded_submit / dr_sharded_wait, one-rank RCCL exchange, %d submits per exchange, %d in flight" % (group, depth),
+                            "qps": nq * n_sub / dt, "recall_at_10_vs_bruteforce_adc": recall_at_k(last[0][:NGT], gt_adc, 10), "status_max": int(last[2].max()),
+                            "ms_of_the_last_exchange": {"search": float(last[3][0]), "all_gather": float(last[3][1]), "merge": float(last[3][2])}}
+        save()
+        print(tag, out["runs"][tag], flush=True)
+    finally:
+        comm.close()
+
+
 # ground truth in the shard's own metric: brute-force ADC top-10 (flat scan of all code words, top-k kept on the device)
 t0 = time.perf_counter()
 gt_adc, gt_adc_sq, scan_ms = sh.pq_scan_topk(q[:max(NGT, 1)], 10)
@@ -166,6 +197,10 @@ for gi, (R, LB) in enumerate(CFG):
             else: os.environ.pop("DR_PQ_ROW_PREFETCH", None)
             run(f"{G}/PQ_L{L}_bw{bw or 'None'}" + ("_no_visited_set" if nv else "") + ("_next_row_prefetch" if pre else ""), L=L, beam_width=bw,
                 mode=_ffi.MODE_PQ, flags=_ffi.F_NO_VISITED_SET if nv else 0)
+            if parts[-1] == "xch":                            # "...:xch": the same point through the graph-sharded path, 1 and 3 submits per exchange
+                for grp in (1, 3):
+                    run_exchange(f"{G}/PQ_L{L}_bw{bw or 'None'}" + ("_no_visited_set" if nv else "") + "_sharded_path_%d_per_exchange" % grp, group=grp, L=L,
+                                 beam_width=bw, mode=_ffi.MODE_PQ, flags=_ffi.F_NO_VISITED_SET if nv else 0)
             if parts[-1] == "stream":                         # "...:stream": the same point again as a host -> host stream with shared launches
                 run_stream(f"{G}/PQ_L{L}_bw{bw or 'None'}" + ("_no_visited_set" if nv else "") + "_stream_shared_launches", L=L, beam_width=bw,
                            mode=_ffi.MODE_PQ, flags=_ffi.F_NO_VISITED_SET if nv else 0)
