@@ -495,6 +495,10 @@ class HipIndex:
 
     def batch_download(self):
         nq, k = self._nq, self._k
+        if nq is None:
+            # (a sharded search uses the selected resident batch as scratch -- include/diskrag_hip.h: the library would write ITS query
+            # count of rows into arrays sized for the batch this handle uploaded)
+            raise RuntimeError("the resident batch was overwritten by a sharded search: batch_upload it again before batch_run / batch_download")
         ids = np.empty((nq, k), dtype=np.uint32)
         dist = np.empty((nq, k), dtype=np.float32)
         cnt = np.empty(nq, dtype=np.uint32)
@@ -701,6 +705,8 @@ def sharded_search(shards, id_bases, queries, k, L=100, beam_width=8, mode=MODE_
     dist = np.empty((nq, k), dtype=np.float32)
     status = np.empty(nq, dtype=np.uint32)
     ms = np.zeros(3, dtype=np.float32)
+    for s in shards:
+        s._nq = None            # (every shard's selected resident batch becomes the exchange's scratch)
     _check(load_library().dr_sharded_search(hs, _p(bases, C.c_uint32), n, comm._h if comm is not None else None,
                                             _p(q, C.c_float), nq, int(k), int(L), int(beam_width or 0), int(mode),
                                             int(band_policy), int(flags), _p(ids, C.c_uint32), _p(dist, C.c_float),
@@ -738,6 +744,8 @@ def sharded_submit(shards, id_bases, queries, k, L=100, beam_width=8, mode=MODE_
     bases = np.ascontiguousarray(id_bases, dtype=np.uint32)
     job = PendingSharded(shards[0], q, nq, int(k))
     t = C.c_uint64(0)
+    for s in shards:
+        s._nq = None            # (every shard's selected resident batch becomes the exchange's scratch)
     _check(load_library().dr_sharded_submit(hs, _p(bases, C.c_uint32), n, comm._h if comm is not None else None,
                                             _p(q, C.c_float), nq, int(k), int(L), int(beam_width or 0), int(mode),
                                             int(band_policy), int(flags), _p(job.ids, C.c_uint32), _p(job.dist, C.c_float),

@@ -163,6 +163,7 @@ struct ShardWork {
     DevBuf<u64> send_keys, all_keys, words;     // my list + status word; every rank's; the ranks' status words
     hipEvent_t e[5] = {};                       // start, local lists ready, exchange done, final merge done, download done
     hipEvent_t up = nullptr;                    // batch on the device
+    hipEvent_t zeroed = nullptr; bool zeroed_valid = false;     // the status words were cleared again behind the last exchange of this work area
     void *pin = nullptr; size_t pin_bytes = 0;
     int state = 0;                              // 0 free, 1 collecting submits, 2 launched (its tickets only have to be collected)
     std::vector<ShardPart> parts;
@@ -175,6 +176,7 @@ struct ShardWork {
     {
         for (auto &x : e) if (x) (void)hipEventDestroy(x);
         if (up) (void)hipEventDestroy(up);
+        if (zeroed) (void)hipEventDestroy(zeroed);
         if (pin) (void)hipHostFree(pin);
     }
 };
@@ -187,6 +189,9 @@ struct ShardScratch {
     std::map<uint64_t, std::pair<int, std::string>> failed;   // tickets finished by a later submit with an error
     std::vector<hipEvent_t> shard_done;   // one per local shard
     hipStream_t xs = nullptr;             // merge / exchange / download stream (without a communicator)
+    hipStream_t us = nullptr;             // the submits' batches go to the device on the first shard's upload stream (not owned): the exchange
+                                          // stream is blocked behind the running searches (it waits for their lists), and the next exchange's
+                                          // upload must not wait with it
     ~ShardScratch()
     {
         for (auto &x : shard_done) if (x) (void)hipEventDestroy(x);

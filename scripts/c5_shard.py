@@ -76,6 +76,7 @@ save()
 print("encoded", out, flush=True)
 
 def run(tag, **kw):
+    sh.batch_upload(q)          # (the sharded path uses the selected resident batch as scratch: put the bench batch back)
     sh.batch_run(10, **kw); sh.batch_sync()
     t1 = time.perf_counter()
     for _ in range(2):
@@ -130,8 +131,11 @@ def run_stream(tag, depth=14, n_sub=48, **kw):
 def run_exchange(tag, group=3, n_sub=48, **kw):
     """the same operating point through the graph-sharded path (dr_sharded_submit / dr_sharded_wait, one-rank RCCL communicator): `group`
     consecutive submits per exchange (dr_sharded_set_group: one launch per shard, one all-gather), 3 exchanges' worth of submits in flight"""
-    comm = _ffi.Comm(_ffi.Comm.unique_id(), 1, 0, 0)
-    try:
+    global _xch_comm
+    if _xch_comm is None:       # (one communicator for the whole run)
+        _xch_comm = _ffi.Comm(_ffi.Comm.unique_id(), 1, 0, 0)
+    comm = _xch_comm
+    if True:
         src = _ffi.pinned_empty(q.shape, np.float32); src[:] = q
         _ffi.sharded_set_group(sh, group)
         depth = 2 if group == 1 else 3 * group
@@ -154,8 +158,9 @@ def run_exchange(tag, group=3, n_sub=48, **kw):
                             "ms_of_the_last_exchange": {"search": float(last[3][0]), "all_gather": float(last[3][1]), "merge": float(last[3][2])}}
         save()
         print(tag, out["runs"][tag], flush=True)
-    finally:
-        comm.close()
+
+
+_xch_comm = None
 
 
 # ground truth in the shard's own metric: brute-force ADC top-10 (flat scan of all code words, top-k kept on the device)
@@ -213,5 +218,7 @@ for gi, (R, LB) in enumerate(CFG):
     sh.debug_force_kind(-1)
     run(f"{G}/M3_PQ_k10_bw8_reference_faithful", L=10, beam_width=8, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
     run(f"{G}/M3_PQ_k10_bw64_reference_faithful", L=10, beam_width=64, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)
+if _xch_comm is not None:
+    _xch_comm.close()
 sh.close()
 print(json.dumps(out))
