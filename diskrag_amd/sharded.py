@@ -8,7 +8,8 @@ device kernel, lists of different processes (one per GPU) travel in ONE RCCL all
 device again: no host staging, no PyTorch. `comm` is an `_ffi.Comm` (RCCL communicator; None for a single process).
 1 process x 8 shards and 8 processes x 1 shard give the same answer. A rank whose shards fail still joins the exchange
 and the call then fails on every rank (DR_E_REMOTE / ShardExchangeError) instead of hanging the others.
-`search_submit` is the pipelined form (two batches in flight: batch i+1 searches while batch i is exchanged).
+`search_submit` is the pipelined form (four exchanges in flight: batch i+1 searches while batch i is exchanged; `set_group(n)`:
+n consecutive submits share one exchange).
 
 A host-logic twin (per-shard `search_batch` calls merged with numpy, optionally exchanged through a torch.distributed
 group that the caller passes in) is kept for objects that are not device indexes: it is what the 2-rank gloo test on
