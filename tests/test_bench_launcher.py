@@ -103,3 +103,11 @@ def test_a_failing_rank_ends_the_job_at_once():
                        env=_env(DR_BENCH_STUB_FAIL_RANK="1"), capture_output=True, text=True, timeout=120)
     assert p.returncode != 0
     assert time.time() - t0 < 60          # not the 1800 s barrier timeout
+
+
+def test_bench_flags_of_round_4_parse():
+    """--headline-only (the rocprofv3 run of scripts/profile_run.sh) and --c5-group (submits per exchange of the sharded path) exist"""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    for flag in ("--headline-only", "--c5-group", "--scaling", "--config"):
+        assert flag in r.stdout, flag
