@@ -16,7 +16,13 @@ MODE_M1, MODE_M2, MODE_M3, MODE_M4 = 1, 2, 3, 4
 PIPE_DEPTH = 4          # DR_PIPE_DEPTH (csrc/engine.hip): LAUNCHES of the pipelined path in flight per handle
 MAX_TICKETS = 128        # DR_MAX_TICKETS (include/diskrag_hip.h): dr_search_submit tickets in flight (small submits share launches)
 MODE_PQ = 5      # engine mode without a reference counterpart: M1's loop on squared ADC distances only (diskrag_hip.h)
+MODE_PQB = 6     # the engine's PQ-only traversal as a batch per step on a total (distance, id) order (diskrag_hip.h DR_MODE_PQB; round 5)
 F_USE_PQ, F_SQDIST, F_RERANK, F_COSINE, F_NO_VISITED_SET = 1, 2, 4, 8, 16
+
+
+def F_POPS(n):
+    """DR_MODE_PQB: frontier entries expanded per step (DR_F_POPS)."""
+    return (int(n) & 15) << 8
 TIER_HBM, TIER_HOST = 0, 1       # where the full-precision rows live (dr_index_*_tiered)
 MAX_RESIDENT = 16
 COMM_ID_BYTES = 128

@@ -37,6 +37,7 @@
 #include "build_kernels.hpp"
 #include "build_pq_kernels.hpp"
 #include "variants.hpp"
+#include "pqb_host.hpp"
 
 static thread_local std::string g_err;
 
@@ -830,10 +831,13 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (ov) ix->cs->nq = ov->nq;
     if (ix->cs->nq == 0) return fail(DR_E_ARG, "no queries uploaded");
     if (ix->cs->nq > 65536 && !ov) return fail(DR_E_UNSUPPORTED, "resident batches are limited to 65536 queries (dr_search_batch chunks larger ones)");
-    if (mode < DR_MODE_M1 || mode > DR_MODE_PQ) return fail(DR_E_ARG, "unknown mode %u", mode);
+    if (mode < DR_MODE_M1 || mode > DR_MODE_PQB) return fail(DR_E_ARG, "unknown mode %u", mode);
+    const bool pqb = (mode == DR_MODE_PQB);      // the batch-per-step PQ-only beam search (pqb_kernel.hpp)
+    if ((flags & DR_F_POPS_MASK) && !pqb) return fail(DR_E_ARG, "DR_F_POPS goes with DR_MODE_PQB");
+    if (pqb && ov) return fail(DR_E_ARG, "DR_MODE_PQB does not serve the builder");
     if (k == 0) return fail(DR_E_ARG, "k must be positive");
-    const bool pq_only = (mode == DR_MODE_M3 && (flags & DR_F_USE_PQ)) || mode == DR_MODE_PQ || (ov && ov->sdc);   // ADC-only traversals
-    const bool rerank = (mode == DR_MODE_PQ) && (flags & DR_F_RERANK);
+    const bool pq_only = (mode == DR_MODE_M3 && (flags & DR_F_USE_PQ)) || mode == DR_MODE_PQ || pqb || (ov && ov->sdc);   // ADC-only traversals
+    const bool rerank = (mode == DR_MODE_PQ || pqb) && (flags & DR_F_RERANK);
     const bool use_pq = (mode == DR_MODE_M1) || pq_only;
     if (use_pq && ix->m == 0) return fail(DR_E_NOPQ, "mode %u needs PQ data (dr_index_set_pq)", mode);
     if (!pq_only || rerank) { const int rcv = need_vectors(ix, rerank ? "DR_F_RERANK" : "this search mode"); if (rcv) return rcv; }
@@ -900,15 +904,32 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // the shared codebook at eight, profiles/r04/ab/ab_c4_long_lists_table_vs_codebook.jsonl; it used to need eight to be preferred)
     if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 5 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
     int kind = -1;
-    for (int i = 0; i < npref && kind < 0; i++) if (usable(pref[i])) kind = pref[i];
+    for (int i = 0; i < npref && kind < 0 && !pqb; i++) if (usable(pref[i])) kind = pref[i];
     {
         static bool env_read = false;
         if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e && !g_force_kind_set) g_force_kind = atoi(e); env_read = true; }
         const int g = g_force_kind;
-        if (g >= 0 && g <= DR_MAX_KIND_ID && usable(g) && !(ov && ov->sdc)) {
+        if (g >= 0 && g <= DR_MAX_KIND_ID && !pqb && usable(g) && !(ov && ov->sdc)) {
             const bool g_m1 = (g == 0 || g == 3 || g == 9 || g == 11 || g == 13 || g == 16 || g == 17), g_adc = (g == 2 || g == 5 || g == 15), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
             if ((g_m1 && k_m1) || (g_adc && k_adc) || (g_ex && !k_m1 && !k_adc)) kind = g;
         }
+    }
+    // DR_MODE_PQB: its own kernel family (pqb_kernel.hpp), independent of D: list chunks x passes per step x (m / 16, table rows in registers)
+    PqbChoice pqc = {};
+    uint32_t pqb_pops = 1, pqb_shift = 0;
+    if (pqb) {
+        pqb_pops = (flags & DR_F_POPS_MASK) >> DR_F_POPS_SHIFT;
+        if (pqb_pops == 0) pqb_pops = 1;
+        if (ix->N >= (1ull << 31)) return fail(DR_E_UNSUPPORTED, "DR_MODE_PQB: N must be below 2^31");
+        while ((1u << pqb_shift) < ix->R) pqb_shift++;
+        const uint64_t passes = ((uint64_t)pqb_pops << pqb_shift) <= 64 ? 1 : (((uint64_t)pqb_pops << pqb_shift) + 63) / 64;
+        if (passes > 4) return fail(DR_E_UNSUPPORTED, "DR_MODE_PQB: pops x next_pow2(R) = %u x %u exceeds 256 neighbour slots per step", pqb_pops, 1u << pqb_shift);
+        const int nc = passes <= 1 ? 1 : passes <= 2 ? 2 : 4;
+        int treg_pref = -1;
+        if (const char *e = getenv("DR_PQB_TREG")) treg_pref = atoi(e);       // A/B: table rows held in registers
+        pqc = dr_pqb_choose(sc, nc, ix->m, treg_pref);
+        if (!pqc.fn) return fail(DR_E_UNSUPPORTED, "DR_MODE_PQB: no kernel for m=%u, capacity %u", ix->m, cap);
+        kind = 20;
     }
     if (kind < 0) return fail(DR_E_UNSUPPORTED, "no kernel variant fits in LDS (D=%u, m=%u, capacity %u)", ix->D, ix->m, cap);
     // A batch smaller than the chip's wavefront slots in 16-wavefront workgroups would fill ceil(nq / 16) CUs and leave the
@@ -916,12 +937,13 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     {
         static const bool no_small = getenv("DR_NO_SMALL_WG") != nullptr;        // A/B
         const int tw = dr_small_twin(kind);
-        if (!no_small && !ov && tw >= 0 && kind != g_force_kind && usable(tw) && (uint64_t)ix->cs->nq < (uint64_t)ix->num_cu * 16) kind = tw;
+        if (!no_small && !ov && !pqb && tw >= 0 && kind != g_force_kind && usable(tw) && (uint64_t)ix->cs->nq < (uint64_t)ix->num_cu * 16) kind = tw;
     }
-    const KindDesc &kd_desc = DR_KINDS[dr_kind_pos(kind)];
-    const void *kfn = ix->kern->search[dr_kind_pos(kind)][sc];
+    static const KindDesc PQB_DESC = { 20, 1, false, 0, true, true, false, false, 0 };
+    const KindDesc &kd_desc = pqb ? PQB_DESC : DR_KINDS[dr_kind_pos(kind)];
+    const void *kfn = pqb ? pqc.fn : ix->kern->search[dr_kind_pos(kind)][sc];
     const int NW = kd_desc.nw;
-    const size_t lds = lds_of(kind);
+    const size_t lds = pqb ? (size_t)(ix->m - (uint32_t)pqc.treg) * 1024 + (size_t)NCHR_OF_SC[sc] * 512 : lds_of(kind);
     if (lds > 160 * 1024) return fail(DR_E_UNSUPPORTED, "LDS footprint %zu B exceeds 160 KiB", lds);
     // (kernel attribute + occupancy are asked once per (variant, LDS size): a single-query call is all overhead)
     int occ = 0;
@@ -940,7 +962,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     const uint32_t slots = grid * NW;
 
     // M1 is capped at min(10L, N) expansions (search_engine.py:429); the other variants are bounded by N.
-    const bool capped = (mode == DR_MODE_M1 || mode == DR_MODE_PQ);
+    const bool capped = (mode == DR_MODE_M1 || mode == DR_MODE_PQ || pqb);
     uint64_t max_steps = capped ? std::min<uint64_t>((uint64_t)L * 10, ix->N) : 0xFFFFFFFFull;
     // visited set: per wavefront slot one word per 24 bit positions (+ an 8-bit query stamp: nothing is cleared
     // between queries, search_kernel.hpp) and the slot's stamp counter
@@ -953,7 +975,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // there the visited words are tens of GB of random-access footprint. DR_BUILD_PQ_NO_VISITED_SET=0 / 1 overrides the size rule.
     bool build_novis = ix->N >= (1ull << 25);
     { const char *e = getenv("DR_BUILD_PQ_NO_VISITED_SET"); if (e) build_novis = e[0] == '1'; }
-    const bool novis = (!ov && mode == DR_MODE_PQ && (flags & DR_F_NO_VISITED_SET) != 0) || (ov && ov->sdc && build_novis);
+    const bool novis = (!ov && mode == DR_MODE_PQ && (flags & DR_F_NO_VISITED_SET) != 0) || pqb || (ov && ov->sdc && build_novis);
     if (!novis && ((size_t)slots * vis_words > vis.n || slots > vis_epoch.n)) {
         // (re)allocation: fresh words and stamps -- queued launches still use the old buffers
         if (vis.p) HIPCHK(hipStreamSynchronize(st));
@@ -962,7 +984,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         HIPCHK(hipMemsetAsync(vis_epoch.p, 0, vis_epoch.n * 4, st));
     }
     // accepted-insert log per query (tie replay): 4096 entries cover L <= 256 with room to spare, deeper lists get more
-    const uint32_t logcap = std::max<uint32_t>(4096, 16 * cap);
+    const uint32_t logcap = pqb ? 0u : std::max<uint32_t>(4096, 16 * cap);      // (DR_MODE_PQB returns a total order: no tie-order pass, no log)
     const int set = ov ? 0 : ix->parity;
     dr_index::BatchSet &bs = ix->sets[set];
     if (bs.owner_group >= 0) { const int rcj = finish_group_locked(ix, bs.owner_group); if (rcj) return rcj; }
@@ -1060,7 +1082,16 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         { const int rcl = launch_lut_build(ix, ix->cs->q.p, nq, ix->lut.p, st); if (rcl) return rcl; }
         p.lut_g = ix->lut.p;
     }
-    void *args[] = { &p };
+    PqbParams pp;
+    if (pqb) {
+        memset(&pp, 0, sizeof pp);
+        pp.adj = ix->adj.p; pp.first = ix->first.p; pp.codes = ix->codes.p; pp.nbcodes = p.nbcodes; pp.lut_g = p.lut_g;
+        pp.N = ix->N; pp.R = ix->R; pp.m = ix->m; pp.medoid = ix->medoid; pp.nq = nq; pp.k = k; pp.cap = cap; pp.bw = bw;
+        pp.pops = pqb_pops; pp.max_steps = p.max_steps; pp.rs_shift = pqb_shift;
+        pp.counter = p.counter; pp.ticket_base = p.ticket_base;
+        pp.res_keys = p.res_keys; pp.res_n = p.res_n; pp.stats = p.stats; pp.out_ids = p.out_ids; pp.out_dist = p.out_dist; pp.out_count = p.out_count;
+    }
+    void *args[] = { pqb ? (void *)&pp : (void *)&p };
     if (!ov) { ix->kev_lut[ix->kev_pending] = want_lut; HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][0], st)); }
     {
         const hipError_t le = hipLaunchKernel(kfn, dim3(grid), dim3(64 * NW), args, lds, st);
@@ -1093,7 +1124,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     f.ntie_stat = ix->fin_stat.p;
     HIPCHK(hipEventRecord(bs.fin_start, ix->fstream));
     static const bool skip_fin = getenv("DR_SKIP_FINALIZE") != nullptr;   // timing experiment only: tie order is then wrong
-    if (!skip_fin && !rerank)      // (the rerank pass has already written a total (distance, id) order)
+    if (!skip_fin && !rerank && !pqb)      // (the rerank pass / DR_MODE_PQB have already written a total (distance, id) order)
     {
         // One wavefront per tied query, 4 per workgroup, spread over the chip (packing 16 per CU slowed each replay by a
         // third). Few queries tie (29 of 10 000 on the bench data), so the grid is sized for twice the largest tie list

@@ -1,0 +1,33 @@
+// pqb_host.hpp -- the kernel table of DR_MODE_PQB (pqb_kernel.hpp). One translation unit per (m / 16, table rows in registers)
+// pair (pqb_m<M16>_t<TREG>.hip, built in parallel by the Makefile), each instantiating list capacities 64 ... 1024 x 1 / 2 / 4
+// passes per step.
+#pragma once
+#include "pqb_kernel.hpp"
+
+struct PqbChoice { const void *fn; int m16, treg; };
+// fn[sizeclass][passes class: 1, 2, 4]
+struct PqbTable { int m16, treg; const void *fn[5][3]; };
+const PqbTable *dr_pqb_table_m0_t0();
+const PqbTable *dr_pqb_table_m1_t0();
+const PqbTable *dr_pqb_table_m2_t0();
+const PqbTable *dr_pqb_table_m2_t16();
+const PqbTable *dr_pqb_table_m2_t24();
+const PqbTable *dr_pqb_table_m3_t16();
+const PqbTable *dr_pqb_table_m4_t16();
+const PqbTable *dr_pqb_table_m4_t32();
+
+// sc: size class of the list (0..4); nc: passes per step (1, 2, 4); m: sub-quantisers; treg_pref: -1 = the engine's choice
+static inline PqbChoice dr_pqb_choose(int sc, int nc, uint32_t m, int treg_pref)
+{
+    const PqbTable *t = nullptr;
+    if (m == 16) t = dr_pqb_table_m1_t0();
+    else if (m == 32) t = treg_pref == 0 ? dr_pqb_table_m2_t0() : treg_pref == 24 ? dr_pqb_table_m2_t24() : dr_pqb_table_m2_t16();
+    else if (m == 48) t = dr_pqb_table_m3_t16();
+    else if (m == 64) t = treg_pref == 16 ? dr_pqb_table_m4_t16() : dr_pqb_table_m4_t32();
+    else if (m <= 128) t = dr_pqb_table_m0_t0();
+    PqbChoice c = { nullptr, 0, 0 };
+    if (!t) return c;
+    const int ci = nc <= 1 ? 0 : nc <= 2 ? 1 : 2;
+    c.fn = t->fn[sc][ci]; c.m16 = t->m16; c.treg = t->treg;
+    return c;
+}

@@ -34,6 +34,18 @@ extern "C" {
  * with DR_F_RERANK, config c3's "PQ traversal + full-precision rerank of the L list" (SURVEY.md 8d). Restated in
  * oracle/ as mode 5; the reference-faithful M3 stays as it is. */
 #define DR_MODE_PQ 5u
+/* The engine's PQ-only traversal restated as a BATCH per step (round 5; no reference counterpart either):
+ * the same pieces -- the table of compute_distance_table (fast_pq.py:294-318), the squared ADC summed in strict sub-quantiser
+ * order (:320-328), an L-sized list, the step cap min(10 L, N) (search_engine.py:429), heapq.nsmallest(beam_width) on the
+ * frontier (:477-479) -- on a TOTAL order key = (distance bits, id): a step expands the `pops` smallest live list entries
+ * (DR_F_POPS, default 1), scores every first-occurrence neighbour of their rows, and merges those whose key is below the
+ * list's largest key (or any, while the list fills) and is not in the list already into the L smallest; newcomers are live;
+ * the search stops when no live entry is left. No visited set (membership in the list decides, as with DR_F_NO_VISITED_SET),
+ * no neighbour-by-neighbour walk to emulate: one third of DR_MODE_PQ's instruction stream. Results come back in
+ * (distance, id) order (squared ADC); with DR_F_RERANK as DR_MODE_PQ's. stats.visited = stats.pq = code words scored,
+ * stats.steps = nodes expanded. N < 2^31; pops * next_pow2(R) <= 256. Restated in oracle/diskrag_oracle.c (pqb_search_one) and
+ * held to it bit for bit (tests/test_gpu_pqb.py). */
+#define DR_MODE_PQB 6u
 
 /* flags */
 #define DR_F_USE_PQ 1u /* M3: use_pq=True (ADC-only traversal, vamana_graph.py:318-320) */
@@ -47,6 +59,10 @@ extern "C" {
                                  * no visited words (N/6 bytes per wavefront slot: 42 GB on a 1.25e8-point shard) and a third of the HBM
                                  * traffic, but nodes that left the list are scored again: stats.visited / stats.pq count EVALUATIONS
                                  * (1.7x with beam_width 8, 3x without trim -- measured slower there, profiles/r04/ab/). Off by default. */
+#define DR_F_POPS_SHIFT 8u
+#define DR_F_POPS_MASK 0xF00u
+#define DR_F_POPS(n) (((uint32_t)(n) & 15u) << DR_F_POPS_SHIFT) /* DR_MODE_PQB: frontier entries expanded per step (DiskANN's beam): narrow rows
+                          (R = 32) fill the 64 lanes two at a time, and a query needs half as many DEPENDENT steps; 0 = 1 */
 #define DR_F_COSINE 8u /* M3 without DR_F_USE_PQ: the in-memory graph's distance_metric='cosine' -- compute_query_distance ->
                           cosine_similarity_cython (vamana_graph.py:324-329, cython_utils.pyx:53-70): 1 - cos, 0 when a norm is
                           0; out_dist = sqrt of it (vamana_graph.py:598). The reference sums in float32 under -ffast-math

@@ -19,6 +19,10 @@
  *                                  the checker for DR_MODE_PQ and is pinned only through the pieces it shares with
  *                                  M1 (loop, heaps) and M3-with-PQ (ADC distance), both golden-pinned
  *
+ *   mode 6 (ORC_PQB)               NOT in the reference either: the batch-per-step statement of the PQ-only traversal
+ *                                   -- pqb_search_one below; built from the golden-pinned A2 table and
+ *                                  A3 sum; the checker for DR_MODE_PQB
+ *
  * Parity pinning: every function here is checked in tests/test_oracle_golden.py against golden vectors that
  * tests/golden/gen_golden.py produced by running the reference itself (imported from /root/reference in the
  * dev container). M1 and M3-with-PQ are pinned bit-exactly (ids, float bits, counters). M2/M4 use
@@ -39,12 +43,14 @@
 #define ORC_M3 3u
 #define ORC_M4 4u
 #define ORC_PQ 5u         /* engine mode DR_MODE_PQ (no reference counterpart): M1's loop on squared ADC distances only */
+#define ORC_PQB 6u        /* engine mode DR_MODE_PQB (no reference counterpart): batch-per-step ADC beam search, pqb_search_one below */
 #define ORC_F_USE_PQ 1u   /* M3: use_pq=True */
 #define ORC_F_CYTHON 2u   /* M4: greedy_search_cython twin (squared L2 via l2_distance_fast_cython) */
 #define ORC_F_QUERY_F64 4u
 #define ORC_F_RERANK 16u  /* ORC_PQ: exact squared L2 (A1) of the final list, (distance, id) order */
 #define ORC_F_NO_VISITED_SET 64u /* ORC_PQ: the statement without a visited set (engine flag DR_F_NO_VISITED_SET): same ids and distances; the counters count evaluations */
 #define ORC_F_COSINE 32u  /* M3 without PQ: distance_metric='cosine' (cosine_similarity_cython, cython_utils.pyx:53-70) */
+#define ORC_F_POPS_SHIFT 8u /* ORC_PQB: bits 8..11 = frontier entries expanded per step (0 = 1), engine flag DR_F_POPS(n) */
 #define ORC_F_PAIRWISE 8u  /* squared-L2 modes: use the numpy pairwise order (what the device computes) instead of the
                              sequential Cython loop, whose -ffast-math order is unpinned anyway */
 
@@ -71,6 +77,114 @@ static inline double sqrt_real_f64(double x) { return sqrt(x); }
 #include "oracle_core.inc"
 #undef REAL
 #undef SFX
+
+/* ---- mode 6 (ORC_PQB): the engine's batch-per-step PQ-only beam search ------------------------------------------
+ * NOT in the reference (its only PQ-only traversal, beam_search_with_pq, vamana_graph.py:535-605, keeps a k-sized heap and
+ * trims its frontier from the wrong end, quirk Q9). This is SURVEY.md 8a row E's batch-per-expansion form, stated on a
+ * TOTAL order so that nothing depends on evaluation order:
+ *   distance      d(i) = squared ADC of node i: T = compute_distance_table(q) (fast_pq.py:294-318), s = 0f; s += T[j][code_j]
+ *                 in strict order of j (fast_pq.py:320-328) -- the golden-pinned A2 / A3
+ *   key(i)        (bits of d(i), i): distances are sums of squares (>= +0), so float order = bit order; ids break ties
+ *   list          at most L entries in ascending key order, each live / not live (expanded or trimmed)
+ *   step          take the p = min(pops, #live, max_steps - steps) smallest live entries, mark them expanded;
+ *                 score every neighbour slot of their rows that is the first occurrence of its id in ITS row (ORC_PAD
+ *                 skipped; the 0-pads of a disk row are neighbour 0 once, quirk Q3); a scored key enters the candidate SET
+ *                 iff (list not full or key < the list's largest key) and it is neither in the list nor in the set --
+ *                 all tests against the list as it was when the step began; list = the L smallest of list + set, new
+ *                 entries live; then, with beam_width > 0, only the beam_width smallest live entries stay live
+ *                 (heapq.nsmallest on the frontier, search_engine.py:477-479)
+ *   stop          no live entry, or max_steps = min(10 L, N) expanded nodes (search_engine.py:429)
+ * There is no visited set: a node that was scored and is not in the list now was rejected or evicted at a largest key >=
+ * today's and can never enter again, so membership in the list is the whole test (nodes met again are scored again; the
+ * counters count evaluations). Output: the k smallest keys (squared ADC, id); with ORC_F_RERANK the whole list is scored
+ * with the exact squared L2 (A1, search_engine.py:374-379) and the k best in (distance, id) order are returned.
+ * stats = { expanded nodes, evaluations, exact (rerank), evaluations }. */
+typedef struct { uint32_t db, id; int live; } pqb_ent;
+static int pqb_less(uint32_t d1, uint32_t i1, uint32_t d2, uint32_t i2) { return d1 != d2 ? d1 < d2 : i1 < i2; }
+static int pqb_cmp(const void *x, const void *y)
+{
+    const pqb_ent *a = (const pqb_ent *)x, *b = (const pqb_ent *)y;
+    if (pqb_less(a->db, a->id, b->db, b->id)) return -1;
+    if (pqb_less(b->db, b->id, a->db, a->id)) return 1;
+    return 0;
+}
+static int pqb_search_one(const orc_index *ix, const float *q, uint32_t k, uint32_t L, uint32_t bw, uint32_t flags,
+                          uint32_t *out_ids, double *out_dist, uint32_t *out_count, uint32_t *stats)
+{
+    const uint64_t N = ix->N;
+    const uint32_t D = ix->D, R = ix->R, m = ix->m;
+    if (!ix->codes || !ix->codebook || m == 0 || D % m) return -2;
+    if (k == 0 || L == 0 || ix->medoid >= N) return -3;
+    uint32_t pops = (flags >> ORC_F_POPS_SHIFT) & 15u;
+    if (pops == 0) pops = 1;
+    float *lut = (float *)malloc((size_t)m * 256 * sizeof(float));
+    build_lut_f32(ix->codebook, q, m, D / m, lut);
+    pqb_ent *list = (pqb_ent *)malloc(((size_t)L + (size_t)pops * R + 1) * sizeof(pqb_ent));
+    size_t n = 0;
+    uint32_t steps = 0, nevals = 0, nexact = 0;
+    const uint64_t max_steps = (uint64_t)L * 10 < N ? (uint64_t)L * 10 : N;
+#define PQB_ADC(i, out) do { float s_ = 0.0f; const uint8_t *c_ = ix->codes + (size_t)(i) * m;             \
+        for (uint32_t j_ = 0; j_ < m; j_++) s_ += lut[j_ * 256 + c_[j_]];                                  \
+        memcpy(&(out), &s_, 4); nevals++; } while (0)
+    {
+        uint32_t d0;
+        PQB_ADC(ix->medoid, d0);
+        list[0].db = d0; list[0].id = ix->medoid; list[0].live = 1; n = 1;
+    }
+    uint32_t *popped = (uint32_t *)malloc(pops * sizeof(uint32_t));
+    for (;;) {
+        size_t nlive = 0;
+        for (size_t i = 0; i < n; i++) nlive += (size_t)list[i].live;
+        if (nlive == 0 || steps >= max_steps) break;
+        uint32_t p = pops;
+        if (p > nlive) p = (uint32_t)nlive;
+        if ((uint64_t)p > max_steps - steps) p = (uint32_t)(max_steps - steps);
+        for (uint32_t t = 0, i = 0; t < p; i++) if (list[i].live) { list[i].live = 0; popped[t++] = list[i].id; }
+        steps += p;
+        const size_t n_old = n;
+        const int full = (n_old >= L);
+        const pqb_ent worst = list[n_old - 1];
+        size_t nc = 0;                                    /* the candidate set lives behind the list */
+        for (uint32_t t = 0; t < p; t++) {
+            const uint32_t *nbrs = ix->adj + (size_t)popped[t] * R;
+            for (uint32_t s = 0; s < R; s++) {
+                const uint32_t nb = nbrs[s];
+                if (nb == ORC_PAD) continue;
+                if (nb >= N) { free(lut); free(list); free(popped); return -4; }
+                int seen = 0;
+                for (uint32_t u = 0; u < s && !seen; u++) seen = (nbrs[u] == nb);
+                if (seen) continue;
+                uint32_t db;
+                PQB_ADC(nb, db);
+                if (full && !pqb_less(db, nb, worst.db, worst.id)) continue;
+                int dup = 0;
+                for (size_t u = 0; u < n_old + nc && !dup; u++) dup = (list[u].id == nb);
+                if (dup) continue;
+                list[n_old + nc].db = db; list[n_old + nc].id = nb; list[n_old + nc].live = 1; nc++;
+            }
+        }
+        n = n_old + nc;
+        qsort(list, n, sizeof(pqb_ent), pqb_cmp);
+        if (n > L) n = L;
+        if (bw) { size_t kept = 0; for (size_t i = 0; i < n; i++) if (list[i].live) { if (kept >= bw) list[i].live = 0; else kept++; } }
+    }
+#undef PQB_ADC
+    if (flags & ORC_F_RERANK) {
+        if (!ix->vectors) { free(lut); free(list); free(popped); return -2; }
+        for (size_t i = 0; i < n; i++) {
+            const float e = pw_sqdiff_f32(ix->vectors + (size_t)list[i].id * D, q, D);
+            memcpy(&list[i].db, &e, 4); nexact++;
+        }
+        qsort(list, n, sizeof(pqb_ent), pqb_cmp);
+    }
+    const uint32_t cnt = (uint32_t)(n < k ? n : k);
+    for (uint32_t i = 0; i < cnt; i++) { float d; memcpy(&d, &list[i].db, 4); out_ids[i] = list[i].id; out_dist[i] = (double)d; }
+    for (uint32_t i = cnt; i < k; i++) { out_ids[i] = ORC_PAD; out_dist[i] = NAN; }
+    *out_count = cnt;
+    if (stats) { stats[0] = steps; stats[1] = nevals; stats[2] = nexact; stats[3] = nevals; }
+    free(lut); free(list); free(popped);
+    return 0;
+}
 
 /* ------------------------------------------------------------------------------------------------ C API */
 
@@ -107,14 +221,18 @@ int orc_search_batch(const float *vectors, const uint32_t *adj, const uint8_t *c
 {
     orc_index ix = { N, D, R, m, medoid, vectors, adj, codes, codebook };
     int rc_all = 0;
-    if (mode < ORC_M1 || mode > ORC_PQ) return -1;
+    if (mode < ORC_M1 || mode > ORC_PQB) return -1;
+    if (mode == ORC_PQB && (flags & ORC_F_QUERY_F64)) return -1;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
 #endif
     for (int64_t i = 0; i < (int64_t)nq; i++) {
         int rc;
         uint32_t *st = stats ? stats + (size_t)i * 4 : NULL;
-        if (flags & ORC_F_QUERY_F64)
+        if (mode == ORC_PQB)
+            rc = pqb_search_one(&ix, (const float *)queries + (size_t)i * D, k, L, bw, flags,
+                                out_ids + (size_t)i * k, out_dist + (size_t)i * k, out_count + i, st);
+        else if (flags & ORC_F_QUERY_F64)
             rc = search_one_f64(&ix, (const double *)queries + (size_t)i * D, mode, k, L, bw, policy, flags,
                                 out_ids + (size_t)i * k, out_dist + (size_t)i * k, out_count + i, st);
         else

@@ -1,0 +1,113 @@
+"""DR_MODE_PQB (round 5): the engine's batch-per-step PQ-only beam search (csrc/pqb_kernel.hpp) against the oracle's restatement
+of it (oracle/diskrag_oracle.c pqb_search_one) -- ids, distance bits, counts and counters bit for bit -- on full indexes and
+PQ-only shards, every list-size class, one to eight frontier entries per step, rows narrower and wider than a wavefront, inline
+neighbour codes, the exact rerank, every table layout (DR_PQB_TREG), the pipelined path; and against DR_MODE_PQ in recall terms."""
+import numpy as np
+import pytest
+
+from tests.conftest import load_golden
+from tests.test_gpu_parity import bits, get_index
+
+pytestmark = pytest.mark.gpu
+
+
+def _stats4(st):
+    return np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1)
+
+
+def _check(eng, g, k, L, bw, pops, flags=0, tag=None):
+    from diskrag_amd import _ffi
+    from oracle import pyoracle as orc
+    w = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.PQB, k, L=L, bw=bw,
+                         flags=orc.F_POPS(pops) | (orc.F_RERANK if flags & _ffi.F_RERANK else 0), codes=g.codes, codebook=g.codebook)
+    ids, dist, cnt, st = eng.search_batch(g.queries, k, L=L, beam_width=bw, mode=_ffi.MODE_PQB, flags=flags | _ffi.F_POPS(pops))
+    assert int(st["status"].max()) == 0, tag
+    assert np.array_equal(ids, w[0]), tag
+    assert np.array_equal(cnt, w[2]), tag
+    valid = w[0] != 0xFFFFFFFF
+    assert np.array_equal(bits(dist)[valid], bits(w[1].astype(np.float32))[valid]), tag
+    assert np.array_equal(_stats4(st), w[3]), tag
+    return ids
+
+
+SHAPES = ["randn128_R16_m32", "sift128_R64_m32", "sift128_R16_m32", "unit1536_R16_m32", "unit1536_R16_m64", "deep96_R32_m16",
+          "unit768_R16_m96", "unit256_R16_m128", "unit256_R16_m4", "randn128_R64_m16"]
+
+
+@pytest.mark.parametrize("name", SHAPES)
+def test_pqb_matches_its_oracle_restatement(name):
+    from diskrag_amd import HipIndex, _ffi
+    g = load_golden(name)
+    ix = get_index(name)
+    shard = HipIndex.create_codes(g.adj, g.medoid, g.vectors.shape[1], g.codebook, g.codes)
+    try:
+        for (L, bw, k) in ((100, 8, 10), (40, 0, 10), (10, 3, 10), (200, 16, 25), (64, 8, 64), (1, 1, 1), (300, 0, 10), (600, 32, 10), (1024, 0, 10)):
+            for pops in (1, 2, 4):
+                if pops * (1 << int(np.ceil(np.log2(g.R)))) > 256:
+                    continue
+                for eng, inline in ((ix, False), (shard, False), (shard, True)):
+                    if inline and g.m % 4:
+                        continue
+                    eng.inline_codes(inline)
+                    _check(eng, g, k, L, bw, pops, tag=(name, L, bw, k, pops, inline))
+                shard.inline_codes(False)
+            _check(ix, g, k, L, bw, 1, flags=_ffi.F_RERANK, tag=(name, L, bw, k, "rerank"))
+        with pytest.raises(_ffi.DiskragHipError):        # the rerank needs the stored vectors
+            shard.search_batch(g.queries, 10, L=50, beam_width=8, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK)
+        with pytest.raises(_ffi.DiskragHipError):        # pops belong to DR_MODE_PQB
+            ix.search_batch(g.queries, 10, L=50, beam_width=8, mode=_ffi.MODE_PQ, flags=_ffi.F_POPS(2))
+    finally:
+        shard.close()
+
+
+def test_pqb_eight_pops_and_wide_rows():
+    """pops * next_pow2(R) up to 256 slots per step: eight rows of 16 per step, and R = 64 rows four at a time."""
+    g = load_golden("unit1536_R16_m32")
+    ix = get_index("unit1536_R16_m32")
+    for pops in (3, 5, 8):
+        _check(ix, g, 10, 100, 16, pops, tag=("R16", pops))
+    g = load_golden("sift128_R64_m32")
+    ix = get_index("sift128_R64_m32")
+    for pops in (3, 4):
+        _check(ix, g, 10, 100, 8, pops, tag=("R64", pops))
+    from diskrag_amd import _ffi
+    with pytest.raises(_ffi.DiskragHipError):            # 8 x 64 slots per step is more than the kernel family holds
+        ix.search_batch(g.queries, 10, L=50, beam_width=8, mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(8))
+
+
+@pytest.mark.parametrize("treg", ["0", "16", "24"])
+def test_pqb_table_layouts_return_the_same_bits(treg, monkeypatch):
+    """m = 32: the table rows in LDS / the last 16 / the last 24 in registers (ds_bpermute lookups) -- the same sums in the same order."""
+    monkeypatch.setenv("DR_PQB_TREG", treg)
+    for name in ("unit1536_R16_m32", "sift128_R64_m32"):
+        g = load_golden(name)
+        ix = get_index(name)
+        for (L, bw, k, pops) in ((100, 8, 10, 1), (300, 0, 10, 2), (64, 8, 64, 4)):
+            _check(ix, g, k, L, bw, pops, tag=(name, treg, L, bw, pops))
+
+
+def test_pqb_through_the_pipelined_path():
+    """dr_search_submit / dr_search_wait with DR_MODE_PQB: coalesced tickets get the bits of blocking calls."""
+    from diskrag_amd import _ffi
+    g = load_golden("unit1536_R16_m32")
+    ix = get_index("unit1536_R16_m32")
+    kw = dict(L=100, beam_width=8, mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(2))
+    ref = ix.search_batch(g.queries, 10, **kw)
+    jobs = [ix.search_submit(g.queries[i::3], 10, **kw) for i in range(3)]
+    for i, j in enumerate(jobs):
+        ids, dist, cnt, st = j.wait()
+        assert np.array_equal(ids, ref[0][i::3]) and np.array_equal(bits(dist), bits(ref[1][i::3])) and np.array_equal(cnt, ref[2][i::3])
+
+
+def test_pqb_finds_what_the_sequential_traversal_finds():
+    """Same L, same frontier trim: the batch-per-step statement returns (nearly) the list DR_MODE_PQ returns -- recall against the
+    brute-force ADC ranking is what it is held to at scale (scripts/ab_pqb.py); here: overlap of the two top-10 lists."""
+    from diskrag_amd import _ffi
+    for name in ("unit1536_R16_m32", "deep96_R32_m16"):
+        g = load_golden(name)
+        ix = get_index(name)
+        a = ix.search_batch(g.queries, 10, L=100, beam_width=8, mode=_ffi.MODE_PQ)[0]
+        for pops in (1, 2, 4):
+            b = ix.search_batch(g.queries, 10, L=100, beam_width=8, mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(pops))[0]
+            ov = np.mean([len(set(x) & set(y)) / 10 for x, y in zip(a, b)])
+            assert ov >= 0.97, (name, pops, ov)
