@@ -71,6 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--min-recall", type=float, default=0.95, help="the metric's recall bar: the bench fails below it")
     ap.add_argument("--c5-group", type=int, default=3, help="c5: submits per exchange (dr_sharded_set_group): one launch per shard and one all-gather for that many "
                                                             "consecutive 10k-query submits; 1 = every submit its own exchange")
+    ap.add_argument("--c5-mode", default="pqb", choices=["pqb", "pq"], help="c5: the traversal -- pqb = DR_MODE_PQB (round 5: a batch per step on a total order; "
+                    "default), pq = DR_MODE_PQ | DR_F_NO_VISITED_SET (round 4's: the sequential statement)")
     ap.add_argument("--config", default="c2", choices=["c2", "c5"], help="c2: the headline (query-sharded replicas); c5: graph-sharded PQ-only search with the RCCL top-k exchange")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every rank its own batches of --num-queries; strong (SURVEY.md 8e): ONE stream of "
@@ -835,20 +837,32 @@ def worker_c5(args, rk):
     sh = HipIndex.create_codes_empty(n_s, D, R, cb, device=device)
     t0 = time.time()
     ch = 8 * blk
+    ngt = min(nq, 1000)
+    ex_ids = ex_dist = None          # exact top-k of this shard for the first ngt queries, accumulated chunk by chunk (the vectors are not kept)
+    ex_s = 0.0
     for r0 in range(0, n_s, ch):
         rows = min(ch, n_s - r0)
         x = gen.draw(rk.rank * stride + r0, rows)
         sh.encode_rows(x, r0)
+        t1 = time.time()
+        part = HipIndex.create_empty(x, R=1, device=device)
+        ci, cd = part.bruteforce_topk(q[:ngt], k)
+        part.close()
+        ci = (ci.astype(np.int64) + rk.rank * n_s + r0).astype(np.uint32)
+        ex_ids, ex_dist = (ci, cd) if ex_ids is None else merge_topk([ex_ids, ci], [ex_dist, cd], k)
+        ex_s += time.time() - t1
         del x
-    enc_s = time.time() - t0
+    enc_s = time.time() - t0 - ex_s
     medoid, build_s = sh.build_vamana_pq(L_build=args.L_build, alpha=1.2, passes=2, seed=7)
     log(rk, f"shard of {n_s} x {D} encoded in {enc_s:.1f}s (codebook {cb_s:.1f}s), graph R={R} built from code words in {build_s:.1f}s")
     base = rk.rank * n_s
     # ground truth in the index's own metric: brute-force ADC top-k of every shard, merged over the ranks
-    ngt = min(nq, 1000)
     g_ids, g_sq, _ = sh.pq_scan_topk(q[:ngt], k)
     gts = rk.gather("gt", {"ids": (g_ids.astype(np.int64) + base).tolist(), "dist": g_sq.tolist()})
     gt, _ = merge_topk([np.array(g["ids"], dtype=np.uint32) for g in gts], [np.array(g["dist"], dtype=np.float32) for g in gts], k)
+    # ... and against the EXACT neighbours (a PQ-only index cannot rerank: this is bounded by the quantiser)
+    exs = rk.gather("gt_exact", {"ids": ex_ids.tolist(), "dist": ex_dist.tolist()})
+    gt_exact, _ = merge_topk([np.array(g["ids"], dtype=np.uint32) for g in exs], [np.array(g["dist"], dtype=np.float32) for g in exs], k)
     # communicator: rank 0 makes the id, the others read it from the scratch directory
     if rk.rank == 0:
         rk.put("rccl_id", _ffi.Comm.unique_id())
@@ -857,7 +871,10 @@ def worker_c5(args, rk):
     qp = _ffi.pinned_empty((nq, D), np.float32)
     qp[:] = q
 
-    c5_flags = _ffi.F_NO_VISITED_SET        # (same results as with a visited set; 24-33 % faster at the full shard size, neutral at bench scale)
+    if args.c5_mode == "pqb":
+        c5_mode, c5_flags = _ffi.MODE_PQB, 0              # round 5: one third of DR_MODE_PQ's instruction stream (pops: the rows that fill 64 slots)
+    else:
+        c5_mode, c5_flags = _ffi.MODE_PQ, _ffi.F_NO_VISITED_SET        # (same results as with a visited set; 24-33 % faster at the full shard size)
 
     # Exchanges of --c5-group submits (a count, never a timing: every rank forms the same exchanges), three exchanges' worth of submits in
     # flight: a 10k-query launch of this kernel is 4.9 queries per wavefront slot and ends in a tail of idle slots
@@ -870,7 +887,7 @@ def worker_c5(args, rk):
         jobs, out, ms = [], None, np.zeros(3)
         t1 = time.perf_counter()
         for i in range(n_calls):
-            jobs.append(_ffi.sharded_submit([sh], [base], qp, k, L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQ, flags=c5_flags, comm=comm))
+            jobs.append(_ffi.sharded_submit([sh], [base], qp, k, L=args.L, beam_width=args.bw, mode=c5_mode, flags=c5_flags, comm=comm))
             if len(jobs) >= depth_c5:
                 out = jobs.pop(0).wait(); ms += out[3]
         for j in jobs:
@@ -885,7 +902,7 @@ def worker_c5(args, rk):
     if int(status.max()) != 0:
         raise RuntimeError("work-area overflow during the bench")
     # one blocking call for the per-phase times (nothing overlapped) and the search kernel of the shard
-    _, _, _, ms1 = _ffi.sharded_search([sh], [base], qp, k, L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQ, flags=c5_flags, comm=comm)
+    _, _, _, ms1 = _ffi.sharded_search([sh], [base], qp, k, L=args.L, beam_width=args.bw, mode=c5_mode, flags=c5_flags, comm=comm)
     sh.batch_sync()                                     # (publishes the shard's kernel timings)
     tm = sh.timing()
     recall = recall_at_k(ids[:ngt], gt, k)
@@ -895,11 +912,13 @@ def worker_c5(args, rk):
            "dtype": "f32 (ADC sums over u8 codes)", "data": "synthetic",
            "config": {"workload": "c5 layout at bench scale: %d shards x %d points of the 1536-d unit-mixture stream (4096 clusters), vectors "
                                   "encoded on the fly and never stored, PQ m=%d, graph built from code words (dr_build_vamana_pq R=%d, L_build=%d), "
-                                  "DR_MODE_PQ | DR_F_NO_VISITED_SET L=%d beam_width=%s, k=%d; every query on every shard; exchange = ONE RCCL all-gather of (nq*k + 1) "
+                                  "%s L=%d beam_width=%s, k=%d; every query on every shard; exchange = ONE RCCL all-gather of (nq*k + 1) "
                                   "packed 64-bit words per rank + device merge; a step = one %d-query batch (dr_sharded_submit/wait), %d submits per exchange "
                                   "(one launch per shard, one all-gather: dr_sharded_set_group), %d submits in flight"
-                                  % (rk.world, n_s, m, R, args.L_build, args.L, args.bw or None, k, nq, grp, depth_c5),
-                      "recall_at_10_vs_bruteforce_adc": recall, "ground_truth_queries": ngt, "rccl_ranks": rk.world,
+                                  % (rk.world, n_s, m, R, args.L_build, "DR_MODE_PQB" if args.c5_mode == "pqb" else "DR_MODE_PQ | DR_F_NO_VISITED_SET", args.L, args.bw or None, k, nq, grp, depth_c5),
+                      "recall_at_10_vs_bruteforce_adc": recall, "recall_at_10_vs_exact_neighbours": recall_at_k(ids[:ngt], gt_exact, k),
+                      "adc_ranking_recall_at_10_vs_exact_neighbours": recall_at_k(gt, gt_exact, k),
+                      "ground_truth_queries": ngt, "rccl_ranks": rk.world, "exact_ground_truth_seconds": ex_s,
                       "build_seconds": build_s, "encode_seconds": enc_s, "codebook_seconds": cb_s,
                       "per_rank_seconds": times, "exchange_bytes_per_rank_per_batch": (nq * k + 1) * 8, "submits_per_exchange": grp, "submits_in_flight": depth_c5,
                       "one_blocking_call_ms": {"search": float(ms1[0]), "all_gather": float(ms1[1]), "merge": float(ms1[2])},

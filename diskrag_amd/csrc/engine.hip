@@ -919,9 +919,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     uint32_t pqb_pops = 1, pqb_shift = 0;
     if (pqb) {
         pqb_pops = (flags & DR_F_POPS_MASK) >> DR_F_POPS_SHIFT;
-        if (pqb_pops == 0) pqb_pops = 1;
         if (ix->N >= (1ull << 31)) return fail(DR_E_UNSUPPORTED, "DR_MODE_PQB: N must be below 2^31");
         while ((1u << pqb_shift) < ix->R) pqb_shift++;
+        if (pqb_pops == 0) pqb_pops = pqb_shift >= 6 ? 1u : (64u >> pqb_shift);      // default: the rows that fill 64 neighbour slots
         const uint64_t passes = ((uint64_t)pqb_pops << pqb_shift) <= 64 ? 1 : (((uint64_t)pqb_pops << pqb_shift) + 63) / 64;
         if (passes > 4) return fail(DR_E_UNSUPPORTED, "DR_MODE_PQB: pops x next_pow2(R) = %u x %u exceeds 256 neighbour slots per step", pqb_pops, 1u << pqb_shift);
         const int nc = passes <= 1 ? 1 : passes <= 2 ? 2 : 4;
@@ -943,7 +943,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     const KindDesc &kd_desc = pqb ? PQB_DESC : DR_KINDS[dr_kind_pos(kind)];
     const void *kfn = pqb ? pqc.fn : ix->kern->search[dr_kind_pos(kind)][sc];
     const int NW = kd_desc.nw;
-    const size_t lds = pqb ? (size_t)(ix->m - (uint32_t)pqc.treg) * 1024 + (size_t)NCHR_OF_SC[sc] * 512 : lds_of(kind);
+    const size_t lds = pqb ? pqb_lds_bytes(ix->m, pqc.treg, NCHR_OF_SC[sc], pqc.nc) : lds_of(kind);
     if (lds > 160 * 1024) return fail(DR_E_UNSUPPORTED, "LDS footprint %zu B exceeds 160 KiB", lds);
     // (kernel attribute + occupancy are asked once per (variant, LDS size): a single-query call is all overhead)
     int occ = 0;
@@ -1090,6 +1090,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         pp.pops = pqb_pops; pp.max_steps = p.max_steps; pp.rs_shift = pqb_shift;
         pp.counter = p.counter; pp.ticket_base = p.ticket_base;
         pp.res_keys = p.res_keys; pp.res_n = p.res_n; pp.stats = p.stats; pp.out_ids = p.out_ids; pp.out_dist = p.out_dist; pp.out_count = p.out_count;
+        pp.phase = p.phase;
     }
     void *args[] = { pqb ? (void *)&pp : (void *)&p };
     if (!ov) { ix->kev_lut[ix->kev_pending] = want_lut; HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][0], st)); }

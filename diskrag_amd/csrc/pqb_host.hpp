@@ -4,11 +4,12 @@
 #pragma once
 #include "pqb_kernel.hpp"
 
-struct PqbChoice { const void *fn; int m16, treg; };
+struct PqbChoice { const void *fn; int m16, treg, nc; };
 // fn[sizeclass][passes class: 1, 2, 4]
 struct PqbTable { int m16, treg; const void *fn[5][3]; };
 const PqbTable *dr_pqb_table_m0_t0();
 const PqbTable *dr_pqb_table_m1_t0();
+const PqbTable *dr_pqb_table_m1_t8();
 const PqbTable *dr_pqb_table_m2_t0();
 const PqbTable *dr_pqb_table_m2_t16();
 const PqbTable *dr_pqb_table_m2_t24();
@@ -20,14 +21,19 @@ const PqbTable *dr_pqb_table_m4_t32();
 static inline PqbChoice dr_pqb_choose(int sc, int nc, uint32_t m, int treg_pref)
 {
     const PqbTable *t = nullptr;
-    if (m == 16) t = dr_pqb_table_m1_t0();
-    else if (m == 32) t = treg_pref == 0 ? dr_pqb_table_m2_t0() : treg_pref == 24 ? dr_pqb_table_m2_t24() : dr_pqb_table_m2_t16();
+    if (m == 16) t = (treg_pref == 0 || nc > 2 || sc > 3) ? dr_pqb_table_m1_t0() : dr_pqb_table_m1_t8();     // (8 of 16 rows in registers: 8 KiB of LDS per wavefront)
+    // m = 32: 24 rows in registers = 12 wavefronts per CU at 168 registers each (c5s 4M, L = 100, beam_width 8, two pops: 1.42 -> 1.27 ms
+    // against 16 rows / 9 wavefronts, profiles/r05/ab/); four passes per step or 1024-entry lists do not fit 168 registers: 16 rows
+    else if (m == 32) {
+        const int tr = treg_pref >= 0 ? treg_pref : (nc <= 2 && sc <= 3) ? 24 : 16;
+        t = tr == 0 ? dr_pqb_table_m2_t0() : tr == 24 ? dr_pqb_table_m2_t24() : dr_pqb_table_m2_t16();
+    }
     else if (m == 48) t = dr_pqb_table_m3_t16();
     else if (m == 64) t = treg_pref == 16 ? dr_pqb_table_m4_t16() : dr_pqb_table_m4_t32();
     else if (m <= 128) t = dr_pqb_table_m0_t0();
-    PqbChoice c = { nullptr, 0, 0 };
+    PqbChoice c = { nullptr, 0, 0, 1 };
     if (!t) return c;
     const int ci = nc <= 1 ? 0 : nc <= 2 ? 1 : 2;
-    c.fn = t->fn[sc][ci]; c.m16 = t->m16; c.treg = t->treg;
+    c.fn = t->fn[sc][ci]; c.m16 = t->m16; c.treg = t->treg; c.nc = ci == 0 ? 1 : ci == 1 ? 2 : 4;
     return c;
 }

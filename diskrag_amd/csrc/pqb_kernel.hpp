@@ -48,13 +48,32 @@ struct PqbParams {
     u32 *out_ids;            // [nq][k]
     float *out_dist;         // [nq][k]
     u32 *out_count;
+    u64 *phase;              // [nq][8] cycle sums (DR_PHASE_TIMING builds only): 0 table landing, 1 pop, 2 rows, 3 code words, 4 ADC,
+                             // 5 candidates, 6 merge + trim, 7 output
 };
 
-#define PQB_NOTLIVE 0x80000000ull      // bit 31 of the id word carries "not live" through the merge scratch (N < 2^31)
+// A list key in the merge scratch: distance bits << 32 | id << 1 | not-live. The state bit is the LOWEST bit, so for a candidate key
+// (state bit 0) `entry < key` and `entry > key` hold or fail exactly as for the pair (distance, id), and `(entry ^ key) <= 1` says
+// "same node" -- the staged list can be searched without masking anything. N < 2^31.
+#define PQB_NOTLIVE 1ull
+
+// inclusive prefix sum over the wave (DPP: row_shr 1, 2, 4, 8, then row_bcast 15 / 31); lanes without a source add 0
+DEV u32 wave_incl_scan_u32(u32 x)
+{
+#define DR_DPP_ADD(ctrl, rmask) x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, false)
+    DR_DPP_ADD(0x111, 0xf);
+    DR_DPP_ADD(0x112, 0xf);
+    DR_DPP_ADD(0x114, 0xf);
+    DR_DPP_ADD(0x118, 0xf);
+    DR_DPP_ADD(0x142, 0xa);
+    DR_DPP_ADD(0x143, 0xc);
+#undef DR_DPP_ADD
+    return x;
+}
 
 // squared ADC of one code word for a compile-time m = 16 * M16, rows 0 .. m-TREG-1 from LDS, the last TREG from registers
 // (tv[jj*4 + v] of lane l = T[m-TREG+jj][64 v + l]); strict order of j. Whole-wave call (ds_bpermute).
-template <int M16, int TREG>
+template <int M16, int TREG, int GW>
 DEV float pqb_adc(const float *lut, const float (&tv)[TREG > 0 ? TREG * 4 : 1], const uint4 (&cw)[M16])
 {
     constexpr int M = M16 * 16, ML = M - TREG;
@@ -62,17 +81,20 @@ DEV float pqb_adc(const float *lut, const float (&tv)[TREG > 0 ? TREG * 4 : 1], 
 #pragma unroll
     for (int w = 0; w < M16; w++) {
         u32 words[4] = { cw[w].x, cw[w].y, cw[w].z, cw[w].w };
-        // four sub-quantisers (one code word) at a time: their lookups (4 LDS reads, or 16 ds_bpermute) in flight together, then
-        // the strict sum. The empty asm makes the next word's decoding wait for this sum: left alone the compiler issues all
+        // GW code words (4 GW sub-quantisers) at a time: their lookups (LDS reads, or four ds_bpermute each) in flight together, then
+        // the strict sum. The empty asm makes the next group's decoding wait for this sum: left alone the compiler issues all
         // 64 permutes of a piece first and keeps their results (and the 32 decoded indices and select masks) live at once.
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            if (w + g > 0) asm volatile("" : "+v"(words[g]) : "v"(s));
-            float t[4];
+        for (int g = 0; g < 4; g += GW) {
+            if (w + g > 0) {
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
+                for (int u = 0; u < GW; u++) asm volatile("" : "+v"(words[g + u]) : "v"(s));
+            }
+            float t[4 * GW];
+#pragma unroll
+            for (int b = 0; b < 4 * GW; b++) {
                 const int jq = w * 16 + g * 4 + b;
-                const u32 c = (words[g] >> (8 * b)) & 255u;
+                const u32 c = (words[g + (b >> 2)] >> (8 * (b & 3))) & 255u;
                 if (jq < ML) t[b] = lut[jq * 256 + c];
                 else {
                     const int jj = jq - ML;
@@ -86,7 +108,7 @@ DEV float pqb_adc(const float *lut, const float (&tv)[TREG > 0 ? TREG * 4 : 1], 
                 }
             }
 #pragma unroll
-            for (int b = 0; b < 4; b++) s = f_add(s, t[b]);
+            for (int b = 0; b < 4 * GW; b++) s = f_add(s, t[b]);
         }
     }
     return s;
@@ -108,23 +130,44 @@ DEV float pqb_adc_generic(const float *lut, const u8 *__restrict__ code, u32 m)
 
 // NCHR  list capacity in 64-entry chunks          NC    64-lane passes per step (>= ceil(pops * next_pow2(R) / 64))
 // M16   m / 16 (0: any m, generic ADC)            TREG  table rows held in registers
+// LDS per wavefront (pqb_lds_bytes): table rows | staged list mk[NCHR*64] u64 | rank histogram [NCHR*64] u32 | accepted keys
+// cbuf[NC*64 + 4] u64 | popped ids [16] u32
+static inline size_t pqb_lds_bytes(uint32_t m, int treg, int nchr, int nc)
+{
+    return (size_t)(m - (uint32_t)treg) * 1024 + (size_t)nchr * 512 + (size_t)nchr * 256 + ((size_t)nc * 64 + 4) * 8 + 64;
+}
+
 template <int NCHR, int NC, int M16, int TREG>
-__global__ __launch_bounds__(64, (TREG >= 24) ? 3 : 2) void pqb_search_kernel(const PqbParams p)
+// (wavefronts per SIMD the registers must allow: 3 with 24 of 32 rows in registers -- 8 KiB of LDS per wavefront, 12 per CU --; 4 for the
+// small table of m = 16 with half of it in registers)
+__global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 : 2) void pqb_search_kernel(const PqbParams p)
 {
     static_assert(TREG == 0 || (M16 > 0 && TREG <= M16 * 16 && TREG % 8 == 0), "register rows need a compile-time m");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
     const u32 m_lds = p.m - (u32)TREG;
     float *lut = reinterpret_cast<float *>(smem);
-    u64 *mk = reinterpret_cast<u64 *>(smem + (size_t)m_lds * 1024);           // merge scratch [NCHR * 64]
+    u64 *mk = reinterpret_cast<u64 *>(smem + (size_t)m_lds * 1024);           // the list, staged: always the registers' copy (+ state bits)
+    u32 *hist = reinterpret_cast<u32 *>(mk + NCHR * 64);                       // [NCHR*64] accepted keys per list rank; zero between steps
+    u64 *cbuf = reinterpret_cast<u64 *>(hist + NCHR * 64);                     // [NC*64 + 4] the step's accepted keys, compacted
+    u32 *popb = reinterpret_cast<u32 *>(cbuf + NC * 64 + 4);                   // [16] ids of the step's popped nodes
     const u32 slot_id = (u32)__builtin_amdgcn_readfirstlane((int)blockIdx.x);
     const u32 nslots = gridDim.x;
     const int cap = (int)p.cap;
     const u32 nwords = (p.R + 63) / 64;
     const u32 rs_mask = (1u << p.rs_shift) - 1u;
+    // code words decoded together in the ADC: two (8 lookups in flight) when one pass per step leaves the registers for it
+#ifdef PQB_FORCE_GW
+    constexpr int GW = PQB_FORCE_GW;       // A/B builds
+#else
+    constexpr int GW = (NC == 1 && (TREG < 24 || NCHR <= 2)) ? 2 : 1;
+#endif
+#pragma unroll
+    for (int c = 0; c < NCHR; c++) hist[c * 64 + lane] = 0u;
 
     u32 qi = slot_id;
     for (u32 round = 0; round < p.nq && qi < p.nq; ++round) {
+        PH_BEGIN();
         // ---- the query's table: m KiB built by lut_build_kernel, landed 1 KiB per wave instruction; the last TREG rows to registers
         float tv[TREG > 0 ? TREG * 4 : 1];
         {
@@ -140,8 +183,9 @@ __global__ __launch_bounds__(64, (TREG >= 24) ? 3 : 2) void pqb_search_kernel(co
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             WSYNC();
         }
-        RegList<NCHR> rk;
-        u64 live[NCHR];
+        PH(0);
+        RegList<NCHR> rk;           // keys in registers: distance bits << 32 | id << 1 (state bit clear; ~0 = unused)
+        u64 live[NCHR];             // live entries, one bit per list position (wave-uniform: scalar registers)
 #pragma unroll
         for (int c = 0; c < NCHR; c++) { rk.v[c] = ~0ull; live[c] = 0ull; }
         int rn = 0;
@@ -152,7 +196,6 @@ __global__ __launch_bounds__(64, (TREG >= 24) ? 3 : 2) void pqb_search_kernel(co
         bool seed = true;
         for (;;) {
             int np = 0;
-            u32 mypop = 0u;
             if (!seed) {
                 int nlive = 0;
 #pragma unroll
@@ -160,19 +203,21 @@ __global__ __launch_bounds__(64, (TREG >= 24) ? 3 : 2) void pqb_search_kernel(co
                 if (nlive == 0 || steps >= p.max_steps) break;
                 if ((u64)steps > p.N + 64) { status |= DR_ST_INTERNAL; break; }
                 np = min(min((int)p.pops, nlive), (int)(p.max_steps - steps));
-                // pop: the np smallest live entries (scalar bit operations); lane i keeps the id of pop i
-#pragma unroll 1
-                for (int i = 0; i < np; i++) {
-                    int pos = -1;
+                // pop: the np smallest live entries -- a live entry's rank among the live ones is a prefix popcount of the masks
+                int base = 0;
 #pragma unroll
-                    for (int c = 0; c < NCHR; c++) {
-                        if (pos < 0 && live[c] != 0ull) { pos = c * 64 + __ffsll((long long)live[c]) - 1; live[c] &= live[c] - 1ull; }
-                    }
-                    const u32 id = (u32)list_get<NCHR>(rk, pos);
-                    mypop = (lane == i) ? id : mypop;
+                for (int c = 0; c < NCHR; c++) {
+                    const u64 lm = live[c];
+                    const int rank = base + __popcll(lm & lanemask_lt());
+                    const bool sel = ((lm >> lane) & 1ull) != 0ull && rank < np;
+                    if (sel) popb[rank] = (u32)rk.v[c] >> 1;
+                    live[c] = lm & ~__ballot(sel);
+                    base += __popcll(lm);
                 }
                 steps += (u32)np;
+                WSYNC();
             }
+            PH(1);
 
             // rows: pass t covers lanes g = 64 t + lane of the step; row ni = g >> rs_shift, slot = g & rs_mask
             u32 nid[NC]; u64 fw[NC]; bool valid[NC]; u32 slot_[NC], cur_[NC];
@@ -187,12 +232,13 @@ __global__ __launch_bounds__(64, (TREG >= 24) ? 3 : 2) void pqb_search_kernel(co
                     valid[t] = (g == 0u); cur_[t] = 0u; nid[t] = p.medoid; fw[t] = 1ull;
                 } else {
                     valid[t] = ni < (u32)np && slot < p.R;
-                    const u32 cur = (u32)__builtin_amdgcn_ds_bpermute((int)(min(ni, (u32)max(np, 1) - 1u) << 2), (int)mypop);
+                    const u32 cur = popb[min(ni, (u32)max(np, 1) - 1u)];
                     cur_[t] = cur;
                     nid[t] = p.adj[(size_t)cur * p.R + sl];
                     fw[t] = p.first[(size_t)cur * nwords + (sl >> 6)];
                 }
             }
+            PH(2);
             // code words (inline: beside the row, no dependency on the ids; else a gather behind them)
             uint4 cw[NC][M16 > 0 ? M16 : 1];
             bool act[NC];
@@ -205,87 +251,135 @@ __global__ __launch_bounds__(64, (TREG >= 24) ? 3 : 2) void pqb_search_kernel(co
                     for (int w = 0; w < M16; w++) cw[t][w] = reinterpret_cast<const uint4 *>(code)[w];
                 }
             }
+            PH(3);
             const bool full = (rn == cap);
             const u64 wk = full ? list_get<NCHR>(rk, cap - 1) : ~0ull;
             u64 key[NC], cm[NC];
+            u64 anyc = 0ull;
 #pragma unroll
             for (int t = 0; t < NC; t++) {
                 float e;
-                if constexpr (M16 > 0) e = pqb_adc<M16, TREG>(lut, tv, cw[t]);
+                if constexpr (M16 > 0) e = pqb_adc<M16, TREG, GW>(lut, tv, cw[t]);
                 else {
                     const u8 *code = (p.nbcodes && !seed) ? p.nbcodes + ((size_t)cur_[t] * p.R + slot_[t]) * p.m : p.codes + (size_t)(act[t] ? nid[t] : 0u) * p.m;
                     e = pqb_adc_generic(lut, code, p.m);
                 }
-                key[t] = ((u64)__float_as_uint(e) << 32) | nid[t];
+                key[t] = ((u64)__float_as_uint(e) << 32) | ((u64)nid[t] << 1);
                 nevals += (u32)__popcll(__ballot(act[t]));
                 cm[t] = __ballot(act[t] && key[t] < wk);
+                anyc |= cm[t];
             }
+            PH(4);
 
-            // candidates one by one: dropped if in the list (or met before in this step); else its rank in the list, and every
-            // lane counts the accepted keys below its own key / its list keys (the merge positions)
-            u64 acc[NC];
-            u32 rT[NC], rA[NC], sT[NCHR];
-#pragma unroll
-            for (int t = 0; t < NC; t++) { acc[t] = 0ull; rT[t] = 0u; rA[t] = 0u; }
-#pragma unroll
-            for (int c = 0; c < NCHR; c++) sT[c] = 0u;
-            int nacc = 0;
-#pragma unroll
-            for (int t = 0; t < NC; t++) {
-#pragma unroll 1
-                while (cm[t] != 0ull) {
-                    const int f = __ffsll((long long)cm[t]) - 1;
-                    cm[t] &= cm[t] - 1ull;
-                    const u64 kf = readlane64(key[t], f);
-                    u64 eq = 0ull;
-                    int clt = 0;
-#pragma unroll
-                    for (int c = 0; c < NCHR; c++) {
-                        eq |= __ballot(rk.v[c] == kf);
-                        clt += __popcll(__ballot(rk.v[c] < kf));
-                    }
-                    if (np > 1) {           // the same node through two of the step's rows: the later copies leave the set
-#pragma unroll
-                        for (int u = t; u < NC; u++) cm[u] &= ~__ballot(key[u] == kf);
-                    }
-                    if (eq != 0ull) continue;
-                    acc[t] |= 1ull << f;
-                    nacc++;
-                    rT[t] = (lane == f) ? (u32)clt : rT[t];
-#pragma unroll
-                    for (int u = 0; u < NC; u++) rA[u] += (kf < key[u]) ? 1u : 0u;
-#pragma unroll
-                    for (int c = 0; c < NCHR; c++) sT[c] += (kf < rk.v[c]) ? 1u : 0u;
-                }
-            }
-            if (nacc > 0) {
-                // ONE merge through LDS: list entries move up by the accepted keys below them, accepted keys land at
-                // (list keys below) + (accepted keys below); "not live" travels in bit 31 of the id word
-#pragma unroll
-                for (int c = 0; c < NCHR; c++) {
-                    const int idx = c * 64 + lane;
-                    const int npos = idx + (int)sT[c];
-                    const u64 nl = ((live[c] >> lane) & 1ull) ? 0ull : PQB_NOTLIVE;
-                    if (idx < rn && npos < cap) mk[npos] = rk.v[c] | nl;
-                }
+            // ---- candidates (key below the list's largest key, or any while the list fills), all lanes at once:
+            // (1) rank in the list = binary search over the staged list; the entry found there says whether the node is IN the list;
+            // (2) several rows per step: the same node through two rows -- the later copy leaves (a loop over the compacted keys);
+            // (3) the accepted keys are compacted into LDS; every accepted lane counts the accepted keys below its own (broadcast
+            //     reads, no dependency between them), and a histogram of the list ranks, prefix-summed, tells every list entry how
+            //     many accepted keys lie below it;
+            // (4) ONE scatter / gather merge through the staged list.
+            if (anyc != 0ull) {
+                constexpr int QIT = (NCHR == 1) ? 3 : (NCHR <= 4) ? 4 : 5;      // 4^QIT >= NCHR * 64
+                u64 acc[NC];
+                int lb[NC], ci[NC];
+                int nacc = 0;
 #pragma unroll
                 for (int t = 0; t < NC; t++) {
-                    const int npos = (int)(rT[t] + rA[t]);
-                    if (((acc[t] >> lane) & 1ull) && npos < cap) mk[npos] = key[t];
-                }
-                WSYNC();
-                const int rn2 = min(rn + nacc, cap);
+                    // #(list keys < key): a 4-ary search over the staged list padded with +inf to 4^QIT entries -- three independent
+                    // LDS reads per level, QIT DEPENDENT round trips instead of the 2 QIT of a binary search
+                    int lo = 0;
+                    bool inl = false;
+                    if (rn > 0) {
 #pragma unroll
-                for (int c = 0; c < NCHR; c++) {
-                    const int idx = c * 64 + lane;
-                    const u64 v = (idx < rn2) ? mk[idx] : ~0ull;
-                    live[c] = __ballot(idx < rn2 && (v & PQB_NOTLIVE) == 0ull);
-                    rk.v[c] = (idx < rn2) ? (v & ~PQB_NOTLIVE) : ~0ull;
+                        for (int it = 0; it < QIT; it++) {
+                            const int st = 1 << (2 * (QIT - 1 - it));
+                            const int i1 = lo + st - 1, i2 = lo + 2 * st - 1, i3 = lo + 3 * st - 1;
+                            const u64 v1 = mk[min(i1, rn - 1)], v2 = mk[min(i2, rn - 1)], v3 = mk[min(i3, rn - 1)];
+                            const int c1 = (i1 < rn && v1 < key[t]) ? 1 : 0, c2 = (i2 < rn && v2 < key[t]) ? 1 : 0, c3 = (i3 < rn && v3 < key[t]) ? 1 : 0;
+                            lo += (c1 + c2 + c3) * st;
+                        }
+                        const u64 vv = mk[min(lo, rn - 1)];
+                        inl = lo < rn && (vv ^ key[t]) <= 1ull;
+                    }
+                    lb[t] = lo;
+                    acc[t] = cm[t] & __ballot(!inl);
+                    ci[t] = nacc + __popcll(acc[t] & lanemask_lt());
+                    nacc += __popcll(acc[t]);
                 }
-                WSYNC();
-                rn = rn2;
-                nins += (u32)nacc;
+                if (np > 1 && nacc > 1) {
+                    // the same node through two of the step's rows: only its first copy (in lane order) stays
+#pragma unroll
+                    for (int t = 0; t < NC; t++) if ((acc[t] >> lane) & 1ull) cbuf[ci[t]] = key[t];
+                    WSYNC();
+                    bool dup[NC];
+#pragma unroll
+                    for (int t = 0; t < NC; t++) dup[t] = false;
+#pragma unroll 8
+                    for (int jq = 0; jq < nacc; jq++) {
+                        const u64 kj = cbuf[jq];
+#pragma unroll
+                        for (int t = 0; t < NC; t++) dup[t] = dup[t] || (kj == key[t] && jq < ci[t]);
+                    }
+                    WSYNC();
+                    nacc = 0;
+#pragma unroll
+                    for (int t = 0; t < NC; t++) {
+                        acc[t] &= ~__ballot(dup[t]);
+                        ci[t] = nacc + __popcll(acc[t] & lanemask_lt());
+                        nacc += __popcll(acc[t]);
+                    }
+                }
+                if (nacc > 0) {
+                    bool isacc[NC];
+#pragma unroll
+                    for (int t = 0; t < NC; t++) {
+                        isacc[t] = ((acc[t] >> lane) & 1ull) != 0ull;
+                        if (isacc[t]) { cbuf[ci[t]] = key[t]; atomicAdd(&hist[lb[t]], 1u); }
+                    }
+                    if (lane < 4) cbuf[nacc + lane] = ~0ull;          // (the count loop below reads four keys per trip)
+                    WSYNC();
+                    u32 rA[NC];
+#pragma unroll
+                    for (int t = 0; t < NC; t++) rA[t] = 0u;
+#pragma unroll 1
+                    for (int jq = 0; jq < nacc; jq += 4) {
+                        const u64 k0 = cbuf[jq], k1 = cbuf[jq + 1], k2 = cbuf[jq + 2], k3 = cbuf[jq + 3];
+#pragma unroll
+                        for (int t = 0; t < NC; t++)
+                            rA[t] += (k0 < key[t] ? 1u : 0u) + (k1 < key[t] ? 1u : 0u) + (k2 < key[t] ? 1u : 0u) + (k3 < key[t] ? 1u : 0u);
+                    }
+                    // list entry i moves up by the accepted keys below it = those whose list rank is <= i
+                    u32 carry = 0u;
+#pragma unroll
+                    for (int c = 0; c < NCHR; c++) {
+                        const int idx = c * 64 + lane;
+                        const u32 inc = wave_incl_scan_u32(hist[idx]) + carry;
+                        hist[idx] = 0u;
+                        carry = readlane32(inc, 63);
+                        const int npos = idx + (int)inc;
+                        const u64 nl = ((live[c] >> lane) & 1ull) ? 0ull : PQB_NOTLIVE;
+                        if (idx < rn && npos < cap) mk[npos] = rk.v[c] | nl;
+                    }
+#pragma unroll
+                    for (int t = 0; t < NC; t++) {
+                        const int npos = lb[t] + (int)rA[t];
+                        if (isacc[t] && npos < cap) mk[npos] = key[t];
+                    }
+                    WSYNC();
+                    const int rn2 = min(rn + nacc, cap);
+#pragma unroll
+                    for (int c = 0; c < NCHR; c++) {
+                        const int idx = c * 64 + lane;
+                        const u64 v = (idx < rn2) ? mk[idx] : ~0ull;
+                        live[c] = __ballot(idx < rn2 && (v & PQB_NOTLIVE) == 0ull);
+                        rk.v[c] = (idx < rn2) ? (v & ~PQB_NOTLIVE) : ~0ull;
+                    }
+                    WSYNC();
+                    rn = rn2;
+                    nins += (u32)nacc;
+                }
             }
+            PH(5);
             seed = false;
             // frontier trim: only the beam_width smallest live entries stay live
             if (p.bw != 0u) {
@@ -306,6 +400,7 @@ __global__ __launch_bounds__(64, (TREG >= 24) ? 3 : 2) void pqb_search_kernel(co
                     }
                 }
             }
+            PH(6);
         }
 
         // ---- results: keys for the rerank pass, the k best (ids, squared ADC), counters
@@ -313,14 +408,14 @@ __global__ __launch_bounds__(64, (TREG >= 24) ? 3 : 2) void pqb_search_kernel(co
 #pragma unroll
             for (int c = 0; c < NCHR; c++) {
                 const int i = c * 64 + lane;
-                if (i < rn) p.res_keys[(size_t)qi * cap + i] = (rk.v[c] & 0xFFFFFFFF00000000ull) | (u32)(~(u32)rk.v[c]);
+                if (i < rn) p.res_keys[(size_t)qi * cap + i] = (rk.v[c] & 0xFFFFFFFF00000000ull) | (u32)(~((u32)rk.v[c] >> 1));
             }
             const int kout = min((int)p.k, rn);
 #pragma unroll
             for (int c = 0; c < NCHR; c++) {
                 const int i = c * 64 + lane;
                 if (i < (int)p.k) {
-                    p.out_ids[(size_t)qi * p.k + i] = (i < kout) ? (u32)rk.v[c] : 0xFFFFFFFFu;
+                    p.out_ids[(size_t)qi * p.k + i] = (i < kout) ? ((u32)rk.v[c] >> 1) : 0xFFFFFFFFu;
                     p.out_dist[(size_t)qi * p.k + i] = (i < kout) ? key_dist(rk.v[c]) : __uint_as_float(0x7FC00000u);
                 }
             }
@@ -337,6 +432,8 @@ __global__ __launch_bounds__(64, (TREG >= 24) ? 3 : 2) void pqb_search_kernel(co
                 p.stats[qi] = st;
             }
         }
+        PH(7);
+        PH_END(qi);
         {
             u32 t = 0;
             if (lane == 0) t = atomicAdd(p.counter, 1u);

@@ -38,7 +38,7 @@ extern "C" {
  * the same pieces -- the table of compute_distance_table (fast_pq.py:294-318), the squared ADC summed in strict sub-quantiser
  * order (:320-328), an L-sized list, the step cap min(10 L, N) (search_engine.py:429), heapq.nsmallest(beam_width) on the
  * frontier (:477-479) -- on a TOTAL order key = (distance bits, id): a step expands the `pops` smallest live list entries
- * (DR_F_POPS, default 1), scores every first-occurrence neighbour of their rows, and merges those whose key is below the
+ * (DR_F_POPS; default: the rows that fill 64 neighbour slots), scores every first-occurrence neighbour of their rows, and merges those whose key is below the
  * list's largest key (or any, while the list fills) and is not in the list already into the L smallest; newcomers are live;
  * the search stops when no live entry is left. No visited set (membership in the list decides, as with DR_F_NO_VISITED_SET),
  * no neighbour-by-neighbour walk to emulate: one third of DR_MODE_PQ's instruction stream. Results come back in
@@ -62,7 +62,8 @@ extern "C" {
 #define DR_F_POPS_SHIFT 8u
 #define DR_F_POPS_MASK 0xF00u
 #define DR_F_POPS(n) (((uint32_t)(n) & 15u) << DR_F_POPS_SHIFT) /* DR_MODE_PQB: frontier entries expanded per step (DiskANN's beam): narrow rows
-                          (R = 32) fill the 64 lanes two at a time, and a query needs half as many DEPENDENT steps; 0 = 1 */
+                          (R = 32) fill the 64 lanes two at a time, and a query needs half as many DEPENDENT steps;
+                          0 = max(1, 64 / next_pow2(R)): as many rows as fill 64 neighbour slots */
 #define DR_F_COSINE 8u /* M3 without DR_F_USE_PQ: the in-memory graph's distance_metric='cosine' -- compute_query_distance ->
                           cosine_similarity_cython (vamana_graph.py:324-329, cython_utils.pyx:53-70): 1 - cos, 0 when a norm is
                           0; out_dist = sqrt of it (vamana_graph.py:598). The reference sums in float32 under -ffast-math

@@ -86,6 +86,7 @@ static inline double sqrt_real_f64(double x) { return sqrt(x); }
  *                 in strict order of j (fast_pq.py:320-328) -- the golden-pinned A2 / A3
  *   key(i)        (bits of d(i), i): distances are sums of squares (>= +0), so float order = bit order; ids break ties
  *   list          at most L entries in ascending key order, each live / not live (expanded or trimmed)
+ *   pops          frontier entries expanded per step: flags bits 8..11, 0 = max(1, 64 / next_pow2(R)) (rows that fill 64 slots)
  *   step          take the p = min(pops, #live, max_steps - steps) smallest live entries, mark them expanded;
  *                 score every neighbour slot of their rows that is the first occurrence of its id in ITS row (ORC_PAD
  *                 skipped; the 0-pads of a disk row are neighbour 0 once, quirk Q3); a scored key enters the candidate SET
@@ -116,7 +117,7 @@ static int pqb_search_one(const orc_index *ix, const float *q, uint32_t k, uint3
     if (!ix->codes || !ix->codebook || m == 0 || D % m) return -2;
     if (k == 0 || L == 0 || ix->medoid >= N) return -3;
     uint32_t pops = (flags >> ORC_F_POPS_SHIFT) & 15u;
-    if (pops == 0) pops = 1;
+    if (pops == 0) { uint32_t rs = 1; while (rs < R) rs <<= 1; pops = rs >= 64 ? 1 : 64 / rs; }   /* default: the rows that fill 64 neighbour slots */
     float *lut = (float *)malloc((size_t)m * 256 * sizeof(float));
     build_lut_f32(ix->codebook, q, m, D / m, lut);
     pqb_ent *list = (pqb_ent *)malloc(((size_t)L + (size_t)pops * R + 1) * sizeof(pqb_ent));

@@ -130,6 +130,20 @@ if spec == "stream":
         run_stream(tag + "_stream_shared_launches", 32768, 14, **kw)
     ix.close()
     sys.exit(0)
+if spec == "pqb":
+    # round 5: DR_MODE_PQB (the PQ traversal as a batch per step, csrc/pqb_kernel.hpp) + exact rerank of the L list, around the shape's
+    # recall-0.95 points, next to round 4's DR_MODE_PQ at the same L / beam_width; then the best points as host -> host streams
+    grid = (((350, 64), (400, 32), (350, 0), (300, 64), (500, 32)) if shape == "c4" else ((250, 0), (250, 128), (300, 64), (200, 0), (300, 0), (400, 32)))
+    for L, bw in grid:
+        run(f"PQ_rerank_L{L}_bw{bw or 'None'}", L=L, beam_width=bw, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)
+        for pops in (1, 2):
+            run(f"PQB_rerank_L{L}_bw{bw or 'None'}_pops{pops}", L=L, beam_width=bw, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK | _ffi.F_POPS(pops))
+    for L, bw in grid[:2]:
+        kw = dict(L=L, beam_width=bw, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK | _ffi.F_POPS(1))
+        run_stream(f"PQB_rerank_L{L}_bw{bw or 'None'}_pops1_stream_one_launch_per_submit", nq, 4, **kw)
+        run_stream(f"PQB_rerank_L{L}_bw{bw or 'None'}_pops1_stream_shared_launches", 32768, 14, **kw)
+    ix.close()
+    sys.exit(0)
 if spec == "extra":
     extra_pass()
     ix.close()

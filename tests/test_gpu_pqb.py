@@ -42,7 +42,7 @@ def test_pqb_matches_its_oracle_restatement(name):
     shard = HipIndex.create_codes(g.adj, g.medoid, g.vectors.shape[1], g.codebook, g.codes)
     try:
         for (L, bw, k) in ((100, 8, 10), (40, 0, 10), (10, 3, 10), (200, 16, 25), (64, 8, 64), (1, 1, 1), (300, 0, 10), (600, 32, 10), (1024, 0, 10)):
-            for pops in (1, 2, 4):
+            for pops in (0, 1, 2, 4):      # (0: the default -- the rows that fill 64 neighbour slots)
                 if pops * (1 << int(np.ceil(np.log2(g.R)))) > 256:
                     continue
                 for eng, inline in ((ix, False), (shard, False), (shard, True)):
