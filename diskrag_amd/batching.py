@@ -61,14 +61,14 @@ class RequestBatcher:
         if self.dimension is not None and q.shape[0] != int(self.dimension):
             # (refused here: inside a batch it would make np.stack fail for every request coalesced with it)
             raise ValueError(f"query has {q.shape[0]} components, the index {int(self.dimension)}")
-        if self._dim_seen is None:
-            self._dim_seen = q.shape[0]
-        elif q.shape[0] != self._dim_seen:
-            raise ValueError(f"query has {q.shape[0]} components, earlier requests had {self._dim_seen}")
         fut: Future = Future()
         with self._cv:
             if self._closed:
                 raise RuntimeError("RequestBatcher is closed")
+            # (an engine without a `dimension`: the size is learnt from the first batch the engine has actually SERVED -- _run latches it --,
+            # never from a request alone: one malformed first request would otherwise refuse every well-formed one for good)
+            if self._dim_seen is not None and q.shape[0] != self._dim_seen:
+                raise ValueError(f"query has {q.shape[0]} components, the engine has served requests of {self._dim_seen}")
             self._pending.append((q, k, fut, time.perf_counter()))
             self._cv.notify()
         return fut
@@ -107,7 +107,7 @@ class RequestBatcher:
             batch, self._pending = self._pending[:self.max_batch], self._pending[self.max_batch:]
         # a caller may have given up on its request (a cancelled Future: an asyncio.wrap_future timeout, a client that went
         # away): it is dropped here and can no longer be cancelled once the batch runs
-        return [b for b in batch if b[2].set_running_or_notify_cancel()]
+        return [b for b in batch if b[2].running() or b[2].set_running_or_notify_cancel()]      # (running: put back by _run, a batch of mixed sizes)
 
     def _run(self):
         while True:
@@ -116,6 +116,13 @@ class RequestBatcher:
                 return
             if not batch:                       # every request of it was cancelled
                 continue
+            sizes = {b[0].shape[0] for b in batch}
+            if len(sizes) > 1:                  # (only while no size is known: requests of each size are served on their own)
+                first = batch[0][0].shape[0]
+                rest = [b for b in batch if b[0].shape[0] != first]
+                batch = [b for b in batch if b[0].shape[0] == first]
+                with self._cv:
+                    self._pending[:0] = rest
             try:
                 qs = np.stack([b[0] for b in batch])
                 ids, dist, cnt, st = self.engine.search_batch(qs, k=self.k_max, L=self.L, beam_width=self.beam_width,
@@ -124,6 +131,9 @@ class RequestBatcher:
                 for _, _, fut, _ in batch:
                     self._deliver(fut, exc=e)
                 continue
+            if self._dim_seen is None and self.dimension is None:
+                with self._cv:
+                    self._dim_seen = qs.shape[1]
             self.batches_sent += 1
             self.queries_sent += len(batch)
             for i, (_, k, fut, _) in enumerate(batch):

@@ -167,6 +167,7 @@ struct ShardWork {
     hipEvent_t zeroed = nullptr; bool zeroed_valid = false;     // the status words were cleared again behind the last exchange of this work area
     void *pin = nullptr; size_t pin_bytes = 0;
     int state = 0;                              // 0 free, 1 collecting submits, 2 launched (its tickets only have to be collected)
+    uint64_t gen = 0;                           // bumped whenever the work area is opened for a new exchange (a waiter that slept re-validates with it)
     std::vector<ShardPart> parts;
     uint32_t nq = 0, cap = 0, k = 0, L = 0, bw = 0, mode = 0, policy = 0, flags = 0; int nranks = 1;
     bool q_u8 = true;

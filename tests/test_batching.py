@@ -138,12 +138,12 @@ def test_a_malformed_request_fails_alone():
         with pytest.raises(ValueError):
             rb.submit(np.zeros(5, np.float32))                             # refused in submit(): never stacked with the others
         assert len(ok.result(5)[0]) == 3
-    eng2 = FakeEngine()                                                    # an engine that does not say its dimension: the first request sets it
+    eng2 = FakeEngine()                                                    # an engine that does not say its dimension: the first SERVED batch sets it
     with RequestBatcher(eng2, k_max=3, L=50, max_batch=8, max_wait_ms=20) as rb:
         ok = rb.submit(np.zeros(4, np.float32))
+        assert len(ok.result(5)[0]) == 3
         with pytest.raises(ValueError):
             rb.submit(np.zeros(6, np.float32))
-        assert len(ok.result(5)[0]) == 3
 
 
 def test_default_list_size_is_fixed_from_k_max():
@@ -156,3 +156,26 @@ def test_default_list_size_is_fixed_from_k_max():
     with RequestBatcher(eng, k_max=5, max_batch=4, max_wait_ms=0) as rb:
         rb.search(np.zeros(4, np.float32), timeout=5)
     assert eng.calls[0][1:3] == (5, 20)
+
+
+def test_a_malformed_first_request_does_not_fix_the_dimension():
+    """An engine without a `dimension` attribute: the size is learnt from the first batch the engine has SERVED, never from a request
+    alone -- a malformed first request fails by itself and well-formed ones keep working (and a later wrong size is refused)."""
+    class Picky(FakeEngine):
+        def search_batch(self, query_vectors, **kw):
+            q = np.asarray(query_vectors)
+            if q.shape[1] != 4:
+                raise ValueError("wrong dimension")
+            return super().search_batch(q, **kw)
+    eng = Picky()
+    with RequestBatcher(eng, k_max=3, L=20, beam_width=8, max_batch=8, max_wait_ms=30) as rb:
+        bad = rb.submit(np.zeros(7, np.float32))              # first request of the batcher's life: the wrong size
+        good = [rb.submit(np.array([10.0 * i, 1, 0, 0], np.float32)) for i in range(5)]      # coalesced with it
+        with pytest.raises(ValueError):
+            bad.result(5)
+        for i, f in enumerate(good):
+            res, _ = f.result(5)
+            assert [int(x) for _, x in res] == [10 * i, 10 * i + 1, 10 * i + 2]
+        with pytest.raises(ValueError):                       # the served size is the batcher's size from now on
+            rb.submit(np.zeros(7, np.float32))
+        assert rb.search(np.array([50.0, 0, 0, 0], np.float32), k=1)[0][0][1] == 50
