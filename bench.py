@@ -73,7 +73,12 @@ def parse_args(argv=None):
                                                             "consecutive 10k-query submits; 1 = every submit its own exchange")
     ap.add_argument("--c5-mode", default="pqb", choices=["pqb", "pq"], help="c5: the traversal -- pqb = DR_MODE_PQB (round 5: a batch per step on a total order; "
                     "default), pq = DR_MODE_PQ | DR_F_NO_VISITED_SET (round 4's: the sequential statement)")
-    ap.add_argument("--config", default="c2", choices=["c2", "c5"], help="c2: the headline (query-sharded replicas); c5: graph-sharded PQ-only search with the RCCL top-k exchange")
+    ap.add_argument("--rows", default="auto", choices=["auto", "f32"], help="c2: auto = the engine's choice (lossless byte rows + byte queries on integer-valued data: variant 13); "
+                    "f32 = the float32-row kernel (variant 9) as the headline -- what every embedding workload gets")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="c2: the headline (query-sharded replicas); c3: d=1536 PQ traversal + full-precision rerank of the L list; c4: d=96 replicated index, "
+                         "reference-faithful M1; c5: graph-sharded PQ-only search with the RCCL top-k exchange. c3 / c4 default to a bench-scale index "
+                         "(--num-vectors 10000000 / 100000000 = the configurations' full sizes: they fit one MI355X)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every rank its own batches of --num-queries; strong (SURVEY.md 8e): ONE stream of "
                          "--num-queries batches, every batch cut into contiguous slices of nq/N queries, one per rank")
@@ -82,7 +87,14 @@ def parse_args(argv=None):
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
     # the shape of the configuration (BASELINE.json configs[1] / configs[4]) unless given
-    dflt = {"c2": dict(dim=128, R=64, L=100, bw=8, L_build=100), "c5": dict(dim=1536, R=128, L=100, bw=32, L_build=128)}[args.config]
+    dflt = {"c2": dict(dim=128, R=64, L=100, bw=8, L_build=100), "c5": dict(dim=1536, R=128, L=100, bw=32, L_build=128),
+            # (the operating points of the full-size runs, profiles/r04/op_c3_*.jsonl / op_c4_*.jsonl and profiles/r05/)
+            "c3": dict(dim=1536, R=64, L=250, bw=0, L_build=100), "c4": dict(dim=96, R=64, L=500, bw=64, L_build=100)}[args.config]
+    if args.config in ("c3", "c4"):
+        if args.n == 1_000_000 and "--num-vectors" not in (argv if argv is not None else sys.argv):
+            args.n = 1_000_000 if args.config == "c3" else 4_000_000
+        if args.config == "c4" and "--m" not in (argv if argv is not None else sys.argv):
+            args.m = 16
     for name, v in dflt.items():
         if getattr(args, name) is None:
             setattr(args, name, v)
@@ -332,7 +344,7 @@ def isolated_pq_scan(device, n_codes=64_000_000, m=32, D=128, nq=4):
 def worker(args):
     rk = Ranks()
     try:
-        rc = worker_c5(args, rk) if args.config == "c5" else worker_c2(args, rk)
+        rc = worker_c5(args, rk) if args.config == "c5" else worker_shape(args, rk) if args.config in ("c3", "c4") else worker_c2(args, rk)
     except BaseException as e:          # the other ranks stop waiting for this one
         rk.abort("%s: %s" % (type(e).__name__, e))
         raise
@@ -384,6 +396,7 @@ def worker_c2(args, rk):
         raise RuntimeError("no HIP device: the engine has no CPU fallback")
     device = rk.local_rank % ndev
     mode = _ffi.MODE_M1
+    base_kind = 9 if args.rows == "f32" else -1          # --rows f32: the float32-row kernel for every launch of the run
 
     # ---------------------------------------------------------------- setup (untimed): data, graph, PQ, ground truth
     t0 = time.time()
@@ -417,9 +430,9 @@ def worker_c2(args, rk):
         a[:] = q_all[b * nq:(b + 1) * nq]
         qb.append(a)
 
-    def run_resident(bw, n_launch, kind=-1, batches=None):
+    def run_resident(bw, n_launch, kind=None, batches=None):
         """n_launch launches rotating over the resident batches; returns seconds (host clock) and mean kernel ms"""
-        ix.debug_force_kind(kind)
+        ix.debug_force_kind(base_kind if kind is None else kind)
         nbb = len(batches) if batches is not None else nb
         for i in range(min(4, n_launch)):
             ix.batch_select(i % nbb); ix.batch_run(k, L=args.L, beam_width=bw, mode=mode)
@@ -431,18 +444,18 @@ def worker_c2(args, rk):
         ix.batch_sync()
         el = time.perf_counter() - t1
         tm = ix.timing()
-        ix.debug_force_kind(-1)
+        ix.debug_force_kind(base_kind)
         return el, tm
 
-    def collect(bw, kind=-1):
+    def collect(bw, kind=None):
         """one launch per resident batch, results of all of them (recall, counters)"""
-        ix.debug_force_kind(kind)
+        ix.debug_force_kind(base_kind if kind is None else kind)
         outs = []
         for b in range(nb):
             ix.batch_select(b)
             ix.batch_run(k, L=args.L, beam_width=bw, mode=mode)
             outs.append(ix.batch_download())
-        ix.debug_force_kind(-1)
+        ix.debug_force_kind(base_kind)
         ids = np.concatenate([o[0] for o in outs]); st = np.concatenate([o[3] for o in outs])
         dist = np.concatenate([o[1] for o in outs])
         if (st["status"] != 0).any():
@@ -453,6 +466,7 @@ def worker_c2(args, rk):
         ix.batch_select(b)
         ix.batch_upload(qb[b])
     ix.batch_select(0)
+    ix.debug_force_kind(base_kind)
 
     def tickets_in_flight(n_q):
         """submits a caller keeps in flight: PIPE_DEPTH launches' worth (a launch coalesces submits up to 32768 queries) + 2"""
@@ -602,13 +616,13 @@ def worker_c2(args, rk):
     # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 read
     # correction applied): collected offline on this same workload by scripts/profile_run.sh, committed under profiles/
     traffic, traffic_src = None, None
-    for rnd in ("r04", "r03", "r02", "r01"):
-        pmc = ROOT / "profiles" / rnd / "pmc_traffic.json"
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        pmc = ROOT / "profiles" / rnd / ("pmc_traffic.json" if args.rows == "auto" else "pmc_traffic_f32_rows.json")
         if traffic is None and pmc.exists() and (args.n, nq, D, args.R, args.L, args.m) == (1_000_000, 10_000, 128, 64, 100, 32):
             rec = json.loads(pmc.read_text()).get("beam_width_%d" % args.bw)
             if rec and (rnd != "r01" or variant == 13):
                 traffic = rec["hbm_bytes_per_launch"]
-                traffic_src = ("profiles/%s/pmc_traffic.json: rocprofv3 --pmc read requests by size (TCC_EA0_RDREQ_32B/64B/128B; FETCH_SIZE x2 before round 4) + WRITE_SIZE, separate passes over scripts/pmc_target.py "
+                traffic_src = ("profiles/%s/" + pmc.name + ": rocprofv3 --pmc read requests by size (TCC_EA0_RDREQ_32B/64B/128B; FETCH_SIZE x2 before round 4) + WRITE_SIZE, separate passes over scripts/pmc_target.py "
                                "-- the same workload and build, collected by scripts/profile_run.sh in ANOTHER run on another box of the pool (a PMC pass "
                                "cannot share a process with the timed region), one batch per launch there: scaled by this run's batches per launch "
                                "(the counters are linear in the queries of a launch); hbm_frac divides it by THIS run's kernel time") % rnd
@@ -706,6 +720,11 @@ def worker_c2(args, rk):
                    "qps_resident": qps_resident, "ms_per_batch_resident": (max(res_times) / launches * 1e3) if res_times else None,
                    "kernel_ms_resident": tm_res["search_kernel_ms"],
                    "qps_pcie_inclusive_pageable_source": qps_pageable,
+                   "qps_blocking_call_median": None if args.headline_only else qps_one_call,       # (scalar twin of the dict below: SURVEY 8d's literal metric)
+                   "float32_rows_qps_resident": float_rows["qps_resident"] if float_rows else None,
+                   "float32_rows_kernel_ms": float_rows["kernel_ms"] if float_rows else None,
+                   "float32_rows_roofline_frac": float_rows["roofline_frac"] if float_rows else None,
+                   "rows": args.rows,
                    "qps_blocking_call": None if args.headline_only else {"median": qps_one_call, "calls": len(call_s), "best": nq / call_s[0], "worst": nq / call_s[-1],
                                          "note": "SURVEY.md 8d's literal metric: nq / wall time of one blocking dr_search_batch call "
                                                  "(pageable source; upload + search + tie order + download, nothing overlapped)"},
@@ -800,6 +819,147 @@ def worker_c2(args, rk):
     ix.close()
     return 0
 
+
+
+# ------------------------------------------------------------------------------------------------ c3 / c4: the other query-sharded shapes
+def worker_shape(args, rk):
+    """BASELINE configs[2] (c3: 10M x 1536 inner product on unit vectors = L2, PQ + full-precision rerank) and configs[3] (c4: DEEP100M-shaped
+    100M x 96, index replicated, queries sharded) at --num-vectors points, index built by the engine's own builder.
+      c3: DR_MODE_PQB | DR_F_RERANK -- the PQ traversal (round 5's batch-per-step kernel) + exact rerank of the L list, SURVEY.md 8d's
+          definition of c3 -- L = 250 without frontier trim: the recall-0.95 point of the full-size index.
+      c4: the reference-faithful M1 (_pq_accelerated_graph_search, search_engine.py:398-506), L = 500, beam_width 64: ITS recall-0.95 point at
+          100M points; `config.pq_rerank` carries the PQ traversal + rerank beside it.
+    value = host memory -> host memory stream of --num-queries batches (dr_search_submit / dr_search_wait, shared launches), every rank its own
+    batches on its own replica (weak scaling, no collective). roofline = the search kernel's algorithmic bytes (SURVEY.md 8d's B_q from the
+    engine's per-query counters) / its mean launch duration over the timed region (HIP events on the search stream)."""
+    import diskrag_amd
+    from diskrag_amd import HipIndex, _ffi
+    from diskrag_amd.synth import recall_at_k, unit_mixture, unit_mixture_parallel
+    ndev = diskrag_amd.device_count()
+    if ndev < 1:
+        raise RuntimeError("no HIP device: the engine has no CPU fallback")
+    device = rk.local_rank % ndev
+    c3 = args.config == "c3"
+    nq, k, D, m, R, n = args.nq, args.k, args.dim, args.m, args.R, args.n
+    nb = max(1, min(args.nb, 4))
+    t0 = time.time()
+    gen = unit_mixture_parallel if n * D >= (1 << 32) else unit_mixture
+    x, q_all = gen(n, D, n_queries=nq * nb, n_clusters=4096, seed=11, latent=64 if c3 else 32)          # (the replicas hold the same index; every rank streams the same batches)
+    log(rk, f"synthetic unit-norm mixture {x.shape} + {nb} batches of {nq} queries in {time.time() - t0:.1f}s")
+    ix = HipIndex.create_empty(x, R=R, device=device)
+    medoid, build_s = ix.build_vamana(L_build=args.L_build, alpha=1.2, passes=2, seed=7)
+    t0 = time.time()
+    want_cpu = rk.rank == 0 and rk.world == 1 and not args.no_cpu
+    cb = ix.pq_train(m, n_sample=100_000, iters=8)
+    codes = ix.pq_encode(cb, want_codes=want_cpu)
+    pq_s = time.time() - t0
+    gt, _ = ix.bruteforce_topk(q_all[:nq * min(nb, 2)], k)
+    log(rk, f"graph in {build_s:.1f}s, PQ m={m} in {pq_s:.1f}s, ground truth done")
+    if not want_cpu:
+        del x
+    kw = dict(L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK) if c3 else dict(L=args.L, beam_width=args.bw, mode=_ffi.MODE_M1)
+    kw2 = dict(L=400, beam_width=32, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK) if not c3 else None      # c4's PQ + rerank point
+    qb = []
+    for b in range(nb):
+        a = _ffi.pinned_empty((nq, D), np.float32)
+        a[:] = q_all[b * nq:(b + 1) * nq]
+        qb.append(a)
+    depth = min(_ffi.MAX_TICKETS - 2, _ffi.PIPE_DEPTH * max(1, 32768 // nq) + 2)
+
+    def stream(n_sub, kw_):
+        jobs, done, last = [], 0, None
+        t1 = time.perf_counter()
+        for i in range(n_sub):
+            jobs.append(ix.search_submit(qb[i % nb], k, reuse_outputs=True, **kw_))
+            if len(jobs) - done >= depth:
+                last = jobs[done].wait(); jobs[done] = None; done += 1
+        for j in range(done, len(jobs)):
+            last = jobs[j].wait()
+        return time.perf_counter() - t1, last
+
+    # a step = --batches-per-step batches (default here: 4: these launches take 5-25 ms each at full size)
+    bps = args.bps if "--batches-per-step" in sys.argv else 4
+    n_sub = args.steps * bps
+    stream(max(2 * depth, args.warmup * bps), kw); ix.batch_sync()
+    rk.barrier()
+    ps0 = ix.pipeline_stats()
+    el, last = stream(n_sub, kw)
+    ix.batch_sync()
+    tm = ix.timing()
+    ps1 = ix.pipeline_stats()
+    times = rk.gather("t_shape", el)
+    nl = max(1, ps1["launches"] - ps0["launches"])
+    qpl = (ps1["queries"] - ps0["queries"]) / nl
+    # counters, recall: one blocking call per ground-truth batch
+    outs = [ix.search_batch(qb[b], k, **kw) for b in range(min(nb, 2))]
+    ids = np.concatenate([o[0] for o in outs]); st = np.concatenate([o[3] for o in outs]); dist = np.concatenate([o[1] for o in outs])
+    if (st["status"] != 0).any():
+        raise RuntimeError("work-area overflow during the bench")
+    lbq = (n_sub - 1) % nb
+    if lbq < len(outs) and not np.array_equal(last[0], outs[lbq][0]):
+        raise RuntimeError("the pipelined path and a blocking call disagree")
+    recall = recall_at_k(ids, gt, k)
+    recalls = rk.gather("recall", recall)
+    if min(recalls) < args.min_recall:
+        raise RuntimeError(f"recall@{k} = {min(recalls):.4f} is below the metric's bar {args.min_recall}")
+    # algorithmic bytes per query (SURVEY.md 8d): query + adjacency rows + code words scored + full-precision rows scored + output
+    S, V, X = st["steps"].astype(np.float64), st["pq_evaluated"].astype(np.float64), st["exact"].astype(np.float64)
+    per_q = 4.0 * D + S * 4.0 * R + V * float(m) + X * 4.0 * D + 8.0 * k
+    k_ms = float(tm["search_kernel_ms"])
+    alg_launch = float(per_q.mean()) * qpl + 4.0 * 256 * D
+    # the rerank pass of c3 runs in its own kernel: its rows are not the traversal kernel's
+    alg_search_launch = float((per_q - (X * 4.0 * D if c3 else 0.0)).mean()) * qpl + 4.0 * 256 * D
+    achieved = alg_search_launch / (k_ms * 1e-3) / 1e9
+    pq_rerank = None
+    if kw2 is not None:
+        stream(2 * depth, kw2); ix.batch_sync()
+        el2, _ = stream(max(8, n_sub // 2), kw2); ix.batch_sync()
+        o2 = [ix.search_batch(qb[b], k, **kw2) for b in range(min(nb, 2))]
+        pq_rerank = {"what": "DR_MODE_PQB | DR_F_RERANK L=400 beam_width=32 (c4's PQ traversal + exact rerank point)", "qps": nq * max(8, n_sub // 2) / el2,
+                     "recall_at_10": recall_at_k(np.concatenate([o[0] for o in o2]), gt, k), "kernel_ms_per_launch": float(ix.timing()["search_kernel_ms"])}
+    out = {"metric": "QPS @ recall@10>=0.95, %s, batch=%d" % ("d=1536 unit-norm (inner product = L2), PQ traversal + full-precision rerank" if c3
+                                                                  else "DEEP-shaped d=96 L2, index replicated, reference-faithful M1", nq),
+           "value": nq * n_sub * rk.world / max(times), "unit": "queries/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": max(times) / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (ADC sums over u8 codes; float32 rerank rows)" if c3 else "f32", "data": "synthetic",
+           "config": {"workload": "%s-shaped synthetic (BASELINE configs[%d]): N=%d d=%d unit-norm mixture (4096 clusters), R=%d, PQ m=%d, %s L=%d beam_width=%s, k=%d, "
+                                  "batch=%d queries; a step = %d batches; host memory -> host memory (dr_search_submit/wait, %d submits in flight, %.0f queries per launch); "
+                                  "index built on the device (dr_build_vamana L_build=%d); full size = %d points"
+                                  % (args.config, 2 if c3 else 3, n, D, R, m, "DR_MODE_PQB | DR_F_RERANK" if c3 else "DR_MODE_M1 (reference-faithful)", args.L, args.bw or None, k, nq, bps, depth, qpl,
+                                     args.L_build, 10_000_000 if c3 else 100_000_000),
+                      "recall_at_10": float(np.mean(recalls)), "build_seconds": build_s, "pq_seconds": pq_s, "parallelism": "query-sharded replicas x%d" % rk.world,
+                      "per_rank_seconds": times, "queries_per_launch": qpl, "kernel_ms_per_launch": k_ms, "kernel_ms_per_10k_queries": k_ms * 10000.0 / qpl,
+                      "table_kernel_ms_per_launch": float(tm["lut_kernel_ms"]),
+                      "per_query": {"expansions": float(S.mean()), "code_words_scored": float(V.mean()), "full_precision_rows_scored": float(X.mean()),
+                                    "algorithmic_bytes": float(per_q.mean())},
+                      "launch": {k_: tm[k_] for k_ in ("variant", "grid", "block", "lds_bytes", "waves_per_cu")},
+                      "pq_rerank": pq_rerank},
+           "roofline": {"bound": "hbm", "kernel": ("pqb_search_kernel (DR_MODE_PQB traversal; the rerank pass is its own kernel)" if c3 else "search_kernel<96,M1> variant %d" % tm["variant"]),
+                        "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                        "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_search_launch, "queries_per_launch": qpl,
+                        "whole_call_algorithmic_bytes_per_launch": alg_launch,
+                        "note": "algorithmic bytes = SURVEY 8d's B_q from the engine's per-query counters x the queries of a launch; these traversals are bound by "
+                                "instruction issue and dependent LDS / memory round trips at 8-12 wavefronts per CU, not by HBM bytes (DESIGN.md 4.5)"}}
+    if want_cpu:
+        from oracle import pyoracle as orc
+        cores = os.cpu_count() or 1
+        adj = ix.get_adjacency()
+        ns = min(args.cpu_sample, nq)
+        q0 = np.array(qb[0][:ns])
+        omode, oflags = (orc.PQB, orc.F_RERANK) if c3 else (orc.M1, 0)
+        t2 = time.perf_counter()
+        oids, odist, ocnt, ost = orc.search_batch(x, adj, q0, medoid, omode, k, L=args.L, bw=args.bw, flags=oflags, codes=codes, codebook=cb, nthreads=cores)
+        cpu_s = time.perf_counter() - t2
+        same = bool(np.array_equal(oids, outs[0][0][:ns]) and np.array_equal(odist.astype(np.float32).view(np.uint32), outs[0][1][:ns].view(np.uint32)))
+        out["cpu_baseline"] = {"value": ns / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
+                               "sample": "first %d of the bench queries, same index, oracle/ C restatement of the same mode on OpenMP threads; GPU results "
+                                         "bit-identical on the sample: %s" % (ns, same)}
+        if not same:
+            raise RuntimeError("GPU results differ from the oracle on the CPU-baseline sample")
+    if rk.rank == 0:
+        print(json.dumps(out), flush=True)
+    ix.close()
+    return 0
 
 # ------------------------------------------------------------------------------------------------ c5: graph-sharded
 def worker_c5(args, rk):

@@ -122,7 +122,7 @@ static int pqb_search_one(const orc_index *ix, const float *q, uint32_t k, uint3
     build_lut_f32(ix->codebook, q, m, D / m, lut);
     pqb_ent *list = (pqb_ent *)malloc(((size_t)L + (size_t)pops * R + 1) * sizeof(pqb_ent));
     size_t n = 0;
-    uint32_t steps = 0, nevals = 0, nexact = 0;
+    uint32_t steps = 0, nevals = 0, nexact = 0, ndup = 0;
     const uint64_t max_steps = (uint64_t)L * 10 < N ? (uint64_t)L * 10 : N;
 #define PQB_ADC(i, out) do { float s_ = 0.0f; const uint8_t *c_ = ix->codes + (size_t)(i) * m;             \
         for (uint32_t j_ = 0; j_ < m; j_++) s_ += lut[j_ * 256 + c_[j_]];                                  \
@@ -160,7 +160,7 @@ static int pqb_search_one(const orc_index *ix, const float *q, uint32_t k, uint3
                 if (full && !pqb_less(db, nb, worst.db, worst.id)) continue;
                 int dup = 0;
                 for (size_t u = 0; u < n_old + nc && !dup; u++) dup = (list[u].id == nb);
-                if (dup) continue;
+                if (dup) { ndup++; continue; }
                 list[n_old + nc].db = db; list[n_old + nc].id = nb; list[n_old + nc].live = 1; nc++;
             }
         }
@@ -183,6 +183,8 @@ static int pqb_search_one(const orc_index *ix, const float *q, uint32_t k, uint3
     for (uint32_t i = cnt; i < k; i++) { out_ids[i] = ORC_PAD; out_dist[i] = NAN; }
     *out_count = cnt;
     if (stats) { stats[0] = steps; stats[1] = nevals; stats[2] = nexact; stats[3] = nevals; }
+    /* diagnostic (scripts/exp_pqb_revisits.py): how many scored slots were nodes that sat IN the list at that moment */
+    if (stats && getenv("ORC_PQB_DIAG") && !(flags & ORC_F_RERANK)) stats[2] = ndup;
     free(lut); free(list); free(popped);
     return 0;
 }
