@@ -928,7 +928,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         const int nc = passes <= 1 ? 1 : passes <= 2 ? 2 : 4;
         int treg_pref = -1;
         if (const char *e = getenv("DR_PQB_TREG")) treg_pref = atoi(e);       // A/B: table rows held in registers
-        pqc = dr_pqb_choose(sc, nc, ix->m, treg_pref);
+        // steps of several passes: the visited filter + compaction (pqb_kernel.hpp VF); DR_PQB_NO_FILTER=1 switches it off (A/B; same results)
+        const bool no_vf = getenv("DR_PQB_NO_FILTER") != nullptr;       // (read per call: the tests run both forms in one process)
+        pqc = dr_pqb_choose(sc, nc, ix->m, treg_pref, !no_vf);
         if (!pqc.fn) return fail(DR_E_UNSUPPORTED, "DR_MODE_PQB: no kernel for m=%u, capacity %u", ix->m, cap);
         kind = 20;
     }
@@ -976,7 +978,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // there the visited words are tens of GB of random-access footprint. DR_BUILD_PQ_NO_VISITED_SET=0 / 1 overrides the size rule.
     bool build_novis = ix->N >= (1ull << 25);
     { const char *e = getenv("DR_BUILD_PQ_NO_VISITED_SET"); if (e) build_novis = e[0] == '1'; }
-    const bool novis = (!ov && mode == DR_MODE_PQ && (flags & DR_F_NO_VISITED_SET) != 0) || pqb || (ov && ov->sdc && build_novis);
+    const bool novis = (!ov && mode == DR_MODE_PQ && (flags & DR_F_NO_VISITED_SET) != 0) || (pqb && !pqc.vf) || (ov && ov->sdc && build_novis);
     if (!novis && ((size_t)slots * vis_words > vis.n || slots > vis_epoch.n)) {
         // (re)allocation: fresh words and stamps -- queued launches still use the old buffers
         if (vis.p) HIPCHK(hipStreamSynchronize(st));
@@ -1002,7 +1004,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
 
     SearchParams p;
     memset(&p, 0, sizeof p);
-    if (!ov && !novis && !ix->adjr_valid) { const int rcb = build_bit_order(ix); if (rcb) return rcb; }
+    if (!ov && !novis && !pqb && !ix->adjr_valid) { const int rcb = build_bit_order(ix); if (rcb) return rcb; }      // (DR_MODE_PQB's filter is indexed by id)
     if (!ov && ix->inline_codes && !ix->nbcodes_valid && ix->codes.p && (mode == DR_MODE_M1 || pq_only)) { const int rci = build_inline_codes(ix); if (rci) return rci; }
     p.vecp = ix->vecp.p; p.adj = ix->adj.p; p.first = ix->first.p; p.codes = ix->codes.p; p.codebook = ix->codebook.p;
     p.adjr = (!ov && !novis && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
@@ -1092,6 +1094,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         pp.counter = p.counter; pp.ticket_base = p.ticket_base;
         pp.res_keys = p.res_keys; pp.res_n = p.res_n; pp.stats = p.stats; pp.out_ids = p.out_ids; pp.out_dist = p.out_dist; pp.out_count = p.out_count;
         pp.phase = p.phase;
+        pp.vis = p.vis; pp.vis_words = p.vis_words; pp.vis_epoch = p.vis_epoch;
     }
     void *args[] = { pqb ? (void *)&pp : (void *)&p };
     if (!ov) { ix->kev_lut[ix->kev_pending] = want_lut; HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][0], st)); }

@@ -48,6 +48,9 @@ struct PqbParams {
     u32 *out_ids;            // [nq][k]
     float *out_dist;         // [nq][k]
     u32 *out_count;
+    u32 *vis;                // VF kernels: [slots][vis_words] the visited FILTER: words of 24 id bits + an 8-bit query stamp (as search_kernel's)
+    u32 vis_words;           // ceil(N / 24), rounded up to a multiple of 4
+    u32 *vis_epoch;          // [slots] stamp of the last query each slot served
     u64 *phase;              // [nq][8] cycle sums (DR_PHASE_TIMING builds only): 0 table landing, 1 pop, 2 rows, 3 code words, 4 ADC,
                              // 5 candidates, 6 merge + trim, 7 output
 };
@@ -137,7 +140,14 @@ static inline size_t pqb_lds_bytes(uint32_t m, int treg, int nchr, int nc)
     return (size_t)(m - (uint32_t)treg) * 1024 + (size_t)nchr * 512 + (size_t)nchr * 256 + ((size_t)nc * 64 + 4) * 8 + 64;
 }
 
-template <int NCHR, int NC, int M16, int TREG>
+// VF    visited FILTER + compaction (steps of several 64-lane passes). Before their code words are fetched, the step's neighbour ids are
+//       tested against a per-slot bitmap of the nodes this query has scored (a node scored before can never enter the list again: it is in
+//       it, or was rejected or evicted at a largest key >= today's -- skipping it changes nothing), the survivors are compacted, and only
+//       ceil(survivors / 64) passes fetch code words and run the ADC -- at 10M points without a frontier trim three of four slots are
+//       repeats. The bitmap is a FILTER, not the authority: test and set are a plain load and a plain store, lanes of one instruction that
+//       share a word lose each other's bits, and a lost bit only means the node is scored again and then found in the list. Results, steps
+//       and accepted inserts are those of the kernel without it; stats.visited / stats.pq count the code words really scored.
+template <int NCHR, int NC, int M16, int TREG, bool VF = false>
 // (wavefronts per SIMD the registers must allow: 3 with 24 of 32 rows in registers -- 8 KiB of LDS per wavefront, 12 per CU --; 4 for the
 // small table of m = 16 with half of it in registers)
 __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 : 2) void pqb_search_kernel(const PqbParams p)
@@ -156,6 +166,9 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
     const int cap = (int)p.cap;
     const u32 nwords = (p.R + 63) / 64;
     const u32 rs_mask = (1u << p.rs_shift) - 1u;
+    u32 *vbm = VF ? p.vis + (size_t)slot_id * p.vis_words : nullptr;
+    u32 vstamp = VF ? (u32)__builtin_amdgcn_readfirstlane((int)p.vis_epoch[slot_id]) : 0u;
+    u32 *nbuf = reinterpret_cast<u32 *>(cbuf);       // [NC*64] the step's unseen neighbour ids, compacted (VF; cbuf is not in use yet at that point)
     // code words decoded together in the ADC: two (8 lookups in flight) when one pass per step leaves the registers for it
 #ifdef PQB_FORCE_GW
     constexpr int GW = PQB_FORCE_GW;       // A/B builds
@@ -184,6 +197,16 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
             WSYNC();
         }
         PH(0);
+        if constexpr (VF) {         // next stamp; after 255 queries the slot's words are wiped and the count restarts (search_kernel.hpp)
+            if (vstamp >= 255u) {
+                uint4 *vb4 = reinterpret_cast<uint4 *>(vbm);
+                for (u32 i = lane; i < p.vis_words / 4; i += 64) vb4[i] = make_uint4(0, 0, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                vstamp = 0u;
+            }
+            vstamp++;
+        }
+        const u32 vtag = vstamp << 24;
         RegList<NCHR> rk;           // keys in registers: distance bits << 32 | id << 1 (state bit clear; ~0 = unused)
         u64 live[NCHR];             // live entries, one bit per list position (wave-uniform: scalar registers)
 #pragma unroll
@@ -239,14 +262,44 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
                 }
             }
             PH(2);
-            // code words (inline: beside the row, no dependency on the ids; else a gather behind them)
-            uint4 cw[NC][M16 > 0 ? M16 : 1];
             bool act[NC];
 #pragma unroll
+            for (int t = 0; t < NC; t++) act[t] = valid[t] && ((fw[t] >> (slot_[t] & 63u)) & 1ull) != 0ull;
+            int n_new = NC * 64;
+            if constexpr (VF) {
+                // the filter: one word per 24 ids, stamped by the query that wrote it (a word of another stamp reads as empty)
+                int base = 0;
+#pragma unroll
+                for (int t = 0; t < NC; t++) {
+                    const u32 id = nid[t];
+                    const u32 vw = __umulhi(id, 0xAAAAAAABu) >> 4;          // id / 24
+                    const u32 vbit = 1u << (id - vw * 24u);
+                    u32 w = 0u;
+                    if (act[t]) w = __hip_atomic_load(&vbm[vw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (served by the L2, never by a stale L1 line)
+                    const u32 old = ((w >> 24) == vstamp) ? (w & 0x00FFFFFFu) : 0u;
+                    const bool isnew = act[t] && (old & vbit) == 0u;
+                    if (isnew) vbm[vw] = vtag | old | vbit;
+                    const u64 nm = __ballot(isnew);
+                    if (isnew) nbuf[base + __popcll(nm & lanemask_lt())] = id;
+                    base += __popcll(nm);
+                }
+                n_new = base;
+                WSYNC();
+#pragma unroll
+                for (int t = 0; t < NC; t++) {
+                    const int idx = t * 64 + lane;
+                    act[t] = idx < n_new;
+                    nid[t] = act[t] ? nbuf[idx] : 0u;
+                }
+                WSYNC();        // (nbuf aliases cbuf: read before the candidates are compacted into it)
+            }
+            // code words (inline: beside the row, no dependency on the ids; else a gather behind them)
+            uint4 cw[NC][M16 > 0 ? M16 : 1];
+#pragma unroll
             for (int t = 0; t < NC; t++) {
-                act[t] = valid[t] && ((fw[t] >> (slot_[t] & 63u)) & 1ull) != 0ull;
+                if (VF && t * 64 >= n_new && t > 0) continue;       // (compacted: the passes behind the last unseen neighbour are empty)
                 if constexpr (M16 > 0) {
-                    const u8 *code = (p.nbcodes && !seed) ? p.nbcodes + ((size_t)cur_[t] * p.R + slot_[t]) * p.m : p.codes + (size_t)(act[t] ? nid[t] : 0u) * p.m;
+                    const u8 *code = (!VF && p.nbcodes && !seed) ? p.nbcodes + ((size_t)cur_[t] * p.R + slot_[t]) * p.m : p.codes + (size_t)(act[t] ? nid[t] : 0u) * p.m;
 #pragma unroll
                     for (int w = 0; w < M16; w++) cw[t][w] = reinterpret_cast<const uint4 *>(code)[w];
                 }
@@ -258,10 +311,11 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
             u64 anyc = 0ull;
 #pragma unroll
             for (int t = 0; t < NC; t++) {
+                if (VF && t * 64 >= n_new && t > 0) { key[t] = ~0ull; cm[t] = 0ull; continue; }
                 float e;
                 if constexpr (M16 > 0) e = pqb_adc<M16, TREG, GW>(lut, tv, cw[t]);
                 else {
-                    const u8 *code = (p.nbcodes && !seed) ? p.nbcodes + ((size_t)cur_[t] * p.R + slot_[t]) * p.m : p.codes + (size_t)(act[t] ? nid[t] : 0u) * p.m;
+                    const u8 *code = (!VF && p.nbcodes && !seed) ? p.nbcodes + ((size_t)cur_[t] * p.R + slot_[t]) * p.m : p.codes + (size_t)(act[t] ? nid[t] : 0u) * p.m;
                     e = pqb_adc_generic(lut, code, p.m);
                 }
                 key[t] = ((u64)__float_as_uint(e) << 32) | ((u64)nid[t] << 1);
@@ -440,4 +494,5 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
             qi = (u32)__builtin_amdgcn_readfirstlane((int)t) - p.ticket_base + nslots;
         }
     }
+    if constexpr (VF) { if (lane == 0) p.vis_epoch[slot_id] = vstamp; }
 }

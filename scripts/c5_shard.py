@@ -196,19 +196,24 @@ for gi, (R, LB) in enumerate(CFG):
         for g in grid.split(","):
             parts = g.split(":")
             L, bw = int(parts[0]), int(parts[1])
-            nv = len(parts) > 2 and parts[2] == "nv"          # "L:bw:nv": the same run without a visited set (DR_F_NO_VISITED_SET, round 4)
-            pre = len(parts) > 3 and parts[3] == "pre"        # "L:bw:nv:pre": ... with the next row's ids prefetched into LDS (DR_PQ_ROW_PREFETCH)
+            nv = "nv" in parts[2:]                            # "L:bw:nv": the same run without a visited set (DR_F_NO_VISITED_SET, round 4)
+            pre = "pre" in parts[2:]                          # "...:pre": ... with the next row's ids prefetched into LDS (DR_PQ_ROW_PREFETCH)
+            pqb = [p_ for p_ in parts[2:] if p_.startswith("pqb")]      # "L:bw:pqb" / "pqb2": DR_MODE_PQB (round 5), default / 2 pops per step
             if pre: os.environ["DR_PQ_ROW_PREFETCH"] = "1"
             else: os.environ.pop("DR_PQ_ROW_PREFETCH", None)
-            run(f"{G}/PQ_L{L}_bw{bw or 'None'}" + ("_no_visited_set" if nv else "") + ("_next_row_prefetch" if pre else ""), L=L, beam_width=bw,
-                mode=_ffi.MODE_PQ, flags=_ffi.F_NO_VISITED_SET if nv else 0)
+            if pqb:
+                pops = int(pqb[0][3:] or 0)
+                kwm = dict(mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(pops))
+                tag0 = f"{G}/PQB_L{L}_bw{bw or 'None'}" + (f"_pops{pops}" if pops else "")
+            else:
+                kwm = dict(mode=_ffi.MODE_PQ, flags=_ffi.F_NO_VISITED_SET if nv else 0)
+                tag0 = f"{G}/PQ_L{L}_bw{bw or 'None'}" + ("_no_visited_set" if nv else "") + ("_next_row_prefetch" if pre else "")
+            run(tag0, L=L, beam_width=bw, **kwm)
             if parts[-1] == "xch":                            # "...:xch": the same point through the graph-sharded path, 1 and 3 submits per exchange
                 for grp in (1, 3):
-                    run_exchange(f"{G}/PQ_L{L}_bw{bw or 'None'}" + ("_no_visited_set" if nv else "") + "_sharded_path_%d_per_exchange" % grp, group=grp, L=L,
-                                 beam_width=bw, mode=_ffi.MODE_PQ, flags=_ffi.F_NO_VISITED_SET if nv else 0)
+                    run_exchange(tag0 + "_sharded_path_%d_per_exchange" % grp, group=grp, L=L, beam_width=bw, **kwm)
             if parts[-1] == "stream":                         # "...:stream": the same point again as a host -> host stream with shared launches
-                run_stream(f"{G}/PQ_L{L}_bw{bw or 'None'}" + ("_no_visited_set" if nv else "") + "_stream_shared_launches", L=L, beam_width=bw,
-                           mode=_ffi.MODE_PQ, flags=_ffi.F_NO_VISITED_SET if nv else 0)
+                run_stream(tag0 + "_stream_shared_launches", L=L, beam_width=bw, **kwm)
         continue
     for L in (100, 200, 400, 800):
         for bw in (8, 0):
