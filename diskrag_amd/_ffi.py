@@ -18,6 +18,7 @@ MAX_TICKETS = 128        # DR_MAX_TICKETS (include/diskrag_hip.h): dr_search_sub
 MODE_PQ = 5      # engine mode without a reference counterpart: M1's loop on squared ADC distances only (diskrag_hip.h)
 MODE_PQB = 6     # the engine's PQ-only traversal as a batch per step on a total (distance, id) order (diskrag_hip.h DR_MODE_PQB; round 5)
 F_USE_PQ, F_SQDIST, F_RERANK, F_COSINE, F_NO_VISITED_SET = 1, 2, 4, 8, 16
+F_IP = 32        # with F_RERANK: inner-product metric on unit-norm data (out_dist = 1 - <q, v>; DR_F_IP)
 
 
 def F_POPS(n):

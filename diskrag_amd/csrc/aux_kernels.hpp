@@ -31,8 +31,9 @@ template <int D> __global__ __launch_bounds__(64) void exact_kernel(const float 
 // k best in (distance, id) order. One wavefront per query, 8 stored vectors per pass; ranks by counting in LDS.
 template <int D> __global__ __launch_bounds__(64) void rerank_kernel(const float *__restrict__ vecp,
         const float *__restrict__ queries_p, u32 nq, const u64 *__restrict__ res_keys, const u32 *__restrict__ res_n, u32 cap,
-        u32 k, u32 *__restrict__ out_ids, float *__restrict__ out_dist, u32 *__restrict__ out_count, KStats *__restrict__ stats)
+        u32 k, u32 *__restrict__ out_ids, float *__restrict__ out_dist, u32 *__restrict__ out_count, KStats *__restrict__ stats, u32 ip)
 {
+    // ip (DR_F_IP): unit-norm data, out_dist = |q - v|^2 / 2 = 1 - <q, v>; a query whose squared norm is not 1 (+- 1e-3) gets NaN + status bit 4
     constexpr bool QREG = (D <= 256);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *qperm = reinterpret_cast<float *>(smem);
@@ -55,14 +56,25 @@ template <int D> __global__ __launch_bounds__(64) void rerank_kernel(const float
         }
         WSYNC();
         const u32 kout = min(k, n);
+        bool q_unit = true;
+        if (ip) {
+            double s2 = 0.0;
+            for (int i = lane; i < D; i += 64) s2 += (double)qpg[i] * (double)qpg[i];      // (a permutation of the query: the same sum)
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
+            q_unit = s2 > 1.0 - 1e-3 && s2 < 1.0 + 1e-3;
+        }
         for (u32 i = lane; i < n; i += 64) {
             const u64 mine = keys[i];
             u32 r = 0;
             for (u32 t = 0; t < n; t++) r += (keys[t] < mine) ? 1u : 0u;        // ids are distinct: a total order
-            if (r < kout) { out_ids[(size_t)q * k + r] = (u32)mine; out_dist[(size_t)q * k + r] = key_dist(mine); }
+            if (r < kout) {
+                out_ids[(size_t)q * k + r] = (u32)mine;
+                out_dist[(size_t)q * k + r] = !ip ? key_dist(mine) : q_unit ? f_mul(key_dist(mine), 0.5f) : __uint_as_float(0x7FC00000u);
+            }
         }
         for (u32 i = kout + lane; i < k; i += 64) { out_ids[(size_t)q * k + i] = 0xFFFFFFFFu; out_dist[(size_t)q * k + i] = __uint_as_float(0x7FC00000u); }
-        if (lane == 0) { out_count[q] = kout; stats[q].exact += n; }
+        if (lane == 0) { out_count[q] = kout; stats[q].exact += n; if (!q_unit) stats[q].status |= 16u; }
     }
 }
 

@@ -279,11 +279,13 @@ struct dr_index {
     DevBuf<uint32_t> fin_stat;    // [1] largest tie-list length since the last sync (finalize_kernel)
     std::map<std::pair<const void *, size_t>, int> occ_cache;
     void *pinned = nullptr; size_t pinned_bytes = 0;      // host slab for result downloads
+    void *pin_q = nullptr; size_t pin_q_bytes = 0;        // page-locked staging of a blocking call's pageable query batch
     bool h2d_pending = false;
     DevBuf<double> f64_q, f64_dist;                 // dr_search_batch_f64 scratch
     DevBuf<uint32_t> f64_ids, f64_cnt, f64_vis;
     DevBuf<KStats> f64_stats;
     uint32_t fin_hint = 0;        // tie-list length to size the tie-order launches for (0: not known yet -> full grid)
+    float unit_norm_dev = -1.0f;  // largest | |v|^2 - 1 | over the stored vectors (DR_F_IP), -1 = not measured (reset when rows are written)
     int adc_live = -1;            // M1 on this index: does the rerank policy A4 really consult the ADC? -1 = not measured yet
     DevBuf<u64> phase;
     uint32_t last_k = 0;
@@ -529,6 +531,7 @@ extern "C" void dr_index_close(dr_index *ix)
     ix->phase.release(); ix->vnorm2.release(); ix->rank.release(); ix->adjr.release(); ix->fin_stat.release(); ix->vec8.release();
     ix->f64_q.release(); ix->f64_dist.release(); ix->f64_ids.release(); ix->f64_cnt.release(); ix->f64_vis.release(); ix->f64_stats.release();
     if (ix->pinned) (void)hipHostFree(ix->pinned);
+    if (ix->pin_q) (void)hipHostFree(ix->pin_q);
     delete ix->shs;
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
     for (auto &pr : ix->kev) for (auto &e : pr) if (e) (void)hipEventDestroy(e);
@@ -562,12 +565,34 @@ static int upload_slot_async(dr_index *ix, QSlot &qs, const float *src, uint32_t
     return 0;
 }
 
+extern "C" bool dr_host_stage_u8(float *dst, const float *q, size_t n, bool want_check);
+static int pin_reserve(void **p, size_t *have, size_t need);
+
 static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq, bool wait = true)
 {
     if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
     HIPCHK(hipSetDevice(ix->device));
+    const bool want_u8 = (ix->vec8_state == 1 || (ix->vec8_state == 0 && ix->D == 128));
+    // A blocking call from PAGEABLE memory (dr_search_batch, wait == false): the batch is staged into the handle's page-locked buffer here --
+    // one pass that also answers "are all components bytes?" -- and the copy engine takes it from there while the call goes on queueing
+    // its kernels (the runtime's own staging of a pageable source blocks the calling thread for the whole copy, and the byte check
+    // was a second pass over the batch: 0.16 ms per 10 000 x 128 queries).
+    bool staged = false, staged_u8 = false;
+    if (!wait) {
+        hipPointerAttribute_t at;
+        const bool pinned = hipPointerGetAttributes(&at, queries) == hipSuccess && (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice);
+        (void)hipGetLastError();
+        if (!pinned) {
+            const size_t bytes = (size_t)nq * ix->D * 4;
+            // (the previous call's copy out of this buffer has completed: every blocking call ends with a synchronised download)
+            const int rcp = pin_reserve(&ix->pin_q, &ix->pin_q_bytes, bytes);
+            if (rcp) return rcp;
+            staged_u8 = dr_host_stage_u8(static_cast<float *>(ix->pin_q), queries, (size_t)nq * ix->D, want_u8);
+            staged = true;
+        }
+    }
     HIPCHK(hipEventRecord(ix->ev[0], ix->stream));
-    const int rc = upload_slot_async(ix, *ix->cs, queries, nq, ix->stream);
+    const int rc = upload_slot_async(ix, *ix->cs, staged ? static_cast<const float *>(ix->pin_q) : queries, nq, ix->stream);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
     // dr_search_batch does not wait here: what consumes the queries is queued behind them on the same stream and the call
@@ -576,7 +601,7 @@ static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq
     if (wait) HIPCHK(hipStreamSynchronize(ix->stream));
     ix->h2d_pending = true;
     // byte queries? (only asked when byte rows exist)
-    ix->cs->q_u8 = (ix->vec8_state == 1 || (ix->vec8_state == 0 && ix->D == 128)) && queries_are_u8(queries, (size_t)nq * ix->D);
+    ix->cs->q_u8 = staged ? staged_u8 : (want_u8 && queries_are_u8(queries, (size_t)nq * ix->D));
     return 0;
 }
 
@@ -840,8 +865,24 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     const bool pq_only = (mode == DR_MODE_M3 && (flags & DR_F_USE_PQ)) || mode == DR_MODE_PQ || pqb || (ov && ov->sdc);   // ADC-only traversals
     const bool rerank = (mode == DR_MODE_PQ || pqb) && (flags & DR_F_RERANK);
     const bool use_pq = (mode == DR_MODE_M1) || pq_only;
+    if ((flags & DR_F_IP) && !rerank) return fail(DR_E_ARG, "DR_F_IP goes with DR_F_RERANK (DR_MODE_PQ / DR_MODE_PQB)");
     if (use_pq && ix->m == 0) return fail(DR_E_NOPQ, "mode %u needs PQ data (dr_index_set_pq)", mode);
     if (!pq_only || rerank) { const int rcv = need_vectors(ix, rerank ? "DR_F_RERANK" : "this search mode"); if (rcv) return rcv; }
+    if (flags & DR_F_IP) {
+        // the inner-product reading of the rerank is only defined on unit-norm rows: measured once per index (largest | |v|^2 - 1 |)
+        if (ix->unit_norm_dev < 0.0f) {
+            HIPCHK(hipSetDevice(ix->device));
+            DevBuf<uint32_t> mx;
+            if (mx.reserve(1, true)) return DR_E_NODEVICE;
+            hipLaunchKernelGGL(unit_norm_dev_kernel, dim3((unsigned)std::min<uint64_t>((ix->N + 255) / 256, 1u << 16)), dim3(256), 0, ix->stream, ix->vecp.p, ix->N, ix->D, mx.p);
+            HIPCHK(hipGetLastError());
+            uint32_t hb = 0;
+            HIPCHK(hipMemcpyAsync(&hb, mx.p, 4, hipMemcpyDeviceToHost, ix->stream));
+            HIPCHK(hipStreamSynchronize(ix->stream));
+            memcpy(&ix->unit_norm_dev, &hb, 4);
+        }
+        if (!(ix->unit_norm_dev <= 1e-3f)) return fail(DR_E_UNSUPPORTED, "DR_F_IP needs unit-norm stored vectors: a squared norm differs from 1 by %g", (double)ix->unit_norm_dev);
+    }
     // result-list capacity: M1/M4 (and the engine's PQ mode) L, M2 beam_width, M3 k (search_engine.py:468-474;
     // vamana_graph.py:746-750, :586-590)
     const uint32_t cap = (mode == DR_MODE_M2) ? bw : (mode == DR_MODE_M3) ? k : L;
@@ -928,9 +969,12 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         const int nc = passes <= 1 ? 1 : passes <= 2 ? 2 : 4;
         int treg_pref = -1;
         if (const char *e = getenv("DR_PQB_TREG")) treg_pref = atoi(e);       // A/B: table rows held in registers
-        // steps of several passes: the visited filter + compaction (pqb_kernel.hpp VF); DR_PQB_NO_FILTER=1 switches it off (A/B; same results)
-        const bool no_vf = getenv("DR_PQB_NO_FILTER") != nullptr;       // (read per call: the tests run both forms in one process)
-        pqc = dr_pqb_choose(sc, nc, ix->m, treg_pref, !no_vf);
+        // steps of several passes CAN run the visited filter + compaction (pqb_kernel.hpp VF; DR_PQB_FILTER=1). Off by default: it scores the
+        // distinct nodes only (c3 1M, L = 250 no trim: 6 239 instead of 14 279 code words per query, c5-shaped R = 128 rows: 2 969 instead of
+        // 7 091) and is 10-30 % SLOWER (profiles/r05/ab/ab_pqb_*_v4.jsonl) -- its third dependent memory round trip per step costs more than
+        // the ADC passes it saves, as round 4 found for DR_MODE_PQ's visited set. Same results either way.
+        const bool want_vf = getenv("DR_PQB_FILTER") != nullptr;        // (read per call: the tests run both forms in one process)
+        pqc = dr_pqb_choose(sc, nc, ix->m, treg_pref, want_vf);
         if (!pqc.fn) return fail(DR_E_UNSUPPORTED, "DR_MODE_PQB: no kernel for m=%u, capacity %u", ix->m, cap);
         kind = 20;
     }
@@ -1110,7 +1154,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         const float *vecp = ix->vecp.p; const float *qpp = ix->cs->qp.p; const u64 *rkp = bs.res_keys.p; const uint32_t *rnp = bs.res_n.p;
         uint32_t capv = cap, kv = k, nqv = nq; uint32_t *oi = bs.out_ids.p; float *od = bs.out_dist.p; uint32_t *oc = bs.out_count.p;
         KStats *stp = bs.stats.p;
-        void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp };
+        uint32_t ipv = (flags & DR_F_IP) ? 1u : 0u;
+        void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp, &ipv };
         const size_t rlds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)cap * 8;
         HIPCHK(hipLaunchKernel(ix->kern->rerank, dim3(std::min<uint32_t>(nq, (uint32_t)ix->num_cu * 16)), dim3(64), rargs, rlds, st));
     }

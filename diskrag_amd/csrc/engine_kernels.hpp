@@ -901,6 +901,20 @@ __global__ void row_norm2_kernel(const float *__restrict__ vecp, u64 N, u32 D, f
     }
 }
 
+// largest | |v|^2 - 1 | over the stored vectors, as the bits of a non-negative float (atomicMax on the bits orders like the values): DR_F_IP
+__global__ void unit_norm_dev_kernel(const float *__restrict__ vecp, u64 N, u32 D, u32 *__restrict__ out_bits)
+{
+    float worst = 0.0f;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        const float *r = vecp + i * D;
+        for (u32 t = 0; t < D; t++) s += (double)r[t] * (double)r[t];
+        const float dev = (float)__builtin_fabs(s - 1.0);
+        worst = dev > worst ? dev : (dev == dev ? worst : __builtin_inff());
+    }
+    atomicMax(out_bits, __float_as_uint(worst));
+}
+
 // The same bound with one LANE per (query, sub-quantiser): wavefront (q-tile, j) holds 64 queries' sub-vectors of j in
 // registers and walks j's 256 centroids, which are the same for every lane -- scalar loads, SGPR operands, no LDS, no
 // barriers -- keeping max_c T[j][c] per lane; pq_bound_sum_kernel then adds the m maxima of a query in A3's order. A batch

@@ -57,3 +57,34 @@ extern "C" bool dr_host_all_u8(const float *q, size_t n)
 #endif
     return all_u8_portable(q, n);
 }
+
+// dr_host_stage_u8: the staging copy of a pageable query batch into page-locked memory AND the byte check, in one pass over the batch
+// (a blocking dr_search_batch used to pay for both: the runtime's own staged copy, then 0.16 ms of scanning per 10 000 x 128 queries).
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static bool stage_u8_avx2(float *dst, const float *q, size_t n)
+{
+    const __m256 lo = _mm256_set1_ps(0.0f), hi = _mm256_set1_ps(255.0f);
+    const __m256 ones = _mm256_castsi256_ps(_mm256_set1_epi32(-1));
+    __m256 bad = _mm256_setzero_ps();
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const __m256 v = _mm256_loadu_ps(q + i);
+        _mm256_storeu_ps(dst + i, v);
+        const __m256 r = _mm256_round_ps(v, _MM_FROUND_TO_ZERO | _MM_FROUND_NO_EXC);
+        const __m256 ok = _mm256_and_ps(_mm256_and_ps(_mm256_cmp_ps(v, lo, _CMP_GE_OQ), _mm256_cmp_ps(v, hi, _CMP_LE_OQ)), _mm256_cmp_ps(r, v, _CMP_EQ_OQ));
+        bad = _mm256_or_ps(bad, _mm256_andnot_ps(ok, ones));
+    }
+    bool okall = _mm256_movemask_ps(bad) == 0;
+    for (; i < n; i++) dst[i] = q[i];
+    return okall && all_u8_portable(q + (n & ~(size_t)7), n & 7);
+}
+#endif
+extern "C" bool dr_host_stage_u8(float *dst, const float *q, size_t n, bool want_check)
+{
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2 && want_check) return stage_u8_avx2(dst, q, n);
+#endif
+    for (size_t i = 0; i < n; i++) dst[i] = q[i];
+    return want_check ? all_u8_portable(q, n) : false;
+}

@@ -59,6 +59,12 @@ extern "C" {
                                  * no visited words (N/6 bytes per wavefront slot: 42 GB on a 1.25e8-point shard) and a third of the HBM
                                  * traffic, but nodes that left the list are scored again: stats.visited / stats.pq count EVALUATIONS
                                  * (1.7x with beam_width 8, 3x without trim -- measured slower there, profiles/r04/ab/). Off by default. */
+#define DR_F_IP 32u /* with DR_F_RERANK (DR_MODE_PQ / DR_MODE_PQB): the INNER-PRODUCT metric of BASELINE configs c3 / c5 on unit-norm data. The reference
+                       has no inner product (vamana_graph.py:294-299: 'l2' and 'cosine' only), so nothing is bit-compared: for unit vectors
+                       1 - <q, v> = |q - v|^2 / 2 (SURVEY.md 8d's equivalence), the rerank orders by the exact squared L2 (A1) as always, and
+                       out_dist = that distance x 0.5 (exact in float32) = 1 - <q, v>. Refused with DR_E_UNSUPPORTED when a stored vector's
+                       squared norm differs from 1 by more than 1e-3 (checked once per index); a QUERY whose squared norm does is answered
+                       with NaN distances and dr_stats.status bit 4 (16). */
 #define DR_F_POPS_SHIFT 8u
 #define DR_F_POPS_MASK 0xF00u
 #define DR_F_POPS(n) (((uint32_t)(n) & 15u) << DR_F_POPS_SHIFT) /* DR_MODE_PQB: frontier entries expanded per step (DiskANN's beam): narrow rows
@@ -87,7 +93,8 @@ typedef struct {
     uint32_t visited; /* nodes_visited = len(visited) */
     uint32_t exact;   /* exact_distance_computations */
     uint32_t pq;      /* pq_distance_computations */
-    uint32_t status;  /* 0 ok; bit0 visited-set overflow, bit1 frontier overflow, bit2 insert-log overflow */
+    uint32_t status;  /* 0 ok; bit0 visited-set overflow, bit1 frontier overflow, bit2 insert-log overflow, bit3 internal guard, bit4 (DR_F_IP) the
+                         query is not unit-norm */
     uint32_t inserts; /* accepted result-list inserts (engine counter, not in the reference) */
     uint32_t pq_evaluated; /* ADC sums actually computed: `pq` minus those whose outcome (rerank policy True) was
                               proven from a per-query upper bound without reading the code words (engine counter) */

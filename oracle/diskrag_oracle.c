@@ -50,6 +50,7 @@
 #define ORC_F_RERANK 16u  /* ORC_PQ: exact squared L2 (A1) of the final list, (distance, id) order */
 #define ORC_F_NO_VISITED_SET 64u /* ORC_PQ: the statement without a visited set (engine flag DR_F_NO_VISITED_SET): same ids and distances; the counters count evaluations */
 #define ORC_F_COSINE 32u  /* M3 without PQ: distance_metric='cosine' (cosine_similarity_cython, cython_utils.pyx:53-70) */
+#define ORC_F_IP 128u      /* with ORC_F_RERANK: engine flag DR_F_IP -- unit-norm data, the returned distance is |q - v|^2 / 2 = 1 - <q, v> (no reference counterpart) */
 #define ORC_F_POPS_SHIFT 8u /* ORC_PQB: bits 8..11 = frontier entries expanded per step (0 = 1), engine flag DR_F_POPS(n) */
 #define ORC_F_PAIRWISE 8u  /* squared-L2 modes: use the numpy pairwise order (what the device computes) instead of the
                              sequential Cython loop, whose -ffast-math order is unpinned anyway */
@@ -179,7 +180,11 @@ static int pqb_search_one(const orc_index *ix, const float *q, uint32_t k, uint3
         qsort(list, n, sizeof(pqb_ent), pqb_cmp);
     }
     const uint32_t cnt = (uint32_t)(n < k ? n : k);
-    for (uint32_t i = 0; i < cnt; i++) { float d; memcpy(&d, &list[i].db, 4); out_ids[i] = list[i].id; out_dist[i] = (double)d; }
+    for (uint32_t i = 0; i < cnt; i++) {
+        float d; memcpy(&d, &list[i].db, 4);
+        if ((flags & ORC_F_RERANK) && (flags & ORC_F_IP)) d = d * 0.5f;
+        out_ids[i] = list[i].id; out_dist[i] = (double)d;
+    }
     for (uint32_t i = cnt; i < k; i++) { out_ids[i] = ORC_PAD; out_dist[i] = NAN; }
     *out_count = cnt;
     if (stats) { stats[0] = steps; stats[1] = nevals; stats[2] = nexact; stats[3] = nevals; }

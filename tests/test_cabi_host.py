@@ -103,7 +103,7 @@ def test_python_constants_match_the_header():
     defs = {k: int(v.rstrip("u"), 0) for k, v in re.findall(r"^#define (DR_[A-Z0-9_]+) \(?(-?(?:0x)?[0-9A-Fa-f]+u?)\)?", hdr, flags=re.M)}
     want = {"DR_MODE_M1": _ffi.MODE_M1, "DR_MODE_M2": _ffi.MODE_M2, "DR_MODE_M3": _ffi.MODE_M3, "DR_MODE_M4": _ffi.MODE_M4,
             "DR_MODE_PQ": _ffi.MODE_PQ, "DR_MODE_PQB": _ffi.MODE_PQB, "DR_F_POPS_SHIFT": 8, "DR_F_POPS_MASK": _ffi.F_POPS(15), "DR_F_USE_PQ": _ffi.F_USE_PQ, "DR_F_SQDIST": _ffi.F_SQDIST, "DR_F_RERANK": _ffi.F_RERANK,
-            "DR_F_COSINE": _ffi.F_COSINE, "DR_F_NO_VISITED_SET": _ffi.F_NO_VISITED_SET, "DR_TIER_HBM": _ffi.TIER_HBM, "DR_TIER_HOST": _ffi.TIER_HOST,
+            "DR_F_COSINE": _ffi.F_COSINE, "DR_F_IP": _ffi.F_IP, "DR_F_NO_VISITED_SET": _ffi.F_NO_VISITED_SET, "DR_TIER_HBM": _ffi.TIER_HBM, "DR_TIER_HOST": _ffi.TIER_HOST,
             "DR_MAX_TICKETS": _ffi.MAX_TICKETS, "DR_E_REMOTE": _ffi.E_REMOTE}
     for name, val in want.items():
         assert defs[name] == val, name

@@ -20,7 +20,7 @@ def _filtered(R, pops):
     import os
     rs = 1 << int(np.ceil(np.log2(R)))
     p = pops if pops else max(1, 64 // rs)
-    return p * rs > 64 and not os.environ.get("DR_PQB_NO_FILTER")
+    return p * rs > 64 and bool(os.environ.get("DR_PQB_FILTER"))
 
 
 def _check(eng, g, k, L, bw, pops, flags=0, tag=None):
@@ -102,22 +102,22 @@ def test_pqb_table_layouts_return_the_same_bits(treg, monkeypatch):
 
 
 def test_pqb_with_and_without_the_visited_filter(monkeypatch):
-    """Steps of several passes with the filter + compaction (default) and without (DR_PQB_NO_FILTER=1): the same ids, distance bits, expansions
-    and accepted inserts; without it the counters are the restatement's exactly; with it fewer code words are scored."""
+    """Steps of several passes with the visited filter + compaction (DR_PQB_FILTER=1; measured slower, off by default) and without: the same ids,
+    distance bits, expansions and accepted inserts; without it the counters are the restatement's exactly; with it fewer code words are scored."""
     from diskrag_amd import _ffi
     for name, pops in (("sift128_R64_m32", 4), ("unit1536_R16_m32", 8), ("deep96_R32_m16", 4), ("randn128_R64_m16", 2)):
         g = load_golden(name)
         ix = get_index(name)
         for (L, bw, k) in ((100, 8, 10), (250, 0, 10), (40, 0, 10)):
-            monkeypatch.delenv("DR_PQB_NO_FILTER", raising=False)
+            monkeypatch.setenv("DR_PQB_FILTER", "1")
             _check(ix, g, k, L, bw, pops, tag=(name, "filter", L, bw))
             a = ix.search_batch(g.queries, k, L=L, beam_width=bw, mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(pops))
-            monkeypatch.setenv("DR_PQB_NO_FILTER", "1")
+            monkeypatch.delenv("DR_PQB_FILTER", raising=False)
             _check(ix, g, k, L, bw, pops, tag=(name, "no filter", L, bw))
             b = ix.search_batch(g.queries, k, L=L, beam_width=bw, mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(pops))
             assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[3]["inserts"], b[3]["inserts"])
             assert a[3]["pq"].sum() < b[3]["pq"].sum()
-    monkeypatch.delenv("DR_PQB_NO_FILTER", raising=False)
+    monkeypatch.delenv("DR_PQB_FILTER", raising=False)
 
 
 def test_pqb_through_the_pipelined_path():
@@ -145,3 +145,31 @@ def test_pqb_finds_what_the_sequential_traversal_finds():
             b = ix.search_batch(g.queries, 10, L=100, beam_width=8, mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(pops))[0]
             ov = np.mean([len(set(x) & set(y)) / 10 for x, y in zip(a, b)])
             assert ov >= 0.97, (name, pops, ov)
+
+
+def test_inner_product_flag_on_unit_norm_data():
+    """DR_F_IP (BASELINE c3 / c5 name the inner product; the reference has none, vamana_graph.py:294-299): with the exact rerank on unit-norm rows
+    the order is the squared-L2 order and out_dist = |q - v|^2 / 2 = 1 - <q, v>; refused on rows that are not unit-norm; a query that is not gets
+    NaN and status bit 4."""
+    from diskrag_amd import _ffi
+    from oracle import pyoracle as orc
+    g = load_golden("unit1536_R16_m32")
+    ix = get_index("unit1536_R16_m32")
+    q = g.queries / np.linalg.norm(g.queries.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    for mode, omode in ((_ffi.MODE_PQB, orc.PQB), (_ffi.MODE_PQ, orc.PQ)):
+        base = ix.search_batch(q, 10, L=100, beam_width=8, mode=mode, flags=_ffi.F_RERANK)
+        ids, dist, cnt, st = ix.search_batch(q, 10, L=100, beam_width=8, mode=mode, flags=_ffi.F_RERANK | _ffi.F_IP)
+        assert int(st["status"].max()) == 0
+        assert np.array_equal(ids, base[0]) and np.array_equal(bits(dist), bits(base[1] * np.float32(0.5)))
+        w = orc.search_batch(g.vectors, g.adj, q, g.medoid, omode, 10, L=100, bw=8, flags=orc.F_RERANK | orc.F_IP, codes=g.codes, codebook=g.codebook)
+        assert np.array_equal(ids, w[0]) and np.array_equal(bits(dist), bits(w[1].astype(np.float32)))
+        ip = 1.0 - np.einsum("qd,qkd->qk", q.astype(np.float64), g.vectors[ids].astype(np.float64))
+        assert np.abs(dist - ip).max() < 2e-6                                    # = 1 - <q, v> on unit vectors
+    bad = q.copy(); bad[3] *= 1.5
+    ids, dist, cnt, st = ix.search_batch(bad, 10, L=100, beam_width=8, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK | _ffi.F_IP)
+    assert st["status"][3] & 16 and np.isnan(dist[3]).all() and not np.isnan(np.delete(dist, 3, axis=0)).any()
+    with pytest.raises(_ffi.DiskragHipError):                                    # SIFT-scale rows are not unit-norm
+        get_index("sift128_R64_m32").search_batch(load_golden("sift128_R64_m32").queries, 10, L=50, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK | _ffi.F_IP)
+    with pytest.raises(_ffi.DiskragHipError):                                    # the flag goes with the rerank
+        ix.search_batch(q, 10, L=50, mode=_ffi.MODE_PQB, flags=_ffi.F_IP)
