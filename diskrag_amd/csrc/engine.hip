@@ -286,7 +286,10 @@ struct dr_index {
     DevBuf<KStats> f64_stats;
     uint32_t fin_hint = 0;        // tie-list length to size the tie-order launches for (0: not known yet -> full grid)
     float unit_norm_dev = -1.0f;  // largest | |v|^2 - 1 | over the stored vectors (DR_F_IP), -1 = not measured (reset when rows are written)
-    int adc_live = -1;            // M1 on this index: does the rerank policy A4 really consult the ADC? -1 = not measured yet
+    int adc_live = -1;            // M1 on this index: does the rerank policy A4 really consult the ADC? -1 = not measured yet (the last class measured)
+    int adc_live_sc[DR_NUM_SIZECLASS] = { -1, -1, -1, -1, -1 };   // ... per list-size class: with the API's L = 20 a 64-neighbour expansion can replace the whole
+                                  // list, the skip cannot be proven and the ADC IS evaluated, while L = 100 on the same index never needs it (round 5: the
+                                  // regime measured on a first L = 20 request used to pin the slow shared-codebook kernel on every later L = 100 batch)
     DevBuf<u64> phase;
     uint32_t last_k = 0;
     dr_timing timing = {};
@@ -944,7 +947,10 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     const int npref = k_m1 ? 5 : (ov && ov->sdc) ? 2 : k_adc ? 3 : ov ? 2 : 4;
     // (round 4: the per-query table wins with as few as five or six wavefronts per CU -- c4 shape, lists of 300-500 entries: 1.38x over
     // the shared codebook at eight, profiles/r04/ab/ab_c4_long_lists_table_vs_codebook.jsonl; it used to need eight to be preferred)
-    if (k_m1 && !ov && ix->adc_live == 1) pref = (lds_of(0) * 5 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
+    if (ix->adc_live < 0) for (int &v : ix->adc_live_sc) v = -1;      // (codes / adjacency / rows changed: every class is measured again)
+    // (a handful of queries -- the API's one-query requests at L = 20 -- stay on the row-landing kernels in 4-wavefront workgroups even when
+    // the ADC is live: one query p50 0.436 -> 0.416 ms, 64 queries 0.664 -> 0.596 ms against the shared-codebook kernel, profiles/r05/latency_small.json)
+    if (k_m1 && !ov && ix->adc_live_sc[sc] == 1 && ix->cs->nq > 256) pref = (lds_of(0) * 5 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
     int kind = -1;
     for (int i = 0; i < npref && kind < 0 && !pqb; i++) if (usable(pref[i])) kind = pref[i];
     {
@@ -1191,7 +1197,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // no host wait here: the next step may be queued right away (dr_batch_sync / dr_batch_download wait)
     ix->timing.grid = grid; ix->timing.block = 64 * NW; ix->timing.lds_bytes = (uint32_t)lds;
     ix->timing.waves_per_cu = (uint32_t)(occ * NW); ix->timing.variant = (uint32_t)kind;
-    if (k_m1 && ix->adc_live < 0) {
+    if (k_m1 && ix->adc_live_sc[sc] < 0) {
         // regime of this (graph, PQ) state: did the rerank policy really consult the ADC on this batch? (the one
         // launch per index state that is waited for on the host)
         HIPCHK(hipStreamSynchronize(st));
@@ -1199,7 +1205,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         HIPCHK(hipMemcpy(st.data(), bs.stats.p, st.size() * sizeof(KStats), hipMemcpyDeviceToHost));
         uint64_t evald = 0, all = 0;
         for (const KStats &x : st) { evald += x.pq_evaluated; all += x.pq; }
-        ix->adc_live = (2 * evald > all) ? 1 : 0;
+        ix->adc_live = ix->adc_live_sc[sc] = (2 * evald > all) ? 1 : 0;
     }
     ix->last_k = k;
     ix->last_nq = nq;

@@ -19,10 +19,12 @@ L_ = _ffi.load_library()
 out = {}
 pts = (("M1_api_default_k5_L20_bw8", dict(k=5, L=20, bw=8, mode=_ffi.MODE_M1, flags=0)), ("M1_k10_L100_bw8", dict(k=10, L=100, bw=8, mode=_ffi.MODE_M1, flags=0)),
        ("PQB_rerank_k10_L100_bw8", dict(k=10, L=100, bw=8, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK)))
-for env in ("0", "1"):
+for env in ("0", "1", "k3", "k17"):
     if env == "1": os.environ["DR_REPREFETCH"] = "1"
     else: os.environ.pop("DR_REPREFETCH", None)
+    ix.debug_force_kind(int(env[1:]) if env.startswith("k") else -1)
     for tag, kw in pts:
+        if env.startswith("k") and kw["mode"] != _ffi.MODE_M1: continue
         for nq in (1, 8, 64):
             k = kw["k"]
             qq = np.ascontiguousarray(q, dtype=np.float32)
@@ -40,7 +42,7 @@ for env in ("0", "1"):
                     ts.append(t1 - t0)
                     if i % 20 == 0: ks.append(ix.timing()["search_kernel_ms"])
             ts = np.array(ts) * 1e3
-            out.setdefault(tag, {})["nq%d%s" % (nq, "_second_chance_prefetch" if env == "1" else "")] = {
+            out.setdefault(tag, {})["nq%d%s" % (nq, "_second_chance_prefetch" if env == "1" else "_forced_variant_" + env[1:] if env.startswith("k") else "")] = {
                 "p50_ms": round(float(np.percentile(ts, 50)), 4), "p99_ms": round(float(np.percentile(ts, 99)), 4), "search_kernel_ms_mean": round(float(np.mean(ks)), 4),
                 "variant": ix.timing()["variant"]}
 print(json.dumps(out, indent=1))

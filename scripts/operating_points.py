@@ -138,6 +138,16 @@ if spec == "pqb":
         run(f"PQ_rerank_L{L}_bw{bw or 'None'}", L=L, beam_width=bw, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK)
         for pops in (1, 2):
             run(f"PQB_rerank_L{L}_bw{bw or 'None'}_pops{pops}", L=L, beam_width=bw, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK | _ffi.F_POPS(pops))
+    # inline neighbour codes (N*R*m bytes: 20 GB at the full c3 size): a row's code words are R*m contiguous bytes = R*m/128 lines instead of R
+    # scattered 128-byte lines -- at 10M points the code-word gathers come from HBM and the traversal runs at the chip's rate of random lines
+    ix.inline_codes(True)
+    for L, bw in grid[:3]:
+        for pops in (1, 2):
+            run(f"PQB_rerank_L{L}_bw{bw or 'None'}_pops{pops}_inline_codes", L=L, beam_width=bw, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK | _ffi.F_POPS(pops))
+    for L, bw in grid[:2]:
+        kw = dict(L=L, beam_width=bw, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK | _ffi.F_POPS(1))
+        run_stream(f"PQB_rerank_L{L}_bw{bw or 'None'}_pops1_inline_codes_stream_shared_launches", 32768, 14, **kw)
+    ix.inline_codes(False)
     for L, bw in grid[:2]:
         kw = dict(L=L, beam_width=bw, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK | _ffi.F_POPS(1))
         run_stream(f"PQB_rerank_L{L}_bw{bw or 'None'}_pops1_stream_one_launch_per_submit", nq, 4, **kw)
