@@ -280,6 +280,13 @@ struct dr_index {
     std::map<std::pair<const void *, size_t>, int> occ_cache;
     void *pinned = nullptr; size_t pinned_bytes = 0;      // host slab for result downloads
     void *pin_q = nullptr; size_t pin_q_bytes = 0;        // page-locked staging of a blocking call's pageable query batch
+    // A SMALL blocking call (dr_search_batch, <= DR_DIRECT_MAX queries): the kernels write ids / distances / counts / counters straight into the
+    // page-locked result slab (no download copies), the tie-order pass runs only if a query was listed for it (a flag word in the slab), on
+    // the search stream (no cross-stream hand-over) -- the one-query requests of the API routes pay launches and one synchronisation, nothing else
+    bool direct = false;          // set by dr_search_batch around run_locked
+    bool direct_used = false;     // run_locked's answer: this launch wrote into the slab
+    bool direct_fin = false;      // ... and a tie-order pass may be needed (direct_f says with what)
+    struct FinalizeParams *direct_f = nullptr;
     bool h2d_pending = false;
     DevBuf<double> f64_q, f64_dist;                 // dr_search_batch_f64 scratch
     DevBuf<uint32_t> f64_ids, f64_cnt, f64_vis;
@@ -535,6 +542,7 @@ extern "C" void dr_index_close(dr_index *ix)
     ix->f64_q.release(); ix->f64_dist.release(); ix->f64_ids.release(); ix->f64_cnt.release(); ix->f64_vis.release(); ix->f64_stats.release();
     if (ix->pinned) (void)hipHostFree(ix->pinned);
     if (ix->pin_q) (void)hipHostFree(ix->pin_q);
+    delete ix->direct_f;
     delete ix->shs;
     for (auto &e : ix->ev) if (e) (void)hipEventDestroy(e);
     for (auto &pr : ix->kev) for (auto &e : pr) if (e) (void)hipEventDestroy(e);
@@ -571,7 +579,7 @@ static int upload_slot_async(dr_index *ix, QSlot &qs, const float *src, uint32_t
 extern "C" bool dr_host_stage_u8(float *dst, const float *q, size_t n, bool want_check);
 static int pin_reserve(void **p, size_t *have, size_t need);
 
-static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq, bool wait = true)
+static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq, bool wait = true, bool with_qp = true)
 {
     if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
     HIPCHK(hipSetDevice(ix->device));
@@ -595,7 +603,7 @@ static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq
         }
     }
     HIPCHK(hipEventRecord(ix->ev[0], ix->stream));
-    const int rc = upload_slot_async(ix, *ix->cs, staged ? static_cast<const float *>(ix->pin_q) : queries, nq, ix->stream);
+    const int rc = upload_slot_async(ix, *ix->cs, staged ? static_cast<const float *>(ix->pin_q) : queries, nq, ix->stream, with_qp);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
     // dr_search_batch does not wait here: what consumes the queries is queued behind them on the same stream and the call
@@ -770,6 +778,7 @@ static void harvest_kernel_times(dr_index *ix, bool publish)
     }
 }
 
+static const uint32_t DR_DIRECT_MAX_BOUND = 256;
 // sqrt-ADC upper bound per query (search_kernel.hpp "exact skip"): per-(query, sub-quantiser) maxima, then the ordered sum
 static int launch_pq_bound(dr_index *ix, QSlot &qs, uint32_t nq, hipStream_t st, uint32_t q0 = 0, uint32_t room = 0)
 {
@@ -789,7 +798,7 @@ static int launch_pq_bound(dr_index *ix, QSlot &qs, uint32_t nq, hipStream_t st,
     default: break;
     }
     static const bool old_form = getenv("DR_PQ_BOUND_BLOCK") != nullptr;      // A/B: the block-per-query form
-    if (fn && !old_form) {
+    if (fn && !old_form && nq > DR_DIRECT_MAX_BOUND) {      // (a handful of queries: ONE launch, the block-per-query form -- the same bits)
         if (qs.pq_max.reserve((size_t)room * ix->m)) return DR_E_NODEVICE;
         float *mxp = qs.pq_max.p + (size_t)q0 * ix->m;
         void *args[] = { &cbp, &qp, &nqv, &Dv, &mxp };
@@ -853,6 +862,7 @@ static int launch_lut_build(dr_index *ix, const float *d_queries, uint32_t nq, f
 static int finish_group_locked(dr_index *ix, int g);
 // Per-query scratch (insert log, result keys) is sized by the batch: very large batches are processed in chunks.
 static const uint32_t DR_MAX_CHUNK = 32768;
+static const uint32_t DR_DIRECT_MAX = 256;      // dr_search_batch calls of at most this many queries take the direct path (see dr_index::direct)
 
 static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_t mode, uint32_t policy, uint32_t flags,
                       const BuildOverride *ov = nullptr)
@@ -1081,6 +1091,24 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.tie_list = bs.tie.p; p.tie_count = bs.counter.p + 1;
     p.log = bs.log.p; p.logcap = logcap;
     p.out_ids = bs.out_ids.p; p.out_dist = bs.out_dist.p; p.out_count = bs.out_count.p;
+    // (small blocking call: outputs land in the page-locked slab -- not on the one call per list-size class whose counters are read back below)
+    const bool direct = ix->direct && !ov && !(mode == DR_MODE_M1 && ix->adc_live_sc[sc] < 0);
+    ix->direct_fin = false; ix->direct_used = direct;
+    if (direct) {
+        const size_t b_ids = (size_t)nq * k * 4, b_cnt = (size_t)nq * 4, b_st = (size_t)nq * sizeof(KStats);
+        const size_t need = 2 * b_ids + b_cnt + b_st + 16;
+        if (ix->pinned_bytes < need) {
+            if (ix->pinned) (void)hipHostFree(ix->pinned);
+            ix->pinned = nullptr; ix->pinned_bytes = 0;
+            if (hipHostMalloc(&ix->pinned, need, hipHostMallocDefault) != hipSuccess) return fail(DR_E_NODEVICE, "hipHostMalloc(%zu) failed", need);
+            ix->pinned_bytes = need;
+        }
+        unsigned char *hp = static_cast<unsigned char *>(ix->pinned);
+        p.out_ids = reinterpret_cast<uint32_t *>(hp); p.out_dist = reinterpret_cast<float *>(hp + b_ids);
+        p.out_count = reinterpret_cast<uint32_t *>(hp + 2 * b_ids); p.stats = reinterpret_cast<KStats *>(hp + 2 * b_ids + b_cnt);
+        p.tie_flag = reinterpret_cast<uint32_t *>(hp + 2 * b_ids + b_cnt + b_st);
+        *p.tie_flag = 0u;
+    }
     p.phase = nullptr;
     p.pq_ub = nullptr;
     p.vnorm2 = nullptr;
@@ -1158,8 +1186,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (rerank) {
         // DR_MODE_PQ + DR_F_RERANK: exact squared L2 of the final list's entries, k best in (distance, id) order
         const float *vecp = ix->vecp.p; const float *qpp = ix->cs->qp.p; const u64 *rkp = bs.res_keys.p; const uint32_t *rnp = bs.res_n.p;
-        uint32_t capv = cap, kv = k, nqv = nq; uint32_t *oi = bs.out_ids.p; float *od = bs.out_dist.p; uint32_t *oc = bs.out_count.p;
-        KStats *stp = bs.stats.p;
+        uint32_t capv = cap, kv = k, nqv = nq; uint32_t *oi = p.out_ids; float *od = p.out_dist; uint32_t *oc = p.out_count;
+        KStats *stp = p.stats;
         uint32_t ipv = (flags & DR_F_IP) ? 1u : 0u;
         void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp, &ipv };
         const size_t rlds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)cap * 8;
@@ -1169,15 +1197,26 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // tie replay for the queries the search kernel listed: one wavefront per query, heap in registers. It runs on
     // its own stream so that it overlaps the NEXT step's search kernel (it needs 19 VGPRs and no LDS, so its
     // wavefronts fit beside the search kernel's); dr_batch_sync / dr_batch_download wait for it.
-    HIPCHK(hipEventRecord(bs.search_done, st));
-    HIPCHK(hipStreamWaitEvent(ix->fstream, bs.search_done, 0));
     FinalizeParams f;
     f.res_keys = bs.res_keys.p; f.res_n = bs.res_n.p; f.tie_list = bs.tie.p; f.tie_count = bs.counter.p + 1;
-    f.log = bs.log.p; f.stats = bs.stats.p;
+    f.log = bs.log.p; f.stats = p.stats;
     f.logcap = logcap; f.cap = cap; f.k = k; f.mode = mode;
-    f.out_ids = bs.out_ids.p; f.out_dist = bs.out_dist.p;
+    f.out_ids = p.out_ids; f.out_dist = p.out_dist;
     if (!ix->fin_stat.p) { if (ix->fin_stat.reserve(1, true)) return DR_E_NODEVICE; }
     f.ntie_stat = ix->fin_stat.p;
+    if (direct) {
+        // the caller (dr_search_batch) synchronises the search stream, looks at the flag word and runs the tie-order pass only if it is set
+        if (!ix->direct_f) ix->direct_f = new FinalizeParams();
+        *ix->direct_f = f;
+        ix->direct_fin = !rerank && !pqb;
+        ix->timing.grid = grid; ix->timing.block = 64 * NW; ix->timing.lds_bytes = (uint32_t)lds;
+        ix->timing.waves_per_cu = (uint32_t)(occ * NW); ix->timing.variant = (uint32_t)kind;
+        ix->last_k = k; ix->last_nq = nq; ix->last_set = set;
+        ix->parity = (ix->parity + 1) % DR_NUM_SETS;
+        return 0;
+    }
+    HIPCHK(hipEventRecord(bs.search_done, st));
+    HIPCHK(hipStreamWaitEvent(ix->fstream, bs.search_done, 0));
     HIPCHK(hipEventRecord(bs.fin_start, ix->fstream));
     static const bool skip_fin = getenv("DR_SKIP_FINALIZE") != nullptr;   // timing experiment only: tie order is then wrong
     if (!skip_fin && !rerank && !pqb)      // (the rerank pass / DR_MODE_PQB have already written a total (distance, id) order)
@@ -1359,6 +1398,45 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
     if (!out_ids || !out_dist || !out_count) return fail(DR_E_ARG, "null output buffer");
     if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
     std::lock_guard<std::mutex> lk(ix->mu);
+    static const bool no_direct = getenv("DR_NO_DIRECT") != nullptr;      // A/B: small calls through the general path
+    if (nq <= DR_DIRECT_MAX && !no_direct) {
+        // ---- a handful of queries (one per request is the shape of the reference's API routes, search_engine.py:530-614, app.py:84-130)
+        HIPCHK(hipSetDevice(ix->device));
+        {   // (pipelined jobs of other threads, or resident steps not waited for yet, own output sets and streams: finished first)
+            bool busy = false;
+            for (int j = 0; j < DR_MAX_JOBS; j++) busy = busy || ix->jobs[j].active;
+            for (const auto &x : ix->sets) busy = busy || x.fin_pending;
+            if (busy) { const int rcq = quiesce_locked(ix); if (rcq) return rcq; const int rcs = sync_locked(ix); if (rcs) return rcs; }
+        }
+        int rc = upload_queries_locked(ix, queries, nq, false, false);
+        ix->direct = true;
+        if (!rc) rc = run_locked(ix, k, L, beam_width, mode, band_policy, flags);
+        ix->direct = false;
+        if (rc) return rc;
+        if (!ix->direct_used) {       // (the call that measures the index's regime went the general way)
+            return download_locked(ix, out_ids, out_dist, out_count, stats);
+        }
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        const size_t b_ids = (size_t)nq * k * 4, b_cnt = (size_t)nq * 4, b_st = (size_t)nq * sizeof(KStats);
+        unsigned char *hp = static_cast<unsigned char *>(ix->pinned);
+        const uint32_t tied = *reinterpret_cast<const uint32_t *>(hp + 2 * b_ids + b_cnt + b_st);
+        if (tied) {
+            dr_index::BatchSet &bs = ix->sets[ix->last_set];
+            if (ix->direct_fin) hipLaunchKernelGGL(finalize_kernel, dim3((nq + 3) / 4), dim3(256), 4 * ((size_t)ix->direct_f->cap + 2 + 64) * 8, ix->stream, *ix->direct_f);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemsetAsync(bs.counter.p + 1, 0, 4, ix->stream));
+            HIPCHK(hipStreamSynchronize(ix->stream));
+        }
+        harvest_kernel_times(ix, true);
+        ix->h2d_pending = false;
+        memcpy(out_ids, hp, b_ids);
+        memcpy(out_dist, hp + b_ids, b_ids);
+        memcpy(out_count, hp + 2 * b_ids, b_cnt);
+        if (stats) memcpy(stats, hp + 2 * b_ids + b_cnt, b_st);
+        ix->timing.d2h_ms = 0.0f; ix->timing.finalize_kernel_ms = 0.0f;
+        ix->timing.total_ms = ix->timing.lut_kernel_ms + ix->timing.search_kernel_ms;
+        return 0;
+    }
     float h2d = 0, ker = 0, fin = 0, d2h = 0;
     for (uint32_t q0 = 0; q0 < nq; q0 += DR_MAX_CHUNK) {
         const uint32_t n = std::min(DR_MAX_CHUNK, nq - q0);

@@ -101,6 +101,7 @@ struct SearchParams {
     float *out_dist;         // [nq][k]
     u32 *out_count;          // [nq]
     u64 *phase;              // [nq][8] cycle sums (DR_PHASE_TIMING builds only)
+    u32 *tie_flag;           // small blocking calls: a word in the host's result slab set when a query was listed for the tie-order pass (else nullptr)
     const float *pq_ub;      // [nq] precomputed sqrt-ADC upper bounds (pq_bound_kernel) or nullptr
     const float *vnorm2;     // [N] squared norms of the stored vectors (DR_F_COSINE: M3 with distance_metric='cosine') or nullptr
     // builder over a PQ-only shard (no stored vectors): query qi IS the stored point build_pts[qi], known by its code
@@ -621,7 +622,7 @@ DEV void write_results(const SearchParams &p, u32 qi, int cap, u32 kmode, bool h
     if (lane == 0) {
         p.res_n[qi] = (u32)rn;
         if (p.out_count) p.out_count[qi] = (u32)kout;
-        if (anyt && has_ties) p.tie_list[atomicAdd(p.tie_count, 1u)] = qi;
+        if (anyt && has_ties) { p.tie_list[atomicAdd(p.tie_count, 1u)] = qi; if (p.tie_flag) *p.tie_flag = 1u; }
         KStats st;
         st.steps = steps; st.visited = nvisited; st.exact = nexact; st.pq = npq; st.status = status;
         st.inserts = ninserts; st.pq_evaluated = npq_eval; st.adj_prefetch_hits = npre_hit;
