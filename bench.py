@@ -590,7 +590,6 @@ def worker_c2(args, rk):
     alg_launch = ((a_all - 4 * 256 * D) / nb) * per_launch + 4 * 256 * D      # per launch of the timed region (q_per_launch queries)
     alg_launch_1 = (a_all - 4 * 256 * D) / nb + 4 * 256 * D                   # per one-batch launch (the resident legs below)
     k_ms = float(tm_head["search_kernel_ms"])                    # mean launch duration over the timed pipelined region
-    achieved_ref = alg_launch / (k_ms * 1e-3) / 1e9
 
     # PCIe-inclusive rate from PAGEABLE caller memory (the library stages it), for reference
     qb_pageable = [np.array(a) for a in qb[:min(nb, 4)]]
@@ -737,7 +736,7 @@ def worker_c2(args, rk):
                    "tied_queries_per_batch": float((dist_out[:, 1:] == dist_out[:, :-1]).any(axis=1).sum()) / nb,
                    "secondary_no_trim": secondary,
                    "row_storage": ("u8: lossless byte copy of the integer-valued vectors (every component checked; distances "
-                                   "bit-identical); roofline.achieved counts D bytes per scored vector, roofline.reference_accounting 4*D, "
+                                   "bit-identical); roofline.achieved counts D bytes per scored vector (what a byte-row kernel has to move), "
                                    "roofline.traffic is what HBM really moved") if byte_rows else "f32",
                    "query_storage": ("u8: every component of the batch is an integer in [0, 255] (checked per batch on the host)"
                                      if variant == 13 else "f32"),
@@ -748,10 +747,6 @@ def worker_c2(args, rk):
                      "hbm_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_kernel, "queries_per_launch": q_per_launch,
                      "row_bytes": D if byte_rows else 4 * D,
-                     "reference_accounting": {"algorithmic_bytes_per_launch": alg_launch, "achieved": achieved_ref,
-                                              "frac": achieved_ref / HBM_PEAK_GBPS,
-                                              "note": "SURVEY 8d's figure with 4*D bytes per scored vector, i.e. what a float-row "
-                                                      "kernel would have to move for the same work; can exceed 1 on byte rows"},
                      "note": "frac = the kernel's own algorithmic bytes (D bytes per scored vector on byte rows) / kernel time / peak; "
                              "hbm_frac is what the PMC counters say HBM moved; the kernel is bound by the chip's rate of random "
                              "requests (DESIGN.md 4.1: ~55 G requests/s measured by tools/gather_probe.hip), not by bytes"},

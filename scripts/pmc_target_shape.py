@@ -11,13 +11,15 @@ bw = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 L = int(sys.argv[4]) if len(sys.argv) > 4 else 100
 D, m, ncl, latent = {"c3": (1536, 32, 4096, 64), "c4": (96, 16, 4096, 32), "c5s": (1536, 32, 4096, 64)}[shape]
 R = 32 if shape == "c5s" else 64
+import os
 mode = _ffi.MODE_PQ if shape == "c5s" else _ffi.MODE_M1
+if shape == "c5s" and os.environ.get("PMC_MODE") == "pqb":
+    mode = _ffi.MODE_PQB                # round 5: the batch-per-step traversal (csrc/pqb_kernel.hpp), default pops
 gen = unit_mixture_parallel if n * D >= (1 << 32) else unit_mixture
 x, q = gen(n, D, n_queries=10000, n_clusters=ncl, seed=11, latent=latent)
 ix = HipIndex.create_empty(x, R=R)
 ix.build_vamana(L_build=100 if shape != "c5s" else 64, alpha=1.2, passes=2, seed=7)
 cb = ix.pq_train(m, n_sample=100000, iters=5); ix.pq_encode(cb)
-import os
 if os.environ.get("DR_INLINE") == "1":
     ix.inline_codes(True)               # code words of a node's neighbours beside its adjacency row (dr_index_inline_codes)
 ix.bruteforce_topk(q[:1], 10)           # calibration: streams the whole vector table once
