@@ -598,12 +598,24 @@ static int upload_queries_locked(dr_index *ix, const float *queries, uint32_t nq
             // (the previous call's copy out of this buffer has completed: every blocking call ends with a synchronised download)
             const int rcp = pin_reserve(&ix->pin_q, &ix->pin_q_bytes, bytes);
             if (rcp) return rcp;
-            staged_u8 = dr_host_stage_u8(static_cast<float *>(ix->pin_q), queries, (size_t)nq * ix->D, want_u8);
             staged = true;
         }
     }
     HIPCHK(hipEventRecord(ix->ev[0], ix->stream));
-    const int rc = upload_slot_async(ix, *ix->cs, staged ? static_cast<const float *>(ix->pin_q) : queries, nq, ix->stream, with_qp);
+    int rc = 0;
+    if (staged) {
+        // in pieces: the copy engine moves piece i while the calling thread stages piece i + 1 (a 10 000 x 128 batch: 0.25 ms of staging and
+        // 0.2 ms of copy that used to run one after the other)
+        const uint32_t piece = nq >= 4096 ? (nq + 3) / 4 : nq;
+        staged_u8 = want_u8;
+        for (uint32_t q0 = 0; q0 < nq && !rc; q0 += piece) {
+            const uint32_t n = std::min(piece, nq - q0);
+            float *dst = static_cast<float *>(ix->pin_q) + (size_t)q0 * ix->D;
+            const bool ok8 = dr_host_stage_u8(dst, queries + (size_t)q0 * ix->D, (size_t)n * ix->D, want_u8);
+            staged_u8 = staged_u8 && ok8;
+            rc = upload_slot_async(ix, *ix->cs, dst, n, ix->stream, with_qp, q0, nq);
+        }
+    } else rc = upload_slot_async(ix, *ix->cs, queries, nq, ix->stream, with_qp);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ix->ev[1], ix->stream));
     // dr_search_batch does not wait here: what consumes the queries is queued behind them on the same stream and the call
