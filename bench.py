@@ -263,6 +263,35 @@ def log(rk, msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+def pin_to_gpu_socket(rk, device):
+    """N > 1 ranks on one node: every rank's host work -- the byte scan and staging of its batches, its waits -- stays on the CPUs next to ITS
+    GPU (`local_cpulist` of the device's PCI function). One rank keeps the whole box (the CPU baseline wants every core). Best effort: a
+    container that hides /sys or a runtime without hipDeviceGetPCIBusId leaves the affinity alone. Returns what it did, for the JSON line."""
+    if rk.world < 2 or os.environ.get("DR_BENCH_NO_PIN"):
+        return None
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
+            return None
+        bdf = buf.value.decode().strip().lower()
+        base = "/sys/bus/pci/devices/" + bdf
+        cpus = set()
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            if part:
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        node = open(base + "/numa_node").read().strip()
+        return {"pci": bdf, "numa_node": int(node), "cpus": len(cpus)}
+    except Exception:       # noqa: BLE001
+        return None
+
+
 # ------------------------------------------------------------------------------------------------ launcher
 def launch(args):
     """`bench.py --gpus N` without a torchrun environment: N worker processes, started BEFORE this process makes any
@@ -397,6 +426,7 @@ def worker_c2(args, rk):
     device = rk.local_rank % ndev
     mode = _ffi.MODE_M1
     base_kind = 9 if args.rows == "f32" else -1          # --rows f32: the float32-row kernel for every launch of the run
+    pinned_to = rk.gather("pin", pin_to_gpu_socket(rk, device))
 
     # ---------------------------------------------------------------- setup (untimed): data, graph, PQ, ground truth
     t0 = time.time()
@@ -710,6 +740,7 @@ def worker_c2(args, rk):
                                + ("; STRONG scaling: every batch is cut into %d contiguous slices, one per GPU (slice of rank 0: %d queries)" % (rk.world, nq) if strong else ""),
                    "recall_at_10": recall, "build_seconds": build_s,
                    "parallelism": ("query-sharded replicas x%d, one batch split over the ranks" if strong else "query-sharded replicas x%d") % rk.world,
+                   "rank_cpu_affinity": pinned_to if rk.world > 1 else None,
                    "per_rank_slice": slices if strong else None,
                    "tickets_in_flight": depth_head, "queries_per_launch": q_per_launch, "submits_per_launch": submits_per_launch,
                    "kernel_launches_in_timed_region": n_kernel_launches, "kernel_ms_per_batch": k_ms / per_launch,
@@ -834,6 +865,7 @@ def worker_shape(args, rk):
     if ndev < 1:
         raise RuntimeError("no HIP device: the engine has no CPU fallback")
     device = rk.local_rank % ndev
+    pin_to_gpu_socket(rk, device)
     c3 = args.config == "c3"
     nq, k, D, m, R, n = args.nq, args.k, args.dim, args.m, args.R, args.n
     nb = max(1, min(args.nb, 4))
@@ -975,6 +1007,7 @@ def worker_c5(args, rk):
     if ndev < 1:
         raise RuntimeError("no HIP device: the engine has no CPU fallback")
     device = rk.local_rank % ndev
+    pin_to_gpu_socket(rk, device)
     nq, k, D, m, R = args.nq, args.k, args.dim, args.m, args.R
     n_s = args.n
     blk = UnitMixtureStream.BLOCK
