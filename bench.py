@@ -89,7 +89,7 @@ def parse_args(argv=None):
     # the shape of the configuration (BASELINE.json configs[1] / configs[4]) unless given
     dflt = {"c2": dict(dim=128, R=64, L=100, bw=8, L_build=100), "c5": dict(dim=1536, R=128, L=100, bw=32, L_build=128),
             # (the operating points of the full-size runs, profiles/r04/op_c3_*.jsonl / op_c4_*.jsonl and profiles/r05/)
-            "c3": dict(dim=1536, R=64, L=250, bw=0, L_build=100), "c4": dict(dim=96, R=64, L=500, bw=64, L_build=100)}[args.config]
+            "c3": dict(dim=1536, R=64, L=250, bw=0, L_build=100), "c4": dict(dim=96, R=64, L=400, bw=32, L_build=100)}[args.config]
     if args.config in ("c3", "c4"):
         if args.n == 1_000_000 and "--num-vectors" not in (argv if argv is not None else sys.argv):
             args.n = 1_000_000 if args.config == "c3" else 4_000_000
@@ -851,13 +851,14 @@ def worker_c2(args, rk):
 def worker_shape(args, rk):
     """BASELINE configs[2] (c3: 10M x 1536 inner product on unit vectors = L2, PQ + full-precision rerank) and configs[3] (c4: DEEP100M-shaped
     100M x 96, index replicated, queries sharded) at --num-vectors points, index built by the engine's own builder.
-      c3: DR_MODE_PQB | DR_F_RERANK -- the PQ traversal (round 5's batch-per-step kernel) + exact rerank of the L list, SURVEY.md 8d's
-          definition of c3 -- L = 250 without frontier trim: the recall-0.95 point of the full-size index.
-      c4: the reference-faithful M1 (_pq_accelerated_graph_search, search_engine.py:398-506), L = 500, beam_width 64: ITS recall-0.95 point at
-          100M points; `config.pq_rerank` carries the PQ traversal + rerank beside it.
+    Both: DR_MODE_PQB | DR_F_RERANK -- the PQ traversal (round 5's batch-per-step kernel) + exact rerank of the L list (SURVEY.md 8d's definition
+    of c3) -- at the recall-0.95 point of the FULL-SIZE index: c3 L = 250 without frontier trim (1.09 M QPS resident / 1.21 M as a stream at 10M points,
+    profiles/r05/op_c3_10M_d1536_pqb.jsonl), c4 L = 400, beam_width 32 (1.75 M / 2.13 M at 100M points, op_c4_100M_d96_pqb.jsonl). c4 also runs the
+    reference-faithful M1 (_pq_accelerated_graph_search, search_engine.py:398-506) at ITS recall-0.95 point, L = 500, beam_width 64 (862 k / 1.00 M at
+    100M points): `config.m1_reference_faithful`.
     value = host memory -> host memory stream of --num-queries batches (dr_search_submit / dr_search_wait, shared launches), every rank its own
-    batches on its own replica (weak scaling, no collective). roofline = the search kernel's algorithmic bytes (SURVEY.md 8d's B_q from the
-    engine's per-query counters) / its mean launch duration over the timed region (HIP events on the search stream)."""
+    replica (weak scaling, no collective). roofline = the traversal kernel's algorithmic bytes (SURVEY.md 8d's B_q from the engine's per-query
+    counters) / its mean launch duration over the timed region (HIP events on the search stream)."""
     import diskrag_amd
     from diskrag_amd import HipIndex, _ffi
     from diskrag_amd.synth import recall_at_k, unit_mixture, unit_mixture_parallel
@@ -884,8 +885,10 @@ def worker_shape(args, rk):
     log(rk, f"graph in {build_s:.1f}s, PQ m={m} in {pq_s:.1f}s, ground truth done")
     if not want_cpu:
         del x
-    kw = dict(L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK) if c3 else dict(L=args.L, beam_width=args.bw, mode=_ffi.MODE_M1)
-    kw2 = dict(L=400, beam_width=32, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK) if not c3 else None      # c4's PQ + rerank point
+    qn = np.linalg.norm(q_all[:64].astype(np.float64), axis=1)
+    ip = _ffi.F_IP if c3 and np.abs(qn * qn - 1.0).max() < 5e-4 else 0       # c3 is named an inner-product config: unit-norm rows and queries
+    kw = dict(L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK | ip)
+    kw2 = dict(L=500, beam_width=64, mode=_ffi.MODE_M1) if not c3 else None      # c4: the reference-faithful M1 beside it
     qb = []
     for b in range(nb):
         a = _ffi.pinned_empty((nq, D), np.float32)
@@ -935,24 +938,25 @@ def worker_shape(args, rk):
     k_ms = float(tm["search_kernel_ms"])
     alg_launch = float(per_q.mean()) * qpl + 4.0 * 256 * D
     # the rerank pass of c3 runs in its own kernel: its rows are not the traversal kernel's
-    alg_search_launch = float((per_q - (X * 4.0 * D if c3 else 0.0)).mean()) * qpl + 4.0 * 256 * D
+    alg_search_launch = float((per_q - X * 4.0 * D).mean()) * qpl + 4.0 * 256 * D
     achieved = alg_search_launch / (k_ms * 1e-3) / 1e9
-    pq_rerank = None
+    m1_ref = None
     if kw2 is not None:
         stream(2 * depth, kw2); ix.batch_sync()
         el2, _ = stream(max(8, n_sub // 2), kw2); ix.batch_sync()
         o2 = [ix.search_batch(qb[b], k, **kw2) for b in range(min(nb, 2))]
-        pq_rerank = {"what": "DR_MODE_PQB | DR_F_RERANK L=400 beam_width=32 (c4's PQ traversal + exact rerank point)", "qps": nq * max(8, n_sub // 2) / el2,
-                     "recall_at_10": recall_at_k(np.concatenate([o[0] for o in o2]), gt, k), "kernel_ms_per_launch": float(ix.timing()["search_kernel_ms"])}
-    out = {"metric": "QPS @ recall@10>=0.95, %s, batch=%d" % ("d=1536 unit-norm (inner product = L2), PQ traversal + full-precision rerank" if c3
-                                                                  else "DEEP-shaped d=96 L2, index replicated, reference-faithful M1", nq),
+        m1_ref = {"what": "DR_MODE_M1 L=500 beam_width=64: the reference-faithful _pq_accelerated_graph_search at ITS recall-0.95 point of the full-size index",
+                  "qps": nq * max(8, n_sub // 2) / el2, "recall_at_10": recall_at_k(np.concatenate([o[0] for o in o2]), gt, k),
+                  "kernel_ms_per_launch": float(ix.timing()["search_kernel_ms"]), "variant": ix.timing()["variant"]}
+    out = {"metric": "QPS @ recall@10>=0.95, %s, PQ traversal + full-precision rerank, batch=%d" % ("d=1536 unit-norm (inner product = L2)" if c3
+                                                                                                  else "DEEP-shaped d=96 L2, index replicated", nq),
            "value": nq * n_sub * rk.world / max(times), "unit": "queries/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": max(times) / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32 (ADC sums over u8 codes; float32 rerank rows)" if c3 else "f32", "data": "synthetic",
+           "dtype": "f32 (ADC sums over u8 codes; float32 rerank rows)", "data": "synthetic",
            "config": {"workload": "%s-shaped synthetic (BASELINE configs[%d]): N=%d d=%d unit-norm mixture (4096 clusters), R=%d, PQ m=%d, %s L=%d beam_width=%s, k=%d, "
                                   "batch=%d queries; a step = %d batches; host memory -> host memory (dr_search_submit/wait, %d submits in flight, %.0f queries per launch); "
                                   "index built on the device (dr_build_vamana L_build=%d); full size = %d points"
-                                  % (args.config, 2 if c3 else 3, n, D, R, m, "DR_MODE_PQB | DR_F_RERANK" if c3 else "DR_MODE_M1 (reference-faithful)", args.L, args.bw or None, k, nq, bps, depth, qpl,
+                                  % (args.config, 2 if c3 else 3, n, D, R, m, "DR_MODE_PQB | DR_F_RERANK" + (" | DR_F_IP" if ip else ""), args.L, args.bw or None, k, nq, bps, depth, qpl,
                                      args.L_build, 10_000_000 if c3 else 100_000_000),
                       "recall_at_10": float(np.mean(recalls)), "build_seconds": build_s, "pq_seconds": pq_s, "parallelism": "query-sharded replicas x%d" % rk.world,
                       "per_rank_seconds": times, "queries_per_launch": qpl, "kernel_ms_per_launch": k_ms, "kernel_ms_per_10k_queries": k_ms * 10000.0 / qpl,
@@ -960,8 +964,8 @@ def worker_shape(args, rk):
                       "per_query": {"expansions": float(S.mean()), "code_words_scored": float(V.mean()), "full_precision_rows_scored": float(X.mean()),
                                     "algorithmic_bytes": float(per_q.mean())},
                       "launch": {k_: tm[k_] for k_ in ("variant", "grid", "block", "lds_bytes", "waves_per_cu")},
-                      "pq_rerank": pq_rerank},
-           "roofline": {"bound": "hbm", "kernel": ("pqb_search_kernel (DR_MODE_PQB traversal; the rerank pass is its own kernel)" if c3 else "search_kernel<96,M1> variant %d" % tm["variant"]),
+                      "m1_reference_faithful": m1_ref},
+           "roofline": {"bound": "hbm", "kernel": "pqb_search_kernel (DR_MODE_PQB traversal; the rerank pass is its own kernel)",
                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_search_launch, "queries_per_launch": qpl,
                         "whole_call_algorithmic_bytes_per_launch": alg_launch,
@@ -973,7 +977,7 @@ def worker_shape(args, rk):
         adj = ix.get_adjacency()
         ns = min(args.cpu_sample, nq)
         q0 = np.array(qb[0][:ns])
-        omode, oflags = (orc.PQB, orc.F_RERANK) if c3 else (orc.M1, 0)
+        omode, oflags = orc.PQB, orc.F_RERANK | (orc.F_IP if ip else 0)
         t2 = time.perf_counter()
         oids, odist, ocnt, ost = orc.search_batch(x, adj, q0, medoid, omode, k, L=args.L, bw=args.bw, flags=oflags, codes=codes, codebook=cb, nthreads=cores)
         cpu_s = time.perf_counter() - t2

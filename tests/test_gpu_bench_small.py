@@ -56,7 +56,7 @@ def test_c5_pipeline_on_one_rank():
 
 @pytest.mark.parametrize("cfg", ["c3", "c4"])
 def test_c3_c4_configs_at_toy_size(cfg):
-    """--config c3 (PQ traversal + exact rerank, d = 1536) and --config c4 (reference-faithful M1, d = 96): roofline + cpu_baseline blocks,
+    """--config c3 (d = 1536) and --config c4 (d = 96; the reference-faithful M1 beside it): PQ traversal + exact rerank, roofline + cpu_baseline blocks,
     the CPU restatement bit-identical on the sample (the bench raises otherwise)."""
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", cfg, "--num-vectors", "20000", "--num-queries", "300", "--steps", "2", "--warmup", "1",
                         "--min-recall", "0.5", "--cpu-sample", "100"], capture_output=True, text=True, timeout=900)
@@ -65,7 +65,7 @@ def test_c3_c4_configs_at_toy_size(cfg):
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["config"]["recall_at_10"] >= 0.5
     assert "bit-identical on the sample: True" in d["cpu_baseline"]["sample"]
     if cfg == "c4":
-        assert d["config"]["pq_rerank"]["qps"] > 0
+        assert d["config"]["m1_reference_faithful"]["qps"] > 0
     one = _run(["--rows", "f32", "--no-secondary"]) if cfg == "c3" else None       # (the float-row headline of c2 rides along once)
     if one:
         assert one["config"]["rows"] == "f32" and one["config"]["launch"]["variant"] == 9 and one["roofline"]["row_bytes"] == 512
