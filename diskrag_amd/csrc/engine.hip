@@ -1410,7 +1410,7 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
     if (!out_ids || !out_dist || !out_count) return fail(DR_E_ARG, "null output buffer");
     if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
     std::lock_guard<std::mutex> lk(ix->mu);
-    static const bool no_direct = getenv("DR_NO_DIRECT") != nullptr;      // A/B: small calls through the general path
+    const bool no_direct = getenv("DR_NO_DIRECT") != nullptr;      // A/B and tests: small calls through the general path (read per call)
     if (nq <= DR_DIRECT_MAX && !no_direct) {
         // ---- a handful of queries (one per request is the shape of the reference's API routes, search_engine.py:530-614, app.py:84-130)
         HIPCHK(hipSetDevice(ix->device));

@@ -130,3 +130,29 @@ def test_other_modes_sample_matches_oracle_at_scale(big):
         valid = oi != PAD
         assert np.array_equal(dist[valid].view(np.uint32), od[valid].astype(np.float32).view(np.uint32)), (mode, k, L, bw)
         assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), ost)
+
+
+@pytest.mark.parametrize("name", ["sift128_R64_m32", "unit1536_R16_m32", "deep96_R32_m16", "faq32_R16_nopq"])
+def test_small_calls_direct_path_equals_the_general_path(name, monkeypatch):
+    """dr_search_batch with <= 256 queries writes its results straight into the page-locked slab and runs the tie-order pass only when a query was
+    listed for it (round 5); DR_NO_DIRECT=1 sends the same call through the general path (download copies, tie-order pass on its own stream):
+    the same ids, distance bits, counts and counters in every mode, ties included (the integer-valued fixture)."""
+    from diskrag_amd import _ffi
+    from tests.conftest import load_golden
+    from tests.test_gpu_parity import bits, get_index
+    g = load_golden(name)
+    ix = get_index(name)
+    runs = [dict(L=100, beam_width=8, mode=_ffi.MODE_M2), dict(L=50, beam_width=0, mode=_ffi.MODE_M4)]
+    if g.m:
+        runs += [dict(L=100, beam_width=8, mode=_ffi.MODE_M1), dict(L=20, beam_width=8, mode=_ffi.MODE_M1, band_policy=1), dict(L=100, beam_width=16, mode=_ffi.MODE_PQB),
+                 dict(L=60, beam_width=0, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK), dict(L=10, beam_width=8, mode=_ffi.MODE_M3, flags=_ffi.F_USE_PQ)]
+    for kw in runs:
+        for q in (g.queries, g.queries[:1], g.queries[:7]):
+            monkeypatch.delenv("DR_NO_DIRECT", raising=False)
+            a = ix.search_batch(q, 10, **kw)
+            monkeypatch.setenv("DR_NO_DIRECT", "1")
+            b = ix.search_batch(q, 10, **kw)
+            monkeypatch.delenv("DR_NO_DIRECT", raising=False)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2]), (name, kw, len(q))
+            for f in ("steps", "visited", "exact", "pq", "status", "inserts"):
+                assert np.array_equal(a[3][f], b[3][f]), (name, kw, f)
