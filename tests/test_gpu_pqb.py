@@ -173,3 +173,47 @@ def test_inner_product_flag_on_unit_norm_data():
         get_index("sift128_R64_m32").search_batch(load_golden("sift128_R64_m32").queries, 10, L=50, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK | _ffi.F_IP)
     with pytest.raises(_ffi.DiskragHipError):                                    # the flag goes with the rerank
         ix.search_batch(q, 10, L=50, mode=_ffi.MODE_PQB, flags=_ffi.F_IP)
+
+
+@pytest.mark.parametrize("R,dim,m", [(48, 64, 16), (128, 128, 32), (96, 96, 48), (32, 128, 64), (20, 64, 8)])
+def test_pqb_on_device_built_graphs_with_ties(R, dim, m):
+    """Shapes the goldens do not reach, on integer-valued data (ADC sums tie: the id decides), graphs built on the device: rows that are not a
+    power of two (R = 48, 96, 20: lanes of a pass left empty), rows wider than a wavefront, m = 48 / 64 / 8 (the generic table-in-LDS kernel),
+    odd list sizes, every pops setting the row width allows, > 256 queries (the general blocking path) -- ids, distance bits and counters
+    against the restatement; and the PQ-only builder's DR_PAD-padded rows."""
+    from diskrag_amd import HipIndex, _ffi
+    from diskrag_amd.synth import sift_like
+    from oracle import pyoracle as orc
+    x, q = sift_like(24000, dim, n_queries=320, n_clusters=48, seed=71 + R, query_seed=72)
+    x[12000:12160] = x[:160]            # duplicate points: the same code word, the same ADC sum -- only the id orders them
+    q[:160] = x[:160]                   # ... and queries that sit on them
+    ix = HipIndex.create_empty(x, R=R)
+    try:
+        medoid, _ = ix.build_vamana(L_build=70, alpha=1.2, passes=2, seed=3)
+        cb = ix.pq_train(m, n_sample=8000, iters=3)
+        codes = ix.pq_encode(cb, want_codes=True)
+        adj = ix.get_adjacency()
+        rs = 1 << int(np.ceil(np.log2(R)))
+        for (L, bw, k) in ((37, 5, 10), (130, 0, 10), (300, 64, 20), (64, 64, 64)):
+            for pops in (0, 1, 2, 3, 4):
+                if pops * rs > 256:
+                    continue
+                w = orc.search_batch(x, adj, q, medoid, orc.PQB, k, L=L, bw=bw, flags=orc.F_POPS(pops), codes=codes, codebook=cb, nthreads=8)
+                ids, dist, cnt, st = ix.search_batch(q, k, L=L, beam_width=bw, mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(pops))
+                assert int(st["status"].max()) == 0
+                assert np.array_equal(ids, w[0]) and np.array_equal(cnt, w[2]), (R, m, L, bw, pops)
+                valid = w[0] != 0xFFFFFFFF
+                assert np.array_equal(bits(dist)[valid], bits(w[1].astype(np.float32))[valid])
+                assert np.array_equal(_stats4(st), w[3]), (R, m, L, bw, pops)
+        assert (bits(dist)[:, 1:] == bits(dist)[:, :-1]).any()          # equal ADC sums among the results: the id broke the tie
+        if m in (16, 32):       # the same points as a PQ-only shard with a graph built from the code words (rows padded with DR_PAD)
+            sh = HipIndex.create_codes_empty(len(x), dim, R, cb)
+            sh.encode_rows(x, 0)
+            med2, _ = sh.build_vamana_pq(L_build=70, alpha=1.2, passes=2, seed=3)
+            adj2 = sh.get_adjacency()
+            w = orc.search_batch(x, adj2, q, med2, orc.PQB, 10, L=100, bw=16, codes=codes, codebook=cb, nthreads=8)
+            ids, dist, cnt, st = sh.search_batch(q, 10, L=100, beam_width=16, mode=_ffi.MODE_PQB)
+            assert np.array_equal(ids, w[0]) and np.array_equal(_stats4(st), w[3])
+            sh.close()
+    finally:
+        ix.close()
