@@ -21,6 +21,11 @@ F_USE_PQ, F_SQDIST, F_RERANK, F_COSINE, F_NO_VISITED_SET = 1, 2, 4, 8, 16
 F_IP = 32        # with F_RERANK: inner-product metric on unit-norm data (out_dist = 1 - <q, v>; DR_F_IP)
 
 
+def POLICY_COIN(seed0):
+    """band_policy: the reference's coin flip itself (np.random.random() < 0.2), as if np.random.seed(seed0 + i) ran before query i (DR_POLICY_COIN)"""
+    return 2 | ((int(seed0) & 0xFFFFFF) << 8)
+
+
 def F_POPS(n):
     """DR_MODE_PQB: frontier entries expanded per step (DR_F_POPS)."""
     return (int(n) & 15) << 8

@@ -887,6 +887,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if ((flags & DR_F_POPS_MASK) && !pqb) return fail(DR_E_ARG, "DR_F_POPS goes with DR_MODE_PQB");
     if (pqb && ov) return fail(DR_E_ARG, "DR_MODE_PQB does not serve the builder");
     if (k == 0) return fail(DR_E_ARG, "k must be positive");
+    if (!ov && (policy & 0xFFu) > 1u) return fail(DR_E_UNSUPPORTED, "band policy %u: the literal coin flip (2 | seed << 8) is served by dr_search_batch / dr_search_batch_f64 only "
+                                                   "(a sequential walk); the batched paths take 0 (always rerank) or 1 (never)", policy & 0xFFu);
     const bool pq_only = (mode == DR_MODE_M3 && (flags & DR_F_USE_PQ)) || mode == DR_MODE_PQ || pqb || (ov && ov->sdc);   // ADC-only traversals
     const bool rerank = (mode == DR_MODE_PQ || pqb) && (flags & DR_F_RERANK);
     const bool use_pq = (mode == DR_MODE_M1) || pq_only;
@@ -1402,6 +1404,9 @@ extern "C" int dr_get_timing(dr_index *ix, dr_timing *out)
 }
 
 
+static int seq_search_locked(dr_index *ix, const void *queries, bool f64, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width, uint32_t mode,
+                             uint32_t band_policy, uint32_t *out_ids, void *out_dist, uint32_t *out_count, dr_stats *stats);
+
 extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t L,
                                uint32_t beam_width, uint32_t mode, uint32_t band_policy, uint32_t flags,
                                uint32_t *out_ids, float *out_dist, uint32_t *out_count, dr_stats *stats)
@@ -1410,6 +1415,11 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
     if (!out_ids || !out_dist || !out_count) return fail(DR_E_ARG, "null output buffer");
     if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
     std::lock_guard<std::mutex> lk(ix->mu);
+    if ((band_policy & 0xFFu) == 2u) {
+        // the reference's coin flip itself (np.random.random() < 0.2 on numpy's MT19937 stream): a sequential walk, served by the literal kernel
+        if (mode != DR_MODE_M1) return fail(DR_E_ARG, "band policy 2 (the literal coin flip) belongs to DR_MODE_M1");
+        return seq_search_locked(ix, queries, false, nq, k, L, beam_width, mode, band_policy, out_ids, out_dist, out_count, stats);
+    }
     const bool no_direct = getenv("DR_NO_DIRECT") != nullptr;      // A/B and tests: small calls through the general path (read per call)
     if (nq <= DR_DIRECT_MAX && !no_direct) {
         // ---- a handful of queries (one per request is the shape of the reference's API routes, search_engine.py:530-614, app.py:84-130)
@@ -1464,33 +1474,32 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
     return 0;
 }
 
-// Float64 queries (the CLI hands np.array(list): diskrag.py:194, quirk Q8). M1 and M2 only -- the two searches the
-// CLI reaches (search_engine.py:566-573). One wavefront per query, at most 64 queries per launch; see search_f64.hpp.
-extern "C" int dr_search_batch_f64(dr_index *ix, const double *queries, uint32_t nq, uint32_t k, uint32_t L,
-                                   uint32_t beam_width, uint32_t mode, uint32_t band_policy, uint32_t flags,
-                                   uint32_t *out_ids, double *out_dist, uint32_t *out_count, dr_stats *stats)
+// The literal sequential kernel (search_f64.hpp): float64 queries (the CLI hands np.array(list): diskrag.py:194, quirk Q8) -- M1 and M2, the two
+// searches the CLI reaches (search_engine.py:566-573) -- and, since round 5, float32 queries with the LITERAL coin flip of the rerank policy
+// (band_policy 2 | seed0 << 8: numpy's MT19937 stream, seeded with seed0 + query index). One wavefront per query, at most 64 queries per launch.
+static int seq_search_locked(dr_index *ix, const void *queries, bool f64, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width, uint32_t mode,
+                             uint32_t band_policy, uint32_t *out_ids, void *out_dist, uint32_t *out_count, dr_stats *stats)
 {
-    (void)flags;
-    if (!ix) return fail(DR_E_ARG, "null index");
-    if (!out_ids || !out_dist || !out_count) return fail(DR_E_ARG, "null output buffer");
-    if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
-    if (mode != DR_MODE_M1 && mode != DR_MODE_M2) return fail(DR_E_UNSUPPORTED, "float64 queries: modes M1 and M2 only");
+    const char *what = f64 ? "float64 search" : "band policy 2 (the literal coin flip)";
+    if (mode != DR_MODE_M1 && mode != DR_MODE_M2) return fail(DR_E_UNSUPPORTED, "%s: modes M1 and M2 only", what);
     if (k == 0) return fail(DR_E_ARG, "k must be positive");
-    std::lock_guard<std::mutex> lk(ix->mu);
-    { const int rcv = need_vectors(ix, "float64 search"); if (rcv) return rcv; }
+    if ((band_policy & 0xFFu) > 2u) return fail(DR_E_ARG, "band policy %u", band_policy & 0xFFu);
+    { const int rcv = need_vectors(ix, what); if (rcv) return rcv; }
     if (mode == DR_MODE_M1 && ix->m == 0) return fail(DR_E_NOPQ, "mode %u needs PQ data (dr_index_set_pq)", mode);
     const uint32_t cap = (mode == DR_MODE_M2) ? beam_width : L;
     if (cap == 0) return fail(DR_E_ARG, "result-list capacity is zero (L / beam_width)");
     if (cap > 512) return fail(DR_E_UNSUPPORTED, "result-list capacity %u > 512", cap);
     HIPCHK(hipSetDevice(ix->device));
+    { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }
     const uint32_t D = ix->D, CH = 64;
+    const size_t esz = f64 ? 8 : 4;
     const bool pq = (mode == DR_MODE_M1);
-    // LDS: 2 queries (f64), both heaps, per-expansion arrays, the table; the candidates heap takes what is left
-    const size_t fixed = (size_t)2 * D * 8 + (size_t)(cap + 1) * 12 + 64 * 8 + 64 * 4 + 64 * 4 + (pq ? (size_t)ix->m * 256 * 4 : 0) + 64;
-    if (fixed + 1024 * 12 > 160 * 1024) return fail(DR_E_UNSUPPORTED, "float64 search does not fit in LDS (D=%u, m=%u, capacity %u)", D, ix->m, cap);
-    const uint32_t cand_cap = (uint32_t)std::min<size_t>((160 * 1024 - fixed) / 12, 8192) & ~1u;
-    const size_t lds = fixed + (size_t)cand_cap * 12;
-    const void *kfn = ix->kern->search_f64;
+    // LDS: 2 queries, both heaps, per-expansion arrays, the table, the generator's state; the candidates heap takes what is left
+    const size_t fixed = (size_t)2 * D * esz + (size_t)(cap + 2) * (esz + 4) + 64 * esz + 64 * 4 + 64 * 4 + (pq ? (size_t)ix->m * 256 * 4 : 0) + 626 * 4 + 64;
+    if (fixed + 1024 * (esz + 4) > 160 * 1024) return fail(DR_E_UNSUPPORTED, "%s does not fit in LDS (D=%u, m=%u, capacity %u)", what, D, ix->m, cap);
+    const uint32_t cand_cap = (uint32_t)std::min<size_t>((160 * 1024 - fixed) / (esz + 4), 8192) & ~1u;
+    const size_t lds = fixed + (size_t)cand_cap * (esz + 4);
+    const void *kfn = f64 ? ix->kern->search_f64 : ix->kern->search_seq_f32;
     HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t vis_words = (uint32_t)((ix->N + 31) / 32);
     // scratch kept on the handle (the CLI asks one query per call: no allocation on its path after the first)
@@ -1507,17 +1516,17 @@ extern "C" int dr_search_batch_f64(dr_index *ix, const double *queries, uint32_t
         p.vecp = ix->vecp.p; p.adj = ix->adj.p; p.first = ix->first.p; p.deg = nullptr; p.codes = ix->codes.p;
         p.codebook = ix->codebook.p; p.perm = ix->perm.p; p.queries = dq.p;
         p.N = ix->N; p.D = D; p.R = ix->R; p.m = ix->m; p.sd = ix->sd; p.medoid = ix->medoid; p.nq = n;
-        p.mode = mode; p.k = k; p.cap = cap; p.L = L; p.bw = beam_width; p.policy = band_policy;
+        p.mode = mode; p.k = k; p.cap = cap; p.L = L; p.bw = beam_width; p.policy = band_policy; p.q0 = q0;
         p.max_steps = pq ? (uint32_t)std::min<uint64_t>((uint64_t)L * 10, ix->N) : 0xFFFFFFFFu;
         p.vis = dvis.p; p.vis_words = vis_words; p.cand_cap = cand_cap;
         p.out_ids = dids.p; p.out_dist = dd.p; p.out_count = dcnt.p; p.stats = dst.p;
-        if (hipMemcpyAsync(dq.p, queries + (size_t)q0 * D, (size_t)n * D * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
-            hipMemsetAsync(dvis.p, 0, (size_t)n * vis_words * 4, ix->stream) != hipSuccess) { rc = fail(DR_E_NODEVICE, "float64 search: upload failed"); break; }
+        if (hipMemcpyAsync(dq.p, static_cast<const unsigned char *>(queries) + (size_t)q0 * D * esz, (size_t)n * D * esz, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+            hipMemsetAsync(dvis.p, 0, (size_t)n * vis_words * 4, ix->stream) != hipSuccess) { rc = fail(DR_E_NODEVICE, "%s: upload failed", what); break; }
         void *args[] = { &p };
-        if (hipLaunchKernel(kfn, dim3(n), dim3(64), args, lds, ix->stream) != hipSuccess) { rc = fail(DR_E_NODEVICE, "float64 search: launch failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        if (hipLaunchKernel(kfn, dim3(n), dim3(64), args, lds, ix->stream) != hipSuccess) { rc = fail(DR_E_NODEVICE, "%s: launch failed: %s", what, hipGetErrorString(hipGetLastError())); break; }
         // results through the pinned host slab (see download_locked)
-        const size_t b_ids = (size_t)n * k * 4, b_d = (size_t)n * k * 8, b_cnt = (size_t)n * 4, b_st = (size_t)n * sizeof(KStats);
-        const size_t need = b_d + b_ids + b_cnt + b_st;
+        const size_t b_ids = (size_t)n * k * 4, b_d = (size_t)n * k * esz, b_cnt = (size_t)n * 4, b_st = (size_t)n * sizeof(KStats);
+        const size_t need = b_d + b_ids + b_cnt + b_st + 16;
         if (ix->pinned_bytes < need) {
             if (ix->pinned) (void)hipHostFree(ix->pinned);
             ix->pinned = nullptr; ix->pinned_bytes = 0;
@@ -1529,13 +1538,25 @@ extern "C" int dr_search_batch_f64(dr_index *ix, const double *queries, uint32_t
             hipMemcpyAsync(hp + b_d, dids.p, b_ids, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
             hipMemcpyAsync(hp + b_d + b_ids, dcnt.p, b_cnt, hipMemcpyDeviceToHost, ix->stream) != hipSuccess ||
             (stats && hipMemcpyAsync(hp + b_d + b_ids + b_cnt, dst.p, b_st, hipMemcpyDeviceToHost, ix->stream) != hipSuccess) ||
-            hipStreamSynchronize(ix->stream) != hipSuccess) { rc = fail(DR_E_NODEVICE, "float64 search: %s", hipGetErrorString(hipGetLastError())); break; }
-        memcpy(out_dist + (size_t)q0 * k, hp, b_d);
+            hipStreamSynchronize(ix->stream) != hipSuccess) { rc = fail(DR_E_NODEVICE, "%s: %s", what, hipGetErrorString(hipGetLastError())); break; }
+        memcpy(static_cast<unsigned char *>(out_dist) + (size_t)q0 * k * esz, hp, b_d);
         memcpy(out_ids + (size_t)q0 * k, hp + b_d, b_ids);
         memcpy(out_count + q0, hp + b_d + b_ids, b_cnt);
         if (stats) memcpy(stats + q0, hp + b_d + b_ids + b_cnt, b_st);
     }
     return rc;
+}
+
+extern "C" int dr_search_batch_f64(dr_index *ix, const double *queries, uint32_t nq, uint32_t k, uint32_t L,
+                                   uint32_t beam_width, uint32_t mode, uint32_t band_policy, uint32_t flags,
+                                   uint32_t *out_ids, double *out_dist, uint32_t *out_count, dr_stats *stats)
+{
+    (void)flags;
+    if (!ix) return fail(DR_E_ARG, "null index");
+    if (!out_ids || !out_dist || !out_count) return fail(DR_E_ARG, "null output buffer");
+    if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    return seq_search_locked(ix, queries, true, nq, k, L, beam_width, mode, band_policy, out_ids, out_dist, out_count, stats);
 }
 
 #include "entry_points.inc"

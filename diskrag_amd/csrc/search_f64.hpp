@@ -9,38 +9,73 @@
 // vector, numpy's pairwise order in double), and the reference's two heaps kept literally -- CPython's heapq sift
 // rules on (key, id) tuples -- by lane 0 in LDS. Exact by construction, including the heap-array tie order of the
 // final stable sort (search_engine.py:483-488); throughput is not the point here (a query takes ~1 ms).
+//
+// Round 5: the kernel is a template on the query's arithmetic type. The float32 instantiation exists for ONE thing the batched engine
+// cannot do: the LITERAL rerank policy A4 -- in the 0.8 - 1.2 band the reference flips a coin, np.random.random() < 0.2, on numpy's global
+// MT19937 stream (search_engine.py:393-395, quirk Q2). The batched kernels decide a whole expansion at once and serve the two
+// deterministic branches of that coin (band_policy 0 / 1); here lane 0 walks the neighbours in stored order anyway, so band_policy
+// 2 | seed0 << 8 draws from the same generator -- init_genrand(seed0 + query index), 53-bit doubles from two 32-bit draws, exactly numpy's
+// legacy np.random.seed / np.random.random -- at the same points of the walk, for float32 (dr_search_batch) and float64
+// (dr_search_batch_f64) queries. Goldens: the reference run UNPATCHED (tests/golden/gen_golden_coinflip.py).
 #pragma once
 #include "search_kernel.hpp"
 
+// numpy's legacy generator (numpy/random/src/mt19937/mt19937.c): state in LDS, driven by lane 0
+DEV void mt_seed(u32 *mt, u32 seed)
+{
+    mt[0] = seed;
+    for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (u32)i;
+    mt[624] = 624u;
+}
+DEV u32 mt_next32(u32 *mt)
+{
+    if (mt[624] == 624u) {
+        for (int i = 0; i < 624; i++) {
+            const u32 y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7FFFFFFFu);
+            mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+        }
+        mt[624] = 0u;
+    }
+    u32 y = mt[mt[624]++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9D2C5680u; y ^= (y << 15) & 0xEFC60000u; y ^= y >> 18;
+    return y;
+}
+DEV double mt_random(u32 *mt)
+{
+    const u32 a = mt_next32(mt) >> 5, b = mt_next32(mt) >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+
 struct F64Params {
     const float *vecp; const u32 *adj; const u64 *first; const u32 *deg; const u8 *codes; const float *codebook;
-    const u32 *perm; const double *queries;
+    const u32 *perm; const void *queries;      // REAL[nq][D]
     u64 N; u32 D, R, m, sd, medoid, nq;
     u32 mode, k, cap, L, bw, policy, max_steps;
     u32 *vis; u32 vis_words; u32 cand_cap;
-    u32 *out_ids; double *out_dist; u32 *out_count; KStats *stats;
+    u32 *out_ids; void *out_dist; u32 *out_count; KStats *stats;      // out_dist: REAL[nq][k]
+    u32 q0;     // index of the launch's first query in the caller's batch (the coin flip is seeded per query)
 };
 
 // (key, id) tuple order: first differing element decides (ids are unique inside a heap)
-DEV bool tup_lt(double ka, u32 ia, double kb, u32 ib) { return ka < kb || (ka == kb && ia < ib); }
+template <typename REAL> DEV bool tup_lt(REAL ka, u32 ia, REAL kb, u32 ib) { return ka < kb || (ka == kb && ia < ib); }
 
 // Lib/heapq.py _siftdown: bubble heap[pos] up towards startpos
-DEV void hq_siftdown(double *hk, u32 *hi, int startpos, int pos)
+template <typename REAL> DEV void hq_siftdown(REAL *hk, u32 *hi, int startpos, int pos)
 {
-    const double nk = hk[pos]; const u32 ni = hi[pos];
+    const REAL nk = hk[pos]; const u32 ni = hi[pos];
     while (pos > startpos) {
         const int parent = (pos - 1) >> 1;
-        const double pk = hk[parent]; const u32 pi = hi[parent];
+        const REAL pk = hk[parent]; const u32 pi = hi[parent];
         if (tup_lt(nk, ni, pk, pi)) { hk[pos] = pk; hi[pos] = pi; pos = parent; continue; }
         break;
     }
     hk[pos] = nk; hi[pos] = ni;
 }
 // Lib/heapq.py _siftup: move the smaller child up until a leaf, then sift the item down from there
-DEV void hq_siftup(double *hk, u32 *hi, int n, int pos)
+template <typename REAL> DEV void hq_siftup(REAL *hk, u32 *hi, int n, int pos)
 {
     const int startpos = pos;
-    const double nk = hk[pos]; const u32 ni = hi[pos];
+    const REAL nk = hk[pos]; const u32 ni = hi[pos];
     int child = 2 * pos + 1;
     while (child < n) {
         const int right = child + 1;
@@ -52,18 +87,36 @@ DEV void hq_siftup(double *hk, u32 *hi, int n, int pos)
     hk[pos] = nk; hi[pos] = ni;
     hq_siftdown(hk, hi, startpos, pos);
 }
-DEV void hq_push(double *hk, u32 *hi, int &n, double k, u32 id) { hk[n] = k; hi[n] = id; n++; hq_siftdown(hk, hi, 0, n - 1); }
-DEV void hq_pop(double *hk, u32 *hi, int &n, double &k, u32 &id)
+template <typename REAL> DEV void hq_push(REAL *hk, u32 *hi, int &n, REAL k, u32 id) { hk[n] = k; hi[n] = id; n++; hq_siftdown(hk, hi, 0, n - 1); }
+template <typename REAL> DEV void hq_pop(REAL *hk, u32 *hi, int &n, REAL &k, u32 &id)
 {
     n--;
-    const double lk = hk[n]; const u32 li = hi[n];
+    const REAL lk = hk[n]; const u32 li = hi[n];
     if (n > 0) { k = hk[0]; id = hi[0]; hk[0] = lk; hi[0] = li; hq_siftup(hk, hi, n, 0); }
     else { k = lk; id = li; }
 }
 
-template <int D>
-__global__ __launch_bounds__(64) void search_f64_kernel(const F64Params p)
+// the type's own arithmetic: numpy's pairwise sums (A1, A2), products and square roots in REAL
+template <typename REAL> struct SeqNum;
+template <> struct SeqNum<double> {
+    template <int D> static DEV double row(const float *r, const double *q, int j) { return pw_row_stream64<0, D, D>(r, q, j); }
+    static DEV double run(const float *c, const double *q, int n) { return pw_run_lane64(c, q, n); }
+    static DEV double mul(double a, double b) { return d_mul(a, b); }
+    static DEV double sqrt_(double a) { return __builtin_sqrt(a); }
+    static DEV double nan_() { return __longlong_as_double(0x7FF8000000000000ll); }
+};
+template <> struct SeqNum<float> {
+    template <int D> static DEV float row(const float *r, const float *q, int j) { return pw_row_stream<0, D, D, false>(r, nullptr, q, j); }
+    static DEV float run(const float *c, const float *q, int n) { return pw_run_lane(c, q, n); }
+    static DEV float mul(float a, float b) { return f_mul(a, b); }
+    static DEV float sqrt_(float a) { return f_sqrt(a); }
+    static DEV float nan_() { return __uint_as_float(0x7FC00000u); }
+};
+
+template <int D, typename REAL>
+__global__ __launch_bounds__(64) void search_seq_kernel(const F64Params p)
 {
+    using NUM = SeqNum<REAL>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
     const int lane = (int)lane_id();
     const int oct = lane >> 3, j = lane & 7;
@@ -71,20 +124,22 @@ __global__ __launch_bounds__(64) void search_f64_kernel(const F64Params p)
     if (qi >= p.nq) return;
     const bool pq = (p.mode == 1u);
     // LDS carve-up
-    double *qperm = reinterpret_cast<double *>(smem64);              // chain-major query
-    double *qorig = qperm + D;                                       // original order (table rows)
-    double *res_k = qorig + D;                                       // results heap: keys = -distance
-    double *cand_k = res_k + (p.cap + 1);                            // candidates heap: keys = distance
-    double *nb_e = cand_k + p.cand_cap;
+    REAL *qperm = reinterpret_cast<REAL *>(smem64);                  // chain-major query
+    REAL *qorig = qperm + D;                                         // original order (table rows)
+    REAL *res_k = qorig + D;                                         // results heap: keys = -distance
+    REAL *cand_k = res_k + (p.cap + 2);                              // candidates heap: keys = distance   (cap + 2: keeps 8-byte alignment for either type)
+    REAL *nb_e = cand_k + p.cand_cap;
     u32 *res_i = reinterpret_cast<u32 *>(nb_e + 64);
-    u32 *cand_i = res_i + (p.cap + 1);
+    u32 *cand_i = res_i + (p.cap + 2);
     u32 *nb_id = cand_i + p.cand_cap;
     float *nb_pq = reinterpret_cast<float *>(nb_id + 64);
     float *lut = nb_pq + 64;                                         // m*256 floats when pq
+    u32 *mt = reinterpret_cast<u32 *>(lut + (pq ? (size_t)p.m * 256 : 0));   // [625] MT19937 state + position (the literal coin flip)
+    const bool coin = (p.policy & 0xFFu) == 2u;
     u32 *vbm = p.vis + (size_t)qi * p.vis_words;                     // zeroed by the host before the launch
 
     for (int i = lane; i < D; i += 64) {
-        const double v = p.queries[(size_t)qi * D + i];
+        const REAL v = reinterpret_cast<const REAL *>(p.queries)[(size_t)qi * D + i];
         qorig[i] = v;
         qperm[p.perm[i]] = v;
     }
@@ -93,9 +148,10 @@ __global__ __launch_bounds__(64) void search_f64_kernel(const F64Params p)
         // A2 in float64, stored as float32 (fast_pq.py:307-316)
         const u32 total = p.m * 256;
         for (u32 e = lane; e < total; e += 64)
-            lut[e] = (float)pw_run_lane64(p.codebook + (size_t)e * p.sd, qorig + (e >> 8) * p.sd, (int)p.sd);
+            lut[e] = (float)NUM::run(p.codebook + (size_t)e * p.sd, qorig + (e >> 8) * p.sd, (int)p.sd);
         WSYNC();
     }
+    if (coin && lane == 0) mt_seed(mt, (p.policy >> 8) + p.q0 + qi);     // np.random.seed(seed0 + query index)
 
     u32 steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0;
     int rn = 0, cn = 0;
@@ -106,8 +162,8 @@ __global__ __launch_bounds__(64) void search_f64_kernel(const F64Params p)
         const u32 start = p.medoid;
         if (lane == 0) atomicOr(&vbm[start >> 5], 1u << (start & 31));
         nvisited = 1;
-        double d0 = pw_row_stream64<0, D, D>(p.vecp + (size_t)start * D, qperm, j);
-        if (!pq) d0 = __builtin_sqrt(d0);
+        REAL d0 = NUM::template row<D>(p.vecp + (size_t)start * D, qperm, j);
+        if (!pq) d0 = NUM::sqrt_(d0);
         nexact = 1;
         if (lane == 0) { hq_push(cand_k, cand_i, cn, d0, start); hq_push(res_k, res_i, rn, -d0, start); }
         cn = 1; rn = 1;
@@ -119,9 +175,9 @@ __global__ __launch_bounds__(64) void search_f64_kernel(const F64Params p)
         steps++;
         // pop + stop rule (search_engine.py:434-439, vamana_graph.py:731-735) by lane 0, broadcast through LDS
         if (lane == 0) {
-            double ck; u32 ci; int n = cn;
+            REAL ck; u32 ci; int n = cn;
             hq_pop(cand_k, cand_i, n, ck, ci);
-            const double W = -res_k[0];
+            const REAL W = -res_k[0];
             nb_id[0] = ci;
             nb_id[1] = (rn >= cap && ck > W) ? 1u : 0u;
         }
@@ -164,8 +220,8 @@ __global__ __launch_bounds__(64) void search_f64_kernel(const F64Params p)
             // scoring the others changes nothing but work, the counter below follows the reference)
             for (int r0 = 0; r0 < nnew; r0 += 8) {
                 const int idx = min(r0 + oct, nnew - 1);
-                double ev = pw_row_stream64<0, D, D>(p.vecp + (size_t)nb_id[idx] * D, qperm, j);
-                if (!pq) ev = __builtin_sqrt(ev);
+                REAL ev = NUM::template row<D>(p.vecp + (size_t)nb_id[idx] * D, qperm, j);
+                if (!pq) ev = NUM::sqrt_(ev);
                 if (j == 0 && r0 + oct < nnew) nb_e[r0 + oct] = ev;
             }
             WSYNC();
@@ -174,23 +230,23 @@ __global__ __launch_bounds__(64) void search_f64_kernel(const F64Params p)
                 int n_c = cn, n_r = rn;
                 u32 ex = 0;
                 for (int i = 0; i < nnew; i++) {
-                    const double W = -res_k[0];
+                    const REAL W = -res_k[0];
                     if (pq) {
-                        const double pd = (double)nb_pq[i];
+                        const REAL pd = (REAL)nb_pq[i];
                         bool pass;
                         if (n_r < (int)p.L) pass = true;
-                        else if (pd < d_mul(0.8, W)) pass = true;
-                        else if (pd < d_mul(1.2, W)) pass = (p.policy == 0u);
+                        else if (pd < NUM::mul((REAL)0.8, W)) pass = true;
+                        else if (pd < NUM::mul((REAL)1.2, W)) pass = coin ? (mt_random(mt) < 0.2) : (p.policy == 0u);     // np.random.random() < 0.2
                         else pass = false;
                         if (!pass) continue;
                     }
                     ex++;
-                    const double e = nb_e[i];
+                    const REAL e = nb_e[i];
                     if (n_r < cap || e < W) {
                         if (n_c >= (int)p.cand_cap) { status |= DR_ST_CAND_OVERFLOW; continue; }
                         hq_push(cand_k, cand_i, n_c, e, nb_id[i]);
                         hq_push(res_k, res_i, n_r, -e, nb_id[i]);
-                        if (n_r > cap) { double dk; u32 di; hq_pop(res_k, res_i, n_r, dk, di); }
+                        if (n_r > cap) { REAL dk; u32 di; hq_pop(res_k, res_i, n_r, dk, di); }
                     }
                 }
                 nb_id[0] = (u32)n_c; nb_id[1] = (u32)n_r; nb_id[2] = ex; nb_id[3] = status;
@@ -207,7 +263,7 @@ __global__ __launch_bounds__(64) void search_f64_kernel(const F64Params p)
                     int best = a;
                     for (int b = a + 1; b < cn; b++)
                         if (tup_lt(cand_k[b], cand_i[b], cand_k[best], cand_i[best])) best = b;
-                    const double tk = cand_k[a]; const u32 ti = cand_i[a];
+                    const REAL tk = cand_k[a]; const u32 ti = cand_i[a];
                     cand_k[a] = cand_k[best]; cand_i[a] = cand_i[best];
                     cand_k[best] = tk; cand_i[best] = ti;
                 }
@@ -222,7 +278,7 @@ __global__ __launch_bounds__(64) void search_f64_kernel(const F64Params p)
     if (lane == 0) {
         for (int i = 0; i < rn; i++) res_k[i] = -res_k[i];
         for (int i = 1; i < rn; i++) {        // insertion sort: stable
-            const double kk = res_k[i]; const u32 ii = res_i[i];
+            const REAL kk = res_k[i]; const u32 ii = res_i[i];
             int b = i - 1;
             while (b >= 0 && (pq ? (res_k[b] > kk) : tup_lt(kk, ii, res_k[b], res_i[b]))) {
                 res_k[b + 1] = res_k[b]; res_i[b + 1] = res_i[b]; b--;
@@ -234,7 +290,7 @@ __global__ __launch_bounds__(64) void search_f64_kernel(const F64Params p)
     const int kout = min(rn, (int)p.k);
     for (int i = lane; i < (int)p.k; i += 64) {
         p.out_ids[(size_t)qi * p.k + i] = (i < kout) ? res_i[i] : 0xFFFFFFFFu;
-        p.out_dist[(size_t)qi * p.k + i] = (i < kout) ? res_k[i] : __longlong_as_double(0x7FF8000000000000ll);
+        reinterpret_cast<REAL *>(p.out_dist)[(size_t)qi * p.k + i] = (i < kout) ? res_k[i] : NUM::nan_();
     }
     if (lane == 0) {
         p.out_count[qi] = (u32)kout;

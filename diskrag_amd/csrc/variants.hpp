@@ -74,6 +74,7 @@ struct DimKernels {
     const void *prune_multi;      // prune_kernel<D, true> (multi-pick form), nullptr where the split row form does not exist
     const void *nearest_pivot;   // aux_kernels.hpp nearest_pivot_kernel (bit order of the visited bitmap)
     const void *search_f64;   // M1 / M2 with float64 queries (the CLI path), search_f64.hpp
+    const void *search_seq_f32;   // the same literal kernel on float32 queries (band policy 2: the reference's coin flip itself)
     const void *rerank;       // aux_kernels.hpp rerank_kernel (DR_MODE_PQ + DR_F_RERANK)
 };
 

@@ -65,6 +65,7 @@ extern "C" {
                        out_dist = that distance x 0.5 (exact in float32) = 1 - <q, v>. Refused with DR_E_UNSUPPORTED when a stored vector's
                        squared norm differs from 1 by more than 1e-3 (checked once per index); a QUERY whose squared norm does is answered
                        with NaN distances and dr_stats.status bit 4 (16). */
+#define DR_POLICY_COIN(seed0) (2u | (((uint32_t)(seed0) & 0xFFFFFFu) << 8)) /* band_policy: the reference's coin flip itself (see dr_search_batch) */
 #define DR_F_POPS_SHIFT 8u
 #define DR_F_POPS_MASK 0xF00u
 #define DR_F_POPS(n) (((uint32_t)(n) & 15u) << DR_F_POPS_SHIFT) /* DR_MODE_PQB: frontier entries expanded per step (DiskANN's beam): narrow rows
@@ -228,7 +229,11 @@ int dr_merge_topk(int device, const uint32_t *ids, const float *dist, uint32_t S
  *   L           result-list size (M1, M4); ignored by M2 (Q6) and M3
  *   beam_width  frontier trim (M1/M2: heapq.nsmallest, 0 = none; M3: pops the smallest, Q9); M2 list size
  *   band_policy Q2: the reference flips a coin (np.random.random() < 0.2) in the 0.8-1.2 band; 0 = always
- *               rerank, 1 = never (the two deterministic policies the golden vectors are generated with)
+ *               rerank, 1 = never (the two deterministic policies most golden vectors are generated with);
+ *               DR_POLICY_COIN(seed0) = 2 | seed0 << 8 (round 5; M1, dr_search_batch and dr_search_batch_f64 only): the coin flip ITSELF, drawn
+ *               from numpy's legacy MT19937 stream as if np.random.seed(seed0 + i) were called before query i of the call -- bit-exact against
+ *               the reference run unpatched (tests/golden/gen_golden_coinflip.py). A sequential walk: served by the literal
+ *               one-wavefront-per-query kernel (~1 ms per query), not by the batched engine
  * Stands behind _pq_accelerated_graph_search(q,k,L,beam_width) (search_engine.py:398) and
  * _exact_graph_search(q,k,L) (search_engine.py:508). */
 int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width,

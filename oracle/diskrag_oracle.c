@@ -64,6 +64,41 @@ typedef struct {
     const float *codebook;   /* [m][256][D/m] or NULL          kmeans_list[j].cluster_centers_ */
 } orc_index;
 
+/* numpy's legacy global generator (np.random.seed(int) -> init_genrand; np.random.random() -> 53-bit double from two 32-bit draws:
+ * numpy/random/src/mt19937/mt19937.c, mt19937_seed / mt19937_gen / mt19937_next_double): what the reference's coin flip draws from
+ * (search_engine.py:393-395, quirk Q2). band policy 2 | seed0 << 8 = "np.random.seed(seed0 + query index) before each query". */
+typedef struct { uint32_t mt[624]; int pos; } orc_mt;
+static void orc_mt_seed(orc_mt *g, uint32_t seed)
+{
+    g->mt[0] = seed;
+    for (int i = 1; i < 624; i++) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->pos = 624;
+}
+static uint32_t orc_mt_next32(orc_mt *g)
+{
+    if (g->pos == 624) {
+        for (int i = 0; i < 624; i++) {
+            const uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7FFFFFFFu);
+            g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+        }
+        g->pos = 0;
+    }
+    uint32_t y = g->mt[g->pos++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9D2C5680u; y ^= (y << 15) & 0xEFC60000u; y ^= y >> 18;
+    return y;
+}
+static double orc_mt_random(orc_mt *g)
+{
+    const uint32_t a = orc_mt_next32(g) >> 5, b = orc_mt_next32(g) >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+/* test seam: the first n doubles of np.random.seed(seed); np.random.random() */
+void orc_mt_doubles(uint32_t seed, uint32_t n, double *out)
+{
+    orc_mt g; orc_mt_seed(&g, seed);
+    for (uint32_t i = 0; i < n; i++) out[i] = orc_mt_random(&g);
+}
+
 static inline float sqrt_real_f32(float x) { return sqrtf(x); }
 static inline double sqrt_real_f64(double x) { return sqrt(x); }
 
@@ -241,10 +276,10 @@ int orc_search_batch(const float *vectors, const uint32_t *adj, const uint8_t *c
             rc = pqb_search_one(&ix, (const float *)queries + (size_t)i * D, k, L, bw, flags,
                                 out_ids + (size_t)i * k, out_dist + (size_t)i * k, out_count + i, st);
         else if (flags & ORC_F_QUERY_F64)
-            rc = search_one_f64(&ix, (const double *)queries + (size_t)i * D, mode, k, L, bw, policy, flags,
+            rc = search_one_f64(&ix, (const double *)queries + (size_t)i * D, (uint32_t)i, mode, k, L, bw, policy, flags,
                                 out_ids + (size_t)i * k, out_dist + (size_t)i * k, out_count + i, st);
         else
-            rc = search_one_f32(&ix, (const float *)queries + (size_t)i * D, mode, k, L, bw, policy, flags,
+            rc = search_one_f32(&ix, (const float *)queries + (size_t)i * D, (uint32_t)i, mode, k, L, bw, policy, flags,
                                 out_ids + (size_t)i * k, out_dist + (size_t)i * k, out_count + i, st);
         if (rc) {
 #ifdef _OPENMP

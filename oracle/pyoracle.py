@@ -51,6 +51,8 @@ def lib():
         L.orc_search_batch.argtypes = [fp, u32p, u8p, fp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u32p, dp, u32p, u32p]
+        L.orc_mt_doubles.restype = None
+        L.orc_mt_doubles.argtypes = [C.c_uint32, C.c_uint32, dp]
         L.orc_bruteforce_topk.restype = None
         L.orc_bruteforce_topk.argtypes = [fp, C.c_uint64, C.c_uint32, fp, C.c_uint32, C.c_uint32, C.c_int, u32p]
         L.orc_l2_seq_f32.restype = C.c_float
@@ -128,6 +130,17 @@ def search_batch(vectors, adj, queries, medoid, mode, k, L=100, bw=0, policy=0, 
     if rc != 0:
         raise RuntimeError(f"orc_search_batch failed rc={rc}")
     return ids, dist, cnt, stats
+
+
+def POLICY_COIN(seed0):
+    """band policy: the reference's coin flip itself (np.random.random() < 0.2), as if np.random.seed(seed0 + qi) ran before query qi"""
+    return 2 | ((int(seed0) & 0xFFFFFF) << 8)
+
+
+def mt_doubles(seed, n):
+    out = np.empty(n, dtype=np.float64)
+    lib().orc_mt_doubles(int(seed), int(n), _p(out, C.c_double))
+    return out
 
 
 def bruteforce_topk(vectors, queries, k, nthreads=1):

@@ -81,3 +81,37 @@ def test_f64_entry_rejects_what_it_does_not_serve():
         ix.search_batch_f64(q, 5, L=20, beam_width=8, mode=_ffi.MODE_M3)      # CLI modes only
     with pytest.raises(ValueError):
         ix.search_batch_f64(q[:, :100], 5)
+
+
+@pytest.mark.parametrize("name", ["unit1536_R16_m32", "unit1536_R16_m64"])
+def test_literal_coin_flip_on_the_device(name):
+    """band_policy = DR_POLICY_COIN(seed0): the reference's coin flip itself, drawn on the device from numpy's MT19937 stream seeded per query --
+    float32 queries (dr_search_batch) and float64 queries (dr_search_batch_f64) against the reference run UNPATCHED: ids, distance bits, counters."""
+    import json
+    from diskrag_amd import _ffi
+    from tests.conftest import GOLDEN
+    g = load_golden(name)
+    ix = get_index(name)
+    z = np.load(GOLDEN / f"coinflip_{name}.npz")
+    for ci, c in enumerate(json.loads(str(z["cases"]))):
+        pol = _ffi.POLICY_COIN(c["seed0"])
+        if c["f64"]:
+            ids, dist, cnt, st = ix.search_batch_f64(g.queries.astype(np.float64), c["k"], L=c["L"], beam_width=c["bw"], mode=_ffi.MODE_M1, band_policy=pol)
+        else:
+            ids, dist, cnt, st = ix.search_batch(g.queries, c["k"], L=c["L"], beam_width=c["bw"], mode=_ffi.MODE_M1, band_policy=pol)
+        assert int(st["status"].max()) == 0
+        assert np.array_equal(ids, z[f"c{ci}_ids"]) and np.array_equal(cnt, z[f"c{ci}_count"]), (name, c)
+        valid = z[f"c{ci}_ids"] != 0xFFFFFFFF
+        if c["f64"]:
+            assert np.array_equal(dist[valid], z[f"c{ci}_dist"][valid])
+        else:
+            assert np.array_equal(dist[valid].view(np.uint32), z[f"c{ci}_dist"][valid].astype(np.float32).view(np.uint32))
+        assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), z[f"c{ci}_stats"]), (name, c)
+    # a chunk boundary (more than 64 queries per call): the seed follows the query's index in the CALL
+    q = np.concatenate([g.queries] * 4)[:100]
+    a = ix.search_batch(q, 10, L=100, beam_width=8, mode=_ffi.MODE_M1, band_policy=_ffi.POLICY_COIN(5))
+    from oracle import pyoracle as orc
+    w = orc.search_batch(g.vectors, g.adj, q, g.medoid, orc.M1, 10, L=100, bw=8, policy=orc.POLICY_COIN(5), codes=g.codes, codebook=g.codebook)
+    assert np.array_equal(a[0], w[0]) and np.array_equal(np.stack([a[3]["steps"], a[3]["visited"], a[3]["exact"], a[3]["pq"]], axis=1), w[3])
+    with pytest.raises(_ffi.DiskragHipError):            # the batched paths take the two deterministic branches only
+        ix.search_submit(g.queries, 10, L=100, beam_width=8, mode=_ffi.MODE_M1, band_policy=_ffi.POLICY_COIN(5)).wait()

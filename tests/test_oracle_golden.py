@@ -215,3 +215,31 @@ def test_pq_mode_without_a_visited_set_equals_the_visited_set_statement(name):
         a = orc.search_batch(g.vectors, g.mem_adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, flags=orc.F_NO_VISITED_SET, codes=g.codes, codebook=g.codebook)
         b = orc.search_batch(g.vectors, g.mem_adj, g.queries, g.medoid, orc.PQ, k, L=L, bw=bw, codes=g.codes, codebook=g.codebook)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[3][:, 0], b[3][:, 0])
+
+
+def test_mt19937_restatement_is_numpys_legacy_generator():
+    """np.random.seed(int) + np.random.random(): what the reference's coin flip draws from (search_engine.py:393-395)."""
+    for seed in (0, 1, 12345, 2 ** 31 + 5, 2 ** 32 - 1):
+        np.random.seed(seed)
+        want = np.array([np.random.random() for _ in range(1500)])
+        assert np.array_equal(orc.mt_doubles(seed, 1500), want), seed
+
+
+@pytest.mark.parametrize("name", ["unit1536_R16_m32", "unit1536_R16_m64"])
+def test_literal_coin_flip_against_the_unpatched_reference(name):
+    """band policy 2: the rerank policy's coin flip itself. The goldens are the reference run UNPATCHED with np.random.seed(seed0 + qi) before
+    query qi (tests/golden/gen_golden_coinflip.py): ids, distance bits (float32 and float64 queries) and the four counters."""
+    import json
+    g = load_golden(name)
+    z = np.load(GOLDEN / f"coinflip_{name}.npz")
+    for ci, c in enumerate(json.loads(str(z["cases"]))):
+        q = g.queries.astype(np.float64) if c["f64"] else g.queries
+        w = orc.search_batch(g.vectors, g.adj, q, g.medoid, orc.M1, c["k"], L=c["L"], bw=c["bw"], policy=orc.POLICY_COIN(c["seed0"]),
+                             codes=g.codes, codebook=g.codebook)
+        assert np.array_equal(w[0], z[f"c{ci}_ids"]) and np.array_equal(w[2], z[f"c{ci}_count"]) and np.array_equal(w[3], z[f"c{ci}_stats"]), (name, c)
+        valid = z[f"c{ci}_ids"] != 0xFFFFFFFF
+        if c["f64"]:
+            assert np.array_equal(w[1][valid], z[f"c{ci}_dist"][valid])
+        else:
+            assert np.array_equal(w[1][valid].astype(np.float32).view(np.uint32), z[f"c{ci}_dist"][valid].astype(np.float32).view(np.uint32))
+        assert z[f"c{ci}_draws"].sum() > 0          # the band was live: coins were flipped
