@@ -183,6 +183,9 @@ class SearchEngineCorrect:
         t0 = time.time()
         f64 = self._is_f64(query_vector)
         run = self.index.search_batch_f64 if f64 else self._one
+        if not f64 and (band_policy & 0xFF) == 2:
+            # _ffi.POLICY_COIN(seed): the reference's coin flip itself (search_engine.py:393-395) -- a sequential walk, a blocking call
+            run = lambda qv, kk, **kw: self.index.search_batch(np.ascontiguousarray(qv, dtype=np.float32).reshape(1, -1), kk, **kw)   # noqa: E731
         ids, dist, cnt, st = run(query_vector, k, L=L, beam_width=beam_width or 0, mode=_ffi.MODE_M1,
                                  band_policy=band_policy)
         self._check_status(st)
