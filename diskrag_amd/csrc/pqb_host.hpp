@@ -34,7 +34,7 @@ static inline PqbChoice dr_pqb_choose(int sc, int nc, uint32_t m, int treg_pref,
     PqbChoice c = { nullptr, 0, 0, 1, false };
     if (!t) return c;
     const int ci = nc <= 1 ? 0 : nc <= 2 ? 1 : 2;
-    c.vf = want_vf && ci > 0;          // (one pass per step: nothing to compact)
+    c.vf = want_vf && ci > 0 && t->fn_vf[sc][ci - 1] != nullptr;          // (one pass per step: nothing to compact; built for m = 32 only)
     c.fn = c.vf ? t->fn_vf[sc][ci - 1] : t->fn[sc][ci]; c.m16 = t->m16; c.treg = t->treg; c.nc = ci == 0 ? 1 : ci == 1 ? 2 : 4;
     return c;
 }
