@@ -283,6 +283,10 @@ struct dr_index {
     // A SMALL blocking call (dr_search_batch, <= DR_DIRECT_MAX queries): the kernels write ids / distances / counts / counters straight into the
     // page-locked result slab (no download copies), the tie-order pass runs only if a query was listed for it (a flag word in the slab), on
     // the search stream (no cross-stream hand-over) -- the one-query requests of the API routes pay launches and one synchronisation, nothing else
+    int lat_adc_live[DR_NUM_SIZECLASS] = { -1, -1, -1, -1, -1 };     // variant 18's own regime per list-size class (its proof is sharper than search_kernel.hpp's): -1 not
+                                  // measured (the scoring wavefronts compute every ADC), 0 the policy asks on < 5 % of the neighbours (they skip it), 1 live
+    int lat_sc = 0;               // list-size class of the last variant-18 launch
+    bool lat_skip = false;        // the re-run of a small call whose query outgrew variant 18's visited-id set: search_kernel.hpp serves it
     bool direct = false;          // set by dr_search_batch around run_locked
     bool direct_used = false;     // run_locked's answer: this launch wrote into the slab
     bool direct_fin = false;      // ... and a tie-order pass may be needed (direct_f says with what)
@@ -874,6 +878,7 @@ static int launch_lut_build(dr_index *ix, const float *d_queries, uint32_t nq, f
 static int finish_group_locked(dr_index *ix, int g);
 // Per-query scratch (insert log, result keys) is sized by the batch: very large batches are processed in chunks.
 static const uint32_t DR_MAX_CHUNK = 32768;
+static const uint32_t DR_LAT_MAX_NQ = 64;       // small blocking calls of at most this many queries: a workgroup per query (variant 18, latency_kernel.hpp)
 static const uint32_t DR_DIRECT_MAX = 256;      // dr_search_batch calls of at most this many queries take the direct path (see dr_index::direct)
 
 static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_t mode, uint32_t policy, uint32_t flags,
@@ -971,7 +976,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     const int npref = k_m1 ? 5 : (ov && ov->sdc) ? 2 : k_adc ? 3 : ov ? 2 : 4;
     // (round 4: the per-query table wins with as few as five or six wavefronts per CU -- c4 shape, lists of 300-500 entries: 1.38x over
     // the shared codebook at eight, profiles/r04/ab/ab_c4_long_lists_table_vs_codebook.jsonl; it used to need eight to be preferred)
-    if (ix->adc_live < 0) for (int &v : ix->adc_live_sc) v = -1;      // (codes / adjacency / rows changed: every class is measured again)
+    if (ix->adc_live < 0) { for (int &v : ix->adc_live_sc) v = -1; for (int &v : ix->lat_adc_live) v = -1; }      // (codes / adjacency / rows changed: every class is measured again)
     // (a handful of queries -- the API's one-query requests at L = 20 -- stay on the row-landing kernels in 4-wavefront workgroups even when
     // the ADC is live: one query p50 0.436 -> 0.416 ms, 64 queries 0.664 -> 0.596 ms against the shared-codebook kernel, profiles/r05/latency_small.json)
     if (k_m1 && !ov && ix->adc_live_sc[sc] == 1 && ix->cs->nq > 256) pref = (lds_of(0) * 5 <= 160 * 1024) ? PREF_M1_LIVE_LUT : PREF_M1_LIVE_CB;
@@ -1016,11 +1021,39 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         const int tw = dr_small_twin(kind);
         if (!no_small && !ov && !pqb && tw >= 0 && kind != g_force_kind && usable(tw) && (uint64_t)ix->cs->nq < (uint64_t)ix->num_cu * 16) kind = tw;
     }
+    // Variant 18 (latency_kernel.hpp): a workgroup of eight wavefronts per query for the handful of queries of a request -- M1 and the exact
+    // traversals (M2, M4, M3 without PQ / cosine), small blocking calls (the direct path) of at most DR_LAT_MAX_NQ queries, or forced
+    // (dr_debug_force_kind 18: any batch). DR_NO_LATENCY=1 switches it off (A/B, read per call); ix->lat_skip is set for the one re-run after
+    // a query outgrew the visited-id set in LDS.
+    // Where it is the engine's own choice (measured, profiles/r05/latency_workgroup_per_query*.json): M1 with lists shorter than 64 entries -- the API's
+    // L = 20 -- where its sharper proof that the rerank policy holds (latency_kernel.hpp) saves the policy's evaluation on nearly every row: one query
+    // 0.36 -> 0.22 ms at L = 20, 0.40 -> 0.24 at 32, 0.38 -> 0.25 at 48. From 64 entries on search_kernel.hpp proves the same and the two are level
+    // (0.24 / 0.25 ms at 64, 0.31 / 0.33 at 100); the exact traversals are 10 % slower one query at a time. DR_LAT_ALL=1 takes it wherever it is eligible.
+    const bool lat_default = k_m1 && cap < 64;
+    uint32_t lat_vh_bits = 0;
+    size_t lat_lds = 0;
+    bool lat = false;
+    if (!ov && !pqb && !k_adc && !(flags & DR_F_COSINE) && (k_m1 || mode == DR_MODE_M2 || mode == DR_MODE_M3 || mode == DR_MODE_M4) &&
+        ix->kern->latency[k_m1 ? 1 : 0][sc] != nullptr && !ix->lat_skip &&
+        (g_force_kind == 18 || (g_force_kind < 0 && ix->direct && ix->cs->nq <= DR_LAT_MAX_NQ && getenv("DR_NO_LATENCY") == nullptr &&
+                                (lat_default || getenv("DR_LAT_ALL") != nullptr)))) {
+        const size_t nwords = (ix->R + 63) / 64;
+        const size_t slot_b = ((nwords * 64 * 4 * (k_m1 ? 3 : 2) + nwords * 8) + 15) & ~(size_t)15;
+        const size_t fixed = (k_m1 ? (size_t)ix->m * 1024 : 0) + (ix->D > 256 ? (size_t)ix->D * 4 : 0) + slot_b * 8 + 8 * 512 + (size_t)NCHR_OF_SC[sc] * 64 * 12 + 768;
+        // visited-id set: 16 384 slots (12 288 ids) where they fit, 32 768 for the long lists; at least 4 096
+        uint32_t bits = cap > 256 ? 15 : 14;
+        if (const char *e = getenv("DR_LAT_VH_BITS")) bits = (uint32_t)atoi(e);      // tests: a set small enough to overflow
+        while (bits > 6 && fixed + ((size_t)4 << bits) > 160 * 1024) bits--;
+        if (fixed + ((size_t)4 << bits) <= 160 * 1024 && (bits >= 12 || getenv("DR_LAT_VH_BITS") != nullptr)) {
+            lat = true; lat_vh_bits = bits; lat_lds = fixed + ((size_t)4 << bits); kind = 18;
+        }
+    }
     static const KindDesc PQB_DESC = { 20, 1, false, 0, true, true, false, false, 0 };
-    const KindDesc &kd_desc = pqb ? PQB_DESC : DR_KINDS[dr_kind_pos(kind)];
-    const void *kfn = pqb ? pqc.fn : ix->kern->search[dr_kind_pos(kind)][sc];
+    static const KindDesc LAT_DESC_M1 = { 18, 8, false, 0, true, true, false, false, 0 }, LAT_DESC_EX = { 18, 8, false, 0, false, false, false, false, 0 };
+    const KindDesc &kd_desc = pqb ? PQB_DESC : lat ? (k_m1 ? LAT_DESC_M1 : LAT_DESC_EX) : DR_KINDS[dr_kind_pos(kind)];
+    const void *kfn = pqb ? pqc.fn : lat ? ix->kern->latency[k_m1 ? 1 : 0][sc] : ix->kern->search[dr_kind_pos(kind)][sc];
     const int NW = kd_desc.nw;
-    const size_t lds = pqb ? pqb_lds_bytes(ix->m, pqc.treg, NCHR_OF_SC[sc], pqc.nc) : lds_of(kind);
+    const size_t lds = pqb ? pqb_lds_bytes(ix->m, pqc.treg, NCHR_OF_SC[sc], pqc.nc) : lat ? lat_lds : lds_of(kind);
     if (lds > 160 * 1024) return fail(DR_E_UNSUPPORTED, "LDS footprint %zu B exceeds 160 KiB", lds);
     // (kernel attribute + occupancy are asked once per (variant, LDS size): a single-query call is all overhead)
     int occ = 0;
@@ -1035,7 +1068,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         }
     }
     const uint32_t nq = ix->cs->nq;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)nq + NW - 1) / NW, (uint64_t)occ * ix->num_cu);
+    const uint32_t grid = lat ? (uint32_t)std::min<uint64_t>(nq, (uint64_t)occ * ix->num_cu)
+                              : (uint32_t)std::min<uint64_t>(((uint64_t)nq + NW - 1) / NW, (uint64_t)occ * ix->num_cu);
     const uint32_t slots = grid * NW;
 
     // M1 is capped at min(10L, N) expansions (search_engine.py:429); the other variants are bounded by N.
@@ -1053,7 +1087,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     bool build_novis = ix->N >= (1ull << 25);
     { const char *e = getenv("DR_BUILD_PQ_NO_VISITED_SET"); if (e) build_novis = e[0] == '1'; }
     const bool novis = (!ov && mode == DR_MODE_PQ && (flags & DR_F_NO_VISITED_SET) != 0) || (pqb && !pqc.vf) || (ov && ov->sdc && build_novis);
-    if (!novis && ((size_t)slots * vis_words > vis.n || slots > vis_epoch.n)) {
+    if (!novis && !lat && ((size_t)slots * vis_words > vis.n || slots > vis_epoch.n)) {
         // (re)allocation: fresh words and stamps -- queued launches still use the old buffers
         if (vis.p) HIPCHK(hipStreamSynchronize(st));
         if (vis.reserve((size_t)slots * vis_words) || vis_epoch.reserve(slots)) return DR_E_NODEVICE;
@@ -1078,7 +1112,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
 
     SearchParams p;
     memset(&p, 0, sizeof p);
-    if (!ov && !novis && !pqb && !ix->adjr_valid) { const int rcb = build_bit_order(ix); if (rcb) return rcb; }      // (DR_MODE_PQB's filter is indexed by id)
+    if (!ov && !novis && !pqb && !lat && !ix->adjr_valid) { const int rcb = build_bit_order(ix); if (rcb) return rcb; }      // (DR_MODE_PQB's filter is indexed by id)
     if (!ov && ix->inline_codes && !ix->nbcodes_valid && ix->codes.p && (mode == DR_MODE_M1 || pq_only)) { const int rci = build_inline_codes(ix); if (rci) return rci; }
     p.vecp = ix->vecp.p; p.adj = ix->adj.p; p.first = ix->first.p; p.codes = ix->codes.p; p.codebook = ix->codebook.p;
     p.adjr = (!ov && !novis && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
@@ -1100,6 +1134,14 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.norm = (mode == DR_MODE_M2 || (mode == DR_MODE_M4 && !(flags & DR_F_SQDIST))) ? 1u : 0u;
     p.max_steps = (uint32_t)std::min<uint64_t>(max_steps, 0xFFFFFFFFull);
     p.vis = vis.p; p.vis_words = vis_words; p.vis_epoch = vis_epoch.p;
+    // (bit 8: the scoring wavefronts skip the ADC -- this index / list-size class was measured: the rerank policy is proven true for
+    //  nearly every row, the rest compute it inside the decisions; DR_LAT_EAGER_ADC=1 / DR_LAT_LAZY_ADC=1 pin it for A/B and tests)
+    {
+        bool lazy = lat && k_m1 && ix->lat_adc_live[sc] == 0;
+        if (getenv("DR_LAT_EAGER_ADC")) lazy = false;
+        if (getenv("DR_LAT_LAZY_ADC")) lazy = lat && k_m1;
+        p.vh_bits = lat_vh_bits | (lazy ? 256u : 0u);
+    }
     p.counter = bs.counter.p;
     p.res_keys = bs.res_keys.p; p.res_n = bs.res_n.p; p.stats = bs.stats.p;
     p.tie_list = bs.tie.p; p.tie_count = bs.counter.p + 1;
@@ -1163,7 +1205,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // monotonic and the launch only needs its starting value (no per-step memset on the search stream). The tie-list
     // length (counter[1]) is zeroed on the tie-order stream after its consumer.
     p.ticket_base = bs.ticket_base;
-    bs.ticket_base += nq;
+    if (lat) ix->lat_sc = sc;
+    if (!lat) bs.ticket_base += nq;      // (variant 18 walks its queries by workgroup index: no tickets drawn)
     if (!ov && ix->kev_pending == dr_index::KEV) harvest_kernel_times(ix, false);
     if (!ov && ix->kev_pending == dr_index::KEV) { HIPCHK(hipStreamSynchronize(ix->stream)); harvest_kernel_times(ix, false); }
     p.lut_g = nullptr;
@@ -1441,6 +1484,29 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
         HIPCHK(hipStreamSynchronize(ix->stream));
         const size_t b_ids = (size_t)nq * k * 4, b_cnt = (size_t)nq * 4, b_st = (size_t)nq * sizeof(KStats);
         unsigned char *hp = static_cast<unsigned char *>(ix->pinned);
+        if (ix->timing.variant == 18u) {
+            // a query outgrew the visited-id set of the workgroup-per-query kernel (status bit 16): the whole call again through search_kernel.hpp
+            const KStats *hs = reinterpret_cast<const KStats *>(hp + 2 * b_ids + b_cnt);
+            bool over = false;
+            uint64_t evald = 0, all = 0;
+            for (uint32_t i = 0; i < nq; i++) { over = over || (hs[i].status & 16u) != 0u; evald += hs[i].pq_evaluated; all += hs[i].pq; }
+            if (mode == DR_MODE_M1 && !over && all > 0) {
+                int &lv = ix->lat_adc_live[ix->lat_sc];
+                if (lv != 0) lv = (20 * evald > all) ? 1 : 0;           // (eager rows: asked on < 5 % of the neighbours -> lazy from now on)
+                else if (5 * evald > all) lv = 1;                       // (lazy rows: back to eager when a fifth of them ask)
+            }
+            if (over) {
+                dr_index::BatchSet &bs = ix->sets[ix->last_set];
+                HIPCHK(hipMemsetAsync(bs.counter.p + 1, 0, 4, ix->stream));
+                ix->direct = true; ix->lat_skip = true;
+                rc = run_locked(ix, k, L, beam_width, mode, band_policy, flags);
+                ix->direct = false; ix->lat_skip = false;
+                if (rc) return rc;
+                if (!ix->direct_used) return download_locked(ix, out_ids, out_dist, out_count, stats);
+                HIPCHK(hipStreamSynchronize(ix->stream));
+                hp = static_cast<unsigned char *>(ix->pinned);
+            }
+        }
         const uint32_t tied = *reinterpret_cast<const uint32_t *>(hp + 2 * b_ids + b_cnt + b_st);
         if (tied) {
             dr_index::BatchSet &bs = ix->sets[ix->last_set];
@@ -1599,7 +1665,7 @@ extern "C" int dr_index_inline_codes(dr_index *ix, int enable)
 
 extern "C" int dr_debug_force_kind(dr_index *ix, int kind, int *out_adc_live)
 {
-    if (kind > DR_MAX_KIND_ID || (kind >= 0 && dr_kind_pos(kind) < 0)) return fail(DR_E_ARG, "unknown kernel variant %d", kind);
+    if (kind != 18 && (kind > DR_MAX_KIND_ID || (kind >= 0 && dr_kind_pos(kind) < 0))) return fail(DR_E_ARG, "unknown kernel variant %d", kind);      // (18: latency_kernel.hpp)
     g_force_kind = kind < 0 ? -1 : kind;
     g_force_kind_set = true;
     if (ix && out_adc_live) { std::lock_guard<std::mutex> lk(ix->mu); *out_adc_live = ix->adc_live; }

@@ -21,6 +21,8 @@
 //  15 = 2 with the table rows of the LAST 16 sub-quantisers held in VGPRs (64 registers, looked up with ds_bpermute) and
 //     only the first m - 16 rows in LDS: at m = 32 a table costs 16 KiB of LDS instead of 32, so 8 wavefronts fit a CU
 //     instead of 4 (two per SIMD: the traversal is bound by instruction latency, not by memory)  (m % 16 == 0, m >= 32)
+//  18 (not a row of DR_KINDS: its own kernel family, latency_kernel.hpp) M1 / exact traversals with a WORKGROUP of eight wavefronts per
+//     query: scoring ahead of the decisions, visited ids in LDS -- the handful of queries of one request (round 5)
 //  16 = 11, 17 = 13 in workgroups of FOUR wavefronts (same code, same 16 wavefronts per CU as four workgroups): a batch
 //     smaller than the chip's 4096 wavefront slots -- the 1250-query slice of an 8-GPU strong-scaling job, a coalesced
 //     handful of requests -- spreads over all 256 CUs instead of filling ceil(nq / 16) of them (round 4)
@@ -76,6 +78,7 @@ struct DimKernels {
     const void *search_f64;   // M1 / M2 with float64 queries (the CLI path), search_f64.hpp
     const void *search_seq_f32;   // the same literal kernel on float32 queries (band policy 2: the reference's coin flip itself)
     const void *rerank;       // aux_kernels.hpp rerank_kernel (DR_MODE_PQ + DR_F_RERANK)
+    const void *latency[2][DR_NUM_SIZECLASS];   // latency_kernel.hpp lat_kernel (variant 18: a workgroup per query): [0] exact traversals, [1] M1
 };
 
 const DimKernels *dr_dim_kernels(int D);

@@ -1,0 +1,69 @@
+"""Latency of small blocking calls: the workgroup-per-query kernel (variant 18, csrc/latency_kernel.hpp -- the engine's choice for
+<= 64 queries) beside the batch kernels (DR_NO_LATENCY=1), interleaved, 1 / 8 / 64 queries per dr_search_batch on the 1M-point bench index.
+Reference-faithful M1 at the API defaults (k 5, L 20, beam_width 8) and at the bench point (k 10, L 100), M2 at beam_width 8 (the CLI's other
+search). Also checks that both give the same ids / distance bits / counters. -> one JSON object.  argv[1]: points (default 1000000)"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+import numpy as np
+sys.path.insert(0, ".")
+from diskrag_amd import HipIndex, _ffi
+from diskrag_amd.synth import sift_like
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+x, q = sift_like(N, 128, n_queries=4096, n_clusters=1024, seed=2024, query_seed=9000)
+if len(sys.argv) > 2 and sys.argv[2] == "float":      # un-rounded rows: the float-row kernels
+    x = x + np.float32(0.25); q = q + np.float32(0.25)
+ix = HipIndex.create_empty(x, R=64)
+ix.build_vamana(L_build=100, alpha=1.2, passes=2, seed=7, pad_with_zero=True)
+cb = ix.pq_train(32, n_sample=100000, iters=5); ix.pq_encode(cb)
+L_ = _ffi.load_library()
+out = {}
+pts = (("M1_api_default_k5_L20_bw8", dict(k=5, L=20, bw=8, mode=_ffi.MODE_M1)), ("M1_k10_L100_bw8", dict(k=10, L=100, bw=8, mode=_ffi.MODE_M1)),
+       ("M2_k10_bw8", dict(k=8, L=100, bw=8, mode=_ffi.MODE_M2)))
+if os.environ.get("LAT_SWEEP"):      # where the workgroup kernel stops paying: list sizes between the API default and the bench point
+    pts = tuple(("M1_k10_L%d_bw8" % L, dict(k=10, L=L, bw=8, mode=_ffi.MODE_M1)) for L in (10, 32, 48, 64, 80, 128, 200))
+os.environ["DR_LAT_ALL"] = "1"        # (the engine picks variant 18 by itself only where it was measured faster: here every eligible call)
+qq = np.ascontiguousarray(q, dtype=np.float32)
+for tag, kw in pts:
+    for nq in (1, 8, 64):
+        k = kw["k"]
+        res = {}
+        # same answers first
+        for name, env in (("workgroup_per_query", None), ("batch_kernels", "1")):
+            if env: os.environ["DR_NO_LATENCY"] = env
+            else: os.environ.pop("DR_NO_LATENCY", None)
+            for _ in range(3):
+                r = ix.search_batch(qq[:nq], k, L=kw["L"], beam_width=kw["bw"], mode=kw["mode"])
+            res[name] = (r, ix.timing()["variant"])
+        a, b = res["workgroup_per_query"][0], res["batch_kernels"][0]
+        same = bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and
+                    all(np.array_equal(a[3][f], b[3][f]) for f in ("steps", "visited", "exact", "pq", "status", "inserts")))
+        oi = np.empty((nq, k), np.uint32); od = np.empty((nq, k), np.float32); oc = np.empty(nq, np.uint32)
+        pi, pd, pc = oi.ctypes.data_as(C.POINTER(C.c_uint32)), od.ctypes.data_as(C.POINTER(C.c_float)), oc.ctypes.data_as(C.POINTER(C.c_uint32))
+        ts = {"workgroup_per_query": [], "batch_kernels": []}
+        ks = {"workgroup_per_query": [], "batch_kernels": []}
+        var = {}
+        for blk in range(6):       # interleaved blocks of 100 calls
+            for name, env in (("workgroup_per_query", None), ("batch_kernels", "1")):
+                if env: os.environ["DR_NO_LATENCY"] = env
+                else: os.environ.pop("DR_NO_LATENCY", None)
+                for i in range(110):
+                    pq_ = qq[((blk * 110 + i) * nq) % (4096 - nq):].ctypes.data_as(C.POINTER(C.c_float))
+                    t0 = time.perf_counter()
+                    rc = L_.dr_search_batch(ix._h, pq_, nq, k, kw["L"], kw["bw"], kw["mode"], 0, 0, pi, pd, pc, None)
+                    t1 = time.perf_counter()
+                    assert rc == 0
+                    if i >= 10:
+                        ts[name].append(t1 - t0)
+                        if i % 20 == 0: ks[name].append(ix.timing()["search_kernel_ms"])
+                var[name] = ix.timing()["variant"]
+        os.environ.pop("DR_NO_LATENCY", None)
+        ent = {"same_results": same, "mean_expansions": round(float(a[3]["steps"].mean()), 1), "mean_rounds_hits": round(float(a[3]["adj_prefetch_hits"].mean()), 1)}
+        for name in ts:
+            t = np.array(ts[name]) * 1e3
+            ent[name] = {"p50_ms": round(float(np.percentile(t, 50)), 4), "p99_ms": round(float(np.percentile(t, 99)), 4),
+                         "search_kernel_ms_mean": round(float(np.mean(ks[name])), 4), "variant": var[name]}
+        out.setdefault(tag, {})["nq%d" % nq] = ent
+print(json.dumps(out, indent=1))

@@ -1,0 +1,175 @@
+"""Variant 18 (csrc/latency_kernel.hpp): a workgroup of eight wavefronts per query for the handful of queries of one request
+(search_engine.py:530-614, app.py:84-130). Held to the reference's goldens and the oracle bit for bit -- ids, distance bits,
+counts and the four counters -- with the variant forced, and as the engine's own choice for small blocking calls. Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import all_cases, load_golden
+from tests.test_gpu_parity import bits, get_index, run_case
+
+pytestmark = pytest.mark.gpu
+
+
+class forced:
+    """the variant pinned for a block (process-wide hook: always released)"""
+
+    def __init__(self, ix, kind):
+        self.ix, self.kind = ix, kind
+
+    def __enter__(self):
+        self.ix.debug_force_kind(self.kind)
+
+    def __exit__(self, *a):
+        self.ix.debug_force_kind(-1)
+
+
+@pytest.mark.parametrize("name,ci", all_cases(modes=("M1",), pred=lambda c: not c.get("f64")))
+def test_m1_goldens_with_the_workgroup_kernel(name, ci):
+    g = load_golden(name)
+    c = g.case(ci)
+    ix = get_index(name)
+    with forced(ix, 18):
+        ids, dist, cnt, st = run_case(name, c)
+        assert ix.timing()["variant"] == 18 and ix.timing()["block"] == 512
+    assert (st["status"] == 0).all()
+    assert np.array_equal(cnt, c["count"])
+    assert np.array_equal(ids, c["ids"])
+    assert np.array_equal(bits(dist), bits(c["dist"]))
+    assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), c["stats"])
+
+
+@pytest.mark.parametrize("name,ci", all_cases(modes=("M2", "M4")) + all_cases(modes=("M3",), pred=lambda c: not c["use_pq"]))
+def test_exact_traversals_with_the_workgroup_kernel(name, ci):
+    """M2 / M4 / M3 without PQ: the same lists as search_kernel.hpp (which test_gpu_parity holds to the oracle), bit for bit."""
+    g = load_golden(name)
+    c = g.case(ci)
+    ix = get_index(name, mem=c["mode"] in ("M3", "M4"))
+    ix.debug_force_kind(-1)
+    w_ids, w_dist, w_cnt, w_st = run_case(name, c)
+    assert ix.timing()["variant"] != 18 or len(c["queries"]) <= 64
+    with forced(ix, 18):
+        ids, dist, cnt, st = run_case(name, c)
+        assert ix.timing()["variant"] == 18
+    assert (st["status"] == 0).all()
+    assert np.array_equal(cnt, w_cnt) and np.array_equal(ids, w_ids) and np.array_equal(bits(dist), bits(w_dist))
+    for f in ("steps", "visited", "exact", "pq", "inserts"):
+        assert np.array_equal(st[f], w_st[f]), f
+
+
+def test_exact_traversals_vs_oracle():
+    from oracle import pyoracle as orc
+    name = "sift128_R64_m32"
+    g = load_golden(name)
+    ix = get_index(name)
+    from diskrag_amd import _ffi
+    with forced(ix, 18):
+        for (L, bw) in ((100, 8), (40, 16), (10, 4)):
+            ids, dist, cnt, st = ix.search_batch(g.queries, 10, L=L, beam_width=bw, mode=_ffi.MODE_M2)
+            assert ix.timing()["variant"] == 18 and (st["status"] == 0).all()
+            oids, odist, ocnt, ost = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.M2, 10, L=L, bw=bw, flags=orc.F_PAIRWISE)
+            assert np.array_equal(ids, oids) and np.array_equal(cnt, ocnt)
+            assert np.array_equal(bits(dist), bits(odist.astype(np.float32)))
+            assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), ost)
+
+
+@pytest.mark.parametrize("D,m", [(128, 32), (96, 16), (256, 32), (768, 32)])
+def test_live_policy_small_calls_pick_the_workgroup_kernel(D, m):
+    """The engine's own choice: blocking calls of 1 ... 64 queries run variant 18 (after the one call per list-size class that measures the
+    A4 regime), larger ones do not; results are the oracle's under both band policies, on data where the rerank policy really consults the ADC."""
+    from diskrag_amd import _ffi
+    from diskrag_amd.synth import unit_mixture
+    from oracle import pyoracle as orc
+    from tests.test_gpu_live_regime import _index
+    x, q = unit_mixture(12000, D, n_queries=70, n_clusters=64, seed=7, latent=24)
+    ix, medoid, adj, cb, codes = _index(x, 32, m)
+    os.environ["DR_LAT_ALL"] = "1"          # (every eligible small call; the engine's own rule -- lists shorter than 64 entries -- is checked at the end)
+    try:
+        for (L, bw, pol) in ((100, 8, 0), (20, 8, 1), (100, 0, 0), (150, 8, 1)):
+            w = orc.search_batch(x, adj, q, medoid, orc.M1, 10, L=L, bw=bw, policy=pol, codes=codes, codebook=cb, nthreads=8)
+            for nq in (1, 1, 7, 64, 70):
+                ids, dist, cnt, st = ix.search_batch(q[:nq], 10, L=L, beam_width=bw, mode=_ffi.MODE_M1, band_policy=pol)
+                assert int(st["status"].max()) == 0
+                assert np.array_equal(ids, w[0][:nq]), (L, bw, pol, nq)
+                valid = w[0][:nq] != 0xFFFFFFFF
+                assert np.array_equal(dist[valid].view(np.uint32), w[1][:nq][valid].astype(np.float32).view(np.uint32))
+                assert np.array_equal(cnt, w[2][:nq])
+                assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), w[3][:nq])
+            assert ix.timing()["variant"] != 18                                 # 70 queries: the batch kernels
+            # the scoring wavefronts may leave the ADC to the decisions (the engine's choice on data where the policy rarely asks): same bits
+            for env in ("DR_LAT_LAZY_ADC", "DR_LAT_EAGER_ADC"):
+                os.environ[env] = "1"
+                try:
+                    ids, dist, cnt, st = ix.search_batch(q[:9], 10, L=L, beam_width=bw, mode=_ffi.MODE_M1, band_policy=pol)
+                finally:
+                    del os.environ[env]
+                assert ix.timing()["variant"] == 18 and int(st["status"].max()) == 0
+                assert np.array_equal(ids, w[0][:9]) and np.array_equal(cnt, w[2][:9]), (env, L, bw, pol)
+                valid = w[0][:9] != 0xFFFFFFFF
+                assert np.array_equal(dist[valid].view(np.uint32), w[1][:9][valid].astype(np.float32).view(np.uint32))
+                assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), w[3][:9])
+            ix.search_batch(q[:3], 10, L=L, beam_width=bw, mode=_ffi.MODE_M1, band_policy=pol)
+            assert ix.timing()["variant"] == 18 and ix.timing()["grid"] == 3     # a workgroup per query
+        del os.environ["DR_LAT_ALL"]
+        for L, want18 in ((20, True), (48, True), (64, False), (100, False)):
+            ix.search_batch(q[:2], 5, L=L, beam_width=8, mode=_ffi.MODE_M1)
+            ix.search_batch(q[:2], 5, L=L, beam_width=8, mode=_ffi.MODE_M1)
+            assert (ix.timing()["variant"] == 18) == want18, L
+        ix.search_batch(q[:2], 5, L=20, beam_width=8, mode=_ffi.MODE_M2)
+        assert ix.timing()["variant"] != 18
+    finally:
+        os.environ.pop("DR_LAT_ALL", None)
+        ix.close()
+
+
+def test_visited_set_overflow_falls_back():
+    """A visited-id set too small for the query: the forced variant reports status bit 16 through the resident path, the small blocking
+    call answers through search_kernel.hpp instead -- same results."""
+    from diskrag_amd import _ffi
+    name = "sift128_R64_m32"
+    g = load_golden(name)
+    ix = get_index(name)
+    ix.debug_force_kind(-1)
+    want = ix.search_batch(g.queries[:5], 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
+    os.environ["DR_LAT_VH_BITS"] = "8"
+    os.environ["DR_LAT_ALL"] = "1"
+    try:
+        got = ix.search_batch(g.queries[:5], 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
+        assert ix.timing()["variant"] != 18
+        assert np.array_equal(got[0], want[0]) and np.array_equal(bits(got[1]), bits(want[1]))
+        for f in ("steps", "visited", "exact", "pq", "status"):
+            assert np.array_equal(got[3][f], want[3][f])
+        with forced(ix, 18):
+            ix.batch_upload(g.queries[:5])
+            ix.batch_run(10, L=100, beam_width=8, mode=_ffi.MODE_M1)
+            _, _, _, st = ix.batch_download()
+            assert ix.timing()["variant"] == 18 and ((st["status"] & 16) != 0).all()
+        del os.environ["DR_LAT_VH_BITS"]
+        got = ix.search_batch(g.queries[:5], 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
+        assert ix.timing()["variant"] == 18
+        assert np.array_equal(got[0], want[0]) and np.array_equal(bits(got[1]), bits(want[1]))
+    finally:
+        os.environ.pop("DR_LAT_VH_BITS", None)
+        os.environ.pop("DR_LAT_ALL", None)
+        ix.debug_force_kind(-1)
+
+
+def test_ties_and_long_lists():
+    """Integer-valued data (tied distances: the tie-order pass reads the workgroup kernel's insert log) and every list-size class."""
+    from diskrag_amd import _ffi
+    from oracle import pyoracle as orc
+    name = "sift128_R64_m32"
+    g = load_golden(name)
+    ix = get_index(name)
+    with forced(ix, 18):
+        for (L, bw, k) in ((64, 8, 10), (128, 0, 10), (200, 8, 50), (300, 16, 10), (600, 8, 100), (1000, 8, 10)):
+            ids, dist, cnt, st = ix.search_batch(g.queries, k, L=L, beam_width=bw, mode=_ffi.MODE_M1)
+            assert ix.timing()["variant"] == 18 and (st["status"] == 0).all()
+            oids, odist, ocnt, ost = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.M1, k, L=L, bw=bw, codes=g.codes,
+                                                      codebook=g.codebook, nthreads=8)
+            assert np.array_equal(ids, oids), (L, bw, k)
+            valid = oids != 0xFFFFFFFF
+            assert np.array_equal(dist[valid].view(np.uint32), odist[valid].astype(np.float32).view(np.uint32))
+            assert np.array_equal(cnt, ocnt)
+            assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), ost)
