@@ -1261,6 +1261,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     f.out_ids = p.out_ids; f.out_dist = p.out_dist;
     if (!ix->fin_stat.p) { if (ix->fin_stat.reserve(1, true)) return DR_E_NODEVICE; }
     f.ntie_stat = ix->fin_stat.p;
+    f.serial = getenv("DR_FINALIZE_SERIAL") != nullptr ? 1u : 0u;
     if (direct) {
         // the caller (dr_search_batch) synchronises the search stream, looks at the flag word and runs the tie-order pass only if it is set
         if (!ix->direct_f) ix->direct_f = new FinalizeParams();
@@ -1464,7 +1465,12 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
         return seq_search_locked(ix, queries, false, nq, k, L, beam_width, mode, band_policy, out_ids, out_dist, out_count, stats);
     }
     const bool no_direct = getenv("DR_NO_DIRECT") != nullptr;      // A/B and tests: small calls through the general path (read per call)
-    if (nq <= DR_DIRECT_MAX && !no_direct) {
+    // (round 5: EVERY blocking call of up to one chunk takes the direct path -- results written straight into the page-locked slab, no download
+    //  copies; DR_DIRECT_MAX=256 restores the old limit for A/B. Above a handful of queries some query ties almost surely: the tie-order pass is
+    //  queued right behind the search instead of after a look at the flag word)
+    uint32_t direct_max = DR_MAX_CHUNK;
+    if (const char *edm = getenv("DR_DIRECT_MAX")) direct_max = (uint32_t)atoi(edm);
+    if (nq <= direct_max && !no_direct) {
         // ---- a handful of queries (one per request is the shape of the reference's API routes, search_engine.py:530-614, app.py:84-130)
         HIPCHK(hipSetDevice(ix->device));
         {   // (pipelined jobs of other threads, or resident steps not waited for yet, own output sets and streams: finished first)
@@ -1480,6 +1486,14 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
         if (rc) return rc;
         if (!ix->direct_used) {       // (the call that measures the index's regime went the general way)
             return download_locked(ix, out_ids, out_dist, out_count, stats);
+        }
+        const bool eager_fin = nq > DR_DIRECT_MAX && ix->direct_fin;
+        if (eager_fin) {
+            dr_index::BatchSet &bs = ix->sets[ix->last_set];
+            const unsigned fgrid = (unsigned)std::min<uint64_t>(((uint64_t)nq + 3) / 4, (uint64_t)ix->num_cu * 8);
+            hipLaunchKernelGGL(finalize_kernel, dim3(fgrid), dim3(256), 4 * ((size_t)ix->direct_f->cap + 2 + 64) * 8, ix->stream, *ix->direct_f);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemsetAsync(bs.counter.p + 1, 0, 4, ix->stream));
         }
         HIPCHK(hipStreamSynchronize(ix->stream));
         const size_t b_ids = (size_t)nq * k * 4, b_cnt = (size_t)nq * 4, b_st = (size_t)nq * sizeof(KStats);
@@ -1508,7 +1522,7 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
             }
         }
         const uint32_t tied = *reinterpret_cast<const uint32_t *>(hp + 2 * b_ids + b_cnt + b_st);
-        if (tied) {
+        if (tied && !eager_fin) {
             dr_index::BatchSet &bs = ix->sets[ix->last_set];
             if (ix->direct_fin) hipLaunchKernelGGL(finalize_kernel, dim3((nq + 3) / 4), dim3(256), 4 * ((size_t)ix->direct_f->cap + 2 + 64) * 8, ix->stream, *ix->direct_f);
             HIPCHK(hipGetLastError());

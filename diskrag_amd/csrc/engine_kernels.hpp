@@ -71,6 +71,7 @@ struct FinalizeParams {
     u32 logcap, cap, k, mode;
     u32 *out_ids; float *out_dist;
     u32 *ntie_stat;     // largest tie-list length seen since the host last looked (sizes the next launches)
+    u32 serial;         // 1: the one-lane replay at every capacity (DR_FINALIZE_SERIAL=1, A/B)
 };
 
 // python tuple (-d, id) "less than" on keys (dist bits << 32 | ~id): x < y  <=>  key(x) > key(y)
@@ -114,8 +115,65 @@ DEV float sort_key(u64 key, u32 mode)
     return mode == 3u ? f_sqrt(d) : d;
 }
 
+// ---- the same two heap operations by the WHOLE wavefront (capacity <= 128: at most 64 internal nodes, 8 levels) --------------------------
+// A sift is a chain of dependent LDS reads when one lane walks it (~1 000 cycles per push + pop at capacity 100, and a tied query replays
+// ~750 of them: the 0.6 ms a blocking call waits for). The moves of a sift are decided by comparisons that do not depend on each other:
+//   heappush  appends at index h and moves the new item up past every ancestor it is smaller than. The ancestors a_k = ((h + 1) >> k) - 1 are
+//             known up front and ordered along the path (heap property), so "smaller than" holds for a PREFIX of them: lane k reads ancestor k,
+//             one ballot counts the prefix t, lanes 1..t move their ancestor one step down the path, the item lands at a_t.
+//   heappop   (heap[0] = the former last item, _siftup(0)) walks the hole down the smaller-child path to a leaf -- whatever the item is -- then
+//             moves the item back up past the path elements it is smaller than. Lane i picks the smaller child of internal node i (all nodes at
+//             once: one LDS round trip), the path is followed through those choices with v_readlane (no memory), lane k reads path element k,
+//             and again a prefix count says how far the elements shift up and where the item lands.
+// Same comparisons on the same values as Lib/heapq.py, so the same array after every operation (tests: every tied fixture query against the
+// reference's order; DR_FINALIZE_SERIAL=1 selects the one-lane form for A/B).
+// returns what index h holds afterwards (the item itself, or the parent it displaced): the entry a heappop that follows takes off the end
+DEV u64 wave_heappush(u64 *H, int h, u64 item)
+{
+    const int lane = lane_id();
+    const int a = (int)(((u32)h + 1u) >> min(lane, 31)) - 1;        // ancestor `lane` levels up (a < 0: past the root)
+    const bool on = lane >= 1 && lane < 31 && a >= 0;
+    const u64 anc = on ? H[a] : 0ull;
+    const int t = __popcll(__ballot(on && py_lt(item, anc)));       // ancestors the item passes (a prefix of the path)
+    const int below = (int)(((u32)h + 1u) >> min(max(lane - 1, 0), 31)) - 1;          // a_{lane - 1}
+    if (on && lane <= t) H[below] = anc;
+    if (lane == t) H[lane == 0 ? h : a] = item;
+    WSYNC();
+    return t == 0 ? item : readlane64(anc, 1);
+}
+// n = entries left after the last one was taken off (the caller read it: `last`); n >= 1
+DEV void wave_heappop(u64 *H, int n, u64 last)
+{
+    const int lane = lane_id();
+    int pref = -1;
+    {
+        const int l = 2 * lane + 1, r = 2 * lane + 2;
+        if (l < n) {
+            const u64 cl = H[l], cr = H[min(r, n - 1)];
+            pref = (r < n && !py_lt(cl, cr)) ? r : l;
+        }
+    }
+    int pcur = 0, depth = 0, myp = 0;
+#pragma unroll
+    for (int kk = 1; kk <= 7; kk++) {
+        if (2 * pcur + 1 < n) {                                     // pcur is an internal node (index < 64 at capacity <= 128)
+            pcur = __builtin_amdgcn_readlane(pref, __builtin_amdgcn_readfirstlane(pcur));
+            depth = kk;
+            myp = (lane == kk) ? pcur : myp;
+        }
+    }
+    const bool on = lane >= 1 && lane <= depth;
+    const u64 el = on ? H[myp] : 0ull;
+    const int up = __popcll(__ballot(on && !py_lt(last, el)));      // path elements that move up one level (a prefix)
+    const int above = (int)wave_shr1_u32((u32)myp, 0u);             // lane k: path node k - 1
+    WSYNC();
+    if (on && lane <= up) H[above] = el;
+    if (lane == up) H[myp] = last;
+    WSYNC();
+}
+
 // One wavefront per listed query; the heap array (cap + 1 entries) and a 64-entry slice of the insert log live in
-// LDS. Lane 0 replays the log; the whole wavefront reads the log and looks keys up in the final array.
+// LDS. The whole wavefront replays the log (capacity <= 128; lane 0 alone above that), reads the log and looks keys up in the final array.
 __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
@@ -144,7 +202,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeParams p)
                 stage[lane] = (i0 + lane < nins) ? lg[i0 + lane] : 0ull;      // one coalesced read of 64 log entries
                 WSYNC();
                 const int lim = (int)min(64u, nins - i0);
-                if (lane == 0) {
+                if (p.cap <= 128u && !p.serial) {
+                    int h = (int)min(i0, p.cap);
+                    for (int u = 0; u < lim; u++) {
+                        const u64 e = stage[u];
+                        const u64 last = wave_heappush(H, h, (e & 0xFFFFFFFF00000000ull) | (u32)(~(u32)e));
+                        h++;
+                        if (h > (int)p.cap) {
+                            --h;
+                            if (h) wave_heappop(H, h, last);
+                        }
+                    }
+                } else if (lane == 0) {
                     int h = (int)min(i0, p.cap);
                     for (int u = 0; u < lim; u++) {
                         const u64 e = stage[u];

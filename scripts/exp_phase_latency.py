@@ -7,6 +7,7 @@ sys.path.insert(0, ".")
 from diskrag_amd import HipIndex, _ffi
 from diskrag_amd.synth import sift_like
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+os.environ["DR_LAT_ALL"] = "1"      # (variant 18 at every list size, not only where the engine prefers it)
 x, q = sift_like(N, 128, n_queries=512, n_clusters=1024, seed=2024, query_seed=9000)
 ix = HipIndex.create_empty(x, R=64)
 ix.build_vamana(L_build=100, alpha=1.2, passes=2, seed=7, pad_with_zero=True)
