@@ -145,6 +145,7 @@ struct PipeGroup {
     uint32_t k = 0, L = 0, bw = 0, mode = 0, policy = 0, flags = 0;
     bool q_u8 = true;                   // every job's queries are bytes (the byte-query variants)
     bool with_qp = false;               // jobs upload the chain-major copy too
+    int lat_sc = -1;                    // launched with variant 18 (M1): its list-size class, else -1
     int set = -1;                       // the BatchSet holding its outputs once launched
     void *pin_out = nullptr; size_t pin_out_bytes = 0;
     hipEvent_t up_done = nullptr, down_done = nullptr;
@@ -255,6 +256,7 @@ struct dr_index {
     hipStream_t up_stream = nullptr, down_stream = nullptr;
     uint32_t last_nq = 0;         // batch size of the last launch (dr_batch_download)
     DevBuf<uint32_t> vis, vis_epoch;   // visited words [slots][vis_words] + the per-slot query stamp (search_kernel.hpp)
+    DevBuf<uint32_t> lat_spill;        // variant 18: [workgroups][2^bits] visited ids beyond the LDS table, all 0xFFFFFFFF between queries (latency_kernel.hpp)
     DevBuf<float> lut;            // [nq][m][256] per-query tables of the launch being queued (lut_build_kernel), rebuilt by every search that uses them:
                                   // ONE scratch per handle -- searches are serialised on the one search stream (round 3 kept one per resident batch:
                                   // 328 MB each at the bench shape, 20 of them)
@@ -286,6 +288,7 @@ struct dr_index {
     int lat_adc_live[DR_NUM_SIZECLASS] = { -1, -1, -1, -1, -1 };     // variant 18's own regime per list-size class (its proof is sharper than search_kernel.hpp's): -1 not
                                   // measured (the scoring wavefronts compute every ADC), 0 the policy asks on < 5 % of the neighbours (they skip it), 1 live
     int lat_sc = 0;               // list-size class of the last variant-18 launch
+    uint32_t lat_spill_bits = 0;  // table size lat_spill was last wiped for
     bool lat_skip = false;        // the re-run of a small call whose query outgrew variant 18's visited-id set: search_kernel.hpp serves it
     bool direct = false;          // set by dr_search_batch around run_locked
     bool direct_used = false;     // run_locked's answer: this launch wrote into the slab
@@ -1022,9 +1025,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         if (!no_small && !ov && !pqb && tw >= 0 && kind != g_force_kind && usable(tw) && (uint64_t)ix->cs->nq < (uint64_t)ix->num_cu * 16) kind = tw;
     }
     // Variant 18 (latency_kernel.hpp): a workgroup of eight wavefronts per query for the handful of queries of a request -- M1 and the exact
-    // traversals (M2, M4, M3 without PQ / cosine), small blocking calls (the direct path) of at most DR_LAT_MAX_NQ queries, or forced
-    // (dr_debug_force_kind 18: any batch). DR_NO_LATENCY=1 switches it off (A/B, read per call); ix->lat_skip is set for the one re-run after
-    // a query outgrew the visited-id set in LDS.
+    // traversals (M2, M4, M3 without PQ / cosine), launches of at most DR_LAT_MAX_NQ queries (blocking calls and the pipelined path's groups:
+    // the facade's one-query requests ride in those), or forced (dr_debug_force_kind 18: any batch). DR_NO_LATENCY=1 switches it off (A/B, read
+    // per call); ix->lat_skip is set for the one re-run of a blocking call whose query outgrew the visited-id set (LDS + its global continuation).
     // Where it is the engine's own choice (measured, profiles/r05/latency_workgroup_per_query*.json): M1 with lists shorter than 64 entries -- the API's
     // L = 20 -- where its sharper proof that the rerank policy holds (latency_kernel.hpp) saves the policy's evaluation on nearly every row: one query
     // 0.36 -> 0.22 ms at L = 20, 0.40 -> 0.24 at 32, 0.38 -> 0.25 at 48. From 64 entries on search_kernel.hpp proves the same and the two are level
@@ -1035,8 +1038,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     bool lat = false;
     if (!ov && !pqb && !k_adc && !(flags & DR_F_COSINE) && (k_m1 || mode == DR_MODE_M2 || mode == DR_MODE_M3 || mode == DR_MODE_M4) &&
         ix->kern->latency[k_m1 ? 1 : 0][sc] != nullptr && !ix->lat_skip &&
-        (g_force_kind == 18 || (g_force_kind < 0 && ix->direct && ix->cs->nq <= DR_LAT_MAX_NQ && getenv("DR_NO_LATENCY") == nullptr &&
-                                (lat_default || getenv("DR_LAT_ALL") != nullptr)))) {
+        (g_force_kind == 18 || (g_force_kind < 0 && ix->cs->nq <= DR_LAT_MAX_NQ && getenv("DR_NO_LATENCY") == nullptr &&
+                                (lat_default || (ix->direct && getenv("DR_LAT_ALL") != nullptr))))) {
         const size_t nwords = (ix->R + 63) / 64;
         const size_t slot_b = ((nwords * 64 * 4 * (k_m1 ? 3 : 2) + nwords * 8) + 15) & ~(size_t)15;
         const size_t fixed = (k_m1 ? (size_t)ix->m * 1024 : 0) + (ix->D > 256 ? (size_t)ix->D * 4 : 0) + slot_b * 8 + 8 * 512 + (size_t)NCHR_OF_SC[sc] * 64 * 12 + 768;
@@ -1136,11 +1139,33 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.vis = vis.p; p.vis_words = vis_words; p.vis_epoch = vis_epoch.p;
     // (bit 8: the scoring wavefronts skip the ADC -- this index / list-size class was measured: the rerank policy is proven true for
     //  nearly every row, the rest compute it inside the decisions; DR_LAT_EAGER_ADC=1 / DR_LAT_LAZY_ADC=1 pin it for A/B and tests)
+    uint32_t lat_sbits = 0;
+    if (lat) {
+        // the continuation of the visited-id set in global memory: 2^17 ids per workgroup (a query of the auto-selected shapes visits at most
+        // min(10 L, N) R < 41 000 nodes: it cannot run out); DR_LAT_SPILL_BITS overrides (0: none -- the overflow status and the re-run, tests)
+        lat_sbits = 17;
+        if (const char *es = getenv("DR_LAT_SPILL_BITS")) lat_sbits = (uint32_t)atoi(es);
+        if (lat_sbits > 20) lat_sbits = 20;
+        if (lat_sbits) {
+            const size_t need = (size_t)grid << lat_sbits;
+            if (need > ix->lat_spill.n) {
+                if (ix->lat_spill.p) HIPCHK(hipStreamSynchronize(st));
+                if (ix->lat_spill.reserve(need)) return DR_E_NODEVICE;
+                HIPCHK(hipMemsetAsync(ix->lat_spill.p, 0xFF, ix->lat_spill.n * 4, st));
+                ix->lat_spill_bits = lat_sbits;
+            } else if (ix->lat_spill_bits != lat_sbits) {
+                // (another table size than the tables were wiped for: the stride changed -- all of it again)
+                HIPCHK(hipMemsetAsync(ix->lat_spill.p, 0xFF, ix->lat_spill.n * 4, st));
+                ix->lat_spill_bits = lat_sbits;
+            }
+        }
+    }
     {
         bool lazy = lat && k_m1 && ix->lat_adc_live[sc] == 0;
         if (getenv("DR_LAT_EAGER_ADC")) lazy = false;
         if (getenv("DR_LAT_LAZY_ADC")) lazy = lat && k_m1;
-        p.vh_bits = lat_vh_bits | (lazy ? 256u : 0u);
+        p.vh_bits = lat_vh_bits | (lazy ? 256u : 0u) | (lat_sbits << 16);
+        if (lat) p.vis = ix->lat_spill.p;
     }
     p.counter = bs.counter.p;
     p.res_keys = bs.res_keys.p; p.res_n = bs.res_n.p; p.stats = bs.stats.p;

@@ -105,14 +105,44 @@ DEV void lat_prefetch_row(const SearchParams &p, u32 id, u32 *dump)
                                      (__attribute__((address_space(3))) void *)(dump + 64), 4, 0, 0);
 }
 
+// The same set continued in global memory once the LDS table holds its share (three quarters of its slots): one table of 2^sbits ids per
+// workgroup, all 0xFFFFFFFF between queries (the workgroup that spilled wipes it behind the query). Ids never move: a lookup asks LDS first,
+// then -- if the query has spilled -- the global table, with loads served by the L2 (a line this CU cached during an earlier query must not
+// answer); inserts are compare-and-swaps in the L2. (Wavefronts that score read it without the decisions' inserts in flight; a stale miss
+// would only cost a row that is scored in vain -- the decisions test-and-set every neighbour again.)
+DEV bool vg_contains(const u32 *vg, u32 gmask, u32 gshift, u32 id)
+{
+    u32 h = (id * 0x9E3779B1u) >> gshift;
+    bool found = false;
+    for (u32 it = 0; it <= gmask; it++) {
+        const u32 v = __hip_atomic_load(&vg[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == id) { found = true; break; }
+        if (v == LAT_NONE) break;
+        h = (h + 1u) & gmask;
+    }
+    return found;
+}
+DEV bool vg_insert(u32 *vg, u32 gmask, u32 gshift, u32 id)
+{
+    u32 h = (id * 0x9E3779B1u) >> gshift;
+    bool isnew = false;
+    for (u32 it = 0; it <= gmask; it++) {
+        const u32 old = atomicCAS(&vg[h], LAT_NONE, id);
+        if (old == LAT_NONE) { isnew = true; break; }
+        if (old == id) break;
+        h = (h + 1u) & gmask;
+    }
+    return isnew;
+}
+
 // ---- scoring: part `part` of `nparts` of node `node` into a slot
 // The slot's ids / scored mask are written by part 0; distance and ADC bits by the part that owns the neighbour's row pass
 // (compacted rows r with (r / 8) % nparts == part). Every wavefront of a node sees the same visited set (nobody inserts while
 // a round is scored), hence the same compaction.
 template <int D, bool FILTER>
 DEV void lat_score(const SearchParams &p, u32 node, u32 *sl_ids, u32 *sl_eb, u32 *sl_ab, u64 *sl_mask, int part, int nparts,
-                   const u32 *vh, u32 vmask, u32 vshift, const float *lut, const QueryRegs<D> &qreg, const float *qperm,
-                   u32 *nb_id, u32 *nb_ln, u32 knorm, u64 *lt_sub = nullptr)
+                   const u32 *vh, u32 vmask, u32 vshift, const u32 *vg, u32 gmask, u32 gshift, const float *lut, const QueryRegs<D> &qreg,
+                   const float *qperm, u32 *nb_id, u32 *nb_ln, u32 knorm, u64 *lt_sub = nullptr)
 {
 #ifdef DR_PHASE_TIMING
     u64 st0 = 0, st1 = 0;
@@ -135,7 +165,7 @@ DEV void lat_score(const SearchParams &p, u32 node, u32 *sl_ids, u32 *sl_eb, u32
         const u64 aux = p.first[(size_t)node * nwords + (cbase >> 6)];
         const bool active = slot < p.R && ((aux >> lane) & 1ull) != 0ull;
         LS(0);
-        const bool seen = active && vh_contains(vh, vmask, vshift, nbid);
+        const bool seen = active && (vh_contains(vh, vmask, vshift, nbid) || (vg != nullptr && vg_contains(vg, gmask, gshift, nbid)));
         const bool tofetch = active && !seen;
         const u64 fm = __ballot(tofetch);
         const int nrow = __popcll(fm);
@@ -269,6 +299,9 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
     const u32 vbits = p.vh_bits & 255u;
     const bool lazy_adc = (p.vh_bits & 256u) != 0u;
     const u32 vslots = 1u << vbits, vmask = vslots - 1u, vshift = 32u - vbits;
+    const u32 sbits = (p.vh_bits >> 16) & 255u;      // the workgroup's share of the spill area (0: none)
+    const u32 gslots = sbits ? (1u << sbits) : 0u, gmask = gslots - 1u, gshift = 32u - sbits;
+    u32 *vgw = sbits ? p.vis + ((size_t)blockIdx.x << sbits) : nullptr;
     off += (size_t)vslots * 4;
     const size_t slot_bytes = (lat_slot_bytes(p.R, FILTER) + 15) & ~(size_t)15;
     unsigned char *slots = smem + off;
@@ -311,10 +344,13 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
                 else load_query_regs_orig<0, D, D>(qg, j, qreg);
             }
         }
+        if (threadIdx.x == 0) ctl[1] = 0u;      // 1: this query's visited ids continue in the global table
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
         // ---- state of the search (wavefront 0)
+        bool spilled = false;
+        u32 nlds = 1;      // ids in the LDS table (the start node)
         float pq_ub = __uint_as_float(0x7F800000u);
         u32 npq_eval = 0, steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0, ninserts = 0, nhits = 0;
         int rn = 0, cnT = 0, tn = 0;
@@ -452,14 +488,23 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
                         const u32 myid = s_ids[cbase + lane];
                         const bool active = myid != LAT_NONE;
                         // visited test-and-set (search_engine.py:444-448), in stored order by construction: ids of a row are distinct
-                        if (nvisited + 64u > vlimit) { status |= DR_ST_VIS_OVERFLOW; break; }
+                        if (!spilled && nlds + 64u > vlimit) {
+                            if (vgw == nullptr) { status |= DR_ST_VIS_OVERFLOW; break; }
+                            spilled = true;
+                            if (lane == 0) ctl[1] = 1u;
+                        }
+                        if (spilled && (nvisited - nlds) + 64u > gslots - (gslots >> 2)) { status |= DR_ST_VIS_OVERFLOW; break; }
                         // (a lane that was visited when the row was scored still is)
-                        const bool isnew = active && ((s_mask[cbase >> 6] >> lane) & 1ull) != 0ull && vh_insert(vh, vmask, vshift, myid);
+                        const bool totest = active && ((s_mask[cbase >> 6] >> lane) & 1ull) != 0ull;
+                        bool isnew;
+                        if (!spilled) isnew = totest && vh_insert(vh, vmask, vshift, myid);
+                        else isnew = totest && !vh_contains(vh, vmask, vshift, myid) && vg_insert(vgw, gmask, gshift, myid);
                         const u64 newmask = __ballot(isnew);
                         const int nnew = __popcll(newmask);
                         LM(2);
                         if (nnew == 0) continue;
                         nvisited += nnew;
+                        if (!spilled) nlds += nnew;
                         const float e = isnew ? __uint_as_float(s_eb[cbase + lane]) : __builtin_inff();
                         // Is the ADC value of this expansion's neighbours needed at all? (search_kernel.hpp: A4 is provably True for all
                         // of them when the list cannot fill up during the expansion, or when pq_ub clears the threshold for the smallest
@@ -876,8 +921,8 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
                 const u32 info = ctl[16 + wave];
                 const int s = (int)(info & 255u), part = (int)((info >> 8) & 255u), nparts = (int)(info >> 16);
                 if (node != LAT_NONE)
-                    lat_score<D, FILTER>(p, node, slot_ids(s), slot_eb(s), slot_ab(s), slot_mask(s), part, nparts, vh, vmask, vshift, lut, qreg, qperm,
-                                         nb_id, nb_ln, knorm
+                    lat_score<D, FILTER>(p, node, slot_ids(s), slot_eb(s), slot_ab(s), slot_mask(s), part, nparts, vh, vmask, vshift,
+                                         ctl[1] != 0u ? vgw : nullptr, gmask, gshift, lut, qreg, qperm, nb_id, nb_ln, knorm
 #ifdef DR_LAT_SUBPHASES
                                          , wave == 0 ? lt_acc : nullptr
 #endif
@@ -895,5 +940,12 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
         LT(7);
         LT_END(qi);
         __syncthreads();        // the next query rewrites the table, the set and the slots
+        if (ctl[1] != 0u) {
+            // this query spilled: its workgroup's global table back to all-empty (sixteen bytes per store, the whole workgroup)
+            uint4 *g4 = reinterpret_cast<uint4 *>(vgw);
+            for (u32 i = threadIdx.x; i < gslots / 4; i += 64 * LAT_NW) g4[i] = make_uint4(LAT_NONE, LAT_NONE, LAT_NONE, LAT_NONE);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 }

@@ -123,9 +123,62 @@ def test_live_policy_small_calls_pick_the_workgroup_kernel(D, m):
         ix.close()
 
 
+def test_visited_set_spills_to_global_memory():
+    """An LDS table of 256 slots: nearly every query continues its visited ids in the workgroup's global table -- same results, and the table
+    is wiped behind each query (the second pass over the same queries and a different batch see an empty one)."""
+    from diskrag_amd import _ffi
+    name = "sift128_R64_m32"
+    g = load_golden(name)
+    ix = get_index(name)
+    ix.debug_force_kind(-1)
+    os.environ["DR_NO_LATENCY"] = "1"
+    try:
+        want = [ix.search_batch(g.queries, 10, L=L, beam_width=bw, mode=_ffi.MODE_M1) for (L, bw) in ((100, 8), (30, 8), (200, 0))]
+    finally:
+        del os.environ["DR_NO_LATENCY"]
+    os.environ["DR_LAT_VH_BITS"] = "8"
+    try:
+        with forced(ix, 18):
+            for rep in range(2):
+                for w, (L, bw) in zip(want, ((100, 8), (30, 8), (200, 0))):
+                    got = ix.search_batch(g.queries, 10, L=L, beam_width=bw, mode=_ffi.MODE_M1)
+                    assert ix.timing()["variant"] == 18 and (got[3]["status"] == 0).all()
+                    assert np.array_equal(got[0], w[0]) and np.array_equal(bits(got[1]), bits(w[1])) and np.array_equal(got[2], w[2])
+                    for f in ("steps", "visited", "exact", "pq", "inserts"):
+                        assert np.array_equal(got[3][f], w[3][f]), f
+    finally:
+        del os.environ["DR_LAT_VH_BITS"]
+        ix.debug_force_kind(-1)
+
+
+def test_one_query_requests_through_submit_and_wait():
+    """The facade's one-query requests go through dr_search_submit / dr_search_wait (search_engine.py _one): launches of a handful of
+    queries at the API's list size run the workgroup kernel there too -- the same bits as the batch kernels."""
+    from diskrag_amd import _ffi
+    name = "sift128_R64_m32"
+    g = load_golden(name)
+    ix = get_index(name)
+    ix.debug_force_kind(-1)
+    os.environ["DR_NO_LATENCY"] = "1"
+    try:
+        want = ix.search_batch(g.queries, 5, L=20, beam_width=8, mode=_ffi.MODE_M1)
+    finally:
+        del os.environ["DR_NO_LATENCY"]
+    for qi in range(6):
+        ids, dist, cnt, st = ix.search_submit(g.queries[qi:qi + 1], 5, L=20, beam_width=8, mode=_ffi.MODE_M1).wait()
+        assert ix.timing()["variant"] == 18
+        assert np.array_equal(ids, want[0][qi:qi + 1]) and np.array_equal(bits(dist), bits(want[1][qi:qi + 1])) and int(st["status"][0]) == 0
+    pend = [ix.search_submit(g.queries[qi:qi + 3], 5, L=20, beam_width=8, mode=_ffi.MODE_M1) for qi in range(0, 12, 3)]
+    for i, pnd in reversed(list(enumerate(pend))):
+        ids, dist, cnt, st = pnd.wait()
+        assert np.array_equal(ids, want[0][3 * i:3 * i + 3]) and np.array_equal(bits(dist), bits(want[1][3 * i:3 * i + 3]))
+        for f in ("steps", "visited", "exact", "pq"):
+            assert np.array_equal(st[f], want[3][f][3 * i:3 * i + 3])
+
+
 def test_visited_set_overflow_falls_back():
-    """A visited-id set too small for the query: the forced variant reports status bit 16 through the resident path, the small blocking
-    call answers through search_kernel.hpp instead -- same results."""
+    """A visited-id set too small for the query (a tiny LDS table and no global continuation): the forced variant reports status bit 16
+    through the resident path, the small blocking call answers through search_kernel.hpp instead -- same results."""
     from diskrag_amd import _ffi
     name = "sift128_R64_m32"
     g = load_golden(name)
@@ -133,6 +186,7 @@ def test_visited_set_overflow_falls_back():
     ix.debug_force_kind(-1)
     want = ix.search_batch(g.queries[:5], 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
     os.environ["DR_LAT_VH_BITS"] = "8"
+    os.environ["DR_LAT_SPILL_BITS"] = "0"
     os.environ["DR_LAT_ALL"] = "1"
     try:
         got = ix.search_batch(g.queries[:5], 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
@@ -145,12 +199,18 @@ def test_visited_set_overflow_falls_back():
             ix.batch_run(10, L=100, beam_width=8, mode=_ffi.MODE_M1)
             _, _, _, st = ix.batch_download()
             assert ix.timing()["variant"] == 18 and ((st["status"] & 16) != 0).all()
+        os.environ["DR_LAT_SPILL_BITS"] = "9"           # (a continuation that is itself too small: 512 slots)
+        got = ix.search_batch(g.queries[:5], 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
+        assert ix.timing()["variant"] != 18
+        assert np.array_equal(got[0], want[0]) and np.array_equal(bits(got[1]), bits(want[1]))
         del os.environ["DR_LAT_VH_BITS"]
+        del os.environ["DR_LAT_SPILL_BITS"]
         got = ix.search_batch(g.queries[:5], 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
         assert ix.timing()["variant"] == 18
         assert np.array_equal(got[0], want[0]) and np.array_equal(bits(got[1]), bits(want[1]))
     finally:
         os.environ.pop("DR_LAT_VH_BITS", None)
+        os.environ.pop("DR_LAT_SPILL_BITS", None)
         os.environ.pop("DR_LAT_ALL", None)
         ix.debug_force_kind(-1)
 
