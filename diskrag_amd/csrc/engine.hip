@@ -881,7 +881,7 @@ static int launch_lut_build(dr_index *ix, const float *d_queries, uint32_t nq, f
 static int finish_group_locked(dr_index *ix, int g);
 // Per-query scratch (insert log, result keys) is sized by the batch: very large batches are processed in chunks.
 static const uint32_t DR_MAX_CHUNK = 32768;
-static const uint32_t DR_LAT_MAX_NQ = 64;       // small blocking calls of at most this many queries: a workgroup per query (variant 18, latency_kernel.hpp)
+static const uint32_t DR_LAT_MAX_NQ = 256;      // launches of at most this many queries (a workgroup per CU): a workgroup per query (variant 18, latency_kernel.hpp) -- measured faster up to 512 at L = 20 (profiles/r05/latency_workgroup_per_query_nq.json)
 static const uint32_t DR_DIRECT_MAX = 256;      // dr_search_batch calls of at most this many queries take the direct path (see dr_index::direct)
 
 static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_t mode, uint32_t policy, uint32_t flags,
@@ -1122,6 +1122,10 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     const bool rowpre = getenv("DR_PQ_ROW_PREFETCH") != nullptr;      // A/B (round 4): ids of the predicted next pop's row landed in LDS
     p.novis = novis ? (1u | (rowpre && !(ov && ov->sdc) ? 2u : 0u)) : 0u;
     if (const char *e = getenv("DR_REPREFETCH")) { if (e[0] == '1') p.novis |= 4u; }      // A/B (round 4): the adjacency prefetch with a second chance (1 % slower)
+    // "ask later" (search_kernel.hpp, lists of at most 64 entries): every new row first, the rerank policy's ADC only if the sharper test that
+    // the exact distances allow cannot prove it true. On while this list-size class is not known to keep the policy busy -- the launch that
+    // measures the class runs with it, so "busy" means busy under the sharper test; DR_NO_ASK_LATER=1 switches it off (A/B, read per call).
+    if (k_m1 && !ov && sc == 0 && ix->adc_live_sc[sc] != 1 && getenv("DR_NO_ASK_LATER") == nullptr) p.novis |= 8u;
     p.nbcodes = (!ov && ix->inline_codes && ix->nbcodes_valid) ? ix->nbcodes.p : nullptr;
     p.vec8 = ix->vec8_state == 1 ? ix->vec8.p : nullptr;
     // chain-major copy of the batch: the builder hands nothing else; a batch uploaded without it (dr_search_submit, D <= 256)
@@ -1524,11 +1528,11 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
         const size_t b_ids = (size_t)nq * k * 4, b_cnt = (size_t)nq * 4, b_st = (size_t)nq * sizeof(KStats);
         unsigned char *hp = static_cast<unsigned char *>(ix->pinned);
         if (ix->timing.variant == 18u) {
-            // a query outgrew the visited-id set of the workgroup-per-query kernel (status bit 16): the whole call again through search_kernel.hpp
+            // a query outgrew the visited-id set of the workgroup-per-query kernel (status bit 0): the whole call again through search_kernel.hpp
             const KStats *hs = reinterpret_cast<const KStats *>(hp + 2 * b_ids + b_cnt);
             bool over = false;
             uint64_t evald = 0, all = 0;
-            for (uint32_t i = 0; i < nq; i++) { over = over || (hs[i].status & 16u) != 0u; evald += hs[i].pq_evaluated; all += hs[i].pq; }
+            for (uint32_t i = 0; i < nq; i++) { over = over || (hs[i].status & 1u) != 0u; evald += hs[i].pq_evaluated; all += hs[i].pq; }
             if (mode == DR_MODE_M1 && !over && all > 0) {
                 int &lv = ix->lat_adc_live[ix->lat_sc];
                 if (lv != 0) lv = (20 * evald > all) ? 1 : 0;           // (eager rows: asked on < 5 % of the neighbours -> lazy from now on)

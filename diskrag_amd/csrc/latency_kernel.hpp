@@ -17,12 +17,15 @@
 // round. Scoring ahead is speculation on pure functions: the decisions see the same numbers in the same order, so ids, distances,
 // counters and the accepted-insert log are those of search_kernel.hpp bit for bit (tests/test_gpu_latency.py holds every golden
 // M1 / M2 fixture to it with the variant forced). The visited set is a hash set of ids in LDS (one query owns the CU): no visited
-// words in HBM, no third round trip; a query that outgrows it sets DR_ST_VIS_OVERFLOW and the engine serves that call again
-// through search_kernel.hpp.
+// words in HBM, no third round trip; a query that outgrows it continues in a per-workgroup table in global memory, and one that
+// outgrows that too sets DR_ST_VIS_OVERFLOW (a blocking call is then served again through search_kernel.hpp).
+// What makes it faster than search_kernel.hpp where it is: with the exact distances known before the rerank policy is
+// asked, "the policy is true for this whole row" can be proven from the neighbours that can still enter the list (see need_adc below)
+// instead of from all new ones -- with the API's L = 20 that is nearly every row against none.
 #pragma once
 #include "search_kernel.hpp"
 
-#define DR_ST_VIS_OVERFLOW 16u
+#define DR_ST_VIS_OVERFLOW 1u       // dr_stats.status bit 0 (include/diskrag_hip.h: "visited-set overflow")
 // -DDR_PHASE_TIMING: wavefront 0's shader-clock sums per query -> SearchParams::phase[qi][8]:
 //   0 setup  1 decisions (pops consumed)  2 scheduling a round  3 the round (barrier to barrier)  4 wavefront 0's own scoring inside it
 //   5 rounds  6 pops consumed  7 output

@@ -1077,6 +1077,7 @@ DEV void search_body(const SearchParams &p)
                     if constexpr (FILTER) {
                         const int nact = __popcll(__ballot(active));
                         if (rn + nact <= (int)p.L) spec = false;
+                        else if (NCHR == 1 && rn == cap && (p.novis & 8u) != 0u) spec = false;       // ("ask later": the code words are fetched if the sharper test fails)
                         else if (rn == cap && cap - 1 - nact >= 0) {
                             const float Wlow = key_dist(list_get<NCHR>(rk, cap - 1 - nact));
                             if (pq_ub < f_mul(Wlow, 0.8f)) spec = false;
@@ -1154,7 +1155,19 @@ DEV void search_body(const SearchParams &p)
                         if (pq_ub < f_mul(Wlow, 0.8f)) need_adc = false;
                     }
                 }
-                const bool all_pass = !need_adc;
+                // Round 5, "ask later" (SearchParams::novis bit 3, set by the engine while the index is not known to keep the policy busy): when the
+                // list is full and neither test above can prove the policy true -- lists shorter than a row, the API's L = 20 -- every new row is
+                // fetched FIRST, as if it were proven. With the exact distances known a sharper test exists: while the list is full its worst
+                // distance only shrinks, so a neighbour is accepted only if it is below today's worst -- c' of them at most (those lanes) --, at
+                // most c' results are replaced and the worst distance stays >= list[cap - 1 - c'] for the whole row. If pq_ub clears THAT
+                // threshold the policy was true for every neighbour and the ADC is never evaluated; if not, it is evaluated now (one more
+                // dependent round trip, on the rare row) and the decisions count the policy as ever -- with every new row scored, which they
+                // never look at for lanes the policy rejects. Exact either way; SIFT-scale data at L = 20: the kernel time halves.
+                bool late_adc = false;
+                // (lists of at most 64 entries only -- the one list-size class whose lists a row can replace whole; the longer classes, the bench
+                // kernel among them, keep their code and their registers)
+                if constexpr (FILTER && NCHR == 1) { if (need_adc && (p.novis & 8u) != 0u && rn == cap) { late_adc = true; need_adc = false; } }
+                bool all_pass = !need_adc;
                 // A4 live: ADC first. It turns into a per-neighbour threshold x on the worst result distance (A4 passes
                 // iff W > x), and while the list is full W only shrinks during the expansion, so a neighbour with
                 // x >= W now can never pass: its stored vector is not fetched at all (the reference would not score it
@@ -1345,6 +1358,23 @@ DEV void search_body(const SearchParams &p)
                     e = rowlane ? nb_e[myrow] : __builtin_inff();
                     if (kcos && rowlane) e = cosine_from_l2(e, p.vnorm2[myid], qn2);
                     if constexpr (FILTER) {
+                        if constexpr (NCHR == 1) if (late_adc) {
+                            const u32 Wb = (u32)(list_get<NCHR>(rk, rn - 1) >> 32);
+                            const int cpr = __popcll(__ballot(isnew && __float_as_uint(e) < Wb));
+                            bool proven = false;
+                            if (cap - 1 - cpr >= 0) proven = pq_ub < f_mul(key_dist(list_get<NCHR>(rk, cap - 1 - cpr)), 0.8f);
+                            if (!proven) {
+                                if (isnew) {
+                                    adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m);
+                                    adc_s = adc_compute<CBLDS>(pq_tab, qorig, p.sd, cw0, cw1, cw2, cw3, mycode, p.m);
+                                }
+                                pq_d = f_sqrt(adc_s);
+                                bool ok = true;
+                                xbits = a4_threshold_bits(pq_d, p.policy == 0u ? 1.2f : 0.8f, ok);
+                                if (__ballot(isnew && !ok) != 0ull) status |= DR_ST_INTERNAL;
+                                need_adc = true; all_pass = false;
+                            }
+                        }
                         npq += nnew;            // the reference counts one PQ distance per new neighbour
                         if (need_adc) npq_eval += nnew;
                     }

@@ -94,8 +94,9 @@ typedef struct {
     uint32_t visited; /* nodes_visited = len(visited) */
     uint32_t exact;   /* exact_distance_computations */
     uint32_t pq;      /* pq_distance_computations */
-    uint32_t status;  /* 0 ok; bit0 visited-set overflow, bit1 frontier overflow, bit2 insert-log overflow, bit3 internal guard, bit4 (DR_F_IP) the
-                         query is not unit-norm */
+    uint32_t status;  /* 0 ok; bit0 visited-set overflow (the workgroup-per-query kernel's id set: a blocking call is then served again by the
+                         batch kernels and never shows it), bit1 frontier overflow, bit2 insert-log overflow, bit3 internal guard, bit4 (DR_F_IP)
+                         the query is not unit-norm */
     uint32_t inserts; /* accepted result-list inserts (engine counter, not in the reference) */
     uint32_t pq_evaluated; /* ADC sums actually computed: `pq` minus those whose outcome (rerank policy True) was
                               proven from a per-query upper bound without reading the code words (engine counter) */

@@ -26,14 +26,17 @@ if os.environ.get("LAT_SWEEP"):      # where the workgroup kernel stops paying: 
     pts = tuple(("M1_k10_L%d_bw8" % L, dict(k=10, L=L, bw=8, mode=_ffi.MODE_M1)) for L in (10, 32, 48, 64, 80, 128, 200))
 os.environ["DR_LAT_ALL"] = "1"        # (the engine picks variant 18 by itself only where it was measured faster: here every eligible call)
 qq = np.ascontiguousarray(q, dtype=np.float32)
+NQS = tuple(int(v) for v in os.environ.get("LAT_NQ", "1,8,64").split(","))
+if max(NQS) > 64: ix.debug_force_kind(-1)
 for tag, kw in pts:
-    for nq in (1, 8, 64):
+    for nq in NQS:
         k = kw["k"]
         res = {}
         # same answers first
         for name, env in (("workgroup_per_query", None), ("batch_kernels", "1")):
             if env: os.environ["DR_NO_LATENCY"] = env
             else: os.environ.pop("DR_NO_LATENCY", None)
+            ix.debug_force_kind(18 if (nq > 64 and not env) else -1)
             for _ in range(3):
                 r = ix.search_batch(qq[:nq], k, L=kw["L"], beam_width=kw["bw"], mode=kw["mode"])
             res[name] = (r, ix.timing()["variant"])
@@ -49,6 +52,7 @@ for tag, kw in pts:
             for name, env in (("workgroup_per_query", None), ("batch_kernels", "1")):
                 if env: os.environ["DR_NO_LATENCY"] = env
                 else: os.environ.pop("DR_NO_LATENCY", None)
+                ix.debug_force_kind(18 if (nq > 64 and not env) else -1)
                 for i in range(110):
                     pq_ = qq[((blk * 110 + i) * nq) % (4096 - nq):].ctypes.data_as(C.POINTER(C.c_float))
                     t0 = time.perf_counter()
@@ -60,6 +64,7 @@ for tag, kw in pts:
                         if i % 20 == 0: ks[name].append(ix.timing()["search_kernel_ms"])
                 var[name] = ix.timing()["variant"]
         os.environ.pop("DR_NO_LATENCY", None)
+        ix.debug_force_kind(-1)
         ent = {"same_results": same, "mean_expansions": round(float(a[3]["steps"].mean()), 1), "mean_rounds_hits": round(float(a[3]["adj_prefetch_hits"].mean()), 1)}
         for name in ts:
             t = np.array(ts[name]) * 1e3

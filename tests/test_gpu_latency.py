@@ -48,7 +48,7 @@ def test_exact_traversals_with_the_workgroup_kernel(name, ci):
     ix = get_index(name, mem=c["mode"] in ("M3", "M4"))
     ix.debug_force_kind(-1)
     w_ids, w_dist, w_cnt, w_st = run_case(name, c)
-    assert ix.timing()["variant"] != 18 or len(c["queries"]) <= 64
+    assert ix.timing()["variant"] != 18
     with forced(ix, 18):
         ids, dist, cnt, st = run_case(name, c)
         assert ix.timing()["variant"] == 18
@@ -76,8 +76,8 @@ def test_exact_traversals_vs_oracle():
 
 @pytest.mark.parametrize("D,m", [(128, 32), (96, 16), (256, 32), (768, 32)])
 def test_live_policy_small_calls_pick_the_workgroup_kernel(D, m):
-    """The engine's own choice: blocking calls of 1 ... 64 queries run variant 18 (after the one call per list-size class that measures the
-    A4 regime), larger ones do not; results are the oracle's under both band policies, on data where the rerank policy really consults the ADC."""
+    """Blocking calls of 1 ... 70 queries through variant 18 (after the one call per list-size class that measures the A4 regime): the oracle's
+    results under both band policies, on data where the rerank policy really consults the ADC; and the engine's own rule for taking it."""
     from diskrag_amd import _ffi
     from diskrag_amd.synth import unit_mixture
     from oracle import pyoracle as orc
@@ -96,7 +96,7 @@ def test_live_policy_small_calls_pick_the_workgroup_kernel(D, m):
                 assert np.array_equal(dist[valid].view(np.uint32), w[1][:nq][valid].astype(np.float32).view(np.uint32))
                 assert np.array_equal(cnt, w[2][:nq])
                 assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), w[3][:nq])
-            assert ix.timing()["variant"] != 18                                 # 70 queries: the batch kernels
+            assert ix.timing()["variant"] == 18                                 # (launches of up to 256 queries)
             # the scoring wavefronts may leave the ADC to the decisions (the engine's choice on data where the policy rarely asks): same bits
             for env in ("DR_LAT_LAZY_ADC", "DR_LAT_EAGER_ADC"):
                 os.environ[env] = "1"
@@ -177,7 +177,7 @@ def test_one_query_requests_through_submit_and_wait():
 
 
 def test_visited_set_overflow_falls_back():
-    """A visited-id set too small for the query (a tiny LDS table and no global continuation): the forced variant reports status bit 16
+    """A visited-id set too small for the query (a tiny LDS table and no global continuation): the forced variant reports status bit 0
     through the resident path, the small blocking call answers through search_kernel.hpp instead -- same results."""
     from diskrag_amd import _ffi
     name = "sift128_R64_m32"
@@ -198,7 +198,7 @@ def test_visited_set_overflow_falls_back():
             ix.batch_upload(g.queries[:5])
             ix.batch_run(10, L=100, beam_width=8, mode=_ffi.MODE_M1)
             _, _, _, st = ix.batch_download()
-            assert ix.timing()["variant"] == 18 and ((st["status"] & 16) != 0).all()
+            assert ix.timing()["variant"] == 18 and ((st["status"] & 1) != 0).all()
         os.environ["DR_LAT_SPILL_BITS"] = "9"           # (a continuation that is itself too small: 512 slots)
         got = ix.search_batch(g.queries[:5], 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
         assert ix.timing()["variant"] != 18
@@ -233,3 +233,46 @@ def test_ties_and_long_lists():
             assert np.array_equal(dist[valid].view(np.uint32), odist[valid].astype(np.float32).view(np.uint32))
             assert np.array_equal(cnt, ocnt)
             assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), ost)
+
+
+@pytest.mark.parametrize("live", [False, True])
+def test_ask_later_on_short_lists(live):
+    """search_kernel.hpp's "ask later" (lists of at most 64 entries: every new row first, the rerank policy's ADC only when the sharper test
+    fails): the batch kernels with it and without it (DR_NO_ASK_LATER=1) against the oracle, on SIFT-scale data (the test nearly always
+    proves the policy true) and on unit-norm data (it nearly never does: the late evaluation runs), every M1 variant."""
+    from diskrag_amd import _ffi
+    from oracle import pyoracle as orc
+    os.environ["DR_NO_LATENCY"] = "1"
+    try:
+        if live:
+            from diskrag_amd.synth import unit_mixture
+            from tests.test_gpu_live_regime import _index
+            x, q = unit_mixture(12000, 128, n_queries=96, n_clusters=64, seed=11, latent=24)
+            ix, medoid, adj, cb, codes = _index(x, 32, 32)
+            kinds = (-1, 0, 3, 9)
+        else:
+            g = load_golden("sift128_R64_m32")
+            ix, x, q, adj, medoid, cb, codes = get_index("sift128_R64_m32"), g.vectors, g.queries, g.adj, g.medoid, g.codebook, g.codes
+            kinds = (-1, 0, 3, 9, 11, 13, 17)
+        for (L, bw, pol) in ((20, 8, 0), (20, 8, 1), (48, 0, 0), (64, 8, 1), (10, 4, 0)):
+            w = orc.search_batch(x, adj, q, medoid, orc.M1, 5, L=L, bw=bw, policy=pol, codes=codes, codebook=cb, nthreads=8)
+            evaluated = {}
+            for env in (None, "1"):
+                if env: os.environ["DR_NO_ASK_LATER"] = env
+                else: os.environ.pop("DR_NO_ASK_LATER", None)
+                for kind in kinds:
+                    ix.debug_force_kind(kind)
+                    ids, dist, cnt, st = ix.search_batch(q, 5, L=L, beam_width=bw, mode=_ffi.MODE_M1, band_policy=pol)
+                    assert int(st["status"].max()) == 0
+                    assert np.array_equal(ids, w[0]) and np.array_equal(cnt, w[2]), (live, L, bw, pol, env, kind)
+                    valid = w[0] != 0xFFFFFFFF
+                    assert np.array_equal(dist[valid].view(np.uint32), w[1][valid].astype(np.float32).view(np.uint32))
+                    assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), w[3])
+                    if kind == 0: evaluated[env] = int(st["pq_evaluated"].sum())
+            if not live and L < 64:
+                assert evaluated[None] < evaluated["1"], (L, evaluated)      # the sharper test spares evaluations (a third of them on this 2 000-point fixture, four fifths on the 1M bench index)
+    finally:
+        os.environ.pop("DR_NO_LATENCY", None)
+        os.environ.pop("DR_NO_ASK_LATER", None)
+        ix.debug_force_kind(-1)
+        if live: ix.close()
