@@ -1028,18 +1028,19 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // traversals (M2, M4, M3 without PQ / cosine), launches of at most DR_LAT_MAX_NQ queries (blocking calls and the pipelined path's groups:
     // the facade's one-query requests ride in those), or forced (dr_debug_force_kind 18: any batch). DR_NO_LATENCY=1 switches it off (A/B, read
     // per call); ix->lat_skip is set for the one re-run of a blocking call whose query outgrew the visited-id set (LDS + its global continuation).
-    // Where it is the engine's own choice (measured, profiles/r05/latency_workgroup_per_query*.json): M1 with lists shorter than 64 entries -- the API's
-    // L = 20 -- where its sharper proof that the rerank policy holds (latency_kernel.hpp) saves the policy's evaluation on nearly every row: one query
-    // 0.36 -> 0.22 ms at L = 20, 0.40 -> 0.24 at 32, 0.38 -> 0.25 at 48. From 64 entries on search_kernel.hpp proves the same and the two are level
-    // (0.24 / 0.25 ms at 64, 0.31 / 0.33 at 100); the exact traversals are 10 % slower one query at a time. DR_LAT_ALL=1 takes it wherever it is eligible.
-    const bool lat_default = k_m1 && cap < 64;
+    // It is NOT the engine's own choice anywhere (measured, profiles/r05/latency_workgroup_per_query*.json): what made it faster than
+    // search_kernel.hpp at the API's L = 20 (one query 0.36 -> 0.22 ms) was its sharper proof that the rerank policy holds, and with the same proof
+    // in search_kernel.hpp ("ask later") the one-wavefront kernels answer that query in 0.20 ms; from 64 entries on the two were level before
+    // (0.31 / 0.33 ms at L = 100) and the exact traversals are 10 % slower one query at a time. DR_LAT_ALL=1 takes it wherever it is eligible (small
+    // blocking calls and the pipelined path's groups alike), dr_debug_force_kind 18 for any batch.
+    const bool lat_default = false;
     uint32_t lat_vh_bits = 0;
     size_t lat_lds = 0;
     bool lat = false;
     if (!ov && !pqb && !k_adc && !(flags & DR_F_COSINE) && (k_m1 || mode == DR_MODE_M2 || mode == DR_MODE_M3 || mode == DR_MODE_M4) &&
         ix->kern->latency[k_m1 ? 1 : 0][sc] != nullptr && !ix->lat_skip &&
         (g_force_kind == 18 || (g_force_kind < 0 && ix->cs->nq <= DR_LAT_MAX_NQ && getenv("DR_NO_LATENCY") == nullptr &&
-                                (lat_default || (ix->direct && getenv("DR_LAT_ALL") != nullptr))))) {
+                                (lat_default || getenv("DR_LAT_ALL") != nullptr)))) {
         const size_t nwords = (ix->R + 63) / 64;
         const size_t slot_b = ((nwords * 64 * 4 * (k_m1 ? 3 : 2) + nwords * 8) + 15) & ~(size_t)15;
         const size_t fixed = (k_m1 ? (size_t)ix->m * 1024 : 0) + (ix->D > 256 ? (size_t)ix->D * 4 : 0) + slot_b * 8 + 8 * 512 + (size_t)NCHR_OF_SC[sc] * 64 * 12 + 768;

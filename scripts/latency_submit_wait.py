@@ -1,6 +1,6 @@
 """One-query requests through dr_search_submit + dr_search_wait (what the facade's _pq_accelerated_graph_search does, search_engine.py _one):
-p50 / p99 per request at the API defaults (k 5, L 20, beam_width 8) on the 1M-point bench index, the engine's choice (variant 18 for launches
-of <= 64 queries of this shape) beside DR_NO_LATENCY=1, interleaved; and 16 request threads sharing launches. -> one JSON object"""
+p50 / p99 per request at the API defaults (k 5, L 20, beam_width 8) on the 1M-point bench index, variant 18 (DR_LAT_ALL=1) beside the engine's
+choice (the one-wavefront kernels), interleaved; and 16 request threads sharing launches. -> one JSON object"""
 import json
 import os
 import sys
@@ -21,8 +21,8 @@ ts = {"workgroup_per_query": [], "batch_kernels": []}
 var = {}
 for blk in range(6):
     for name, env in (("workgroup_per_query", None), ("batch_kernels", "1")):
-        if env: os.environ["DR_NO_LATENCY"] = env
-        else: os.environ.pop("DR_NO_LATENCY", None)
+        if env: os.environ["DR_NO_LATENCY"] = env; os.environ.pop("DR_LAT_ALL", None)
+        else: os.environ.pop("DR_NO_LATENCY", None); os.environ["DR_LAT_ALL"] = "1"
         for i in range(110):
             qq = q[(blk * 110 + i) % 4000:][:1]
             t0 = time.perf_counter()
@@ -35,8 +35,8 @@ for name in ts:
     out["one_request_at_a_time_" + name] = {"p50_ms": round(float(np.percentile(t, 50)), 4), "p99_ms": round(float(np.percentile(t, 99)), 4), "variant": var[name]}
 # 16 request threads, one query per request
 for name, env in (("workgroup_per_query", None), ("batch_kernels", "1")):
-    if env: os.environ["DR_NO_LATENCY"] = env
-    else: os.environ.pop("DR_NO_LATENCY", None)
+    if env: os.environ["DR_NO_LATENCY"] = env; os.environ.pop("DR_LAT_ALL", None)
+    else: os.environ.pop("DR_NO_LATENCY", None); os.environ["DR_LAT_ALL"] = "1"
     lat = []
     def worker(t):
         for i in range(200):
@@ -52,5 +52,5 @@ for name, env in (("workgroup_per_query", None), ("batch_kernels", "1")):
     a = np.array(lat) * 1e3
     out["16_request_threads_" + name] = {"requests_per_s": round(16 * 200 / wall, 1), "p50_ms": round(float(np.percentile(a, 50)), 4), "p99_ms": round(float(np.percentile(a, 99)), 4),
                                           "pipeline_since_start": ix.pipeline_stats()}
-os.environ.pop("DR_NO_LATENCY", None)
+os.environ.pop("DR_NO_LATENCY", None); os.environ.pop("DR_LAT_ALL", None)
 print(json.dumps(out, indent=1))

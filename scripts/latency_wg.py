@@ -1,5 +1,5 @@
-"""Latency of small blocking calls: the workgroup-per-query kernel (variant 18, csrc/latency_kernel.hpp -- the engine's choice for
-<= 64 queries) beside the batch kernels (DR_NO_LATENCY=1), interleaved, 1 / 8 / 64 queries per dr_search_batch on the 1M-point bench index.
+"""Latency of small blocking calls: the workgroup-per-query kernel (variant 18, csrc/latency_kernel.hpp: DR_LAT_ALL=1) beside the batch kernels
+(the engine's choice) with and without "ask later" (DR_NO_ASK_LATER=1: round 4's behaviour), interleaved, 1 / 8 / 64 queries per dr_search_batch on the 1M-point bench index.
 Reference-faithful M1 at the API defaults (k 5, L 20, beam_width 8) and at the bench point (k 10, L 100), M2 at beam_width 8 (the CLI's other
 search). Also checks that both give the same ids / distance bits / counters. -> one JSON object.  argv[1]: points (default 1000000)"""
 import ctypes as C
@@ -24,7 +24,11 @@ pts = (("M1_api_default_k5_L20_bw8", dict(k=5, L=20, bw=8, mode=_ffi.MODE_M1)), 
        ("M2_k10_bw8", dict(k=8, L=100, bw=8, mode=_ffi.MODE_M2)))
 if os.environ.get("LAT_SWEEP"):      # where the workgroup kernel stops paying: list sizes between the API default and the bench point
     pts = tuple(("M1_k10_L%d_bw8" % L, dict(k=10, L=L, bw=8, mode=_ffi.MODE_M1)) for L in (10, 32, 48, 64, 80, 128, 200))
-os.environ["DR_LAT_ALL"] = "1"        # (the engine picks variant 18 by itself only where it was measured faster: here every eligible call)
+LEGS = (("workgroup_per_query", {"DR_LAT_ALL": "1"}), ("batch_kernels", {"DR_NO_LATENCY": "1"}),
+        ("batch_kernels_policy_asked_first", {"DR_NO_LATENCY": "1", "DR_NO_ASK_LATER": "1"}))      # (the last one: round 4's behaviour at short lists)
+def set_leg(env):
+    for k in ("DR_LAT_ALL", "DR_NO_LATENCY", "DR_NO_ASK_LATER"): os.environ.pop(k, None)
+    os.environ.update(env)
 qq = np.ascontiguousarray(q, dtype=np.float32)
 NQS = tuple(int(v) for v in os.environ.get("LAT_NQ", "1,8,64").split(","))
 if max(NQS) > 64: ix.debug_force_kind(-1)
@@ -33,26 +37,25 @@ for tag, kw in pts:
         k = kw["k"]
         res = {}
         # same answers first
-        for name, env in (("workgroup_per_query", None), ("batch_kernels", "1")):
-            if env: os.environ["DR_NO_LATENCY"] = env
-            else: os.environ.pop("DR_NO_LATENCY", None)
-            ix.debug_force_kind(18 if (nq > 64 and not env) else -1)
+        for name, env in LEGS:
+            set_leg(env)
+            ix.debug_force_kind(18 if (nq > 256 and name == "workgroup_per_query") else -1)
             for _ in range(3):
                 r = ix.search_batch(qq[:nq], k, L=kw["L"], beam_width=kw["bw"], mode=kw["mode"])
             res[name] = (r, ix.timing()["variant"])
-        a, b = res["workgroup_per_query"][0], res["batch_kernels"][0]
-        same = bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and
-                    all(np.array_equal(a[3][f], b[3][f]) for f in ("steps", "visited", "exact", "pq", "status", "inserts")))
+        a = res["workgroup_per_query"][0]
+        same = all(bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and
+                        all(np.array_equal(a[3][f], b[3][f]) for f in ("steps", "visited", "exact", "pq", "status", "inserts")))
+                   for b in (res["batch_kernels"][0], res["batch_kernels_policy_asked_first"][0]))
         oi = np.empty((nq, k), np.uint32); od = np.empty((nq, k), np.float32); oc = np.empty(nq, np.uint32)
         pi, pd, pc = oi.ctypes.data_as(C.POINTER(C.c_uint32)), od.ctypes.data_as(C.POINTER(C.c_float)), oc.ctypes.data_as(C.POINTER(C.c_uint32))
-        ts = {"workgroup_per_query": [], "batch_kernels": []}
-        ks = {"workgroup_per_query": [], "batch_kernels": []}
+        ts = {n: [] for n, _ in LEGS}
+        ks = {n: [] for n, _ in LEGS}
         var = {}
         for blk in range(6):       # interleaved blocks of 100 calls
-            for name, env in (("workgroup_per_query", None), ("batch_kernels", "1")):
-                if env: os.environ["DR_NO_LATENCY"] = env
-                else: os.environ.pop("DR_NO_LATENCY", None)
-                ix.debug_force_kind(18 if (nq > 64 and not env) else -1)
+            for name, env in LEGS:
+                set_leg(env)
+                ix.debug_force_kind(18 if (nq > 256 and name == "workgroup_per_query") else -1)
                 for i in range(110):
                     pq_ = qq[((blk * 110 + i) * nq) % (4096 - nq):].ctypes.data_as(C.POINTER(C.c_float))
                     t0 = time.perf_counter()
@@ -63,7 +66,7 @@ for tag, kw in pts:
                         ts[name].append(t1 - t0)
                         if i % 20 == 0: ks[name].append(ix.timing()["search_kernel_ms"])
                 var[name] = ix.timing()["variant"]
-        os.environ.pop("DR_NO_LATENCY", None)
+        set_leg({})
         ix.debug_force_kind(-1)
         ent = {"same_results": same, "mean_expansions": round(float(a[3]["steps"].mean()), 1), "mean_rounds_hits": round(float(a[3]["adj_prefetch_hits"].mean()), 1)}
         for name in ts:
