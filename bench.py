@@ -638,6 +638,26 @@ def worker_c2(args, rk):
         call_s.append(time.perf_counter() - t1)
     call_s = sorted(call_s[2:]) or [float("inf")]     # (the first two calls size the slot's buffers)
     qps_one_call = nq / call_s[len(call_s) // 2]
+    # the reference's real serving shape (search_engine.py:530-614, app.py:84-130): ONE query per blocking call, host buffer in, results out --
+    # p50 over 300 calls at the API's defaults (k 5, L 20, beam_width 8) and at this bench's point; and a 10 000-query batch at the API's
+    # list size through the resident path (round 5: "ask later")
+    one_query_ms, qps_api_default = {}, None
+    if not args.headline_only and mode == _ffi.MODE_M1:
+        for tag, kk, LL in (("api_default_k5_L20", 5, 20), ("bench_point", k, args.L)):
+            ts = []
+            for i in range(330):
+                src = qb_pageable[0][i % nq: i % nq + 1]
+                t1 = time.perf_counter()
+                ix.search_batch(src, kk, L=LL, beam_width=args.bw, mode=mode)
+                ts.append(time.perf_counter() - t1)
+            one_query_ms[tag] = float(np.percentile(np.array(ts[30:]) * 1e3, 50))
+        ix.batch_upload(qb_pageable[0])
+        for _ in range(2): ix.batch_run(5, L=20, beam_width=args.bw, mode=mode)
+        ix.batch_sync()
+        t1 = time.perf_counter()
+        for _ in range(10): ix.batch_run(5, L=20, beam_width=args.bw, mode=mode)
+        ix.batch_sync()
+        qps_api_default = nq * 10 / (time.perf_counter() - t1)
     if nb == 16:
         ix.batch_upload(qb[15])
     ix.batch_select(0)
@@ -751,6 +771,9 @@ def worker_c2(args, rk):
                    "kernel_ms_resident": tm_res["search_kernel_ms"],
                    "qps_pcie_inclusive_pageable_source": qps_pageable,
                    "qps_blocking_call_median": None if args.headline_only else qps_one_call,       # (scalar twin of the dict below: SURVEY 8d's literal metric)
+                   "one_query_call_p50_ms_api_default_k5_L20": one_query_ms.get("api_default_k5_L20"),
+                   "one_query_call_p50_ms_bench_point": one_query_ms.get("bench_point"),
+                   "qps_resident_api_default_k5_L20": qps_api_default,
                    "float32_rows_qps_resident": float_rows["qps_resident"] if float_rows else None,
                    "float32_rows_kernel_ms": float_rows["kernel_ms"] if float_rows else None,
                    "float32_rows_roofline_frac": float_rows["roofline_frac"] if float_rows else None,
