@@ -280,3 +280,39 @@ def test_ask_later_on_short_lists(live):
         os.environ.pop("DR_NO_ASK_LATER", None)
         ix.debug_force_kind(-1)
         if live: ix.close()
+
+
+def test_tie_replay_by_the_whole_wavefront_equals_the_one_lane_replay():
+    """finalize_kernel's wave-parallel heappush / heappop (capacity <= 128) against the one-lane form (DR_FINALIZE_SERIAL=1) and the oracle's
+    CPython heap, on data made of few distinct values (nearly every query ties inside its first k) at capacities around the switch."""
+    from diskrag_amd import _ffi
+    from oracle import pyoracle as orc
+    from tests.test_gpu_live_regime import _index
+    rs = np.random.RandomState(17)
+    x = rs.randint(0, 12, size=(6000, 128)).astype(np.float32)         # squared distances are small integers: ties in most lists (values 0..3 tie so often that the 64-entry side list of tied evictions overflows: status bit 1)
+    q = rs.randint(0, 12, size=(150, 128)).astype(np.float32)
+    ix, medoid, adj, cb, codes = _index(x, 32, 32)
+    try:
+        for (L, bw, k) in ((100, 8, 10), (128, 0, 50), (64, 8, 64), (20, 8, 5), (129, 8, 20), (7, 4, 7), (300, 16, 100)):
+            w = orc.search_batch(x, adj, q, medoid, orc.M1, k, L=L, bw=bw, codes=codes, codebook=cb, nthreads=8)
+            res = {}
+            for env in (None, "1"):
+                if env: os.environ["DR_FINALIZE_SERIAL"] = env
+                else: os.environ.pop("DR_FINALIZE_SERIAL", None)
+                for nq in (150, 3):          # the general path and the direct path of small calls
+                    ids, dist, cnt, st = ix.search_batch(q[:nq], k, L=L, beam_width=bw, mode=_ffi.MODE_M1)
+                    assert int(st["status"].max()) == 0
+                    assert np.array_equal(ids, w[0][:nq]), (L, bw, k, env, nq)
+                    valid = w[0][:nq] != 0xFFFFFFFF
+                    assert np.array_equal(dist[valid].view(np.uint32), w[1][:nq][valid].astype(np.float32).view(np.uint32))
+            # the data really ties: a good share of the queries hold equal distances inside their first k (a quarter at k = 10)
+            d = w[1]
+            assert (np.diff(d, axis=1) == 0).any(axis=1).mean() > (0.15 if k >= 10 else 0.03), (L, bw, k)
+        # M2 sorts full tuples (no replay), M4 / M3 replay with their own keys
+        for (mode, omode, k, L, bw, fl, ofl) in ((_ffi.MODE_M4, orc.M4, 10, 50, 0, _ffi.F_SQDIST, orc.F_CYTHON | orc.F_PAIRWISE), (_ffi.MODE_M2, orc.M2, 8, 0, 8, 0, orc.F_PAIRWISE)):
+            w = orc.search_batch(x, adj, q, medoid, omode, k, L=L, bw=bw, flags=ofl, nthreads=8)
+            ids, dist, cnt, st = ix.search_batch(q, k, L=L, beam_width=bw, mode=mode, flags=fl)
+            assert np.array_equal(ids, w[0]) and np.array_equal(dist.view(np.uint32), w[1].astype(np.float32).view(np.uint32))
+    finally:
+        os.environ.pop("DR_FINALIZE_SERIAL", None)
+        ix.close()
