@@ -1028,12 +1028,14 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // traversals (M2, M4, M3 without PQ / cosine), launches of at most DR_LAT_MAX_NQ queries (blocking calls and the pipelined path's groups:
     // the facade's one-query requests ride in those), or forced (dr_debug_force_kind 18: any batch). DR_NO_LATENCY=1 switches it off (A/B, read
     // per call); ix->lat_skip is set for the one re-run of a blocking call whose query outgrew the visited-id set (LDS + its global continuation).
-    // It is NOT the engine's own choice anywhere (measured, profiles/r05/latency_workgroup_per_query*.json): what made it faster than
-    // search_kernel.hpp at the API's L = 20 (one query 0.36 -> 0.22 ms) was its sharper proof that the rerank policy holds, and with the same proof
-    // in search_kernel.hpp ("ask later") the one-wavefront kernels answer that query in 0.20 ms; from 64 entries on the two were level before
-    // (0.31 / 0.33 ms at L = 100) and the exact traversals are 10 % slower one query at a time. DR_LAT_ALL=1 takes it wherever it is eligible (small
-    // blocking calls and the pipelined path's groups alike), dr_debug_force_kind 18 for any batch.
-    const bool lat_default = false;
+    // The engine's own choice for LONG rows only (D > 256; measured). At D = 128 what made it faster than search_kernel.hpp at the
+    // API's L = 20 (one query 0.36 -> 0.22 ms) was its sharper proof that the rerank policy holds, and with the same proof in search_kernel.hpp
+    // ("ask later") the one-wavefront kernels answer that query in 0.20 ms (variant 18: 0.23; 0.35 against 0.30 ms at L = 100). At D = 1536 a row
+    // is 6 KiB and scoring a node's rows with eight wavefronts instead of one is worth more than the hand-over costs: unit-norm 200k x 1536, one
+    // query at the API defaults 0.375 -> 0.342 ms, L = 100 0.66 -> 0.56 ms (16 queries 1.30 -> 0.99), the exact beam search 0.28 -> 0.18 ms
+    // (profiles/r05/latency_embeddings*.json). DR_LAT_ALL=1 takes it wherever it is eligible, DR_NO_LATENCY=1 nowhere, dr_debug_force_kind 18
+    // for any batch.
+    const bool lat_default = k_m1 ? ix->D > 960 : ix->D > 256;      // (D = 768: M1 0.225 against 0.245 ms -- not taken; the exact beam search 0.162 -> 0.146 ms)
     uint32_t lat_vh_bits = 0;
     size_t lat_lds = 0;
     bool lat = false;
@@ -1042,7 +1044,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         (g_force_kind == 18 || (g_force_kind < 0 && ix->cs->nq <= DR_LAT_MAX_NQ && getenv("DR_NO_LATENCY") == nullptr &&
                                 (lat_default || getenv("DR_LAT_ALL") != nullptr)))) {
         const size_t nwords = (ix->R + 63) / 64;
-        const size_t slot_b = ((nwords * 64 * 4 * (k_m1 ? 3 : 2) + nwords * 8) + 15) & ~(size_t)15;
+        const size_t slot_b = ((nwords * 64 * 4 * (k_m1 ? 3 : 2) + nwords * 16) + 15) & ~(size_t)15;
         const size_t fixed = (k_m1 ? (size_t)ix->m * 1024 : 0) + (ix->D > 256 ? (size_t)ix->D * 4 : 0) + slot_b * 8 + 8 * 512 + (size_t)NCHR_OF_SC[sc] * 64 * 12 + 768;
         // visited-id set: 16 384 slots (12 288 ids) where they fit, 32 768 for the long lists; at least 4 096
         uint32_t bits = cap > 256 ? 15 : 14;
@@ -1169,7 +1171,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         bool lazy = lat && k_m1 && ix->lat_adc_live[sc] == 0;
         if (getenv("DR_LAT_EAGER_ADC")) lazy = false;
         if (getenv("DR_LAT_LAZY_ADC")) lazy = lat && k_m1;
-        p.vh_bits = lat_vh_bits | (lazy ? 256u : 0u) | (lat_sbits << 16);
+        uint32_t want = 0;
+        if (const char *ew = getenv("DR_LAT_WANT")) want = (uint32_t)atoi(ew) & 15u;      // A/B: nodes scored per round
+        p.vh_bits = lat_vh_bits | (lazy ? 256u : 0u) | (lat_sbits << 16) | (want << 24);
         if (lat) p.vis = ix->lat_spill.p;
     }
     p.counter = bs.counter.p;

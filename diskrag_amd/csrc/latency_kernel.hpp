@@ -143,7 +143,7 @@ DEV bool vg_insert(u32 *vg, u32 gmask, u32 gshift, u32 id)
 // (compacted rows r with (r / 8) % nparts == part). Every wavefront of a node sees the same visited set (nobody inserts while
 // a round is scored), hence the same compaction.
 template <int D, bool FILTER>
-DEV void lat_score(const SearchParams &p, u32 node, u32 *sl_ids, u32 *sl_eb, u32 *sl_ab, u64 *sl_mask, int part, int nparts,
+DEV void lat_score(const SearchParams &p, u32 node, u32 *sl_ids, u32 *sl_eb, u32 *sl_ab, u64 *sl_mask, u64 *sl_rowmask, u32 wpub, bool wfull, int part, int nparts,
                    const u32 *vh, u32 vmask, u32 vshift, const u32 *vg, u32 gmask, u32 gshift, const float *lut, const QueryRegs<D> &qreg,
                    const float *qperm, u32 *nb_id, u32 *nb_ln, u32 knorm, u64 *lt_sub = nullptr)
 {
@@ -170,20 +170,45 @@ DEV void lat_score(const SearchParams &p, u32 node, u32 *sl_ids, u32 *sl_eb, u32
         LS(0);
         const bool seen = active && (vh_contains(vh, vmask, vshift, nbid) || (vg != nullptr && vg_contains(vg, gmask, gshift, nbid)));
         const bool tofetch = active && !seen;
-        const u64 fm = __ballot(tofetch);
-        const int nrow = __popcll(fm);
-        const int myrow = __popcll(fm & lanemask_lt());
+        const u64 fm0 = __ballot(tofetch);
         if (part == 0) {
             sl_ids[slot] = active ? nbid : LAT_NONE;
-            if (lane == 0) sl_mask[cbase >> 6] = fm;
+            if (lane == 0) sl_mask[cbase >> 6] = fm0;
         }
-        if (nrow == 0) continue;
-        const bool mine = tofetch && ((myrow >> 3) & (nparts - 1)) == part;      // (nparts is 1, 2, 4 or 8)
+        if (fm0 == 0ull) { if (part == 0 && lane == 0) sl_rowmask[cbase >> 6] = 0ull; continue; }
         uint4 cw0 = make_uint4(0, 0, 0, 0), cw1 = cw0, cw2 = cw0, cw3 = cw0;
         const u8 *mycode = p.codes + (size_t)nbid * p.m;
         const bool lazy_adc = (p.vh_bits & 256u) != 0u;      // the rerank policy is (measured) proven true on this index: the few rows that ask compute their ADC in the decisions
-        if constexpr (FILTER) { if (mine && !lazy_adc) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m); }
-        if (tofetch) { nb_id[myrow] = nbid; nb_ln[myrow] = (u32)lane; }
+        // Long rows (D > 256: a 6-KiB row at D = 1536): the policy's own filter BEFORE the rows, as search_kernel.hpp has it -- a neighbour whose
+        // threshold x (A4 passes iff W > x) is not below the worst distance W that was in effect when the round was scheduled can never pass while
+        // the list stays full (W only shrinks), so its row is not fetched (the decisions never look at the distance of such a lane). Every
+        // part evaluates every lane's ADC (the lanes are there anyway), so all parts agree on the rows; it costs a third dependent round trip
+        // (row ids -> code words -> rows), which the short rows do not repay -- they fetch code words and rows side by side.
+        constexpr bool PREFILTER = FILTER && D > 256;
+        bool rowl = tofetch;
+        if constexpr (PREFILTER) {
+            if (!lazy_adc) {
+                float pqd = 0.0f;
+                if (tofetch) {
+                    adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m);
+                    pqd = f_sqrt(adc_compute<false>(lut, nullptr, p.sd, cw0, cw1, cw2, cw3, mycode, p.m));
+                    if (part == 0) sl_ab[slot] = __float_as_uint(pqd);
+                }
+                if (wfull) {
+                    bool ok = true;
+                    const u32 xb = a4_threshold_bits(pqd, p.policy == 0u ? 1.2f : 0.8f, ok);
+                    rowl = tofetch && (xb < wpub || !ok);
+                }
+            }
+        }
+        const u64 fm = __ballot(rowl);
+        const int nrow = __popcll(fm);
+        const int myrow = __popcll(fm & lanemask_lt());
+        if (part == 0 && lane == 0) sl_rowmask[cbase >> 6] = fm;
+        if (nrow == 0) continue;
+        const bool mine = rowl && ((myrow >> 3) & (nparts - 1)) == part;      // (nparts is 1, 2, 4 or 8)
+        if constexpr (FILTER && !PREFILTER) { if (mine && !lazy_adc) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m); }
+        if (rowl) { nb_id[myrow] = nbid; nb_ln[myrow] = (u32)lane; }
         WSYNC();
         LS(2);
         const int npass = (nrow + 7) >> 3;
@@ -266,7 +291,7 @@ DEV void lat_score(const SearchParams &p, u32 node, u32 *sl_ids, u32 *sl_eb, u32
             }
         }
         LS(7);
-        if constexpr (FILTER) {
+        if constexpr (FILTER && !(FILTER && D > 256)) {
             // asymmetric_distance = sqrt(sum_j T[j, code_j]) (fast_pq.py:320-333), from the query's table in LDS
             if (mine && !lazy_adc) sl_ab[slot] = __float_as_uint(f_sqrt(adc_compute<false>(lut, nullptr, p.sd, cw0, cw1, cw2, cw3, mycode, p.m)));
         }
@@ -276,7 +301,7 @@ DEV void lat_score(const SearchParams &p, u32 node, u32 *sl_ids, u32 *sl_eb, u32
 }
 
 // LDS footprint (the host computes the same sum: engine.hip lat_lds_bytes)
-DEV size_t lat_slot_bytes(u32 R, bool filter) { const size_t rs = (size_t)((R + 63) / 64) * 64; return rs * 4 * (filter ? 3 : 2) + (size_t)((R + 63) / 64) * 8; }
+DEV size_t lat_slot_bytes(u32 R, bool filter) { const size_t rs = (size_t)((R + 63) / 64) * 64; return rs * 4 * (filter ? 3 : 2) + (size_t)((R + 63) / 64) * 16; }
 
 template <int D, bool FILTER, int NCHR>
 __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
@@ -321,7 +346,12 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
     auto slot_ids = [&](int s) { return reinterpret_cast<u32 *>(slots + (size_t)s * slot_bytes); };
     auto slot_eb = [&](int s) { return slot_ids(s) + RS; };
     auto slot_ab = [&](int s) { return slot_ids(s) + 2 * RS; };
-    auto slot_mask = [&](int s) { return reinterpret_cast<u64 *>(slot_ids(s) + (FILTER ? 3 : 2) * RS); };
+    auto slot_mask = [&](int s) { return reinterpret_cast<u64 *>(slot_ids(s) + (FILTER ? 3 : 2) * RS); };      // [nwords] not visited when scored, then [nwords] rows scored
+    // nodes wanted per round: with long rows (D > 256) the popped node and, with the rerank policy, one more -- a node scored by one wavefront
+    // alone IS the round's length there (measured at D = 1536, profiles/r05/latency_embeddings_sweep.json: 2 beats 1 / 3 / 4 / 8 for M1, 1 beats 2
+    // for the exact traversals); bits 24..27 of vh_bits override it (DR_LAT_WANT, A/B). (A deeper row pipeline for the one pass a wavefront
+    // scores -- all eight chunks of a 6-KiB row in flight, DR_CHUNK_NBUF=8 -- spills 65 registers around the list and is 15-30 % slower.)
+    const int WANT = ((p.vh_bits >> 24) & 15u) ? (int)min((p.vh_bits >> 24) & 15u, (u32)LAT_NW) : ((D > 256) ? (FILTER ? 2 : 1) : LAT_NW);
 
     for (u32 qi = blockIdx.x; qi < p.nq; qi += gridDim.x) {
         LT_DECL();
@@ -427,14 +457,15 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
                             const bool live = (c * 64 + lane < rn) && fl.v[c] == 0u;
                             const u64 lm = __ballot(live);
                             const int rank = base + __popcll(lm & lanemask_lt());
-                            if (live && rank < LAT_NW) ctl[24 + rank] = ~(u32)rk.v[c];
+                            if (live && rank < WANT) ctl[24 + rank] = ~(u32)rk.v[c];
                             base += __popcll(lm);
                         }
-                        int nw = min(base, LAT_NW);
+                        int nw = min(base, WANT);
+                        if (lane == 0) { ctl[2] = (u32)(list_get<NCHR>(rk, rn - 1) >> 32); ctl[3] = (rn == cap) ? 1u : 0u; }      // the worst distance the round's policy filter may rely on
                         WSYNC();
                         u32 wid = lane < nw ? ctl[24 + min(lane, LAT_NW - 1)] : LAT_NONE;
                         if (__ballot(lane < nw && wid == cur) == 0ull) {
-                            const int pos = min(nw, LAT_NW - 1);
+                            const int pos = min(nw, WANT - 1);
                             if (lane == pos) wid = cur;
                             nw = pos + 1;
                         }
@@ -508,7 +539,10 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
                         if (nnew == 0) continue;
                         nvisited += nnew;
                         if (!spilled) nlds += nnew;
-                        const float e = isnew ? __uint_as_float(s_eb[cbase + lane]) : __builtin_inff();
+                        // (a new lane whose row the round's policy filter left out has no distance: the decisions never look at it -- its
+                        //  threshold is not below the worst distance, so it is no candidate and the sharper proof below fails with it)
+                        const bool rowscored = ((s_mask[nwords + (cbase >> 6)] >> lane) & 1ull) != 0ull;
+                        const float e = (isnew && rowscored) ? __uint_as_float(s_eb[cbase + lane]) : __builtin_inff();
                         // Is the ADC value of this expansion's neighbours needed at all? (search_kernel.hpp: A4 is provably True for all
                         // of them when the list cannot fill up during the expansion, or when pq_ub clears the threshold for the smallest
                         // worst distance the expansion can reach)
@@ -924,7 +958,7 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
                 const u32 info = ctl[16 + wave];
                 const int s = (int)(info & 255u), part = (int)((info >> 8) & 255u), nparts = (int)(info >> 16);
                 if (node != LAT_NONE)
-                    lat_score<D, FILTER>(p, node, slot_ids(s), slot_eb(s), slot_ab(s), slot_mask(s), part, nparts, vh, vmask, vshift,
+                    lat_score<D, FILTER>(p, node, slot_ids(s), slot_eb(s), slot_ab(s), slot_mask(s), slot_mask(s) + nwords, ctl[2], ctl[3] != 0u, part, nparts, vh, vmask, vshift,
                                          ctl[1] != 0u ? vgw : nullptr, gmask, gshift, lut, qreg, qperm, nb_id, nb_ln, knorm
 #ifdef DR_LAT_SUBPHASES
                                          , wave == 0 ? lt_acc : nullptr

@@ -21,7 +21,7 @@
 //  15 = 2 with the table rows of the LAST 16 sub-quantisers held in VGPRs (64 registers, looked up with ds_bpermute) and
 //     only the first m - 16 rows in LDS: at m = 32 a table costs 16 KiB of LDS instead of 32, so 8 wavefronts fit a CU
 //     instead of 4 (two per SIMD: the traversal is bound by instruction latency, not by memory)  (m % 16 == 0, m >= 32)
-//  18 (not a row of DR_KINDS: its own kernel family, latency_kernel.hpp; DR_LAT_ALL=1 or forced -- never the engine's own choice) M1 / exact traversals with a WORKGROUP of eight wavefronts per
+//  18 (not a row of DR_KINDS: its own kernel family, latency_kernel.hpp; the engine's choice for launches of <= 256 queries on long rows -- M1 above 960 dimensions, exact traversals above 256 --, DR_LAT_ALL=1 / forced elsewhere) M1 / exact traversals with a WORKGROUP of eight wavefronts per
 //     query: scoring ahead of the decisions, visited ids in LDS -- the handful of queries of one request (round 5)
 //  16 = 11, 17 = 13 in workgroups of FOUR wavefronts (same code, same 16 wavefronts per CU as four workgroups): a batch
 //     smaller than the chip's 4096 wavefront slots -- the 1250-query slice of an 8-GPU strong-scaling job, a coalesced

@@ -2,7 +2,7 @@
 directly (every request its own dr_search_batch call; the handle serialises them), through RequestBatcher, and (round 4) as
 submit + wait per request: dr_search_wait does not hold the handle, so concurrent requests are coalesced into shared launches
 by the library itself.
-usage: exp_request_batcher.py  -> gpurun_out/r04/request_batcher.json"""
+usage: exp_request_batcher.py [k L]  -> gpurun_out/request_batcher_k<k>_L<L>.json (default k 10, L 100; round 5 also at the API defaults 5 20)"""
 import json
 import sys
 import threading
@@ -13,6 +13,8 @@ from diskrag_amd import HipIndex, _ffi
 from diskrag_amd.batching import RequestBatcher
 from diskrag_amd.synth import sift_like
 
+K_ = int(sys.argv[1]) if len(sys.argv) > 2 else 10
+L_ = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 x, q = sift_like(1000000, 128, n_queries=20000, n_clusters=1024, seed=2024, query_seed=9000)
 ix = HipIndex.create_empty(x, R=64)
 ix.build_vamana(L_build=100, alpha=1.2, passes=2, seed=7)
@@ -38,22 +40,22 @@ def run(threads, per_thread, fn):
     return {"requests_per_s": threads * per_thread / dt, "p50_ms": float(np.percentile(l, 50)), "p99_ms": float(np.percentile(l, 99))}
 
 
-out = {"index": "1M x 128, R 64, m 32 (the bench index)", "request": "M1, k 10, L 100, beam_width 8", "runs": {}}
-direct = lambda v: ix.search_batch(v, 10, L=100, beam_width=8, mode=_ffi.MODE_M1)
+out = {"index": "1M x 128, R 64, m 32 (the bench index)", "request": "M1, k %d, L %d, beam_width 8" % (K_, L_), "runs": {}}
+direct = lambda v: ix.search_batch(v, K_, L=L_, beam_width=8, mode=_ffi.MODE_M1)
 for v in q[:64]: direct(v)
 for T in (1, 16, 64, 256):
     s0 = ix.pipeline_stats()
     rec = {"direct": run(T, max(20, 2000 // T), direct),
-           "submit_wait_per_request": run(T, max(20, 4000 // T), lambda v: ix.search_submit(v.reshape(1, -1), 10, L=100, beam_width=8, mode=_ffi.MODE_M1).wait())}
+           "submit_wait_per_request": run(T, max(20, 4000 // T), lambda v: ix.search_submit(v.reshape(1, -1), K_, L=L_, beam_width=8, mode=_ffi.MODE_M1).wait())}
     s1 = ix.pipeline_stats()
     rec["submit_wait_per_request"]["requests_per_launch"] = (s1["tickets"] - s0["tickets"]) / max(1, s1["launches"] - s0["launches"])
     for wait in (0.0, 0.2, 1.0):
-        with RequestBatcher(Eng(), k_max=10, L=100, beam_width=8, max_batch=4096, max_wait_ms=wait) as rb:
+        with RequestBatcher(Eng(), k_max=K_, L=L_, beam_width=8, max_batch=4096, max_wait_ms=wait) as rb:
             r = run(T, max(20, 4000 // T), lambda v: rb.search(v))
             r["mean_batch"] = rb.queries_sent / max(rb.batches_sent, 1)
         rec[f"batcher_wait_{wait}ms"] = r
     out["runs"][f"{T}_threads"] = rec
     print(T, rec, flush=True)
 import os
-os.makedirs("gpurun_out/r04", exist_ok=True)
-json.dump(out, open("gpurun_out/r04/request_batcher.json", "w"), indent=1)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/request_batcher_k%d_L%d.json" % (K_, L_), "w"), indent=1)
