@@ -8,7 +8,11 @@ from diskrag_amd import HipIndex, _ffi
 from diskrag_amd.synth import sift_like
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 os.environ["DR_LAT_ALL"] = "1"      # (variant 18 at every list size, not only where the engine prefers it)
-x, q = sift_like(N, 128, n_queries=512, n_clusters=1024, seed=2024, query_seed=9000)
+if len(sys.argv) > 2 and sys.argv[2] == "emb":      # the embedding shape: unit-norm mixture, D = 1536, the rerank policy live
+    from diskrag_amd.synth import unit_mixture
+    x, q = unit_mixture(N, 1536, n_queries=512, n_clusters=256, seed=5, latent=32)
+else:
+    x, q = sift_like(N, 128, n_queries=512, n_clusters=1024, seed=2024, query_seed=9000)
 ix = HipIndex.create_empty(x, R=64)
 ix.build_vamana(L_build=100, alpha=1.2, passes=2, seed=7, pad_with_zero=True)
 cb = ix.pq_train(32, n_sample=20000, iters=3); ix.pq_encode(cb)
