@@ -28,8 +28,10 @@ template <int D> __global__ __launch_bounds__(64) void exact_kernel(const float 
 
 // DR_MODE_PQ + DR_F_RERANK (config c3: "PQ traversal + full-precision rerank of the L list"): exact
 // squared L2 (A1 order, the same device function as everywhere) of every entry of a query's final result list, then the
-// k best in (distance, id) order. One wavefront per query, 8 stored vectors per pass; ranks by counting in LDS.
-template <int D> __global__ __launch_bounds__(64) void rerank_kernel(const float *__restrict__ vecp,
+// k best in (distance, id) order. One WORKGROUP per query -- one wavefront for batches that fill the chip, eight for the handful of
+// queries of a request (round 5: a lone wavefront streams the 100 rows of an L = 100 list pass after pass, 13 passes of 6-KiB rows at D = 1536;
+// eight take two each) --, 8 stored vectors per wavefront pass; ranks by counting in LDS.
+template <int D> __global__ __launch_bounds__(512) void rerank_kernel(const float *__restrict__ vecp,
         const float *__restrict__ queries_p, u32 nq, const u64 *__restrict__ res_keys, const u32 *__restrict__ res_n, u32 cap,
         u32 k, u32 *__restrict__ out_ids, float *__restrict__ out_dist, u32 *__restrict__ out_count, KStats *__restrict__ stats, u32 ip)
 {
@@ -39,22 +41,23 @@ template <int D> __global__ __launch_bounds__(64) void rerank_kernel(const float
     float *qperm = reinterpret_cast<float *>(smem);
     u64 *keys = reinterpret_cast<u64 *>(smem + (QREG ? 0 : (size_t)D * 4));
     const int lane = threadIdx.x & 63, j = lane & 7, oct = lane >> 3;
+    const u32 wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     for (u32 q = blockIdx.x; q < nq; q += gridDim.x) {
         const float *qpg = queries_p + (size_t)q * D;
         QueryRegs<D> qreg;
-        WSYNC();
+        __syncthreads();
         if constexpr (QREG) load_query_regs<0, D, D>(qpg, j, qreg);
-        else { for (int i = lane; i < D; i += 64) qperm[i] = qpg[i]; }
-        WSYNC();
+        else { for (int i = threadIdx.x; i < D; i += blockDim.x) qperm[i] = qpg[i]; }
+        __syncthreads();
         const u32 n = min(res_n[q], cap);
         const u64 *rk = res_keys + (size_t)q * cap;
-        for (u32 base = 0; base < n; base += 8) {
+        for (u32 base = wave * 8; base < n; base += 8 * nwv) {
             const u32 idx = min(base + (u32)oct, n - 1);
             const u32 id = ~(u32)rk[idx];
             const float e = pw_row_stream<0, D, D, QREG>(vecp + (size_t)id * D, &qreg, qperm, j);
             if (j == 0 && base + oct < n) keys[base + oct] = ((u64)__float_as_uint(e) << 32) | id;   // e >= 0: bits order = value order
         }
-        WSYNC();
+        __syncthreads();
         const u32 kout = min(k, n);
         bool q_unit = true;
         if (ip) {
@@ -64,7 +67,7 @@ template <int D> __global__ __launch_bounds__(64) void rerank_kernel(const float
             for (int o = 32; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o);
             q_unit = s2 > 1.0 - 1e-3 && s2 < 1.0 + 1e-3;
         }
-        for (u32 i = lane; i < n; i += 64) {
+        for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
             const u64 mine = keys[i];
             u32 r = 0;
             for (u32 t = 0; t < n; t++) r += (keys[t] < mine) ? 1u : 0u;        // ids are distinct: a total order
@@ -73,8 +76,8 @@ template <int D> __global__ __launch_bounds__(64) void rerank_kernel(const float
                 out_dist[(size_t)q * k + r] = !ip ? key_dist(mine) : q_unit ? f_mul(key_dist(mine), 0.5f) : __uint_as_float(0x7FC00000u);
             }
         }
-        for (u32 i = kout + lane; i < k; i += 64) { out_ids[(size_t)q * k + i] = 0xFFFFFFFFu; out_dist[(size_t)q * k + i] = __uint_as_float(0x7FC00000u); }
-        if (lane == 0) { out_count[q] = kout; stats[q].exact += n; if (!q_unit) stats[q].status |= 16u; }
+        for (u32 i = kout + threadIdx.x; i < k; i += blockDim.x) { out_ids[(size_t)q * k + i] = 0xFFFFFFFFu; out_dist[(size_t)q * k + i] = __uint_as_float(0x7FC00000u); }
+        if (threadIdx.x == 0) { out_count[q] = kout; stats[q].exact += n; if (!q_unit) stats[q].status |= 16u; }
     }
 }
 

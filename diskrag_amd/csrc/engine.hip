@@ -1282,7 +1282,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         uint32_t ipv = (flags & DR_F_IP) ? 1u : 0u;
         void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp, &ipv };
         const size_t rlds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)cap * 8;
-        HIPCHK(hipLaunchKernel(ix->kern->rerank, dim3(std::min<uint32_t>(nq, (uint32_t)ix->num_cu * 16)), dim3(64), rargs, rlds, st));
+        // (a handful of queries: eight wavefronts per query share its list's rows; a batch that fills the chip: one wavefront per query)
+        const unsigned rblock = nq <= (uint32_t)ix->num_cu * 2 ? 512u : 64u;
+        HIPCHK(hipLaunchKernel(ix->kern->rerank, dim3(std::min<uint32_t>(nq, (uint32_t)ix->num_cu * 16)), dim3(rblock), rargs, rlds, st));
     }
 
     // tie replay for the queries the search kernel listed: one wavefront per query, heap in registers. It runs on
