@@ -16,6 +16,7 @@ x, q = unit_mixture(N, D, n_queries=1024, n_clusters=256, seed=5, latent=32)
 ix = HipIndex.create_empty(x, R=64)
 t0 = time.time(); ix.build_vamana(L_build=100, alpha=1.2, passes=2, seed=7, pad_with_zero=True); tb = time.time() - t0
 cb = ix.pq_train(32, n_sample=50000, iters=5); ix.pq_encode(cb)
+if os.environ.get("LAT_INLINE_CODES"): ix.inline_codes(True)       # dr_index_inline_codes: every adjacency slot carries its neighbour's code word
 L_ = _ffi.load_library()
 out = {"index": "%d x %d unit-norm mixture, R 64, m 32; built in %.1f s" % (N, D, tb)}
 pts = (("M1_k5_L20_bw8_policy0", dict(k=5, L=20, bw=8, mode=_ffi.MODE_M1, pol=0, flags=0)), ("M1_k5_L20_bw8_policy1", dict(k=5, L=20, bw=8, mode=_ffi.MODE_M1, pol=1, flags=0)),
