@@ -1045,7 +1045,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
                                 (lat_default || getenv("DR_LAT_ALL") != nullptr)))) {
         const size_t nwords = (ix->R + 63) / 64;
         const size_t slot_b = ((nwords * 64 * 4 * (k_m1 ? 3 : 2) + nwords * 16) + 15) & ~(size_t)15;
-        const size_t fixed = (k_m1 ? (size_t)ix->m * 1024 : 0) + (ix->D > 256 ? (size_t)ix->D * 4 : 0) + slot_b * 8 + 8 * 512 + (size_t)NCHR_OF_SC[sc] * 64 * 12 + 768;
+        const size_t fixed = (k_m1 ? (size_t)ix->m * 1024 : 0) + (ix->D > 256 ? (size_t)ix->D * 4 : 0) + slot_b * 8 + 8 * 512 + (size_t)NCHR_OF_SC[sc] * 64 * 12 + 768 + 1024;
         // visited-id set: 16 384 slots (12 288 ids) where they fit, 32 768 for the long lists; at least 4 096
         uint32_t bits = cap > 256 ? 15 : 14;
         if (const char *e = getenv("DR_LAT_VH_BITS")) bits = (uint32_t)atoi(e);      // tests: a set small enough to overflow
@@ -1133,7 +1133,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.vec8 = ix->vec8_state == 1 ? ix->vec8.p : nullptr;
     // chain-major copy of the batch: the builder hands nothing else; a batch uploaded without it (dr_search_submit, D <= 256)
     // gets it here if this search needs it (large dimensions keep the query in LDS chain-major; the rerank pass reads it)
-    if (!ov && !ix->cs->qp_valid && (ix->D > 256 || rerank)) {
+    if (!ov && !ix->cs->qp_valid && ((ix->D > 256 && !lat) || rerank)) {      // (variant 18 permutes its query itself)
         hipLaunchKernelGGL(permute_queries_kernel, dim3(nq), dim3(64), 0, st, ix->cs->q.p, nq, ix->D, ix->perm.p, ix->cs->qp.p);
         HIPCHK(hipGetLastError());
         ix->cs->qp_valid = true;
@@ -1211,7 +1211,10 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         }
         p.vnorm2 = ix->vnorm2.p;
     }
-    if (mode == DR_MODE_M1) {
+    p.perm = ix->perm.p;
+    if (mode == DR_MODE_M1 && lat && !ix->cs->pq_ub_valid) {
+        p.pq_ub = nullptr;      // variant 18 sums the row maxima of the table it holds in LDS: no bound kernels in front of a small launch
+    } else if (mode == DR_MODE_M1) {
         // per-query ADC upper bounds: a function of (queries, codebook) only, computed once per uploaded batch
         if (!ix->cs->pq_ub_valid) {
             { const int rcb = launch_pq_bound(ix, *ix->cs, nq, st); if (rcb) return rcb; }

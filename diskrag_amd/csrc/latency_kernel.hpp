@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
     off += (size_t)NCHR * 64 * 12;
     u32 *ctl = reinterpret_cast<u32 *>(smem + off);      // [0] tasks of the round (0: the query is finished); [8..15] task node; [16..23] task slot | part << 8 | nparts << 16;
                                                           // [24..31] wanted ids, [32..39] node / [40..47] slot of the wanted that need scoring, [48..55] slot -> new tag
-                                                          // [64..191] dump area of the adjacency prefetch
+                                                          // [64..191] dump area of the adjacency prefetch, [192..447] row maxima of the query's table (fused ADC bound)
     auto slot_ids = [&](int s) { return reinterpret_cast<u32 *>(slots + (size_t)s * slot_bytes); };
     auto slot_eb = [&](int s) { return slot_ids(s) + RS; };
     auto slot_ab = [&](int s) { return slot_ids(s) + 2 * RS; };
@@ -371,7 +371,11 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
         {
             const float *qg = p.queries + (size_t)qi * D;
             const float *qpg = p.queries_p + (size_t)qi * D;
-            if constexpr (!QREG) { for (int i = threadIdx.x; i < D; i += 64 * LAT_NW) qperm[i] = qpg[i]; }
+            // (no chain-major copy of the batch: the element permutation is applied here -- one launch less in front of a one-query call)
+            if constexpr (!QREG) {
+                if (p.queries_p != nullptr) { for (int i = threadIdx.x; i < D; i += 64 * LAT_NW) qperm[i] = qpg[i]; }
+                else { for (int i = threadIdx.x; i < D; i += 64 * LAT_NW) qperm[p.perm[i]] = qg[i]; }
+            }
             if constexpr (QREG) {
                 if (p.queries_p != nullptr) load_query_regs<0, D, D>(qpg, j, qreg);
                 else load_query_regs_orig<0, D, D>(qg, j, qreg);
@@ -396,8 +400,26 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
         u64 *qlog = p.log + (size_t)qi * p.logcap;
         // a set that is three quarters full is an overflow (probe sequences stay short, the table never fills)
         const u32 vlimit = vslots - (vslots >> 2);
+        if constexpr (FILTER) {
+            // sqrt(sum_j max_c T[j][c]), the sum in A3's order (pq_bound_kernel's value: the same table entries, the same additions) from the table
+            // in LDS when the engine did not queue the bound kernels: row j's maximum by wavefront j mod 8, the ordered sum by one lane
+            if (p.pq_ub == nullptr) {
+                float *rowmax = reinterpret_cast<float *>(ctl + 192);
+                for (u32 jq = (u32)wave; jq < p.m; jq += LAT_NW) {
+                    const float4 t4 = reinterpret_cast<const float4 *>(lut + (size_t)jq * 256)[lane];
+                    const float mx = wave_max(fmaxf(fmaxf(t4.x, t4.y), fmaxf(t4.z, t4.w)));
+                    if (lane == 0) rowmax[jq] = mx;
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    float sacc = 0.0f;
+                    for (u32 jq = 0; jq < p.m; jq++) sacc = f_add(sacc, rowmax[jq]);
+                    pq_ub = f_sqrt(sacc);
+                }
+            }
+        }
         if (wave == 0) {
-            if constexpr (FILTER) pq_ub = p.pq_ub[qi];
+            if constexpr (FILTER) { if (p.pq_ub != nullptr) pq_ub = p.pq_ub[qi]; }
 #pragma unroll
             for (int c = 0; c < NCHR; c++) { rk.v[c] = ~0ull; fl.v[c] = 0u; }
             tl.v[0] = ~0ull;

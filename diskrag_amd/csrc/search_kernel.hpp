@@ -121,7 +121,8 @@ struct SearchParams {
     // bit 2: the adjacency prefetch of the byte-query variants WITH a second chance (A/B switch DR_REPREFETCH=1; measured: hits 58 -> 97 %,
     // kernel 1 % slower -- profiles/r04/ab/ab_c2_second_chance_prefetch.jsonl).
     u32 novis;
-    u32 vh_bits;             // latency_kernel.hpp: log2 of the slots of the visited-id hash set in LDS
+    u32 vh_bits;             // latency_kernel.hpp: log2 of the slots of the visited-id hash set in LDS (+ option bits)
+    const u32 *perm;         // [D] position of original element e in the chain-major layout (latency_kernel.hpp permutes a query itself when queries_p is null)
 };
 
 DEV u32 lane_id() { return threadIdx.x & 63; }
