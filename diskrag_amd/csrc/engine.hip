@@ -1032,7 +1032,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // API's L = 20 (one query 0.36 -> 0.22 ms) was its sharper proof that the rerank policy holds, and with the same proof in search_kernel.hpp
     // ("ask later") the one-wavefront kernels answer that query in 0.20 ms (variant 18: 0.23; 0.35 against 0.30 ms at L = 100). At D = 1536 a row
     // is 6 KiB and scoring a node's rows with eight wavefronts instead of one is worth more than the hand-over costs: unit-norm 200k x 1536, one
-    // query at the API defaults 0.375 -> 0.342 ms, L = 100 0.66 -> 0.56 ms (16 queries 1.30 -> 0.99), the exact beam search 0.28 -> 0.18 ms
+    // query at the API defaults 0.37 -> 0.27 ms, L = 100 0.66 -> 0.50 ms (16 queries 1.30 -> 0.93), the exact beam search 0.28 -> 0.17 ms
     // (profiles/r05/latency_embeddings*.json). DR_LAT_ALL=1 takes it wherever it is eligible, DR_NO_LATENCY=1 nowhere, dr_debug_force_kind 18
     // for any batch.
     const bool lat_default = k_m1 ? ix->D > 960 : ix->D > 256;      // (D = 768: M1 0.225 against 0.245 ms -- not taken; the exact beam search 0.162 -> 0.146 ms)
