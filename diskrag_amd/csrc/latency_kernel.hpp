@@ -175,7 +175,9 @@ DEV void lat_score(const SearchParams &p, u32 node, u32 *sl_ids, u32 *sl_eb, u32
             sl_ids[slot] = active ? nbid : LAT_NONE;
             if (lane == 0) sl_mask[cbase >> 6] = fm0;
         }
-        if (fm0 == 0ull) { if (part == 0 && lane == 0) sl_rowmask[cbase >> 6] = 0ull; continue; }
+        constexpr bool PREFILTER = FILTER && D > 256;
+        // (the second mask exists for the kernels that filter rows only: written unconditionally it cost the D <= 256 kernels 57 spilled registers)
+        if (fm0 == 0ull) { if constexpr (PREFILTER) { if (part == 0 && lane == 0) sl_rowmask[cbase >> 6] = 0ull; } continue; }
         uint4 cw0 = make_uint4(0, 0, 0, 0), cw1 = cw0, cw2 = cw0, cw3 = cw0;
         const u8 *mycode = p.codes + (size_t)nbid * p.m;
         const bool lazy_adc = (p.vh_bits & 256u) != 0u;      // the rerank policy is (measured) proven true on this index: the few rows that ask compute their ADC in the decisions
@@ -184,7 +186,6 @@ DEV void lat_score(const SearchParams &p, u32 node, u32 *sl_ids, u32 *sl_eb, u32
         // the list stays full (W only shrinks), so its row is not fetched (the decisions never look at the distance of such a lane). Every
         // part evaluates every lane's ADC (the lanes are there anyway), so all parts agree on the rows; it costs a third dependent round trip
         // (row ids -> code words -> rows), which the short rows do not repay -- they fetch code words and rows side by side.
-        constexpr bool PREFILTER = FILTER && D > 256;
         bool rowl = tofetch;
         if constexpr (PREFILTER) {
             if (!lazy_adc) {
@@ -204,7 +205,7 @@ DEV void lat_score(const SearchParams &p, u32 node, u32 *sl_ids, u32 *sl_eb, u32
         const u64 fm = __ballot(rowl);
         const int nrow = __popcll(fm);
         const int myrow = __popcll(fm & lanemask_lt());
-        if (part == 0 && lane == 0) sl_rowmask[cbase >> 6] = fm;
+        if constexpr (PREFILTER) { if (part == 0 && lane == 0) sl_rowmask[cbase >> 6] = fm; }
         if (nrow == 0) continue;
         const bool mine = rowl && ((myrow >> 3) & (nparts - 1)) == part;      // (nparts is 1, 2, 4 or 8)
         if constexpr (FILTER && !PREFILTER) { if (mine && !lazy_adc) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m); }
@@ -563,7 +564,8 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
                         if (!spilled) nlds += nnew;
                         // (a new lane whose row the round's policy filter left out has no distance: the decisions never look at it -- its
                         //  threshold is not below the worst distance, so it is no candidate and the sharper proof below fails with it)
-                        const bool rowscored = ((s_mask[nwords + (cbase >> 6)] >> lane) & 1ull) != 0ull;
+                        bool rowscored = true;      // (without the filter every lane that was not visited when the row was scored has its distance)
+                        if constexpr (FILTER && D > 256) rowscored = ((s_mask[nwords + (cbase >> 6)] >> lane) & 1ull) != 0ull;
                         const float e = (isnew && rowscored) ? __uint_as_float(s_eb[cbase + lane]) : __builtin_inff();
                         // Is the ADC value of this expansion's neighbours needed at all? (search_kernel.hpp: A4 is provably True for all
                         // of them when the list cannot fill up during the expansion, or when pq_ub clears the threshold for the smallest
