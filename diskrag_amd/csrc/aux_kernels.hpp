@@ -33,8 +33,11 @@ template <int D> __global__ __launch_bounds__(64) void exact_kernel(const float 
 // eight take two each) --, 8 stored vectors per wavefront pass; ranks by counting in LDS.
 template <int D> __global__ __launch_bounds__(512) void rerank_kernel(const float *__restrict__ vecp,
         const float *__restrict__ queries_p, u32 nq, const u64 *__restrict__ res_keys, const u32 *__restrict__ res_n, u32 cap,
-        u32 k, u32 *__restrict__ out_ids, float *__restrict__ out_dist, u32 *__restrict__ out_count, KStats *__restrict__ stats, u32 ip)
+        u32 k, u32 *__restrict__ out_ids, float *__restrict__ out_dist, u32 *__restrict__ out_count, KStats *__restrict__ stats, u32 ip,
+        const float *__restrict__ queries, const u32 *__restrict__ perm)
 {
+    // (queries_p == nullptr: no chain-major copy of the batch was made -- the handful of queries of a request; the element permutation is applied
+    //  here from `queries` / `perm`, one launch less in front of the answer)
     // ip (DR_F_IP): unit-norm data, out_dist = |q - v|^2 / 2 = 1 - <q, v>; a query whose squared norm is not 1 (+- 1e-3) gets NaN + status bit 4
     constexpr bool QREG = (D <= 256);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -43,11 +46,12 @@ template <int D> __global__ __launch_bounds__(512) void rerank_kernel(const floa
     const int lane = threadIdx.x & 63, j = lane & 7, oct = lane >> 3;
     const u32 wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     for (u32 q = blockIdx.x; q < nq; q += gridDim.x) {
-        const float *qpg = queries_p + (size_t)q * D;
+        const float *qpg = (queries_p ? queries_p : queries) + (size_t)q * D;      // (the ip check below sums squares: any element order)
         QueryRegs<D> qreg;
         __syncthreads();
-        if constexpr (QREG) load_query_regs<0, D, D>(qpg, j, qreg);
-        else { for (int i = threadIdx.x; i < D; i += blockDim.x) qperm[i] = qpg[i]; }
+        if constexpr (QREG) { if (queries_p) load_query_regs<0, D, D>(qpg, j, qreg); else load_query_regs_orig<0, D, D>(qpg, j, qreg); }
+        else if (queries_p) { for (int i = threadIdx.x; i < D; i += blockDim.x) qperm[i] = qpg[i]; }
+        else { for (int i = threadIdx.x; i < D; i += blockDim.x) qperm[perm[i]] = qpg[i]; }
         __syncthreads();
         const u32 n = min(res_n[q], cap);
         const u64 *rk = res_keys + (size_t)q * cap;

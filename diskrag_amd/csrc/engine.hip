@@ -1133,7 +1133,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.vec8 = ix->vec8_state == 1 ? ix->vec8.p : nullptr;
     // chain-major copy of the batch: the builder hands nothing else; a batch uploaded without it (dr_search_submit, D <= 256)
     // gets it here if this search needs it (large dimensions keep the query in LDS chain-major; the rerank pass reads it)
-    if (!ov && !ix->cs->qp_valid && ((ix->D > 256 && !lat) || rerank)) {      // (variant 18 permutes its query itself)
+    const bool rerank_permutes = rerank && ix->cs->nq <= 64;      // (a handful of queries: rerank_kernel applies the permutation itself)
+    if (!ov && !ix->cs->qp_valid && ((ix->D > 256 && !lat && !pqb && mode != DR_MODE_PQ) || (rerank && !rerank_permutes))) {      // (variant 18 permutes its query itself; the ADC-only traversals never read it)
         hipLaunchKernelGGL(permute_queries_kernel, dim3(nq), dim3(64), 0, st, ix->cs->q.p, nq, ix->D, ix->perm.p, ix->cs->qp.p);
         HIPCHK(hipGetLastError());
         ix->cs->qp_valid = true;
@@ -1279,11 +1280,12 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     ix->kev_pending++;
     if (rerank) {
         // DR_MODE_PQ + DR_F_RERANK: exact squared L2 of the final list's entries, k best in (distance, id) order
-        const float *vecp = ix->vecp.p; const float *qpp = ix->cs->qp.p; const u64 *rkp = bs.res_keys.p; const uint32_t *rnp = bs.res_n.p;
+        const float *vecp = ix->vecp.p; const float *qpp = ix->cs->qp_valid ? ix->cs->qp.p : nullptr; const u64 *rkp = bs.res_keys.p; const uint32_t *rnp = bs.res_n.p;
+        const float *qorig = ix->cs->q.p; const uint32_t *permp = ix->perm.p;
         uint32_t capv = cap, kv = k, nqv = nq; uint32_t *oi = p.out_ids; float *od = p.out_dist; uint32_t *oc = p.out_count;
         KStats *stp = p.stats;
         uint32_t ipv = (flags & DR_F_IP) ? 1u : 0u;
-        void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp, &ipv };
+        void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp, &ipv, &qorig, &permp };
         const size_t rlds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)cap * 8;
         // (a handful of queries: eight wavefronts per query share its list's rows; a batch that fills the chip: one wavefront per query)
         const unsigned rblock = nq <= (uint32_t)ix->num_cu * 2 ? 512u : 64u;
