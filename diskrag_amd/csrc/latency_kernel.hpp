@@ -774,7 +774,10 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
                         if (cm != 0ull && !fast_done && !ranks_done) npq_eval += (1u << 24);
 #endif
                         if (cm != 0ull && !fast_done && !ranks_done) {
-                            const bool by_ballot = __popcll(cm) * (NCHR + 2) <= 48;
+                            // (more than eight candidates: the pair masks below are built from candidate keys staged in LDS -- broadcast reads and
+                            //  independent compares, no readlane round per candidate -- and the counts against the list by binary search)
+                            const bool lds_pairs = __popcll(cm) > 8;
+                            const bool by_ballot = !lds_pairs && __popcll(cm) * (NCHR + 2) <= 48;
                             if (!by_ballot) {
 #pragma unroll
                                 for (int ch = 0; ch < NCHR; ch++) if (ch * 64 + lane < rn) mk[ch * 64 + lane] = rk.v[ch];
@@ -801,6 +804,27 @@ __global__ __launch_bounds__(64 * LAT_NW) void lat_kernel(const SearchParams p)
                             u64 Mt = 0ull, Mx = 0ull, lessm = 0ull, oldm[NCHR];
 #pragma unroll
                             for (int ch = 0; ch < NCHR; ch++) oldm[ch] = 0ull;
+                            if (lds_pairs) {
+                                const int c = __popcll(cm);
+                                u64 *ck = reinterpret_cast<u64 *>(nb_id);      // wavefront 0's scoring scratch: candidate keys in stored order
+                                u32 *cl = mf;                                   // ... and their lanes (the merge flags' scratch is idle until the merge)
+                                if (iscand) { const int pc = __popcll(cm & lanemask_lt()); ck[pc] = mykey; cl[pc] = (u32)lane; }
+                                WSYNC();
+#pragma unroll 4
+                                for (int t = 0; t < c; t++) {
+                                    const u64 kf = ck[t];
+                                    const u32 lf = cl[t];
+                                    const u32 ef = (u32)(kf >> 32);
+                                    const u64 bit = 1ull << lf;
+                                    const bool earlier = lf < (u32)lane;
+                                    Mt |= (earlier && ef <= tbits) ? bit : 0ull;
+                                    if (count_pass) Mx |= (earlier && ef <= xbits) ? bit : 0ull;
+                                    lessm |= (kf < mykey) ? bit : 0ull;
+#pragma unroll
+                                    for (int ch = 0; ch < NCHR; ch++) oldm[ch] |= (kf < rk.v[ch]) ? bit : 0ull;
+                                }
+                                WSYNC();
+                            } else
 #pragma unroll
                             for (int half = 0; half < 2; half++) {
                                 u32 mt = 0u, mx = 0u, ls = 0u, om[NCHR];
