@@ -57,7 +57,7 @@ EXPORTS = ["dr_device_count", "dr_last_error", "dr_index_open", "dr_index_create
            "dr_bruteforce_topk", "dr_get_node", "dr_index_close", "dr_index_create_empty", "dr_build_vamana",
            "dr_get_adjacency", "dr_pq_train", "dr_pq_encode", "dr_debug_phase_cycles", "dr_batch_sync",
            "dr_debug_force_kind", "dr_search_batch_f64",
-           "dr_index_create_codes", "dr_index_drop_vectors", "dr_pq_scan_best",
+           "dr_index_create_codes", "dr_index_drop_vectors", "dr_index_attach_row_file", "dr_pq_scan_best",
            "dr_batch_select", "dr_search_submit", "dr_search_wait", "dr_search_flush", "dr_set_coalesce", "dr_pipeline_stats", "dr_debug_hold", "dr_host_alloc", "dr_host_free",
            "dr_comm_unique_id", "dr_comm_init", "dr_comm_rank", "dr_comm_destroy", "dr_sharded_search", "dr_sharded_submit", "dr_sharded_wait", "dr_sharded_set_group", "dr_sharded_flush", "dr_merge_topk",
            "dr_debug_prune", "dr_debug_prune_pq", "dr_pq_train_ex", "dr_index_create_codes_empty", "dr_pq_encode_rows", "dr_build_vamana_pq",
@@ -105,6 +105,8 @@ def load_library():
                                         C.c_uint32, C.c_int]
     L.dr_index_drop_vectors.restype = C.c_int
     L.dr_index_drop_vectors.argtypes = [vp]
+    L.dr_index_attach_row_file.restype = C.c_int
+    L.dr_index_attach_row_file.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_uint64]
     L.dr_index_set_pq.restype = C.c_int
     L.dr_index_set_pq.argtypes = [vp, fp, u8p, C.c_uint32]
     L.dr_index_set_adjacency.restype = C.c_int
@@ -333,6 +335,10 @@ class HipIndex:
     def drop_vectors(self):
         """Frees the stored vectors: the index becomes a PQ-only shard (M3 with F_USE_PQ only)."""
         _check(load_library().dr_index_drop_vectors(self._h))
+
+    def attach_row_file(self, index_dat, record_bytes=0, vector_offset=0):
+        """Disk tier: the rows of a PQ-only index live in `index_dat` (the reference's record layout by default); DR_F_RERANK reads them from there."""
+        _check(load_library().dr_index_attach_row_file(self._h, str(index_dat).encode(), int(record_bytes), int(vector_offset)))
 
     def build_vamana(self, L_build=100, alpha=1.2, passes=2, seed=1, pad_with_zero=True, max_batch=0):
         med = C.c_uint32(0)

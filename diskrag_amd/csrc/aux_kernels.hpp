@@ -34,8 +34,10 @@ template <int D> __global__ __launch_bounds__(64) void exact_kernel(const float 
 template <int D> __global__ __launch_bounds__(512) void rerank_kernel(const float *__restrict__ vecp,
         const float *__restrict__ queries_p, u32 nq, const u64 *__restrict__ res_keys, const u32 *__restrict__ res_n, u32 cap,
         u32 k, u32 *__restrict__ out_ids, float *__restrict__ out_dist, u32 *__restrict__ out_count, KStats *__restrict__ stats, u32 ip,
-        const float *__restrict__ queries, const u32 *__restrict__ perm)
+        const float *__restrict__ queries, const u32 *__restrict__ perm, const u32 *__restrict__ id_map)
 {
+    // (id_map != nullptr: the disk tier -- `vecp` holds only the rows of this batch's lists, fetched from index.dat: the keys carry a row's
+    //  position in that buffer and id_map gives the node it is; distances are ranked with the NODE id, as everywhere)
     // (queries_p == nullptr: no chain-major copy of the batch was made -- the handful of queries of a request; the element permutation is applied
     //  here from `queries` / `perm`, one launch less in front of the answer)
     // ip (DR_F_IP): unit-norm data, out_dist = |q - v|^2 / 2 = 1 - <q, v>; a query whose squared norm is not 1 (+- 1e-3) gets NaN + status bit 4
@@ -57,8 +59,9 @@ template <int D> __global__ __launch_bounds__(512) void rerank_kernel(const floa
         const u64 *rk = res_keys + (size_t)q * cap;
         for (u32 base = wave * 8; base < n; base += 8 * nwv) {
             const u32 idx = min(base + (u32)oct, n - 1);
-            const u32 id = ~(u32)rk[idx];
-            const float e = pw_row_stream<0, D, D, QREG>(vecp + (size_t)id * D, &qreg, qperm, j);
+            const u32 rowi = ~(u32)rk[idx];
+            const u32 id = id_map ? id_map[rowi] : rowi;
+            const float e = pw_row_stream<0, D, D, QREG>(vecp + (size_t)rowi * D, &qreg, qperm, j);
             if (j == 0 && base + oct < n) keys[base + oct] = ((u64)__float_as_uint(e) << 32) | id;   // e >= 0: bits order = value order
         }
         __syncthreads();

@@ -8,6 +8,7 @@
 // lists, insert logs, stats; one HIP stream per handle; calls on a handle are serialised by a mutex.
 #include <hip/hip_runtime.h>
 
+#include <errno.h>
 #include <fcntl.h>
 #include <math.h>
 #include <stdarg.h>
@@ -256,6 +257,14 @@ struct dr_index {
     hipStream_t up_stream = nullptr, down_stream = nullptr;
     uint32_t last_nq = 0;         // batch size of the last launch (dr_batch_download)
     DevBuf<uint32_t> vis, vis_epoch;   // visited words [slots][vis_words] + the per-slot query stamp (search_kernel.hpp)
+    // Disk tier of the full-precision rows (dr_index_attach_row_file; the reference's MMapNodeReader, io/diskann_persist.py:201-234): a PQ-only index
+    // whose rows stay in index.dat -- DR_F_RERANK reads the rows of a batch's final lists from the file (O_DIRECT where the file system allows it)
+    int row_fd = -1; bool row_direct = false;
+    uint64_t row_stride = 0, row_off = 0;       // bytes between records, offset of the first record's vector
+    void *row_pin = nullptr; size_t row_pin_bytes = 0;      // page-locked staging of the fetched rows + ids
+    DevBuf<float> row_raw, row_perm;            // the batch's rows on the device: file order, chain-major
+    DevBuf<uint32_t> row_ids;                   // node id of each fetched row
+    DevBuf<u64> row_keys;                       // the lists re-keyed by position in row_perm
     DevBuf<uint32_t> lat_spill;        // variant 18: [workgroups][2^bits] visited ids beyond the LDS table, all 0xFFFFFFFF between queries (latency_kernel.hpp)
     DevBuf<float> lut;            // [nq][m][256] per-query tables of the launch being queued (lut_build_kernel), rebuilt by every search that uses them:
                                   // ONE scratch per handle -- searches are serialised on the one search stream (round 3 kept one per resident batch:
@@ -526,6 +535,8 @@ extern "C" int dr_index_drop_vectors(dr_index *ix)
 
 extern "C" void dr_index_close(dr_index *ix)
 {
+    if (ix && ix->row_fd >= 0) { close(ix->row_fd); ix->row_fd = -1; }
+    if (ix && ix->row_pin) { (void)hipHostFree(ix->row_pin); ix->row_pin = nullptr; }
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) if (st) (void)hipStreamSynchronize(st);
@@ -878,6 +889,66 @@ static int launch_lut_build(dr_index *ix, const float *d_queries, uint32_t nq, f
     return 0;
 }
 
+// ---- disk tier: rows of index.dat by node id (io/diskann_persist.py:17-31: record i = D float32 then R uint32) -------------------------------
+static int pin_reserve(void **p, size_t *have, size_t need);
+static int disk_fetch_rows(dr_index *ix, const uint32_t *ids, size_t n, float *dst)
+{
+    if (ix->row_fd < 0) return fail(DR_E_IO, "no row file attached");
+    const size_t rowb = (size_t)ix->D * 4;
+    const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>({ (size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency()), (n + 63) / 64 }));
+    std::atomic<int> bad{0};
+    auto work = [&](size_t lo, size_t hi) {
+        void *blk = nullptr;
+        const size_t blkb = ((rowb + 4095) & ~(size_t)4095) + 8192;
+        if (ix->row_direct && posix_memalign(&blk, 4096, blkb) != 0) { bad = 1; return; }
+        for (size_t i = lo; i < hi && !bad; i++) {
+            const uint64_t off = ix->row_off + (uint64_t)ids[i] * ix->row_stride;
+            if (ix->row_direct) {
+                const uint64_t a0 = off & ~(uint64_t)4095;
+                const size_t len = (size_t)(((off + rowb + 4095) & ~(uint64_t)4095) - a0);
+                const ssize_t got = pread(ix->row_fd, blk, len, (off_t)a0);
+                if (got < (ssize_t)(off - a0 + rowb)) { bad = 1; break; }       // (the last block of the file may be short)
+                memcpy(dst + i * ix->D, static_cast<unsigned char *>(blk) + (off - a0), rowb);
+            } else {
+                size_t done = 0;
+                while (done < rowb) {
+                    const ssize_t got = pread(ix->row_fd, reinterpret_cast<unsigned char *>(dst + i * ix->D) + done, rowb - done, (off_t)(off + done));
+                    if (got <= 0) { bad = 1; break; }
+                    done += (size_t)got;
+                }
+            }
+        }
+        free(blk);
+    };
+    if (nth <= 1) work(0, n);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nth; t++) th.emplace_back(work, n * t / nth, n * (t + 1) / nth);
+        for (auto &x : th) x.join();
+    }
+    if (bad) return fail(DR_E_IO, "reading rows from the index file failed: %s", strerror(errno));
+    return 0;
+}
+
+extern "C" int dr_index_attach_row_file(dr_index *ix, const char *index_dat, uint64_t record_bytes, uint64_t vector_offset)
+{
+    if (!ix || !index_dat) return fail(DR_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (record_bytes == 0) record_bytes = ((uint64_t)ix->D + ix->R) * 4;        // the reference's record (diskann_persist.py:17-24)
+    if (record_bytes < (uint64_t)ix->D * 4) return fail(DR_E_ARG, "a record of %llu bytes cannot hold a %u-dimensional vector", (unsigned long long)record_bytes, ix->D);
+    struct stat stt;
+    if (stat(index_dat, &stt) != 0) return fail(DR_E_IO, "cannot stat %s: %s", index_dat, strerror(errno));
+    if ((uint64_t)stt.st_size < vector_offset + (ix->N - 1) * record_bytes + (uint64_t)ix->D * 4)
+        return fail(DR_E_IO, "%s holds %lld bytes, %llu points of %llu-byte records need more", index_dat, (long long)stt.st_size, (unsigned long long)ix->N, (unsigned long long)record_bytes);
+    int fd = -1; bool direct = false;
+    if (getenv("DR_ROW_FILE_BUFFERED") == nullptr) { fd = open(index_dat, O_RDONLY | O_DIRECT); direct = fd >= 0; }
+    if (fd < 0) fd = open(index_dat, O_RDONLY);          // (tmpfs and some network file systems refuse O_DIRECT: buffered reads)
+    if (fd < 0) return fail(DR_E_IO, "cannot open %s: %s", index_dat, strerror(errno));
+    if (ix->row_fd >= 0) close(ix->row_fd);
+    ix->row_fd = fd; ix->row_direct = direct; ix->row_stride = record_bytes; ix->row_off = vector_offset;
+    return 0;
+}
+
 static int finish_group_locked(dr_index *ix, int g);
 // Per-query scratch (insert log, result keys) is sized by the batch: very large batches are processed in chunks.
 static const uint32_t DR_MAX_CHUNK = 32768;
@@ -902,7 +973,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     const bool use_pq = (mode == DR_MODE_M1) || pq_only;
     if ((flags & DR_F_IP) && !rerank) return fail(DR_E_ARG, "DR_F_IP goes with DR_F_RERANK (DR_MODE_PQ / DR_MODE_PQB)");
     if (use_pq && ix->m == 0) return fail(DR_E_NOPQ, "mode %u needs PQ data (dr_index_set_pq)", mode);
-    if (!pq_only || rerank) { const int rcv = need_vectors(ix, rerank ? "DR_F_RERANK" : "this search mode"); if (rcv) return rcv; }
+    const bool disk_rerank = rerank && !ix->has_vectors && ix->row_fd >= 0;      // the rows of the final lists come from index.dat
+    if ((!pq_only || rerank) && !disk_rerank) { const int rcv = need_vectors(ix, rerank ? "DR_F_RERANK (stored vectors or dr_index_attach_row_file)" : "this search mode"); if (rcv) return rcv; }
+    if (disk_rerank && (flags & DR_F_IP)) return fail(DR_E_UNSUPPORTED, "DR_F_IP needs the stored vectors' norms: not served from the disk tier");
     if (flags & DR_F_IP) {
         // the inner-product reading of the rerank is only defined on unit-norm rows: measured once per index (largest | |v|^2 - 1 |)
         if (ix->unit_norm_dev < 0.0f) {
@@ -1278,14 +1351,65 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (ov) return 0;   // the builder consumes res_keys / res_n directly on the stream
     HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][1], st));
     ix->kev_pending++;
-    if (rerank) {
+    if (rerank && disk_rerank) {
+        // The disk tier: the traversal ran on the code words in HBM; the rows of the final lists are read from index.dat now -- the lists come to the
+        // host, a pool of threads preads each row (aligned blocks under O_DIRECT), the rows go up, are permuted to the chain-major layout by the ingest
+        // kernel and scored by the same rerank kernel (positions in the fetched buffer as keys, node ids through id_map). In query chunks of at most
+        // 256 MiB of rows. Synchronous: this tier is bound by the file system, not by the GPU.
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<u64> hk((size_t)nq * cap); std::vector<uint32_t> hn(nq);
+        HIPCHK(hipMemcpy(hk.data(), bs.res_keys.p, hk.size() * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hn.data(), bs.res_n.p, hn.size() * 4, hipMemcpyDeviceToHost));
+        const size_t rowb = (size_t)ix->D * 4;
+        const uint32_t qchunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nq, ((size_t)256 << 20) / (rowb * cap)));
+        for (uint32_t q0 = 0; q0 < nq; q0 += qchunk) {
+            const uint32_t nqc = std::min(qchunk, nq - q0);
+            size_t total = 0;
+            for (uint32_t q = 0; q < nqc; q++) total += std::min<uint32_t>(hn[q0 + q], cap);
+            const size_t need = total * rowb + total * 4 + (size_t)nqc * cap * 8 + 64;
+            { const int rcp = pin_reserve(&ix->row_pin, &ix->row_pin_bytes, need); if (rcp) return rcp; }
+            float *rows_h = static_cast<float *>(ix->row_pin);
+            uint32_t *ids_h = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(ix->row_pin) + total * rowb);
+            u64 *keys_h = reinterpret_cast<u64 *>(static_cast<unsigned char *>(ix->row_pin) + ((total * rowb + total * 4 + 7) & ~(size_t)7));
+            size_t pos = 0;
+            for (uint32_t q = 0; q < nqc; q++) {
+                const uint32_t n = std::min<uint32_t>(hn[q0 + q], cap);
+                for (uint32_t i = 0; i < cap; i++) {
+                    const u64 key = hk[(size_t)(q0 + q) * cap + i];
+                    if (i < n) { ids_h[pos] = ~(uint32_t)key; keys_h[(size_t)q * cap + i] = (key & 0xFFFFFFFF00000000ull) | (uint32_t)(~(uint32_t)pos); pos++; }
+                    else keys_h[(size_t)q * cap + i] = ~0ull;
+                }
+            }
+            { const int rcf = disk_fetch_rows(ix, ids_h, total, rows_h); if (rcf) return rcf; }
+            if (ix->row_raw.reserve(std::max<size_t>(total, 1) * ix->D) || ix->row_perm.reserve(std::max<size_t>(total, 1) * ix->D) ||
+                ix->row_ids.reserve(std::max<size_t>(total, 1)) || ix->row_keys.reserve((size_t)nqc * cap)) return DR_E_NODEVICE;
+            if (total) {
+                HIPCHK(hipMemcpyAsync(ix->row_raw.p, rows_h, total * rowb, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(ix->row_ids.p, ids_h, total * 4, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(ingest_records_kernel, dim3((unsigned)total), dim3(256), 0, st, reinterpret_cast<const u32 *>(ix->row_raw.p), (u64)total, ix->D, 0u, ix->D,
+                                   ix->perm.p, ix->row_perm.p, (u32 *)nullptr);
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipMemcpyAsync(ix->row_keys.p, keys_h, (size_t)nqc * cap * 8, hipMemcpyHostToDevice, st));
+            const float *vecp = ix->row_perm.p; const float *qpp = ix->cs->qp_valid ? ix->cs->qp.p + (size_t)q0 * ix->D : nullptr; const u64 *rkp = ix->row_keys.p;
+            const uint32_t *rnp = bs.res_n.p + q0; const float *qorig = ix->cs->q.p + (size_t)q0 * ix->D; const uint32_t *permp = ix->perm.p; const uint32_t *idm = ix->row_ids.p;
+            uint32_t capv = cap, kv = k, nqv = nqc; uint32_t *oi = p.out_ids + (size_t)q0 * k; float *od = p.out_dist + (size_t)q0 * k; uint32_t *oc = p.out_count + q0;
+            KStats *stp = p.stats + q0;
+            uint32_t ipv = 0u;
+            void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp, &ipv, &qorig, &permp, &idm };
+            const size_t rlds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)cap * 8;
+            const unsigned rblock = nqc <= (uint32_t)ix->num_cu * 2 ? 512u : 64u;
+            HIPCHK(hipLaunchKernel(ix->kern->rerank, dim3(std::min<uint32_t>(nqc, (uint32_t)ix->num_cu * 16)), dim3(rblock), rargs, rlds, st));
+            HIPCHK(hipStreamSynchronize(st));       // (the staging buffer is reused by the next chunk)
+        }
+    } else if (rerank) {
         // DR_MODE_PQ + DR_F_RERANK: exact squared L2 of the final list's entries, k best in (distance, id) order
         const float *vecp = ix->vecp.p; const float *qpp = ix->cs->qp_valid ? ix->cs->qp.p : nullptr; const u64 *rkp = bs.res_keys.p; const uint32_t *rnp = bs.res_n.p;
-        const float *qorig = ix->cs->q.p; const uint32_t *permp = ix->perm.p;
+        const float *qorig = ix->cs->q.p; const uint32_t *permp = ix->perm.p; const uint32_t *idm = nullptr;
         uint32_t capv = cap, kv = k, nqv = nq; uint32_t *oi = p.out_ids; float *od = p.out_dist; uint32_t *oc = p.out_count;
         KStats *stp = p.stats;
         uint32_t ipv = (flags & DR_F_IP) ? 1u : 0u;
-        void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp, &ipv, &qorig, &permp };
+        void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp, &ipv, &qorig, &permp, &idm };
         const size_t rlds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)cap * 8;
         // (a handful of queries: eight wavefronts per query share its list's rows; a batch that fills the chip: one wavefront per query)
         const unsigned rblock = nq <= (uint32_t)ix->num_cu * 2 ? 512u : 64u;

@@ -168,6 +168,13 @@ int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_t *codes, u
 int dr_index_create_codes(dr_index **out, const uint32_t *adj, uint64_t N, uint32_t D, uint32_t R, uint32_t medoid,
                           const float *codebook, const uint8_t *codes, uint32_t m, int device);
 int dr_index_drop_vectors(dr_index *ix);
+/* Disk tier of the full-precision rows -- the counterpart of the reference's MMapNodeReader (io/diskann_persist.py:201-234: node records read from
+ * index.dat on demand). A PQ-only index (dr_index_create_codes / dr_index_drop_vectors: graph + code words in HBM) is given the file its rows live
+ * in: record i starts at vector_offset + i * record_bytes and begins with D float32 (record_bytes 0 = the reference's record, (D + R) * 4 bytes,
+ * diskann_persist.py:17-24). DR_MODE_PQ / DR_MODE_PQB with DR_F_RERANK then traverse on the code words and read the rows of the final lists from the
+ * file (O_DIRECT block reads by a pool of host threads where the file system allows it, buffered reads otherwise) for the exact rerank: the same
+ * ids and distances as with the rows in HBM, at the file system's pace. DR_E_IO if the file is missing or too short. */
+int dr_index_attach_row_file(dr_index *ix, const char *index_dat, uint64_t record_bytes, uint64_t vector_offset);
 
 int dr_index_set_adjacency(dr_index *ix, const uint32_t *adj);
 
