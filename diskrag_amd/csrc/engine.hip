@@ -1108,7 +1108,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // query at the API defaults 0.37 -> 0.27 ms, L = 100 0.66 -> 0.50 ms (16 queries 1.30 -> 0.93), the exact beam search 0.28 -> 0.17 ms
     // (profiles/r05/latency_embeddings*.json). DR_LAT_ALL=1 takes it wherever it is eligible, DR_NO_LATENCY=1 nowhere, dr_debug_force_kind 18
     // for any batch.
-    const bool lat_default = k_m1 ? ix->D > 960 : ix->D > 256;      // (D = 768: M1 0.225 against 0.245 ms -- not taken; the exact beam search 0.162 -> 0.146 ms)
+    // (lists of at most 256 entries: an M1 query then visits at most 10 L R <= 164 000 nodes, which the visited-id set and its continuation hold --
+    //  only blocking calls have the re-run for a query that outgrows them)
+    const bool lat_default = cap <= 256 && (k_m1 ? ix->D > 960 : ix->D > 256);      // (D = 768: M1 0.225 against 0.245 ms -- not taken; the exact beam search 0.162 -> 0.146 ms)
     uint32_t lat_vh_bits = 0;
     size_t lat_lds = 0;
     bool lat = false;
@@ -1222,9 +1224,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     //  nearly every row, the rest compute it inside the decisions; DR_LAT_EAGER_ADC=1 / DR_LAT_LAZY_ADC=1 pin it for A/B and tests)
     uint32_t lat_sbits = 0;
     if (lat) {
-        // the continuation of the visited-id set in global memory: 2^17 ids per workgroup (a query of the auto-selected shapes visits at most
-        // min(10 L, N) R < 41 000 nodes: it cannot run out); DR_LAT_SPILL_BITS overrides (0: none -- the overflow status and the re-run, tests)
-        lat_sbits = 17;
+        // the continuation of the visited-id set in global memory: 2^18 slots per workgroup, 196 608 ids (an M1 query of the auto-selected shapes
+        // visits at most min(10 L, N) R <= 163 840 nodes: it cannot run out); DR_LAT_SPILL_BITS overrides (0: none -- the overflow status and the re-run, tests)
+        lat_sbits = 18;
         if (const char *es = getenv("DR_LAT_SPILL_BITS")) lat_sbits = (uint32_t)atoi(es);
         if (lat_sbits > 20) lat_sbits = 20;
         if (lat_sbits) {
