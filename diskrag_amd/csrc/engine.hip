@@ -828,11 +828,18 @@ static int launch_pq_bound(dr_index *ix, QSlot &qs, uint32_t nq, hipStream_t st,
     default: break;
     }
     static const bool old_form = getenv("DR_PQ_BOUND_BLOCK") != nullptr;      // A/B: the block-per-query form
-    if (fn && !old_form && nq > DR_DIRECT_MAX_BOUND) {      // (a handful of queries: ONE launch, the block-per-query form -- the same bits)
+    if (fn && !old_form && nq > DR_DIRECT_MAX_BOUND) {      // (a handful of queries: the block-per-(query, sub-quantiser) form below -- the same bits)
         if (qs.pq_max.reserve((size_t)room * ix->m)) return DR_E_NODEVICE;
         float *mxp = qs.pq_max.p + (size_t)q0 * ix->m;
         void *args[] = { &cbp, &qp, &nqv, &Dv, &mxp };
         HIPCHK(hipLaunchKernel(fn, dim3((nq + 63) / 64, ix->m), dim3(64), args, 0, st));
+        hipLaunchKernelGGL(pq_bound_sum_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, mxp, nq, ix->m, qs.pq_ub.p + q0);
+        HIPCHK(hipGetLastError());
+    } else if (!old_form && nq <= DR_DIRECT_MAX_BOUND) {
+        // a handful of queries: a block per (query, sub-quantiser), then the ordered sums (DR_PQ_BOUND_BLOCK=1: the one-block-per-query form)
+        if (qs.pq_max.reserve((size_t)room * ix->m)) return DR_E_NODEVICE;
+        float *mxp = qs.pq_max.p + (size_t)q0 * ix->m;
+        hipLaunchKernelGGL(pq_bound_rowmax_kernel, dim3(nq, ix->m), dim3(256), 0, st, cbp, qp, nqv, Dv, ix->sd, mxp);
         hipLaunchKernelGGL(pq_bound_sum_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, mxp, nq, ix->m, qs.pq_ub.p + q0);
         HIPCHK(hipGetLastError());
     } else {

@@ -1011,6 +1011,21 @@ __global__ __launch_bounds__(64) void pq_bound_max_kernel(const float *__restric
     }
     if (qi < nq) out_max[(size_t)jq * nq + qi] = mx;
 }
+// The same maxima for a HANDFUL of queries (round 5): one 256-thread block per (query, sub-quantiser) -- thread c holds T[j][c] (pw_run_lane: pq_bound_kernel's
+// entry), the block keeps its maximum. pq_bound_kernel walks the m sub-quantisers of a query one after the other, a dependent codebook read each: 23 us at
+// D = 128 and 53 us at D = 1536 (sub_dim 48) in front of every small M1 call; here they run side by side and pq_bound_sum_kernel adds them in A3's order.
+__global__ __launch_bounds__(256) void pq_bound_rowmax_kernel(const float *__restrict__ codebook, const float *__restrict__ queries, u32 nq, u32 D, u32 sd,
+                                                              float *__restrict__ out_max /*[m][nq]*/)
+{
+    __shared__ float wmax[4];
+    const u32 qi = blockIdx.x, jq = blockIdx.y, tid = threadIdx.x;
+    float mx = pw_run_lane(codebook + ((size_t)jq * 256 + tid) * sd, queries + (size_t)qi * D + jq * sd, (int)sd);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) out_max[(size_t)jq * nq + qi] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+}
 __global__ void pq_bound_sum_kernel(const float *__restrict__ mx, u32 nq, u32 m, float *__restrict__ out)
 {
     const u32 qi = blockIdx.x * blockDim.x + threadIdx.x;
