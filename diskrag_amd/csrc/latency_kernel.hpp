@@ -55,20 +55,6 @@
 #define LAT_NW 8                    // wavefronts per workgroup = slots = tasks per round
 #define LAT_NONE 0xFFFFFFFFu
 
-// max over the wave of a u32 (identity 0), result broadcast (search_kernel.hpp wave_min_u32's scan with max)
-DEV u32 wave_max_u32(u32 x)
-{
-#define DR_DPP_MAX(ctrl, rmask) x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, false))
-    DR_DPP_MAX(0x111, 0xf);
-    DR_DPP_MAX(0x112, 0xf);
-    DR_DPP_MAX(0x114, 0xf);
-    DR_DPP_MAX(0x118, 0xf);
-    DR_DPP_MAX(0x142, 0xa);
-    DR_DPP_MAX(0x143, 0xc);
-#undef DR_DPP_MAX
-    return readlane32(x, 63);
-}
-
 // ---- visited ids: open addressing, linear probing, empty = 0xFFFFFFFF (DR_PAD is never a node)
 DEV bool vh_contains(const u32 *vh, u32 vmask, u32 vshift, u32 id)
 {

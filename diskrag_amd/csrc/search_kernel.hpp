@@ -169,6 +169,20 @@ DEV u32 wave_min_u32(u32 x)
     return readlane32(x, 63);
 }
 
+// max over the wave of a u32 (identity 0), result broadcast (search_kernel.hpp wave_min_u32's scan with max)
+DEV u32 wave_max_u32(u32 x)
+{
+#define DR_DPP_MAX(ctrl, rmask) x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, false))
+    DR_DPP_MAX(0x111, 0xf);
+    DR_DPP_MAX(0x112, 0xf);
+    DR_DPP_MAX(0x114, 0xf);
+    DR_DPP_MAX(0x118, 0xf);
+    DR_DPP_MAX(0x142, 0xa);
+    DR_DPP_MAX(0x143, 0xc);
+#undef DR_DPP_MAX
+    return readlane32(x, 63);
+}
+
 // ---- register-resident sorted lists -----------------------------------------------------------------------
 // Ascending array of NCH*64 keys; lane l of chunk c holds index c*64+l. Result list key = dist bits << 32 | ~id
 // (last element = what heapq pops from the reference's max-heap of (-dist, id): largest distance, smallest id
@@ -1450,7 +1464,71 @@ DEV void search_body(const SearchParams &p)
                     u32 sT[NCHR];           // accepted keys below a list key
 #pragma unroll
                     for (int ch = 0; ch < NCHR; ch++) sT[ch] = 0u;
-                    if (cm != 0ull) {
+                    // The 4-wavefront workgroups (variants 16 / 17: the launches of a handful of queries, where a wavefront's own instruction stream is the
+                    // time): when the policy is proven true for the row (or absent) and EVERY candidate is accepted whatever the order, none of the
+                    // machinery below is needed -- latency_kernel.hpp's first decision path, derived there: with c candidates and d = rn + c - cap list
+                    // entries to drop, all candidates below list[rn - d] and list[rn - d] strictly above list[rn - d - 1] mean c accepts, d evictions
+                    // that only count (no tie with the new worst distance), and one loop over the candidates gives the merge ranks.
+                    bool fast_done = false;
+                    if constexpr (NW == 4 && KIND != DIST_ADC_SQ) {
+                        if (!count_pass && cm != 0ull && __popcll(cm) <= 16) {
+                            const int c = __popcll(cm);
+                            const int d = max(0, rn + c - cap);
+                            const bool iscand = ((cm >> lane) & 1ull) != 0ull;
+                            bool fast = true;
+                            if (d > 0) {
+                                const u32 emax = wave_max_u32(iscand ? ebits : 0u);
+                                const u32 kd = (u32)(list_get<NCHR>(rk, rn - d) >> 32);
+                                fast = emax < kd;
+                                if (rn - d - 1 >= 0) fast = fast && (u32)(list_get<NCHR>(rk, rn - d - 1) >> 32) < kd;
+                            }
+                            if (fast) {
+                                u32 lessc = 0u, rTc = 0u, sTc[NCHR];
+#pragma unroll
+                                for (int ch = 0; ch < NCHR; ch++) sTc[ch] = 0u;
+                                for (u64 mm = cm; mm != 0ull; mm &= mm - 1ull) {
+                                    const int f = __ffsll((long long)mm) - 1;
+                                    const u64 kf = readlane64(mykey, f);
+                                    lessc += (kf < mykey) ? 1u : 0u;
+                                    u32 cnt = 0u;
+#pragma unroll
+                                    for (int ch = 0; ch < NCHR; ch++) {
+                                        sTc[ch] += (kf < rk.v[ch]) ? 1u : 0u;
+                                        cnt += (u32)__popcll(__ballot(rk.v[ch] < kf));      // (unused slots hold ~0)
+                                    }
+                                    rTc = (lane == f) ? cnt : rTc;
+                                }
+                                {
+                                    const u32 o = ninserts + (u32)__popcll(cm & lanemask_lt());
+                                    if (iscand && o < p.logcap) qlog[o] = ((u64)ebits << 32) | myid;
+                                    if (ninserts + (u32)c > p.logcap && p.logcap > 0) status |= DR_ST_LOG_OVERFLOW;
+                                    ninserts += (u32)c;
+                                }
+                                const int keep = rn - d, rn2 = rn + c - d;
+                                int nlive_out = 0;
+#pragma unroll
+                                for (int ch = 0; ch < NCHR; ch++) {
+                                    const int idx = ch * 64 + lane;
+                                    if (idx < keep) { mk[idx + (int)sTc[ch]] = rk.v[ch]; mf[idx + (int)sTc[ch]] = fl.v[ch]; }
+                                    if (d > 0) nlive_out += __popcll(__ballot(idx >= keep && idx < rn && fl.v[ch] == 0u));
+                                }
+                                if (iscand) { mk[rTc + lessc] = mykey; mf[rTc + lessc] = 0u; }
+                                WSYNC();
+#pragma unroll
+                                for (int ch = 0; ch < NCHR; ch++) {
+                                    const int idx = ch * 64 + lane;
+                                    rk.v[ch] = (idx < rn2) ? mk[idx] : ~0ull;
+                                    fl.v[ch] = (idx < rn2) ? mf[idx] : 0u;
+                                }
+                                junk += (u32)nlive_out;
+                                cnT += c - nlive_out;
+                                rn = rn2;
+                                WSYNC();
+                                fast_done = true;
+                            }
+                        }
+                    }
+                    if (cm != 0ull && !fast_done) {
                         // (1) counts against the old list. Few candidates (the steady state of a full list: only
                         // neighbours that beat the worst entry are candidates): one wave-wide compare per list chunk
                         // and candidate inside the mask loop below -- the list is sorted in REGISTERS, a ballot counts
