@@ -1464,13 +1464,14 @@ DEV void search_body(const SearchParams &p)
                     u32 sT[NCHR];           // accepted keys below a list key
 #pragma unroll
                     for (int ch = 0; ch < NCHR; ch++) sT[ch] = 0u;
-                    // The 4-wavefront workgroups (variants 16 / 17: the launches of a handful of queries, where a wavefront's own instruction stream is the
-                    // time): when the policy is proven true for the row (or absent) and EVERY candidate is accepted whatever the order, none of the
-                    // machinery below is needed -- latency_kernel.hpp's first decision path, derived there: with c candidates and d = rn + c - cap list
+                    // When the policy is proven true for the row (or absent) and EVERY candidate is accepted whatever the order, none of the machinery below
+                    // is needed -- latency_kernel.hpp's first decision path, derived there (round 5; first in the 4-wavefront workgroups of the small
+                    // launches: one query at L = 100 0.298 -> 0.281 ms; then everywhere: interleaved A/B on one box, profiles/r05/ab/ab_accept_all_path.log --
+                    // value 8.79-8.96 -> 9.12-9.22 M QPS, resident 7.61 -> 8.00 M, the float-row kernel 2.10 -> 2.07 ms; registers unchanged): with c candidates and d = rn + c - cap list
                     // entries to drop, all candidates below list[rn - d] and list[rn - d] strictly above list[rn - d - 1] mean c accepts, d evictions
                     // that only count (no tie with the new worst distance), and one loop over the candidates gives the merge ranks.
                     bool fast_done = false;
-                    if constexpr (NW == 4 && KIND != DIST_ADC_SQ) {
+                    if constexpr (KIND != DIST_ADC_SQ) {
                         if (!count_pass && cm != 0ull && __popcll(cm) <= 16) {
                             const int c = __popcll(cm);
                             const int d = max(0, rn + c - cap);
