@@ -1468,8 +1468,8 @@ DEV void search_body(const SearchParams &p)
                     // is needed -- latency_kernel.hpp's first decision path, derived there (round 5; first in the 4-wavefront workgroups of the small
                     // launches: one query at L = 100 0.298 -> 0.281 ms; then everywhere: interleaved A/B on one box, profiles/r05/ab/ab_accept_all_path.log --
                     // value 8.79-8.96 -> 9.12-9.22 M QPS, resident 7.61 -> 8.00 M, the float-row kernel 2.10 -> 2.07 ms; registers unchanged): with c candidates and d = rn + c - cap list
-                    // entries to drop, all candidates below list[rn - d] and list[rn - d] strictly above list[rn - d - 1] mean c accepts, d evictions
-                    // that only count (no tie with the new worst distance), and one loop over the candidates gives the merge ranks.
+                    // entries to drop, all candidates below list[rn - d] mean c accepts and d evictions, and one loop over the candidates gives the merge
+                    // ranks (evicted live entries: counted, or -- tied with the new worst distance -- kept in the side list, as in the general path).
                     bool fast_done = false;
                     if constexpr (KIND != DIST_ADC_SQ) {
                         if (!count_pass && cm != 0ull && __popcll(cm) <= 16) {
@@ -1481,7 +1481,6 @@ DEV void search_body(const SearchParams &p)
                                 const u32 emax = wave_max_u32(iscand ? ebits : 0u);
                                 const u32 kd = (u32)(list_get<NCHR>(rk, rn - d) >> 32);
                                 fast = emax < kd;
-                                if (rn - d - 1 >= 0) fast = fast && (u32)(list_get<NCHR>(rk, rn - d - 1) >> 32) < kd;
                             }
                             if (fast) {
                                 u32 lessc = 0u, rTc = 0u, sTc[NCHR];
@@ -1506,22 +1505,40 @@ DEV void search_body(const SearchParams &p)
                                     ninserts += (u32)c;
                                 }
                                 const int keep = rn - d, rn2 = rn + c - d;
-                                int nlive_out = 0;
 #pragma unroll
                                 for (int ch = 0; ch < NCHR; ch++) {
                                     const int idx = ch * 64 + lane;
                                     if (idx < keep) { mk[idx + (int)sTc[ch]] = rk.v[ch]; mf[idx + (int)sTc[ch]] = fl.v[ch]; }
-                                    if (d > 0) nlive_out += __popcll(__ballot(idx >= keep && idx < rn && fl.v[ch] == 0u));
                                 }
                                 if (iscand) { mk[rTc + lessc] = mykey; mf[rTc + lessc] = 0u; }
                                 WSYNC();
+                                // the d entries pushed out: live ones stay in the reference's frontier -- worse than every result: only counted; tied with
+                                // the new worst distance (the cut fell inside a run of equal distances): side list, as below
+                                int nlive_out = 0;
+                                if (d > 0) {
+                                    const u32 Wfb = (u32)(mk[rn2 - 1] >> 32);
+#pragma unroll
+                                    for (int ch = 0; ch < NCHR; ch++) {
+                                        const int idx = ch * 64 + lane;
+                                        const bool out = idx >= keep && idx < rn && fl.v[ch] == 0u;
+                                        const u32 db = (u32)(rk.v[ch] >> 32);
+                                        nlive_out += __popcll(__ballot(out));
+                                        junk += (u32)__popcll(__ballot(out && db > Wfb));
+                                        u64 tm = __ballot(out && db <= Wfb);
+                                        while (tm != 0ull) {
+                                            const int f = __ffsll((long long)tm) - 1;
+                                            tm &= tm - 1ull;
+                                            if (tn < 64) { u64 d2; bool dd2; tn = list_insert<1>(tl, tn, 64, fkey(readlane64(rk.v[ch], f)), d2, dd2); }
+                                            else status |= DR_ST_CAND_OVERFLOW;
+                                        }
+                                    }
+                                }
 #pragma unroll
                                 for (int ch = 0; ch < NCHR; ch++) {
                                     const int idx = ch * 64 + lane;
                                     rk.v[ch] = (idx < rn2) ? mk[idx] : ~0ull;
                                     fl.v[ch] = (idx < rn2) ? mf[idx] : 0u;
                                 }
-                                junk += (u32)nlive_out;
                                 cnT += c - nlive_out;
                                 rn = rn2;
                                 WSYNC();
