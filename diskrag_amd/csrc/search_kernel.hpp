@@ -1472,7 +1472,7 @@ DEV void search_body(const SearchParams &p)
                     // ranks (evicted live entries: counted, or -- tied with the new worst distance -- kept in the side list, as in the general path).
                     bool fast_done = false;
                     if constexpr (KIND != DIST_ADC_SQ) {
-                        if (!count_pass && cm != 0ull && __popcll(cm) <= 16) {
+                        if (!count_pass && cm != 0ull) {      // (any number of candidates: a filling list accepts its whole row)
                             const int c = __popcll(cm);
                             const int d = max(0, rn + c - cap);
                             const bool iscand = ((cm >> lane) & 1ull) != 0ull;
