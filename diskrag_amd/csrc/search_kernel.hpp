@@ -1472,17 +1472,22 @@ DEV void search_body(const SearchParams &p)
                     // ranks (evicted live entries: counted, or -- tied with the new worst distance -- kept in the side list, as in the general path).
                     bool fast_done = false;
                     if constexpr (KIND != DIST_ADC_SQ) {
-                        if (!count_pass && cm != 0ull) {      // (any number of candidates: a filling list accepts its whole row)
+                        // (With the policy counting -- live data -- the same argument runs on t_i = max(e_i, x_i): a candidate is a lane whose threshold x_i
+                        //  is below the worst distance; if every candidate's t_i is below list[rn - d], each has #(S_i <= t_i) <= (rn - d) + (c - 1) < cap:
+                        //  accepted, and scored because x_i <= t_i; the new lanes that are no candidates fail A4 at every W_i <= W_0. So all c are scored
+                        //  and accepted: nexact += c.)
+                        if (cm != 0ull) {      // (any number of candidates: a filling list accepts its whole row)
                             const int c = __popcll(cm);
                             const int d = max(0, rn + c - cap);
                             const bool iscand = ((cm >> lane) & 1ull) != 0ull;
                             bool fast = true;
                             if (d > 0) {
-                                const u32 emax = wave_max_u32(iscand ? ebits : 0u);
+                                const u32 emax = wave_max_u32(iscand ? tbits : 0u);      // (tbits == ebits where the policy does not count)
                                 const u32 kd = (u32)(list_get<NCHR>(rk, rn - d) >> 32);
                                 fast = emax < kd;
                             }
                             if (fast) {
+                                if (count_pass) nexact += (u32)c;
                                 u32 lessc = 0u, rTc = 0u, sTc[NCHR];
 #pragma unroll
                                 for (int ch = 0; ch < NCHR; ch++) sTc[ch] = 0u;
