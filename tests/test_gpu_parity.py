@@ -253,6 +253,65 @@ def test_flat_pq_scan_matches_adc_and_finds_the_nearest_code(name):
     assert np.array_equal(only_best[0], bid) and np.array_equal(bits(only_best[1]), bits(bsq))
 
 
+@pytest.mark.parametrize("D,m", [(64, 16), (128, 32), (96, 48), (128, 64)])
+def test_flat_pq_scan_several_queries_per_pass(D, m, monkeypatch):
+    """nq >= 2: pq_scan_multi_kernel (one pass over the code words serves 4 -- m <= 32 -- or 2 queries, tables interleaved in LDS) == A3 of the
+    reference per query (oracle), bit for bit, == the one-query-per-block-row kernel; ragged last groups, n not a multiple of the block."""
+    from diskrag_amd import HipIndex
+    from oracle import pyoracle as orc
+    rs = np.random.RandomState(11 + m)
+    n = 5231
+    codes = rs.randint(0, 256, size=(n, m)).astype(np.uint8)
+    codes[100] = codes[4000]      # (equal sums: the smaller id wins)
+    cb = rs.randn(m, 256, D // m).astype(np.float32)
+    ix = HipIndex.create_codes(np.zeros((n, 1), dtype=np.uint32), 0, D, cb, codes)
+    try:
+        for nq in (2, 3, 4, 5, 9):
+            q = rs.randn(nq, D).astype(np.float32)
+            q[-1] = cb[:, 7, :].reshape(-1) if nq == 3 else q[-1]
+            bid, bsq, ms, allsq = ix.pq_scan_best(q, want_output=True)
+            bid2, bsq2, _ = ix.pq_scan_best(q)
+            monkeypatch.setenv("DR_PQ_SCAN_PER_QUERY", "1")
+            bid1, bsq1, _, all1 = ix.pq_scan_best(q, want_output=True)
+            monkeypatch.delenv("DR_PQ_SCAN_PER_QUERY")
+            assert np.array_equal(bits(allsq), bits(all1)) and np.array_equal(bid, bid1) and np.array_equal(bits(bsq), bits(bsq1))
+            for qi in range(nq):
+                want = orc.adc(orc.build_lut(cb, q[qi]), codes)[0]
+                assert np.array_equal(bits(allsq[qi]), bits(want))
+                assert int(bid[qi]) == int(np.flatnonzero(want == want.min())[0]) == int(bid2[qi])
+                assert bits(np.float32(bsq[qi])) == bits(want.min()) == bits(np.float32(bsq2[qi]))
+    finally:
+        ix.close()
+
+
+@pytest.mark.parametrize("D,m", [(64, 16), (128, 32), (96, 48), (128, 64)])
+def test_pq_scan_topk_several_queries_per_pass(D, m, monkeypatch):
+    """dr_pq_scan_topk with nq >= 2 (pq_scan_topk_multi_kernel: 4 or 2 queries share a pass over the code words) == the k smallest (distance, id)
+    pairs of the flat scan (pinned on the oracle above) == the one-query-per-block-row kernel; duplicated code words: the smaller id wins."""
+    from diskrag_amd import HipIndex
+    rs = np.random.RandomState(5 + m)
+    n = 70001
+    codes = rs.randint(0, 256, size=(n, m)).astype(np.uint8)
+    codes[n // 2:n // 2 + 3000] = codes[:3000]
+    cb = rs.randn(m, 256, D // m).astype(np.float32)
+    ix = HipIndex.create_codes(np.zeros((n, 1), dtype=np.uint32), 0, D, cb, codes)
+    try:
+        for nq, k in ((2, 10), (5, 64), (9, 1), (23, 10)):
+            q = rs.randn(nq, D).astype(np.float32)
+            full = ix.pq_scan_best(q, want_output=True)[3]
+            ids, sq, _ = ix.pq_scan_topk(q, k)
+            monkeypatch.setenv("DR_PQ_SCAN_PER_QUERY", "1")
+            ids1, sq1, _ = ix.pq_scan_topk(q, k)
+            monkeypatch.delenv("DR_PQ_SCAN_PER_QUERY")
+            assert np.array_equal(ids, ids1) and np.array_equal(bits(sq), bits(sq1))
+            for qi in range(nq):
+                order = np.lexsort((np.arange(n), full[qi]))[:k]
+                assert np.array_equal(ids[qi], order.astype(np.uint32)), (nq, k, qi)
+                assert np.array_equal(bits(sq[qi]), bits(full[qi][order]))
+    finally:
+        ix.close()
+
+
 def test_flat_pq_scan_generic_m():
     """m not a multiple of 16 (D=96, m=24): the generic scan path; same contract as the fast kernel."""
     from diskrag_amd import HipIndex
