@@ -52,6 +52,14 @@
 #define PH_END(qi) do {} while (0)
 #endif
 
+// (-DDR_PHASE_TIMING -DDR_DEC_SUB: the decision pass by the path a row takes, over slots that are otherwise nearly empty -- 4 = rows without a
+//  candidate, 7 = every candidate accepted, 6 = verdicts in closed form, 0 = the general path; each stamp also counts its rows in bits 36.. of the slot: scripts/exp_phase_single.py)
+#if defined(DR_PHASE_TIMING) && defined(DR_DEC_SUB)
+#define PHD(i) do { PH(i); ph_acc[i] += 1ull << 36; } while (0)
+#else
+#define PHD(i) do {} while (0)
+#endif
+
 #define DR_ST_CAND_OVERFLOW 2u
 #define DR_ST_LOG_OVERFLOW 4u
 #define DR_ST_INTERNAL 8u      // a loop guard fired (never expected; bounds every loop so a bug cannot hang the GPU)
@@ -1478,79 +1486,161 @@ DEV void search_body(const SearchParams &p)
                         //  and accepted: nexact += c.)
                         if (cm != 0ull) {      // (any number of candidates: a filling list accepts its whole row)
                             const int c = __popcll(cm);
-                            const int d = max(0, rn + c - cap);
                             const bool iscand = ((cm >> lane) & 1ull) != 0ull;
-                            bool fast = true;
-                            if (d > 0) {
-                                const u32 emax = wave_max_u32(iscand ? tbits : 0u);      // (tbits == ebits where the policy does not count)
-                                const u32 kd = (u32)(list_get<NCHR>(rk, rn - d) >> 32);
-                                fast = emax < kd;
-                            }
-                            if (fast) {
-                                if (count_pass) nexact += (u32)c;
-                                u32 lessc = 0u, rTc = 0u, sTc[NCHR];
-#pragma unroll
-                                for (int ch = 0; ch < NCHR; ch++) sTc[ch] = 0u;
-                                for (u64 mm = cm; mm != 0ull; mm &= mm - 1ull) {
-                                    const int f = __ffsll((long long)mm) - 1;
-                                    const u64 kf = readlane64(mykey, f);
-                                    lessc += (kf < mykey) ? 1u : 0u;
-                                    u32 cnt = 0u;
-#pragma unroll
-                                    for (int ch = 0; ch < NCHR; ch++) {
-                                        sTc[ch] += (kf < rk.v[ch]) ? 1u : 0u;
-                                        cnt += (u32)__popcll(__ballot(rk.v[ch] < kf));      // (unused slots hold ~0)
-                                    }
-                                    rTc = (lane == f) ? cnt : rTc;
+                            u64 am = cm;            // the accepted candidates
+                            bool closed = true;
+                            {
+                                const int d0 = max(0, rn + c - cap);
+                                bool fast = true;
+                                u32 kd = 0xFFFFFFFFu;
+                                if (d0 > 0) {
+                                    const u32 emax = wave_max_u32(iscand ? tbits : 0u);      // (tbits == ebits where the policy does not count)
+                                    kd = (u32)(list_get<NCHR>(rk, rn - d0) >> 32);
+                                    fast = emax < kd;
                                 }
-                                {
-                                    const u32 o = ninserts + (u32)__popcll(cm & lanemask_lt());
-                                    if (iscand && o < p.logcap) qlog[o] = ((u64)ebits << 32) | myid;
-                                    if (ninserts + (u32)c > p.logcap && p.logcap > 0) status |= DR_ST_LOG_OVERFLOW;
-                                    ninserts += (u32)c;
-                                }
-                                const int keep = rn - d, rn2 = rn + c - d;
+                                if (!fast) {
+                                    // Some candidate may be turned away or pushed out again. Where the policy does not count (proven true for the row, or
+                                    // absent) the verdicts are still a closed form -- the first round of the fixed point below, which is its answer then:
+                                    // a neighbour turned away earlier had e_j >= W_j >= W_i, so it is never among the e_j <= e_i of an accepted i, and
+                                    // counting it cannot rescue a rejected one --
+                                    //     accepted_i  <=>  #(old entries with distance <= e_i) + #(earlier candidates with e_j <= e_i) < cap:
+                                    // one compare + ballot per list chunk and one over the candidate lanes, no masks, no LDS -- and only for the candidates
+                                    // at or above list[rn - d0]: one below it has at most cap - c old entries and c - 1 candidates under it. (Round 5, last
+                                    // session: at the bench point 12 of a query's 45 rows -- the ones that fill and settle the list, 32 candidates each --
+                                    // took the general path at ~11 000 cycles each, a fifth of a lone query's time: profiles/r05/phase_shares_decision_paths.txt.
+                                    // Interleaved A/B, profiles/r05/ab/ab_closed_form_verdicts.log: resident 8.02-8.05 -> 8.31-8.35 M QPS, value +2-4 %, one
+                                    // query at L = 100 0.254 -> 0.242 ms of kernel; same bits.) Rows on which the policy counts keep the general path.
+                                    if (count_pass) closed = false;
+                                    else {
+                                        const u64 um = __ballot(iscand && ebits >= kd);
+                                        am = cm & ~um;
+                                        for (u64 mm = um; mm != 0ull; mm &= mm - 1ull) {
+                                            const int f = __ffsll((long long)mm) - 1;
+                                            const u32 ef = readlane32(ebits, f);
+                                            u32 nle = (u32)__popcll(__ballot(iscand && lane < f && ebits <= ef));
 #pragma unroll
-                                for (int ch = 0; ch < NCHR; ch++) {
-                                    const int idx = ch * 64 + lane;
-                                    if (idx < keep) { mk[idx + (int)sTc[ch]] = rk.v[ch]; mf[idx + (int)sTc[ch]] = fl.v[ch]; }
-                                }
-                                if (iscand) { mk[rTc + lessc] = mykey; mf[rTc + lessc] = 0u; }
-                                WSYNC();
-                                // the d entries pushed out: live ones stay in the reference's frontier -- worse than every result: only counted; tied with
-                                // the new worst distance (the cut fell inside a run of equal distances): side list, as below
-                                int nlive_out = 0;
-                                if (d > 0) {
-                                    const u32 Wfb = (u32)(mk[rn2 - 1] >> 32);
-#pragma unroll
-                                    for (int ch = 0; ch < NCHR; ch++) {
-                                        const int idx = ch * 64 + lane;
-                                        const bool out = idx >= keep && idx < rn && fl.v[ch] == 0u;
-                                        const u32 db = (u32)(rk.v[ch] >> 32);
-                                        nlive_out += __popcll(__ballot(out));
-                                        junk += (u32)__popcll(__ballot(out && db > Wfb));
-                                        u64 tm = __ballot(out && db <= Wfb);
-                                        while (tm != 0ull) {
-                                            const int f = __ffsll((long long)tm) - 1;
-                                            tm &= tm - 1ull;
-                                            if (tn < 64) { u64 d2; bool dd2; tn = list_insert<1>(tl, tn, 64, fkey(readlane64(rk.v[ch], f)), d2, dd2); }
-                                            else status |= DR_ST_CAND_OVERFLOW;
+                                            for (int ch = 0; ch < NCHR; ch++) nle += (u32)__popcll(__ballot((u32)(rk.v[ch] >> 32) <= ef));      // (unused slots hold ~0)
+                                            am |= (nle < (u32)cap) ? (1ull << f) : 0ull;
                                         }
                                     }
                                 }
-#pragma unroll
-                                for (int ch = 0; ch < NCHR; ch++) {
-                                    const int idx = ch * 64 + lane;
-                                    rk.v[ch] = (idx < rn2) ? mk[idx] : ~0ull;
-                                    fl.v[ch] = (idx < rn2) ? mf[idx] : 0u;
-                                }
-                                cnT += c - nlive_out;
-                                rn = rn2;
-                                WSYNC();
+                            }
+                            if (closed) {
                                 fast_done = true;
+                                if (am != 0ull) {
+                                    const int nacc = __popcll(am);
+                                    const int d = max(0, rn + nacc - cap);
+                                    const bool isacc = ((am >> lane) & 1ull) != 0ull;
+                                    if (count_pass) nexact += (u32)c;      // (reached with every candidate accepted only)
+                                    u32 lessc = 0u, rTc = 0u, sTc[NCHR];
+#pragma unroll
+                                    for (int ch = 0; ch < NCHR; ch++) sTc[ch] = 0u;
+                                    if (nacc <= 12) {
+                                        for (u64 mm = am; mm != 0ull; mm &= mm - 1ull) {
+                                            const int f = __ffsll((long long)mm) - 1;
+                                            const u64 kf = readlane64(mykey, f);
+                                            lessc += (kf < mykey) ? 1u : 0u;
+                                            u32 cnt = 0u;
+#pragma unroll
+                                            for (int ch = 0; ch < NCHR; ch++) {
+                                                sTc[ch] += (kf < rk.v[ch]) ? 1u : 0u;
+                                                cnt += (u32)__popcll(__ballot(rk.v[ch] < kf));      // (unused slots hold ~0)
+                                            }
+                                            rTc = (lane == f) ? cnt : rTc;
+                                        }
+                                    } else {
+                                        // many accepted candidates (the rows that fill the list): their ranks among the OLD keys by the per-lane binary search
+                                        // over the list staged in LDS -- one pass for all of them instead of a ballot per candidate and chunk --, and the loop
+                                        // keeps only its compares (no result travels to the scalar unit: ~60 instead of ~150 cycles per candidate for a lone wave)
+#pragma unroll
+                                        for (int ch = 0; ch < NCHR; ch++) if (ch * 64 + lane < rn) mk[ch * 64 + lane] = rk.v[ch];
+                                        WSYNC();
+                                        int lo = 0, hi = rn;
+                                        if (isacc) {
+                                            constexpr int ITER = (NCHR == 1) ? 7 : (NCHR == 2) ? 8 : (NCHR == 4) ? 9 : (NCHR == 8) ? 10 : 11;
+#pragma unroll
+                                            for (int it = 0; it < ITER; it++) {
+                                                const int m1 = (lo + hi) >> 1;
+                                                const u64 v1 = mk[min(m1, rn - 1)];
+                                                if (lo < hi) { if (v1 < mykey) lo = m1 + 1; else hi = m1; }
+                                            }
+                                        }
+                                        rTc = (u32)lo;
+                                        for (u64 mm = am; mm != 0ull; mm &= mm - 1ull) {
+                                            const int f = __ffsll((long long)mm) - 1;
+                                            const u64 kf = readlane64(mykey, f);
+                                            lessc += (kf < mykey) ? 1u : 0u;
+#pragma unroll
+                                            for (int ch = 0; ch < NCHR; ch++) sTc[ch] += (kf < rk.v[ch]) ? 1u : 0u;
+                                        }
+                                        WSYNC();      // every search has read the staged list before the merge scatters over it
+                                    }
+                                    {
+                                        const u32 o = ninserts + (u32)__popcll(am & lanemask_lt());
+                                        if (isacc && o < p.logcap) qlog[o] = ((u64)ebits << 32) | myid;
+                                        if (ninserts + (u32)nacc > p.logcap && p.logcap > 0) status |= DR_ST_LOG_OVERFLOW;
+                                        ninserts += (u32)nacc;
+                                    }
+                                    const int rn2 = rn + nacc - d;
+                                    int npT[NCHR];
+#pragma unroll
+                                    for (int ch = 0; ch < NCHR; ch++) {
+                                        const int idx = ch * 64 + lane;
+                                        npT[ch] = idx + (int)sTc[ch];
+                                        if (idx < rn && npT[ch] < cap) { mk[npT[ch]] = rk.v[ch]; mf[npT[ch]] = fl.v[ch]; }
+                                    }
+                                    const int npA = (int)(rTc + lessc);
+                                    if (isacc && npA < cap) { mk[npA] = mykey; mf[npA] = 0u; }
+                                    WSYNC();
+                                    // the d entries pushed out (old ones, or candidates accepted and pushed out again by later ones): live ones stay in the
+                                    // reference's frontier -- worse than every result: only counted; tied with the new worst distance (the cut fell inside a
+                                    // run of equal distances): side list, as in the general path below
+                                    int nlive_out = 0, nout = 0;
+                                    if (d > 0) {
+                                        const u32 Wfb = (u32)(mk[rn2 - 1] >> 32);
+#pragma unroll
+                                        for (int ch = 0; ch < NCHR; ch++) {
+                                            const bool out = (ch * 64 + lane < rn) && npT[ch] >= cap && fl.v[ch] == 0u;
+                                            const u32 db = (u32)(rk.v[ch] >> 32);
+                                            nlive_out += __popcll(__ballot(out));
+                                            junk += (u32)__popcll(__ballot(out && db > Wfb));
+                                            u64 tm = __ballot(out && db <= Wfb);
+                                            while (tm != 0ull) {
+                                                const int f = __ffsll((long long)tm) - 1;
+                                                tm &= tm - 1ull;
+                                                if (tn < 64) { u64 d2; bool dd2; tn = list_insert<1>(tl, tn, 64, fkey(readlane64(rk.v[ch], f)), d2, dd2); }
+                                                else status |= DR_ST_CAND_OVERFLOW;
+                                            }
+                                        }
+                                        const bool outc = isacc && npA >= cap;
+                                        const u64 om = __ballot(outc);
+                                        if (om != 0ull) {
+                                            nout = __popcll(om);
+                                            junk += (u32)__popcll(__ballot(outc && ebits > Wfb));
+                                            u64 tm = __ballot(outc && ebits <= Wfb);
+                                            while (tm != 0ull) {
+                                                const int f = __ffsll((long long)tm) - 1;
+                                                tm &= tm - 1ull;
+                                                if (tn < 64) { u64 d2; bool dd2; tn = list_insert<1>(tl, tn, 64, fkey(readlane64(mykey, f)), d2, dd2); }
+                                                else status |= DR_ST_CAND_OVERFLOW;
+                                            }
+                                        }
+                                    }
+#pragma unroll
+                                    for (int ch = 0; ch < NCHR; ch++) {
+                                        const int idx = ch * 64 + lane;
+                                        rk.v[ch] = (idx < rn2) ? mk[idx] : ~0ull;
+                                        fl.v[ch] = (idx < rn2) ? mf[idx] : 0u;
+                                    }
+                                    cnT += nacc - nout - nlive_out;
+                                    rn = rn2;
+                                    WSYNC();
+                                }
+                                if (am == cm) PHD(7); else PHD(6);
                             }
                         }
                     }
+                    if (cm == 0ull) PHD(4);
                     if (cm != 0ull && !fast_done) {
                         // (1) counts against the old list. Few candidates (the steady state of a full list: only
                         // neighbours that beat the worst entry are candidates): one wave-wide compare per list chunk
@@ -1716,6 +1806,7 @@ DEV void search_body(const SearchParams &p)
                         rn = rn2;
                         WSYNC();
                     }
+                    if (cm != 0ull && !fast_done) PHD(0);
                 }
             }
             PH(6);
