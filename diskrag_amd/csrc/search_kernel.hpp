@@ -1488,7 +1488,8 @@ DEV void search_body(const SearchParams &p)
                             const int c = __popcll(cm);
                             const bool iscand = ((cm >> lane) & 1ull) != 0ull;
                             u64 am = cm;            // the accepted candidates
-                            bool closed = true;
+                            u32 nsc = (u32)c;       // the scored ones (where the policy counts)
+                            constexpr bool closed = true;
                             {
                                 const int d0 = max(0, rn + c - cap);
                                 bool fast = true;
@@ -1509,17 +1510,29 @@ DEV void search_body(const SearchParams &p)
                                     // session: at the bench point 12 of a query's 45 rows -- the ones that fill and settle the list, 32 candidates each --
                                     // took the general path at ~11 000 cycles each, a fifth of a lone query's time: profiles/r05/phase_shares_decision_paths.txt.
                                     // Interleaved A/B, profiles/r05/ab/ab_closed_form_verdicts.log: resident 8.02-8.05 -> 8.31-8.35 M QPS, value +2-4 %, one
-                                    // query at L = 100 0.254 -> 0.242 ms of kernel; same bits.) Rows on which the policy counts keep the general path.
-                                    if (count_pass) closed = false;
-                                    else {
-                                        const u64 um = __ballot(iscand && ebits >= kd);
+                                    // query at L = 100 0.254 -> 0.242 ms of kernel; same bits.)
+                                    // Where the policy counts the same walk is exact with t_i = max(e_i, x_i) in place of e_i once it runs in STORED order over
+                                    // the candidates at or above list[rn - d0] and counts only neighbours accepted so far (the ones below that entry are
+                                    // accepted whatever happens, the ones walked earlier have their verdict): #(S_i <= t_i) itself, no fixed point. Scored
+                                    // (the policy's count): the same count at x_i.
+                                    {
+                                        const u64 um = __ballot(iscand && tbits >= kd);
                                         am = cm & ~um;
+                                        nsc = (u32)__popcll(am);
                                         for (u64 mm = um; mm != 0ull; mm &= mm - 1ull) {
                                             const int f = __ffsll((long long)mm) - 1;
-                                            const u32 ef = readlane32(ebits, f);
-                                            u32 nle = (u32)__popcll(__ballot(iscand && lane < f && ebits <= ef));
+                                            const u32 tf = readlane32(tbits, f);
+                                            const bool earlier = ((am >> lane) & 1ull) != 0ull && lane < f;
+                                            u32 nle = (u32)__popcll(__ballot(earlier && ebits <= tf));
 #pragma unroll
-                                            for (int ch = 0; ch < NCHR; ch++) nle += (u32)__popcll(__ballot((u32)(rk.v[ch] >> 32) <= ef));      // (unused slots hold ~0)
+                                            for (int ch = 0; ch < NCHR; ch++) nle += (u32)__popcll(__ballot((u32)(rk.v[ch] >> 32) <= tf));      // (unused slots hold ~0)
+                                            if (count_pass) {
+                                                const u32 xf = readlane32(xbits, f);
+                                                u32 nx = (u32)__popcll(__ballot(earlier && ebits <= xf));
+#pragma unroll
+                                                for (int ch = 0; ch < NCHR; ch++) nx += (u32)__popcll(__ballot((u32)(rk.v[ch] >> 32) <= xf));
+                                                nsc += (nx < (u32)cap) ? 1u : 0u;
+                                            }
                                             am |= (nle < (u32)cap) ? (1ull << f) : 0ull;
                                         }
                                     }
@@ -1527,11 +1540,11 @@ DEV void search_body(const SearchParams &p)
                             }
                             if (closed) {
                                 fast_done = true;
+                                if (count_pass) nexact += nsc;
                                 if (am != 0ull) {
                                     const int nacc = __popcll(am);
                                     const int d = max(0, rn + nacc - cap);
                                     const bool isacc = ((am >> lane) & 1ull) != 0ull;
-                                    if (count_pass) nexact += (u32)c;      // (reached with every candidate accepted only)
                                     u32 lessc = 0u, rTc = 0u, sTc[NCHR];
 #pragma unroll
                                     for (int ch = 0; ch < NCHR; ch++) sTc[ch] = 0u;
