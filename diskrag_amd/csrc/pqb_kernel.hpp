@@ -60,19 +60,7 @@ struct PqbParams {
 // "same node" -- the staged list can be searched without masking anything. N < 2^31.
 #define PQB_NOTLIVE 1ull
 
-// inclusive prefix sum over the wave (DPP: row_shr 1, 2, 4, 8, then row_bcast 15 / 31); lanes without a source add 0
-DEV u32 wave_incl_scan_u32(u32 x)
-{
-#define DR_DPP_ADD(ctrl, rmask) x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, false)
-    DR_DPP_ADD(0x111, 0xf);
-    DR_DPP_ADD(0x112, 0xf);
-    DR_DPP_ADD(0x114, 0xf);
-    DR_DPP_ADD(0x118, 0xf);
-    DR_DPP_ADD(0x142, 0xa);
-    DR_DPP_ADD(0x143, 0xc);
-#undef DR_DPP_ADD
-    return x;
-}
+// (wave_incl_scan_u32: search_kernel.hpp)
 
 // squared ADC of one code word for a compile-time m = 16 * M16, rows 0 .. m-TREG-1 from LDS, the last TREG from registers
 // (tv[jj*4 + v] of lane l = T[m-TREG+jj][64 v + l]); strict order of j. Whole-wave call (ds_bpermute).

@@ -178,6 +178,18 @@ DEV u32 wave_min_u32(u32 x)
 }
 
 // max over the wave of a u32 (identity 0), result broadcast (search_kernel.hpp wave_min_u32's scan with max)
+// inclusive prefix sum over the wavefront's lanes (rows of 16 by shifts, then the row totals broadcast forward)
+DEV u32 wave_incl_scan_u32(u32 x)
+{
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);      // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 DEV u32 wave_max_u32(u32 x)
 {
 #define DR_DPP_MAX(ctrl, rmask) x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, false))
@@ -1492,14 +1504,13 @@ DEV void search_body(const SearchParams &p)
                             constexpr bool closed = true;
                             {
                                 const int d0 = max(0, rn + c - cap);
-                                bool fast = true;
-                                u32 kd = 0xFFFFFFFFu;
+                                // the candidates at or above list[rn - d0] (tbits == ebits where the policy does not count): none -> all accepted
+                                u64 um = 0ull;
                                 if (d0 > 0) {
-                                    const u32 emax = wave_max_u32(iscand ? tbits : 0u);      // (tbits == ebits where the policy does not count)
-                                    kd = (u32)(list_get<NCHR>(rk, rn - d0) >> 32);
-                                    fast = emax < kd;
+                                    const u32 kd = (u32)(list_get<NCHR>(rk, rn - d0) >> 32);
+                                    um = __ballot(iscand && tbits >= kd);
                                 }
-                                if (!fast) {
+                                if (um != 0ull) {
                                     // Some candidate may be turned away or pushed out again. Where the policy does not count (proven true for the row, or
                                     // absent) the verdicts are still a closed form -- the first round of the fixed point below, which is its answer then:
                                     // a neighbour turned away earlier had e_j >= W_j >= W_i, so it is never among the e_j <= e_i of an accepted i, and
@@ -1516,7 +1527,6 @@ DEV void search_body(const SearchParams &p)
                                     // accepted whatever happens, the ones walked earlier have their verdict): #(S_i <= t_i) itself, no fixed point. Scored
                                     // (the policy's count): the same count at x_i.
                                     {
-                                        const u64 um = __ballot(iscand && tbits >= kd);
                                         am = cm & ~um;
                                         nsc = (u32)__popcll(am);
                                         for (u64 mm = um; mm != 0ull; mm &= mm - 1ull) {
@@ -1566,7 +1576,10 @@ DEV void search_body(const SearchParams &p)
                                         // over the list staged in LDS -- one pass for all of them instead of a ballot per candidate and chunk --, and the loop
                                         // keeps only its compares (no result travels to the scalar unit: ~60 instead of ~150 cycles per candidate for a lone wave)
 #pragma unroll
-                                        for (int ch = 0; ch < NCHR; ch++) if (ch * 64 + lane < rn) mk[ch * 64 + lane] = rk.v[ch];
+                                        for (int ch = 0; ch < NCHR; ch++) {
+                                            if (ch * 64 + lane < rn) mk[ch * 64 + lane] = rk.v[ch];
+                                            mf[ch * 64 + lane] = 0u;
+                                        }
                                         WSYNC();
                                         int lo = 0, hi = rn;
                                         if (isacc) {
@@ -1577,16 +1590,27 @@ DEV void search_body(const SearchParams &p)
                                                 const u64 v1 = mk[min(m1, rn - 1)];
                                                 if (lo < hi) { if (v1 < mykey) lo = m1 + 1; else hi = m1; }
                                             }
+                                            // an accepted key with `lo` old keys below it sits below old[lo], old[lo + 1], ...: the old entries' shifts are the
+                                            // running sum of this histogram (the state scratch is idle until the merge)
+                                            if (lo < rn) atomicAdd(&mf[lo], 1u);
                                         }
                                         rTc = (u32)lo;
                                         for (u64 mm = am; mm != 0ull; mm &= mm - 1ull) {
                                             const int f = __ffsll((long long)mm) - 1;
                                             const u64 kf = readlane64(mykey, f);
                                             lessc += (kf < mykey) ? 1u : 0u;
-#pragma unroll
-                                            for (int ch = 0; ch < NCHR; ch++) sTc[ch] += (kf < rk.v[ch]) ? 1u : 0u;
                                         }
-                                        WSYNC();      // every search has read the staged list before the merge scatters over it
+                                        WSYNC();
+                                        {
+                                            u32 carry = 0u;
+#pragma unroll
+                                            for (int ch = 0; ch < NCHR; ch++) {
+                                                const u32 sc = wave_incl_scan_u32(mf[ch * 64 + lane]) + carry;
+                                                sTc[ch] = sc;
+                                                if (ch + 1 < NCHR) carry = readlane32(sc, 63);
+                                            }
+                                        }
+                                        WSYNC();      // every search has read the staged list and the histogram before the merge scatters over them
                                     }
                                     {
                                         const u32 o = ninserts + (u32)__popcll(am & lanemask_lt());
