@@ -1634,19 +1634,24 @@ DEV void search_body(const SearchParams &p)
                                     // run of equal distances): side list, as in the general path below
                                     int nlive_out = 0, nout = 0;
                                     if (d > 0) {
+                                        // (with a beam width the entries at the end of the list have long been trimmed from the frontier: usually none of the
+                                        //  pushed-out ones is live and one ballot per chunk says so)
                                         const u32 Wfb = (u32)(mk[rn2 - 1] >> 32);
 #pragma unroll
                                         for (int ch = 0; ch < NCHR; ch++) {
                                             const bool out = (ch * 64 + lane < rn) && npT[ch] >= cap && fl.v[ch] == 0u;
-                                            const u32 db = (u32)(rk.v[ch] >> 32);
-                                            nlive_out += __popcll(__ballot(out));
-                                            junk += (u32)__popcll(__ballot(out && db > Wfb));
-                                            u64 tm = __ballot(out && db <= Wfb);
-                                            while (tm != 0ull) {
-                                                const int f = __ffsll((long long)tm) - 1;
-                                                tm &= tm - 1ull;
-                                                if (tn < 64) { u64 d2; bool dd2; tn = list_insert<1>(tl, tn, 64, fkey(readlane64(rk.v[ch], f)), d2, dd2); }
-                                                else status |= DR_ST_CAND_OVERFLOW;
+                                            const u64 lo_ = __ballot(out);
+                                            if (lo_ != 0ull) {
+                                                const u32 db = (u32)(rk.v[ch] >> 32);
+                                                nlive_out += __popcll(lo_);
+                                                junk += (u32)__popcll(__ballot(out && db > Wfb));
+                                                u64 tm = __ballot(out && db <= Wfb);
+                                                while (tm != 0ull) {
+                                                    const int f = __ffsll((long long)tm) - 1;
+                                                    tm &= tm - 1ull;
+                                                    if (tn < 64) { u64 d2; bool dd2; tn = list_insert<1>(tl, tn, 64, fkey(readlane64(rk.v[ch], f)), d2, dd2); }
+                                                    else status |= DR_ST_CAND_OVERFLOW;
+                                                }
                                             }
                                         }
                                         const bool outc = isacc && npA >= cap;
