@@ -903,24 +903,28 @@ static int disk_fetch_rows(dr_index *ix, const uint32_t *ids, size_t n, float *d
     if (ix->row_fd < 0) return fail(DR_E_IO, "no row file attached");
     const size_t rowb = (size_t)ix->D * 4;
     const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>({ (size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency()), (n + 63) / 64 }));
+    // (first failure wins: 1 = allocation, 2 = short read (end of file inside a row), 3 = pread error with the WORKER's errno kept beside the offset)
     std::atomic<int> bad{0};
+    std::atomic<int> bad_errno{0};
+    std::atomic<uint64_t> bad_off{0};
+    auto flag = [&](int what, int en, uint64_t off) { int z = 0; if (bad.compare_exchange_strong(z, what)) { bad_errno = en; bad_off = off; } };
     auto work = [&](size_t lo, size_t hi) {
         void *blk = nullptr;
         const size_t blkb = ((rowb + 4095) & ~(size_t)4095) + 8192;
-        if (ix->row_direct && posix_memalign(&blk, 4096, blkb) != 0) { bad = 1; return; }
+        if (ix->row_direct && posix_memalign(&blk, 4096, blkb) != 0) { flag(1, ENOMEM, 0); return; }
         for (size_t i = lo; i < hi && !bad; i++) {
             const uint64_t off = ix->row_off + (uint64_t)ids[i] * ix->row_stride;
             if (ix->row_direct) {
                 const uint64_t a0 = off & ~(uint64_t)4095;
                 const size_t len = (size_t)(((off + rowb + 4095) & ~(uint64_t)4095) - a0);
                 const ssize_t got = pread(ix->row_fd, blk, len, (off_t)a0);
-                if (got < (ssize_t)(off - a0 + rowb)) { bad = 1; break; }       // (the last block of the file may be short)
+                if (got < (ssize_t)(off - a0 + rowb)) { flag(got < 0 ? 3 : 2, got < 0 ? errno : 0, off); break; }       // (the last block of the file may be short)
                 memcpy(dst + i * ix->D, static_cast<unsigned char *>(blk) + (off - a0), rowb);
             } else {
                 size_t done = 0;
                 while (done < rowb) {
                     const ssize_t got = pread(ix->row_fd, reinterpret_cast<unsigned char *>(dst + i * ix->D) + done, rowb - done, (off_t)(off + done));
-                    if (got <= 0) { bad = 1; break; }
+                    if (got <= 0) { flag(got < 0 ? 3 : 2, got < 0 ? errno : 0, off + done); break; }
                     done += (size_t)got;
                 }
             }
@@ -933,7 +937,9 @@ static int disk_fetch_rows(dr_index *ix, const uint32_t *ids, size_t n, float *d
         for (unsigned t = 0; t < nth; t++) th.emplace_back(work, n * t / nth, n * (t + 1) / nth);
         for (auto &x : th) x.join();
     }
-    if (bad) return fail(DR_E_IO, "reading rows from the index file failed: %s", strerror(errno));
+    if (bad == 1) return fail(DR_E_IO, "reading rows from the index file failed: no memory for an aligned read block");
+    if (bad == 2) return fail(DR_E_IO, "reading rows from the index file failed: short read at offset %llu (the file ends inside a row)", (unsigned long long)bad_off.load());
+    if (bad) return fail(DR_E_IO, "reading rows from the index file failed at offset %llu: %s", (unsigned long long)bad_off.load(), strerror(bad_errno.load()));
     return 0;
 }
 
@@ -941,6 +947,8 @@ extern "C" int dr_index_attach_row_file(dr_index *ix, const char *index_dat, uin
 {
     if (!ix || !index_dat) return fail(DR_E_ARG, "null argument");
     std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->N == 0) return fail(DR_E_ARG, "an empty index has no rows to attach");
+    if (ix->has_vectors) return fail(DR_E_ARG, "the index holds its rows already (HBM or host tier): the row file is the tier of a PQ-only index (dr_index_create_codes / dr_index_drop_vectors)");
     if (record_bytes == 0) record_bytes = ((uint64_t)ix->D + ix->R) * 4;        // the reference's record (diskann_persist.py:17-24)
     if (record_bytes < (uint64_t)ix->D * 4) return fail(DR_E_ARG, "a record of %llu bytes cannot hold a %u-dimensional vector", (unsigned long long)record_bytes, ix->D);
     struct stat stt;
@@ -1081,7 +1089,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         pqb_pops = (flags & DR_F_POPS_MASK) >> DR_F_POPS_SHIFT;
         if (ix->N >= (1ull << 31)) return fail(DR_E_UNSUPPORTED, "DR_MODE_PQB: N must be below 2^31");
         while ((1u << pqb_shift) < ix->R) pqb_shift++;
-        if (pqb_pops == 0) pqb_pops = pqb_shift >= 6 ? 1u : (64u >> pqb_shift);      // default: the rows that fill 64 neighbour slots
+        if (pqb_pops == 0) pqb_pops = pqb_shift >= 6 ? 1u : std::min(16u, 64u >> pqb_shift);      // default: the rows that fill 64 neighbour slots (R <= 2: 16, the size of the kernel's popped-id array)
+        if (pqb_pops > 16) return fail(DR_E_UNSUPPORTED, "DR_MODE_PQB: at most 16 rows per step (asked: %u)", pqb_pops);
         const uint64_t passes = ((uint64_t)pqb_pops << pqb_shift) <= 64 ? 1 : (((uint64_t)pqb_pops << pqb_shift) + 63) / 64;
         if (passes > 4) return fail(DR_E_UNSUPPORTED, "DR_MODE_PQB: pops x next_pow2(R) = %u x %u exceeds 256 neighbour slots per step", pqb_pops, 1u << pqb_shift);
         const int nc = passes <= 1 ? 1 : passes <= 2 ? 2 : 4;
@@ -1121,6 +1130,11 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     uint32_t lat_vh_bits = 0;
     size_t lat_lds = 0;
     bool lat = false;
+    // Only a blocking call on the direct path is served again when a query outgrows the visited-id set (status bit 0). Everywhere else --
+    // pipelined groups (the facade's one-query requests), DR_NO_DIRECT, the sharded path -- variant 18 is taken only where NO query can:
+    // an M1 query visits at most min(10 L, N) R nodes (R = 128, L = 256: 327 680), the exact traversals at most N; the set holds 3/4 of its
+    // LDS slots + 3/4 of its continuation's (lat_capacity below, from the sizes this launch would get).
+    const uint64_t lat_visit_bound = k_m1 ? std::min<uint64_t>((uint64_t)L * 10, ix->N) * ix->R : ix->N;
     if (!ov && !pqb && !k_adc && !(flags & DR_F_COSINE) && (k_m1 || mode == DR_MODE_M2 || mode == DR_MODE_M3 || mode == DR_MODE_M4) &&
         ix->kern->latency[k_m1 ? 1 : 0][sc] != nullptr && !ix->lat_skip &&
         (g_force_kind == 18 || (g_force_kind < 0 && ix->cs->nq <= DR_LAT_MAX_NQ && getenv("DR_NO_LATENCY") == nullptr &&
@@ -1132,7 +1146,12 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         uint32_t bits = cap > 256 ? 15 : 14;
         if (const char *e = getenv("DR_LAT_VH_BITS")) bits = (uint32_t)atoi(e);      // tests: a set small enough to overflow
         while (bits > 6 && fixed + ((size_t)4 << bits) > 160 * 1024) bits--;
-        if (fixed + ((size_t)4 << bits) <= 160 * 1024 && (bits >= 12 || getenv("DR_LAT_VH_BITS") != nullptr)) {
+        uint32_t sbits_would = 18;
+        if (const char *es = getenv("DR_LAT_SPILL_BITS")) sbits_would = std::min<uint32_t>((uint32_t)atoi(es), 20u);
+        const uint64_t lat_capacity = (3ull << bits) / 4 + (sbits_would ? (3ull << sbits_would) / 4 - 64 : 0);
+        const bool has_rerun = ix->direct;       // (dr_search_batch's direct path: the one place with the re-run)
+        if (fixed + ((size_t)4 << bits) <= 160 * 1024 && (bits >= 12 || getenv("DR_LAT_VH_BITS") != nullptr) &&
+            (has_rerun || g_force_kind == 18 || lat_visit_bound <= lat_capacity)) {
             lat = true; lat_vh_bits = bits; lat_lds = fixed + ((size_t)4 << bits); kind = 18;
         }
     }
@@ -1657,7 +1676,14 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
         ix->direct = true;
         if (!rc) rc = run_locked(ix, k, L, beam_width, mode, band_policy, flags);
         ix->direct = false;
-        if (rc) return rc;
+        if (rc) {
+            // (the batch's copy out of the page-locked staging buffer may still be in flight: the next call restages into it)
+            const std::string keep = g_err;
+            (void)hipStreamSynchronize(ix->stream); (void)hipGetLastError();
+            ix->h2d_pending = false;
+            g_err = keep;
+            return rc;
+        }
         if (!ix->direct_used) {       // (the call that measures the index's regime went the general way)
             return download_locked(ix, out_ids, out_dist, out_count, stats);
         }
@@ -1691,6 +1717,12 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
                 ix->direct = false; ix->lat_skip = false;
                 if (rc) return rc;
                 if (!ix->direct_used) return download_locked(ix, out_ids, out_dist, out_count, stats);
+                if (eager_fin && ix->direct_fin) {      // (the tie-order pass queued above replayed the abandoned run's log: again, for this one)
+                    const unsigned fgrid = (unsigned)std::min<uint64_t>(((uint64_t)nq + 3) / 4, (uint64_t)ix->num_cu * 8);
+                    hipLaunchKernelGGL(finalize_kernel, dim3(fgrid), dim3(256), 4 * ((size_t)ix->direct_f->cap + 2 + 64) * 8, ix->stream, *ix->direct_f);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipMemsetAsync(ix->sets[ix->last_set].counter.p + 1, 0, 4, ix->stream));
+                }
                 HIPCHK(hipStreamSynchronize(ix->stream));
                 hp = static_cast<unsigned char *>(ix->pinned);
             }
@@ -1704,7 +1736,12 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
             HIPCHK(hipStreamSynchronize(ix->stream));
         }
         harvest_kernel_times(ix, true);
-        ix->h2d_pending = false;
+        if (ix->h2d_pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ix->ev[0], ix->ev[1]) == hipSuccess) ix->timing.h2d_ms = ms;
+            (void)hipGetLastError();
+            ix->h2d_pending = false;
+        }
         memcpy(out_ids, hp, b_ids);
         memcpy(out_dist, hp + b_ids, b_ids);
         memcpy(out_count, hp + 2 * b_ids, b_cnt);
@@ -1720,7 +1757,13 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
         if (!rc) rc = run_locked(ix, k, L, beam_width, mode, band_policy, flags);
         if (!rc) rc = download_locked(ix, out_ids + (size_t)q0 * k, out_dist + (size_t)q0 * k, out_count + q0,
                                       stats ? stats + q0 : nullptr);
-        if (rc) return rc;
+        if (rc) {
+            const std::string keep = g_err;
+            (void)hipStreamSynchronize(ix->stream); (void)hipGetLastError();      // (the staging buffer's copy: as above)
+            ix->h2d_pending = false;
+            g_err = keep;
+            return rc;
+        }
         h2d += ix->timing.h2d_ms; ker += ix->timing.search_kernel_ms; fin += ix->timing.finalize_kernel_ms; d2h += ix->timing.d2h_ms;
     }
     ix->timing.h2d_ms = h2d; ix->timing.search_kernel_ms = ker; ix->timing.finalize_kernel_ms = fin; ix->timing.d2h_ms = d2h;

@@ -157,10 +157,14 @@ class SearchEngineCorrect:
     # ------------------------------------------------------------------ B1 / B2
     @staticmethod
     def _check_status(stats):
+        bits = int(np.bitwise_or.reduce(stats["status"])) if len(stats) else 0
+        if bits & 16:       # dr_stats.status bit 4 (include/diskrag_hip.h): DR_F_IP on a query that is not unit-norm
+            n = int(((stats["status"] & 16) != 0).sum())
+            raise _ffi.DiskragHipError(_ffi.E_ARG, f"{n} queries are not unit-norm: the inner-product reading of the rerank (DR_F_IP) "
+                                       "is defined on unit-norm queries and rows only")
         bad = stats["status"] != 0
         if bad.any():
-            raise _ffi.DiskragHipError(_ffi.E_OVERFLOW, f"work-area overflow in {int(bad.sum())} queries "
-                                       f"(status bits {int(np.bitwise_or.reduce(stats['status']))})")
+            raise _ffi.DiskragHipError(_ffi.E_OVERFLOW, f"work-area overflow in {int(bad.sum())} queries (status bits {bits})")
 
     @staticmethod
     def _is_f64(query_vector) -> bool:

@@ -1,4 +1,4 @@
-"""One rank of the 2-process sharded-search test (tests/test_gpu_sharded_2proc.py). Started as a fresh child process BEFORE any GPU call;
+"""One rank of the multi-process sharded-search tests (tests/test_gpu_sharded_procs.py: 2 and 8 ranks). Started as a fresh child process BEFORE any GPU call;
 DR_RCCL_LIB points at tests/fake_rccl/libfake_rccl.so (an all-gather over shared memory: RCCL refuses two ranks on one GPU).
 usage: rank_main.py <scenario> <rank> <nranks> <scratch dir>   -> writes <scratch>/result.<rank>.json"""
 import json
