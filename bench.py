@@ -263,31 +263,51 @@ def log(rk, msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def pin_to_gpu_socket(rk, device):
-    """N > 1 ranks on one node: every rank's host work -- the byte scan and staging of its batches, its waits -- stays on the CPUs next to ITS
-    GPU (`local_cpulist` of the device's PCI function). One rank keeps the whole box (the CPU baseline wants every core). Best effort: a
-    container that hides /sys or a runtime without hipDeviceGetPCIBusId leaves the affinity alone. Returns what it did, for the JSON line."""
-    if rk.world < 2 or os.environ.get("DR_BENCH_NO_PIN"):
+def _pci_bus_id(device):
+    """PCI address (domain:bus:device.function) of HIP device `device`, or None"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    buf = ctypes.create_string_buffer(64)
+    if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
         return None
+    return buf.value.decode().strip().lower()
+
+
+def local_cpus_of(bdf, sysroot="/sys"):
+    """the CPUs next to a PCI function (its `local_cpulist`) and its NUMA node, or (None, None) where the tree does not show them"""
+    base = os.path.join(sysroot, "bus/pci/devices", bdf)
     try:
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        buf = ctypes.create_string_buffer(64)
-        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
-            return None
-        bdf = buf.value.decode().strip().lower()
-        base = "/sys/bus/pci/devices/" + bdf
         cpus = set()
-        for part in open(base + "/local_cpulist").read().strip().split(","):
+        for part in open(os.path.join(base, "local_cpulist")).read().strip().split(","):
             if part:
                 lo, _, hi = part.partition("-")
                 cpus.update(range(int(lo), int(hi or lo) + 1))
+        node = int(open(os.path.join(base, "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return None, None
+    return cpus, node
+
+
+def pin_to_gpu_socket(rk, device, sysroot=None, bus_id=_pci_bus_id):
+    """N > 1 ranks on one node: every rank's host work -- the byte scan and staging of its batches, its waits -- stays on the CPUs next to ITS
+    GPU (`local_cpulist` of the device's PCI function). One rank keeps the whole box (the CPU baseline wants every core). Best effort: a
+    container that hides /sys or a runtime without hipDeviceGetPCIBusId leaves the affinity alone. Returns what it did, for the JSON line.
+    (`sysroot` / `bus_id`: tests/test_bench_launcher.py runs it against a fake tree of eight devices on two sockets; DR_BENCH_SYSFS_ROOT does
+    the same from outside.)"""
+    if rk.world < 2 or os.environ.get("DR_BENCH_NO_PIN"):
+        return None
+    try:
+        bdf = bus_id(device)
+        if not bdf:
+            return None
+        cpus, node = local_cpus_of(bdf, sysroot or os.environ.get("DR_BENCH_SYSFS_ROOT", "/sys"))
+        if not cpus:
+            return None
         cpus &= os.sched_getaffinity(0)
         if not cpus:
             return None
         os.sched_setaffinity(0, cpus)
-        node = open(base + "/numa_node").read().strip()
-        return {"pci": bdf, "numa_node": int(node), "cpus": len(cpus)}
+        return {"pci": bdf, "numa_node": node, "cpus": len(cpus)}
     except Exception:       # noqa: BLE001
         return None
 
@@ -437,6 +457,7 @@ def worker_c2(args, rk):
     pinned_to = rk.gather("pin", pin_to_gpu_socket(rk, device))
 
     # ---------------------------------------------------------------- setup (untimed): data, graph, PQ, ground truth
+    t_setup = time.time()
     t0 = time.time()
     if strong:      # the job's batches are the same on every rank; this rank keeps its slice of each
         x, q_job = sift_like(args.n, D, n_queries=nq_job * nb, n_clusters=1024, seed=2024, query_seed=9000)
@@ -459,6 +480,11 @@ def worker_c2(args, rk):
     t0 = time.time()
     gt, _ = ix.bruteforce_topk(q_all, k)
     log(rk, f"brute-force ground truth for {nq * nb} queries in {time.time() - t0:.1f}s")
+
+    # what a rank's set-up costs the node (every rank generates the data, builds the graph and computes its own ground truth: N ranks = N times
+    # this host memory and N concurrent builds -- DESIGN.md section 7 states both at the driver's N = 8)
+    import resource
+    setup_all = rk.gather("setup", {"setup_seconds": time.time() - t_setup, "max_rss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0})
 
     # the batches as a caller would hold them: page-locked host arrays (dr_host_alloc) -- and pageable copies for the
     # secondary figure
@@ -769,6 +795,7 @@ def worker_c2(args, rk):
                    "recall_at_10": recall, "build_seconds": build_s,
                    "parallelism": ("query-sharded replicas x%d, one batch split over the ranks" if strong else "query-sharded replicas x%d") % rk.world,
                    "rank_cpu_affinity": pinned_to if rk.world > 1 else None,
+                   "per_rank_setup": setup_all,
                    "per_rank_slice": slices if strong else None,
                    "tickets_in_flight": depth_head, "queries_per_launch": q_per_launch, "submits_per_launch": submits_per_launch,
                    "kernel_launches_in_timed_region": n_kernel_launches, "kernel_ms_per_batch": k_ms / per_launch,

@@ -1096,12 +1096,9 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         const int nc = passes <= 1 ? 1 : passes <= 2 ? 2 : 4;
         int treg_pref = -1;
         if (const char *e = getenv("DR_PQB_TREG")) treg_pref = atoi(e);       // A/B: table rows held in registers
-        // steps of several passes CAN run the visited filter + compaction (pqb_kernel.hpp VF; DR_PQB_FILTER=1). Off by default: it scores the
-        // distinct nodes only (c3 1M, L = 250 no trim: 6 239 instead of 14 279 code words per query, c5-shaped R = 128 rows: 2 969 instead of
-        // 7 091) and is 10-30 % SLOWER (profiles/r05/ab/ab_pqb_*_v4.jsonl) -- its third dependent memory round trip per step costs more than
-        // the ADC passes it saves, as round 4 found for DR_MODE_PQ's visited set. Same results either way.
-        const bool want_vf = getenv("DR_PQB_FILTER") != nullptr;        // (read per call: the tests run both forms in one process)
-        pqc = dr_pqb_choose(sc, nc, ix->m, treg_pref, want_vf);
+        // (round 5's visited filter + compaction for steps of several passes -- it scored the distinct nodes only and was 10-30 % slower,
+        //  profiles/r05/ab/ab_pqb_*_v4.jsonl -- was removed in round 6)
+        pqc = dr_pqb_choose(sc, nc, ix->m, treg_pref);
         if (!pqc.fn) return fail(DR_E_UNSUPPORTED, "DR_MODE_PQB: no kernel for m=%u, capacity %u", ix->m, cap);
         kind = 20;
     }
@@ -1193,7 +1190,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // there the visited words are tens of GB of random-access footprint. DR_BUILD_PQ_NO_VISITED_SET=0 / 1 overrides the size rule.
     bool build_novis = ix->N >= (1ull << 25);
     { const char *e = getenv("DR_BUILD_PQ_NO_VISITED_SET"); if (e) build_novis = e[0] == '1'; }
-    const bool novis = (!ov && mode == DR_MODE_PQ && (flags & DR_F_NO_VISITED_SET) != 0) || (pqb && !pqc.vf) || (ov && ov->sdc && build_novis);
+    const bool novis = (!ov && mode == DR_MODE_PQ && (flags & DR_F_NO_VISITED_SET) != 0) || pqb || (ov && ov->sdc && build_novis);
     if (!novis && !lat && ((size_t)slots * vis_words > vis.n || slots > vis_epoch.n)) {
         // (re)allocation: fresh words and stamps -- queued launches still use the old buffers
         if (vis.p) HIPCHK(hipStreamSynchronize(st));
@@ -1368,7 +1365,6 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         pp.counter = p.counter; pp.ticket_base = p.ticket_base;
         pp.res_keys = p.res_keys; pp.res_n = p.res_n; pp.stats = p.stats; pp.out_ids = p.out_ids; pp.out_dist = p.out_dist; pp.out_count = p.out_count;
         pp.phase = p.phase;
-        pp.vis = p.vis; pp.vis_words = p.vis_words; pp.vis_epoch = p.vis_epoch;
     }
     void *args[] = { pqb ? (void *)&pp : (void *)&p };
     if (!ov) { ix->kev_lut[ix->kev_pending] = want_lut; HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][0], st)); }

@@ -4,9 +4,9 @@
 #pragma once
 #include "pqb_kernel.hpp"
 
-struct PqbChoice { const void *fn; int m16, treg, nc; bool vf; };
-// fn[sizeclass][passes class: 1, 2, 4]; fn_vf[sizeclass][passes class 2, 4]: the same with the visited filter + compaction
-struct PqbTable { int m16, treg; const void *fn[5][3]; const void *fn_vf[5][2]; };
+struct PqbChoice { const void *fn; int m16, treg, nc; };
+// fn[sizeclass][passes class: 1, 2, 4]
+struct PqbTable { int m16, treg; const void *fn[5][3]; };
 const PqbTable *dr_pqb_table_m0_t0();
 const PqbTable *dr_pqb_table_m1_t0();
 const PqbTable *dr_pqb_table_m1_t8();
@@ -18,7 +18,7 @@ const PqbTable *dr_pqb_table_m4_t16();
 const PqbTable *dr_pqb_table_m4_t32();
 
 // sc: size class of the list (0..4); nc: passes per step (1, 2, 4); m: sub-quantisers; treg_pref: -1 = the engine's choice
-static inline PqbChoice dr_pqb_choose(int sc, int nc, uint32_t m, int treg_pref, bool want_vf)
+static inline PqbChoice dr_pqb_choose(int sc, int nc, uint32_t m, int treg_pref)
 {
     const PqbTable *t = nullptr;
     if (m == 16) t = (treg_pref == 0 || nc > 2 || sc > 3) ? dr_pqb_table_m1_t0() : dr_pqb_table_m1_t8();     // (8 of 16 rows in registers: 8 KiB of LDS per wavefront)
@@ -31,10 +31,9 @@ static inline PqbChoice dr_pqb_choose(int sc, int nc, uint32_t m, int treg_pref,
     else if (m == 48) t = dr_pqb_table_m3_t16();
     else if (m == 64) t = treg_pref == 16 ? dr_pqb_table_m4_t16() : dr_pqb_table_m4_t32();
     else if (m <= 128) t = dr_pqb_table_m0_t0();
-    PqbChoice c = { nullptr, 0, 0, 1, false };
+    PqbChoice c = { nullptr, 0, 0, 1 };
     if (!t) return c;
     const int ci = nc <= 1 ? 0 : nc <= 2 ? 1 : 2;
-    c.vf = want_vf && ci > 0 && t->fn_vf[sc][ci - 1] != nullptr;          // (one pass per step: nothing to compact; built for m = 32 only)
-    c.fn = c.vf ? t->fn_vf[sc][ci - 1] : t->fn[sc][ci]; c.m16 = t->m16; c.treg = t->treg; c.nc = ci == 0 ? 1 : ci == 1 ? 2 : 4;
+    c.fn = t->fn[sc][ci]; c.m16 = t->m16; c.treg = t->treg; c.nc = ci == 0 ? 1 : ci == 1 ? 2 : 4;
     return c;
 }

@@ -21,7 +21,8 @@
 // DR_MODE_PQ spends half of its instructions deciding what the reference's neighbour-by-neighbour loop would have done (three
 // binary searches over the list, candidate masks, a fixed point, the insert log for the tie-order pass), a step here is
 //   pop (scalar bit operations on the live masks) -> rows -> code words -> ADC -> one ballot against the largest key ->
-//   per surviving candidate: its rank in the list by wave-wide compares -> ONE scatter / gather merge through LDS.
+//   every lane's rank in the list (first level against list entries read out of the registers, two or three 4-ary levels over the
+//   staged list) -> its rank among the accepted keys (a loop over the accepted lanes, keys by v_readlane) -> ONE scatter / gather merge.
 // Expanding several frontier entries per step (pops; DiskANN's beam) fills the 64 lanes when rows are narrow (R = 32: two rows
 // per ADC pass) and halves the number of DEPENDENT memory round trips per query.
 //
@@ -48,9 +49,6 @@ struct PqbParams {
     u32 *out_ids;            // [nq][k]
     float *out_dist;         // [nq][k]
     u32 *out_count;
-    u32 *vis;                // VF kernels: [slots][vis_words] the visited FILTER: words of 24 id bits + an 8-bit query stamp (as search_kernel's)
-    u32 vis_words;           // ceil(N / 24), rounded up to a multiple of 4
-    u32 *vis_epoch;          // [slots] stamp of the last query each slot served
     u64 *phase;              // [nq][8] cycle sums (DR_PHASE_TIMING builds only): 0 table landing, 1 pop, 2 rows, 3 code words, 4 ADC,
                              // 5 candidates, 6 merge + trim, 7 output
 };
@@ -128,17 +126,14 @@ static inline size_t pqb_lds_bytes(uint32_t m, int treg, int nchr, int nc)
     return (size_t)(m - (uint32_t)treg) * 1024 + (size_t)nchr * 512 + (size_t)nchr * 256 + ((size_t)nc * 64 + 4) * 8 + 64;
 }
 
-// VF    visited FILTER + compaction (steps of several 64-lane passes). Before their code words are fetched, the step's neighbour ids are
-//       tested against a per-slot bitmap of the nodes this query has scored (a node scored before can never enter the list again: it is in
-//       it, or was rejected or evicted at a largest key >= today's -- skipping it changes nothing), the survivors are compacted, and only
-//       ceil(survivors / 64) passes fetch code words and run the ADC -- at 10M points without a frontier trim three of four slots are
-//       repeats. The bitmap is a FILTER, not the authority: test and set are a plain load and a plain store, lanes of one instruction that
-//       share a word lose each other's bits, and a lost bit only means the node is scored again and then found in the list. Results, steps
-//       and accepted inserts are those of the kernel without it; stats.visited / stats.pq count the code words really scored.
-template <int NCHR, int NC, int M16, int TREG, bool VF = false>
+template <int NCHR, int NC, int M16, int TREG>
 // (wavefronts per SIMD the registers must allow: 3 with 24 of 32 rows in registers -- 8 KiB of LDS per wavefront, 12 per CU --; 4 for the
 // small table of m = 16 with half of it in registers)
+#ifdef PQB_FORCE_WAVES4      // A/B: the <= 128-register form -- four wavefronts per SIMD whatever it spills
+__global__ __launch_bounds__(64, 4) void pqb_search_kernel(const PqbParams p)
+#else
 __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 : 2) void pqb_search_kernel(const PqbParams p)
+#endif
 {
     static_assert(TREG == 0 || (M16 > 0 && TREG <= M16 * 16 && TREG % 8 == 0), "register rows need a compile-time m");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -154,9 +149,6 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
     const int cap = (int)p.cap;
     const u32 nwords = (p.R + 63) / 64;
     const u32 rs_mask = (1u << p.rs_shift) - 1u;
-    u32 *vbm = VF ? p.vis + (size_t)slot_id * p.vis_words : nullptr;
-    u32 vstamp = VF ? (u32)__builtin_amdgcn_readfirstlane((int)p.vis_epoch[slot_id]) : 0u;
-    u32 *nbuf = reinterpret_cast<u32 *>(cbuf);       // [NC*64] the step's unseen neighbour ids, compacted (VF; cbuf is not in use yet at that point)
     // code words decoded together in the ADC: two (8 lookups in flight) when one pass per step leaves the registers for it
 #ifdef PQB_FORCE_GW
     constexpr int GW = PQB_FORCE_GW;       // A/B builds
@@ -185,16 +177,6 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
             WSYNC();
         }
         PH(0);
-        if constexpr (VF) {         // next stamp; after 255 queries the slot's words are wiped and the count restarts (search_kernel.hpp)
-            if (vstamp >= 255u) {
-                uint4 *vb4 = reinterpret_cast<uint4 *>(vbm);
-                for (u32 i = lane; i < p.vis_words / 4; i += 64) vb4[i] = make_uint4(0, 0, 0, 0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                vstamp = 0u;
-            }
-            vstamp++;
-        }
-        const u32 vtag = vstamp << 24;
         RegList<NCHR> rk;           // keys in registers: distance bits << 32 | id << 1 (state bit clear; ~0 = unused)
         u64 live[NCHR];             // live entries, one bit per list position (wave-uniform: scalar registers)
 #pragma unroll
@@ -253,41 +235,12 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
             bool act[NC];
 #pragma unroll
             for (int t = 0; t < NC; t++) act[t] = valid[t] && ((fw[t] >> (slot_[t] & 63u)) & 1ull) != 0ull;
-            int n_new = NC * 64;
-            if constexpr (VF) {
-                // the filter: one word per 24 ids, stamped by the query that wrote it (a word of another stamp reads as empty)
-                int base = 0;
-#pragma unroll
-                for (int t = 0; t < NC; t++) {
-                    const u32 id = nid[t];
-                    const u32 vw = __umulhi(id, 0xAAAAAAABu) >> 4;          // id / 24
-                    const u32 vbit = 1u << (id - vw * 24u);
-                    u32 w = 0u;
-                    if (act[t]) w = __hip_atomic_load(&vbm[vw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (served by the L2, never by a stale L1 line)
-                    const u32 old = ((w >> 24) == vstamp) ? (w & 0x00FFFFFFu) : 0u;
-                    const bool isnew = act[t] && (old & vbit) == 0u;
-                    if (isnew) vbm[vw] = vtag | old | vbit;
-                    const u64 nm = __ballot(isnew);
-                    if (isnew) nbuf[base + __popcll(nm & lanemask_lt())] = id;
-                    base += __popcll(nm);
-                }
-                n_new = base;
-                WSYNC();
-#pragma unroll
-                for (int t = 0; t < NC; t++) {
-                    const int idx = t * 64 + lane;
-                    act[t] = idx < n_new;
-                    nid[t] = act[t] ? nbuf[idx] : 0u;
-                }
-                WSYNC();        // (nbuf aliases cbuf: read before the candidates are compacted into it)
-            }
             // code words (inline: beside the row, no dependency on the ids; else a gather behind them)
             uint4 cw[NC][M16 > 0 ? M16 : 1];
 #pragma unroll
             for (int t = 0; t < NC; t++) {
-                if (VF && t * 64 >= n_new && t > 0) continue;       // (compacted: the passes behind the last unseen neighbour are empty)
                 if constexpr (M16 > 0) {
-                    const u8 *code = (!VF && p.nbcodes && !seed) ? p.nbcodes + ((size_t)cur_[t] * p.R + slot_[t]) * p.m : p.codes + (size_t)(act[t] ? nid[t] : 0u) * p.m;
+                    const u8 *code = (p.nbcodes && !seed) ? p.nbcodes + ((size_t)cur_[t] * p.R + slot_[t]) * p.m : p.codes + (size_t)(act[t] ? nid[t] : 0u) * p.m;
 #pragma unroll
                     for (int w = 0; w < M16; w++) cw[t][w] = reinterpret_cast<const uint4 *>(code)[w];
                 }
@@ -299,11 +252,10 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
             u64 anyc = 0ull;
 #pragma unroll
             for (int t = 0; t < NC; t++) {
-                if (VF && t * 64 >= n_new && t > 0) { key[t] = ~0ull; cm[t] = 0ull; continue; }
                 float e;
                 if constexpr (M16 > 0) e = pqb_adc<M16, TREG, GW>(lut, tv, cw[t]);
                 else {
-                    const u8 *code = (!VF && p.nbcodes && !seed) ? p.nbcodes + ((size_t)cur_[t] * p.R + slot_[t]) * p.m : p.codes + (size_t)(act[t] ? nid[t] : 0u) * p.m;
+                    const u8 *code = (p.nbcodes && !seed) ? p.nbcodes + ((size_t)cur_[t] * p.R + slot_[t]) * p.m : p.codes + (size_t)(act[t] ? nid[t] : 0u) * p.m;
                     e = pqb_adc_generic(lut, code, p.m);
                 }
                 key[t] = ((u64)__float_as_uint(e) << 32) | ((u64)nid[t] << 1);
@@ -314,24 +266,34 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
             PH(4);
 
             // ---- candidates (key below the list's largest key, or any while the list fills), all lanes at once:
-            // (1) rank in the list = binary search over the staged list; the entry found there says whether the node is IN the list;
-            // (2) several rows per step: the same node through two rows -- the later copy leaves (a loop over the compacted keys);
-            // (3) the accepted keys are compacted into LDS; every accepted lane counts the accepted keys below its own (broadcast
-            //     reads, no dependency between them), and a histogram of the list ranks, prefix-summed, tells every list entry how
-            //     many accepted keys lie below it;
+            // (1) rank in the list. First level WITHOUT a memory access: the list is sorted in the registers, its entries at the fixed positions
+            //     SEG - 1, 2 SEG - 1, ... are read out with v_readlane (wave-uniform: scalar operands of the compares) and cut the list into K0
+            //     segments; then LEV 4-ary levels over the staged list inside the lane's segment (three independent LDS reads per level). The
+            //     last level reads a fourth entry, so the entry AT the rank -- which says whether the node is IN the list -- needs no round trip
+            //     of its own: LEV dependent LDS round trips (2 for lists of up to 256 entries) where round 5 took 5-6;
+            // (2) rank among the accepted keys: a loop over the accepted LANES (the mask is wave-uniform, the key comes out of its register
+            //     with v_readlane: no LDS). The same loop sees a node accepted through two of the step's rows (equal keys): the later copy
+            //     leaves and the loop runs once more, on the rare steps where that happens. Long candidate sets (a filling list) count
+            //     through LDS, four keys per trip, as round 5 did for all;
+            // (3) a histogram of the list ranks, prefix-summed, tells every list entry how many accepted keys lie below it;
             // (4) ONE scatter / gather merge through the staged list.
             if (anyc != 0ull) {
-                constexpr int QIT = (NCHR == 1) ? 3 : (NCHR <= 4) ? 4 : 5;      // 4^QIT >= NCHR * 64
+                constexpr int K0 = (NCHR * 4 < 16) ? NCHR * 4 : 16;          // first-level segments
+                constexpr int SEG = NCHR * 64 / K0;                          // 16 (lists of up to 256 entries), 32, 64
+                constexpr int LEV = (SEG <= 16) ? 2 : 3;                     // 4^LEV >= SEG
                 u64 acc[NC];
-                int lb[NC], ci[NC];
+                int lb[NC];
                 int nacc = 0;
+                u64 spl[K0 - 1];
+#pragma unroll
+                for (int i = 0; i < K0 - 1; i++) spl[i] = readlane64(rk.v[((i + 1) * SEG - 1) >> 6], ((i + 1) * SEG - 1) & 63);      // (unused entries are ~0: never below a key)
 #pragma unroll
                 for (int t = 0; t < NC; t++) {
-                    // #(list keys < key): a 4-ary search over the staged list padded with +inf to 4^QIT entries -- three independent
-                    // LDS reads per level, QIT DEPENDENT round trips instead of the 2 QIT of a binary search
                     int lo = 0;
                     bool inl = false;
                     if (rn > 0) {
+#ifdef PQB_SEARCH_V1      // A/B: round 5's search -- QIT 4-ary levels over the staged list from the top, the entry at the rank read afterwards
+                        constexpr int QIT = (NCHR == 1) ? 3 : (NCHR <= 4) ? 4 : 5;
 #pragma unroll
                         for (int it = 0; it < QIT; it++) {
                             const int st = 1 << (2 * (QIT - 1 - it));
@@ -340,56 +302,101 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
                             const int c1 = (i1 < rn && v1 < key[t]) ? 1 : 0, c2 = (i2 < rn && v2 < key[t]) ? 1 : 0, c3 = (i3 < rn && v3 < key[t]) ? 1 : 0;
                             lo += (c1 + c2 + c3) * st;
                         }
-                        const u64 vv = mk[min(lo, rn - 1)];
+                        const u64 vv1 = mk[min(lo, rn - 1)];
+                        inl = lo < rn && (vv1 ^ key[t]) <= 1ull;
+                    }
+                    if (false) {
+#endif
+#pragma unroll
+                        for (int i = 0; i < K0 - 1; i++) lo += (spl[i] < key[t]) ? SEG : 0;
+#pragma unroll
+                        for (int it = 0; it < LEV - 1; it++) {
+                            const int st = 1 << (2 * (LEV - 1 - it));
+                            const int i1 = lo + st - 1, i2 = lo + 2 * st - 1, i3 = lo + 3 * st - 1;
+                            const u64 v1 = mk[min(i1, rn - 1)], v2 = mk[min(i2, rn - 1)], v3 = mk[min(i3, rn - 1)];
+                            const int c1 = (i1 < rn && v1 < key[t]) ? 1 : 0, c2 = (i2 < rn && v2 < key[t]) ? 1 : 0, c3 = (i3 < rn && v3 < key[t]) ? 1 : 0;
+                            lo += (c1 + c2 + c3) * st;
+                        }
+                        // last level: the rank is lo ... lo + 3, and the entry at the rank is one of the four read here
+                        const u64 e0 = mk[min(lo, rn - 1)], e1 = mk[min(lo + 1, rn - 1)], e2 = mk[min(lo + 2, rn - 1)], e3 = mk[min(lo + 3, rn - 1)];
+                        const int c = ((lo < rn && e0 < key[t]) ? 1 : 0) + ((lo + 1 < rn && e1 < key[t]) ? 1 : 0) + ((lo + 2 < rn && e2 < key[t]) ? 1 : 0);
+                        const u64 vv = (c == 0) ? e0 : (c == 1) ? e1 : (c == 2) ? e2 : e3;
+                        lo += c;
                         inl = lo < rn && (vv ^ key[t]) <= 1ull;
                     }
                     lb[t] = lo;
                     acc[t] = cm[t] & __ballot(!inl);
-                    ci[t] = nacc + __popcll(acc[t] & lanemask_lt());
                     nacc += __popcll(acc[t]);
                 }
-                if (np > 1 && nacc > 1) {
-                    // the same node through two of the step's rows: only its first copy (in lane order) stays
-#pragma unroll
-                    for (int t = 0; t < NC; t++) if ((acc[t] >> lane) & 1ull) cbuf[ci[t]] = key[t];
-                    WSYNC();
-                    bool dup[NC];
-#pragma unroll
-                    for (int t = 0; t < NC; t++) dup[t] = false;
-#pragma unroll 8
-                    for (int jq = 0; jq < nacc; jq++) {
-                        const u64 kj = cbuf[jq];
-#pragma unroll
-                        for (int t = 0; t < NC; t++) dup[t] = dup[t] || (kj == key[t] && jq < ci[t]);
-                    }
-                    WSYNC();
-                    nacc = 0;
-#pragma unroll
-                    for (int t = 0; t < NC; t++) {
-                        acc[t] &= ~__ballot(dup[t]);
-                        ci[t] = nacc + __popcll(acc[t] & lanemask_lt());
-                        nacc += __popcll(acc[t]);
-                    }
-                }
                 if (nacc > 0) {
+#ifdef PQB_LOOP_MAX
+                    constexpr int LOOP_MAX = PQB_LOOP_MAX;        // A/B
+#else
+                    constexpr int LOOP_MAX = 24;          // accepted keys counted by the readlane loop (more: through LDS)
+#endif
                     bool isacc[NC];
-#pragma unroll
-                    for (int t = 0; t < NC; t++) {
-                        isacc[t] = ((acc[t] >> lane) & 1ull) != 0ull;
-                        if (isacc[t]) { cbuf[ci[t]] = key[t]; atomicAdd(&hist[lb[t]], 1u); }
-                    }
-                    if (lane < 4) cbuf[nacc + lane] = ~0ull;          // (the count loop below reads four keys per trip)
-                    WSYNC();
                     u32 rA[NC];
-#pragma unroll
-                    for (int t = 0; t < NC; t++) rA[t] = 0u;
 #pragma unroll 1
-                    for (int jq = 0; jq < nacc; jq += 4) {
-                        const u64 k0 = cbuf[jq], k1 = cbuf[jq + 1], k2 = cbuf[jq + 2], k3 = cbuf[jq + 3];
+                    for (int again = 0; again < 2; again++) {
+                        bool dupt[NC];
 #pragma unroll
-                        for (int t = 0; t < NC; t++)
-                            rA[t] += (k0 < key[t] ? 1u : 0u) + (k1 < key[t] ? 1u : 0u) + (k2 < key[t] ? 1u : 0u) + (k3 < key[t] ? 1u : 0u);
+                        for (int t = 0; t < NC; t++) { isacc[t] = ((acc[t] >> lane) & 1ull) != 0ull; rA[t] = 0u; dupt[t] = false; }
+                        if (nacc <= LOOP_MAX) {
+#pragma unroll
+                            for (int u = 0; u < NC; u++) {
+                                u64 mrem = acc[u];
+                                while (mrem != 0ull) {
+                                    const int j = __builtin_ctzll(mrem);
+                                    mrem &= mrem - 1ull;
+                                    const u64 kj = readlane64(key[u], j);
+#pragma unroll
+                                    for (int t = 0; t < NC; t++) {
+                                        rA[t] += (kj < key[t]) ? 1u : 0u;
+                                        // equal keys = the same node through two of the step's rows: the copy in the earlier (pass, lane) stays
+                                        if (t > u) dupt[t] = dupt[t] || kj == key[t];
+                                        else if (t == u) dupt[t] = dupt[t] || (kj == key[t] && j < lane);
+                                    }
+                                }
+                            }
+                        } else {
+                            int ci[NC];
+                            int base = 0;
+#pragma unroll
+                            for (int t = 0; t < NC; t++) {
+                                ci[t] = base + __popcll(acc[t] & lanemask_lt());
+                                base += __popcll(acc[t]);
+                                if (isacc[t]) cbuf[ci[t]] = key[t];
+                            }
+                            if (lane < 4) cbuf[nacc + lane] = ~0ull;          // (four keys per trip)
+                            WSYNC();
+#pragma unroll 1
+                            for (int jq = 0; jq < nacc; jq += 4) {
+                                const u64 k0 = cbuf[jq], k1 = cbuf[jq + 1], k2 = cbuf[jq + 2], k3 = cbuf[jq + 3];
+#pragma unroll
+                                for (int t = 0; t < NC; t++) {
+                                    rA[t] += (k0 < key[t] ? 1u : 0u) + (k1 < key[t] ? 1u : 0u) + (k2 < key[t] ? 1u : 0u) + (k3 < key[t] ? 1u : 0u);
+                                    dupt[t] = dupt[t] || (k0 == key[t] && jq < ci[t]) || (k1 == key[t] && jq + 1 < ci[t]) || (k2 == key[t] && jq + 2 < ci[t]) ||
+                                              (k3 == key[t] && jq + 3 < ci[t]);
+                                }
+                            }
+                            WSYNC();
+                        }
+                        if (np <= 1 || again == 1) break;          // (one row per step: its first-occurrence slots hold distinct nodes)
+                        u64 anyd = 0ull;
+                        int nacc2 = 0;
+#pragma unroll
+                        for (int t = 0; t < NC; t++) {
+                            const u64 dm = __ballot(dupt[t]) & acc[t];
+                            anyd |= dm;
+                            acc[t] &= ~dm;
+                            nacc2 += __popcll(acc[t]);
+                        }
+                        if (anyd == 0ull) break;
+                        nacc = nacc2;          // later copies left: the counts are taken again without them
                     }
+#pragma unroll
+                    for (int t = 0; t < NC; t++) if (isacc[t]) atomicAdd(&hist[lb[t]], 1u);
+                    WSYNC();
                     // list entry i moves up by the accepted keys below it = those whose list rank is <= i
                     u32 carry = 0u;
 #pragma unroll
@@ -482,5 +489,4 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
             qi = (u32)__builtin_amdgcn_readfirstlane((int)t) - p.ticket_base + nslots;
         }
     }
-    if constexpr (VF) { if (lane == 0) p.vis_epoch[slot_id] = vstamp; }
 }

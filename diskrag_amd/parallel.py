@@ -1,17 +1,16 @@
 """Multi-GPU host logic: how queries and id ranges are cut, and the canonical merge -- the host
 statement of what the device does (dr_sharded_search: device merge kernel + RCCL all-gather, include/diskrag_hip.h;
-bench.py: query-sharded replicas with file barriers). Nothing on the GPU path imports torch; the `torch.distributed`
-helpers below (`allgather_merge_topk`, `gather_rows`, `max_over_ranks`) exist for the 2-rank gloo test on CPU, which
-checks the sharding and merge logic across processes without a GPU.
+bench.py: query-sharded replicas with file barriers). numpy only: the package imports no torch anywhere -- the
+`torch.distributed` twin of the exchange that the 2-rank gloo test runs on CPU lives with the tests (tests/gloo_twin.py).
 
 Two layouts:
   * query-sharded replicas (configs c2-c4): every rank holds the whole index, takes a contiguous slice of the
     batch (`shard_slice`) and searches it locally. No data-path collective; results are concatenated by rank order
-    (`gather_rows` when one rank needs them all).
+    (rank 0 of bench.py reads them from the ranks' files).
   * graph-sharded (c5): every rank holds a disjoint id range [base, base + n_local) with its own sub-graph; every
     query runs on every shard; the per-shard top-k lists (local ids + shard base) are exchanged with ONE
     all-gather of (nq*k + 1) 64-bit words per rank -- packed (distance, id) keys and the rank's status word -- and merged
-    in canonical (distance, id) order (`allgather_merge_topk`). A rank whose local phase failed still joins the collective,
+    in canonical (distance, id) order. A rank whose local phase failed still joins the collective,
     with an empty list and a non-zero status word: the call then fails on EVERY rank (`ShardExchangeError`) instead of
     leaving the others blocked in the collective (dr_sharded_submit, csrc/comm.inc, is the device statement of the same
     protocol).
@@ -84,66 +83,3 @@ def unpack_keys(keys):
     ids[empty] = PAD
     d[empty] = np.nan
     return ids, d
-
-
-def allgather_merge_topk(local_ids, local_dist, shard_base, k, group=None, device=None, local_status=0):
-    """Graph-sharded merge: local ids are shard-local; adds `shard_base`, packs the list into 64-bit keys, puts this rank's
-    status word behind it and all-gathers the nq*k + 1 words of every rank with ONE collective, then merges. A rank calls
-    this even when its local phase failed (`local_status` != 0, any lists): if any rank's status is non-zero every rank
-    raises ShardExchangeError after the collective. Needs an initialised torch.distributed process group."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    local_ids = np.asarray(local_ids, dtype=np.uint32)
-    gids = np.where(local_ids == PAD, PAD, (local_ids.astype(np.uint64) + np.uint64(shard_base)).astype(np.uint32))
-    keys = pack_keys(gids, local_dist)
-    if local_status:
-        keys = np.full_like(keys, np.uint64(0xFFFFFFFFFFFFFFFF))
-    nq, kk = keys.shape
-    words = np.concatenate([keys.reshape(-1), np.array([local_status], dtype=np.uint64)])
-    t = torch.from_numpy(words.view(np.int64).copy())      # (collectives have no unsigned 64-bit type: ship the bits)
-    if device is not None:
-        t = t.to(device)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t, group=group)
-    got = [o.cpu().numpy().view(np.uint64) for o in out]
-    statuses = [int(g[-1]) for g in got]
-    if any(statuses):
-        raise ShardExchangeError(statuses)
-    lists = [unpack_keys(g[:-1].reshape(nq, kk)) for g in got]
-    return merge_topk([a for a, _ in lists], [b for _, b in lists], k)
-
-
-def gather_rows(local_rows, group=None, device=None):
-    """Concatenates per-rank row blocks (query-sharded results) on every rank, in rank order."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rows = np.ascontiguousarray(local_rows)
-    orig_dtype = rows.dtype
-    if orig_dtype == np.uint32:          # collectives have no unsigned 32-bit type: ship the bits as int32
-        rows = rows.view(np.int32)
-    t = torch.from_numpy(rows)
-    if device is not None:
-        t = t.to(device)
-    counts = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device), group=group)
-    mx = int(max(c.item() for c in counts))
-    padded = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    padded[:t.shape[0]] = t
-    out = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(out, padded, group=group)
-    res = np.concatenate([o[:int(c.item())].cpu().numpy() for o, c in zip(out, counts)], axis=0)
-    return res.view(np.uint32) if orig_dtype == np.uint32 else res
-
-
-def max_over_ranks(value, group=None, device=None):
-    """Slowest rank's time: the bench divides the job's queries by this."""
-    import torch
-    import torch.distributed as dist
-
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    return float(t.item())

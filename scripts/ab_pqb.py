@@ -40,7 +40,6 @@ for pops in (1, 2, 4):
         variants.append((f"PQB_pops{pops}", dict(mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(pops)), {}))
 for pops in (2, 4):       # steps of several passes: the visited filter + compaction (default) against the plain form, and 24 register rows (spills at 4 passes)
     if 64 < pops * (1 << int(np.ceil(np.log2(R)))) <= 256:
-        variants.append((f"PQB_pops{pops}_filter", dict(mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(pops)), {"DR_PQB_FILTER": "1"}))
         if m == 32: variants.append((f"PQB_pops{pops}_treg24", dict(mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(pops)), {"DR_PQB_TREG": "24"}))
 best_pops = 2 if R <= 64 else 1
 if m == 32:

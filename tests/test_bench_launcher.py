@@ -111,3 +111,89 @@ def test_bench_flags_of_round_4_parse():
     assert r.returncode == 0
     for flag in ("--headline-only", "--c5-group", "--scaling", "--config"):
         assert flag in r.stdout, flag
+
+
+# ---- world = 8: the size of the node the driver measures on
+def test_gpus_8_weak_and_strong_at_the_drivers_size():
+    """eight ranks through the launcher: barriers, the gathered times, 1250-query slices that tile a 10 000-query batch, ONE JSON line"""
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batches-per-step", "4"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and len(d["config"]["per_rank_seconds"]) == 8
+    assert abs(d["value"] - 8 * 10000 * 3 * 4 / max(d["config"]["per_rank_seconds"])) < 1e-6 * d["value"]
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batches-per-step", "3", "--scaling", "strong"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    sl = sorted(d["config"]["per_rank_slice"])
+    assert d["scaling"] == "strong" and len(sl) == 8 and all(b - a == 1250 for a, b in sl) and sl[0][0] == 0 and sl[-1][1] == 10000
+    assert all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+    assert abs(d["value"] - 10000 * 2 * 3 / max(d["config"]["per_rank_seconds"])) < 1e-6 * d["value"]
+
+
+def test_one_failing_rank_among_eight_ends_the_job_at_once():
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       env=_env(DR_BENCH_STUB_FAIL_RANK="5"), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and time.time() - t0 < 120
+
+
+def _fake_sysfs(root, sockets):
+    """eight GPUs' PCI functions under root/bus/pci/devices, `sockets[i]` = (cpulist, numa node) of device i"""
+    bdfs = []
+    for i, (cpulist, node) in enumerate(sockets):
+        bdf = "0000:%02x:00.0" % (0x05 + 0x10 * i)
+        d = root / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "local_cpulist").write_text(cpulist + "\n")
+        (d / "numa_node").write_text("%d\n" % node)
+        bdfs.append(bdf)
+    return bdfs
+
+
+def test_pin_to_gpu_socket_on_a_fake_tree_of_eight_devices_on_two_sockets(tmp_path, monkeypatch):
+    sys.path.insert(0, str(ROOT))
+    import bench
+    have = sorted(os.sched_getaffinity(0))
+    if len(have) < 2:
+        import pytest
+        pytest.skip("one CPU: nothing to split")
+    half = len(have) // 2
+    s0, s1 = have[:half], have[half:]
+
+    def cpulist(cs):      # ranges and single CPUs, as the kernel prints them
+        return ",".join("%d-%d" % (a, a) if i % 2 else str(a) for i, a in enumerate(cs))
+    bdfs = _fake_sysfs(tmp_path, [(cpulist(s0), 0)] * 4 + [(cpulist(s1), 1)] * 4)
+
+    class RK:
+        world = 8
+    got = []
+    try:
+        for dev in range(8):
+            os.sched_setaffinity(0, have)
+            r = bench.pin_to_gpu_socket(RK, dev, sysroot=str(tmp_path), bus_id=lambda d: bdfs[d])
+            got.append((r, os.sched_getaffinity(0)))
+        for dev, (r, aff) in enumerate(got):
+            want = set(s0 if dev < 4 else s1)
+            assert r == {"pci": bdfs[dev], "numa_node": 0 if dev < 4 else 1, "cpus": len(want)} and aff == want
+        assert got[0][1].isdisjoint(got[7][1])                                    # the two sockets' ranks never share a CPU
+        # graceful no-ops: the tree hides the device, the runtime has no bus id, one rank, the opt-out
+        os.sched_setaffinity(0, have)
+        assert bench.pin_to_gpu_socket(RK, 0, sysroot=str(tmp_path / "nothing"), bus_id=lambda d: bdfs[d]) is None
+        assert bench.pin_to_gpu_socket(RK, 0, sysroot=str(tmp_path), bus_id=lambda d: None) is None
+        RK.world = 1
+        assert bench.pin_to_gpu_socket(RK, 0, sysroot=str(tmp_path), bus_id=lambda d: bdfs[d]) is None
+        RK.world = 8
+        monkeypatch.setenv("DR_BENCH_NO_PIN", "1")
+        assert bench.pin_to_gpu_socket(RK, 0, sysroot=str(tmp_path), bus_id=lambda d: bdfs[d]) is None
+        monkeypatch.delenv("DR_BENCH_NO_PIN")
+        # a list of CPUs this process may not use (a cgroup narrower than the socket): nothing is changed
+        _fake_sysfs(tmp_path / "other", [("100000-100003", 0)])
+        assert bench.pin_to_gpu_socket(RK, 0, sysroot=str(tmp_path / "other"), bus_id=lambda d: "0000:05:00.0") is None
+        assert os.sched_getaffinity(0) == set(have)
+    finally:
+        os.sched_setaffinity(0, have)

@@ -69,3 +69,32 @@ def test_c3_c4_configs_at_toy_size(cfg):
     one = _run(["--rows", "f32", "--no-secondary"]) if cfg == "c3" else None       # (the float-row headline of c2 rides along once)
     if one:
         assert one["config"]["rows"] == "f32" and one["config"]["launch"]["variant"] == 9 and one["roofline"]["row_bytes"] == 512
+
+
+# ---- world = 8 on one GPU: the job the driver launches on an 8-GPU node, with eight ranks sharing this pool's one device
+def test_eight_ranks_on_one_gpu_weak_and_strong():
+    d = _run(["--gpus", "8", "--no-secondary", "--num-queries", "800"])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and len(d["config"]["per_rank_seconds"]) == 8 and d["config"]["recall_at_10"] >= 0.5
+    assert abs(d["value"] - 8 * 800 * 2 * 3 / max(d["config"]["per_rank_seconds"])) < 1e-6 * d["value"]
+    s = d["config"]["strong_scaling"]
+    assert s["queries_per_batch_per_gpu"] == 100 and len(s["per_rank_seconds"]) == 8
+    d = _run(["--gpus", "8", "--scaling", "strong", "--no-secondary", "--num-queries", "800"])
+    assert d["scaling"] == "strong" and d["config"]["per_rank_slice"] == [[100 * r, 100 * (r + 1)] for r in range(8)] and d["config"]["recall_at_10"] >= 0.5
+    # per-rank host memory and set-up time: every rank builds the graph and the ground truth itself (DESIGN.md section 7 states them at full size)
+    assert len(d["config"]["per_rank_setup"]) == 8 and all(x["max_rss_mb"] > 0 and x["setup_seconds"] > 0 for x in d["config"]["per_rank_setup"])
+
+
+def test_c5_pipeline_with_eight_ranks_through_the_stand_in_exchange():
+    """bench.py --config c5 --gpus 8: eight real processes, eight shards, grouped exchanges with eight status words -- csrc/comm.inc at nranks = 8
+    through tests/fake_rccl (RCCL refuses several ranks on one device)."""
+    import os
+    fake = ROOT / "tests" / "fake_rccl"
+    so = fake / "libfake_rccl.so"
+    if not so.exists() or so.stat().st_mtime < (fake / "fake_rccl.cpp").stat().st_mtime:
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(so), str(fake / "fake_rccl.cpp"), "-lrt"])
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", "c5", "--gpus", "8", "--num-vectors", "16384", "--num-queries", "400", "--steps", "6", "--warmup", "2",
+                        "--min-recall", "0.5"], capture_output=True, text=True, timeout=1200, env=dict(os.environ, DR_RCCL_LIB=str(so)))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["config"]["rccl_ranks"] == 8 and len(d["config"]["per_rank_seconds"]) == 8
+    assert d["value"] > 0 and d["config"]["recall_at_10_vs_bruteforce_adc"] >= 0.5 and d["config"]["submits_per_exchange"] == 3

@@ -1,5 +1,6 @@
 """N > 1 host path on CPU: two gloo ranks exercise query sharding, the graph-sharded top-k all-gather + merge and
-the max-over-ranks timing, checked against single-process oracle runs on a golden fixture."""
+the max-over-ranks timing, checked against single-process oracle runs on a golden fixture. The torch.distributed side is
+tests/gloo_twin.py (test infrastructure); the numpy statements under test are diskrag_amd/parallel.py."""
 import os
 import socket
 
@@ -20,6 +21,7 @@ def _free_port():
 def _worker(rank, world, port, ret):
     import torch.distributed as dist
     from diskrag_amd import parallel
+    from tests import gloo_twin
     from oracle import pyoracle as orc
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -31,17 +33,18 @@ def _worker(rank, world, port, ret):
         sl = parallel.shard_slice(len(g.queries), world, rank)
         ids, dist_, cnt, _ = orc.search_batch(g.vectors, g.adj, g.queries[sl], g.medoid, orc.M1, k, L=50, bw=0,
                                               codes=g.codes, codebook=g.codebook)
-        all_ids = parallel.gather_rows(ids)
+        all_ids = gloo_twin.gather_rows(ids)
         # --- graph-sharded: each rank owns half of the ids and searches ALL queries by brute force over its half
         n = len(g.vectors)
         own = parallel.shard_slice(n, world, rank)
         lids = orc.bruteforce_topk(g.vectors[own], g.queries, k)
         ldist = np.array([[orc.sqdist(g.vectors[own][i], q) for i in row] for row, q in zip(lids, g.queries)],
                          dtype=np.float32)
-        mids, mdist = parallel.allgather_merge_topk(lids, ldist, own.start, k)
-        slow = parallel.max_over_ranks(1.0 + rank)
+        mids, mdist = gloo_twin.allgather_merge_topk(lids, ldist, own.start, k)
+        slow = gloo_twin.max_over_ranks(1.0 + rank)
         # --- the graph-sharded driver itself, two shards per rank, with the oracle standing in for the device index
-        from diskrag_amd.sharded import GraphShard, ShardedSearch
+        from diskrag_amd.sharded import GraphShard
+        from tests.gloo_twin import HostShardedSearch as ShardedSearch
 
         class OracleShard:   # HipIndex.search_batch's signature over a brute-force shard (host logic under test)
             def __init__(self, vecs):
@@ -153,7 +156,8 @@ def _failing_worker(rank, world, port, ret):
     the next call, with healthy shards, works -- the protocol left nothing behind"""
     import torch.distributed as dist
     from diskrag_amd import parallel
-    from diskrag_amd.sharded import GraphShard, ShardedSearch
+    from diskrag_amd.sharded import GraphShard
+    from tests.gloo_twin import HostShardedSearch as ShardedSearch
     from oracle import pyoracle as orc
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -211,3 +215,12 @@ def test_a_failing_rank_fails_the_call_on_every_rank_and_hangs_nobody():
     assert np.array_equal(r0[1][1], r1[1][1])
     assert all(set(a.tolist()) == set(b.tolist()) for a, b in zip(r0[1][1], gt))            # (sets: ties may order differently from the brute force)
     assert r0[2] == ("local", "shard without PQ data") and r1[2] == ("remote", [1, 0])      # call 3: rank 0 failed
+
+
+def test_the_product_package_imports_no_torch():
+    """diskrag_amd/ is numpy + ctypes: the gloo twin of the exchange lives under tests/ """
+    import re
+    from pathlib import Path
+    pkg = Path(__file__).resolve().parent.parent / "diskrag_amd"
+    for f in pkg.glob("*.py"):
+        assert not re.search(r"^\s*(import|from)\s+torch", f.read_text(), re.M), f.name
