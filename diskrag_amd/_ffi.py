@@ -29,6 +29,13 @@ def POLICY_COIN(seed0):
 def F_POPS(n):
     """DR_MODE_PQB: frontier entries expanded per step (DR_F_POPS)."""
     return (int(n) & 15) << 8
+def F_RERANK_TOP(n):
+    """DR_MODE_PQB | DR_F_RERANK: rerank only the n list entries with the smallest ADC (DR_F_RERANK_TOP; 0 = the whole list)."""
+    if not 0 <= int(n) <= 1023:
+        raise ValueError("DR_F_RERANK_TOP takes 0 ... 1023")
+    return int(n) << 12
+
+
 TIER_HBM, TIER_HOST = 0, 1       # where the full-precision rows live (dr_index_*_tiered)
 MAX_RESIDENT = 16
 COMM_ID_BYTES = 128

@@ -34,7 +34,7 @@ template <int D> __global__ __launch_bounds__(64) void exact_kernel(const float 
 template <int D> __global__ __launch_bounds__(512) void rerank_kernel(const float *__restrict__ vecp,
         const float *__restrict__ queries_p, u32 nq, const u64 *__restrict__ res_keys, const u32 *__restrict__ res_n, u32 cap,
         u32 k, u32 *__restrict__ out_ids, float *__restrict__ out_dist, u32 *__restrict__ out_count, KStats *__restrict__ stats, u32 ip,
-        const float *__restrict__ queries, const u32 *__restrict__ perm, const u32 *__restrict__ id_map)
+        const float *__restrict__ queries, const u32 *__restrict__ perm, const u32 *__restrict__ id_map, u32 top)
 {
     // (id_map != nullptr: the disk tier -- `vecp` holds only the rows of this batch's lists, fetched from index.dat: the keys carry a row's
     //  position in that buffer and id_map gives the node it is; distances are ranked with the NODE id, as everywhere)
@@ -55,7 +55,7 @@ template <int D> __global__ __launch_bounds__(512) void rerank_kernel(const floa
         else if (queries_p) { for (int i = threadIdx.x; i < D; i += blockDim.x) qperm[i] = qpg[i]; }
         else { for (int i = threadIdx.x; i < D; i += blockDim.x) qperm[perm[i]] = qpg[i]; }
         __syncthreads();
-        const u32 n = min(res_n[q], cap);
+        const u32 n = min(min(res_n[q], cap), top ? top : cap);      // (DR_F_RERANK_TOP: the list is in (ADC, id) order -- its first `top` entries)
         const u64 *rk = res_keys + (size_t)q * cap;
         for (u32 base = wave * 8; base < n; base += 8 * nwv) {
             const u32 idx = min(base + (u32)oct, n - 1);

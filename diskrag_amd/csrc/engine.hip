@@ -987,6 +987,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     const bool rerank = (mode == DR_MODE_PQ || pqb) && (flags & DR_F_RERANK);
     const bool use_pq = (mode == DR_MODE_M1) || pq_only;
     if ((flags & DR_F_IP) && !rerank) return fail(DR_E_ARG, "DR_F_IP goes with DR_F_RERANK (DR_MODE_PQ / DR_MODE_PQB)");
+    const uint32_t rerank_top = (flags & DR_F_RERANK_TOP_MASK) >> DR_F_RERANK_TOP_SHIFT;
+    if (rerank_top && !(pqb && rerank)) return fail(DR_E_ARG, "DR_F_RERANK_TOP goes with DR_MODE_PQB | DR_F_RERANK");
     if (use_pq && ix->m == 0) return fail(DR_E_NOPQ, "mode %u needs PQ data (dr_index_set_pq)", mode);
     const bool disk_rerank = rerank && !ix->has_vectors && ix->row_fd >= 0;      // the rows of the final lists come from index.dat
     if ((!pq_only || rerank) && !disk_rerank) { const int rcv = need_vectors(ix, rerank ? "DR_F_RERANK (stored vectors or dr_index_attach_row_file)" : "this search mode"); if (rcv) return rcv; }
@@ -1389,7 +1391,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         for (uint32_t q0 = 0; q0 < nq; q0 += qchunk) {
             const uint32_t nqc = std::min(qchunk, nq - q0);
             size_t total = 0;
-            for (uint32_t q = 0; q < nqc; q++) total += std::min<uint32_t>(hn[q0 + q], cap);
+            for (uint32_t q = 0; q < nqc; q++) total += std::min<uint32_t>(std::min<uint32_t>(hn[q0 + q], cap), rerank_top ? rerank_top : cap);
             const size_t need = total * rowb + total * 4 + (size_t)nqc * cap * 8 + 64;
             { const int rcp = pin_reserve(&ix->row_pin, &ix->row_pin_bytes, need); if (rcp) return rcp; }
             float *rows_h = static_cast<float *>(ix->row_pin);
@@ -1397,7 +1399,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
             u64 *keys_h = reinterpret_cast<u64 *>(static_cast<unsigned char *>(ix->row_pin) + ((total * rowb + total * 4 + 7) & ~(size_t)7));
             size_t pos = 0;
             for (uint32_t q = 0; q < nqc; q++) {
-                const uint32_t n = std::min<uint32_t>(hn[q0 + q], cap);
+                const uint32_t n = std::min<uint32_t>(std::min<uint32_t>(hn[q0 + q], cap), rerank_top ? rerank_top : cap);
                 for (uint32_t i = 0; i < cap; i++) {
                     const u64 key = hk[(size_t)(q0 + q) * cap + i];
                     if (i < n) { ids_h[pos] = ~(uint32_t)key; keys_h[(size_t)q * cap + i] = (key & 0xFFFFFFFF00000000ull) | (uint32_t)(~(uint32_t)pos); pos++; }
@@ -1420,7 +1422,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
             uint32_t capv = cap, kv = k, nqv = nqc; uint32_t *oi = p.out_ids + (size_t)q0 * k; float *od = p.out_dist + (size_t)q0 * k; uint32_t *oc = p.out_count + q0;
             KStats *stp = p.stats + q0;
             uint32_t ipv = 0u;
-            void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp, &ipv, &qorig, &permp, &idm };
+            uint32_t topv = rerank_top;      // (the same cut as the host's above: only those rows were fetched)
+            void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp, &ipv, &qorig, &permp, &idm, &topv };
             const size_t rlds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)cap * 8;
             const unsigned rblock = nqc <= (uint32_t)ix->num_cu * 2 ? 512u : 64u;
             HIPCHK(hipLaunchKernel(ix->kern->rerank, dim3(std::min<uint32_t>(nqc, (uint32_t)ix->num_cu * 16)), dim3(rblock), rargs, rlds, st));
@@ -1433,7 +1436,8 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         uint32_t capv = cap, kv = k, nqv = nq; uint32_t *oi = p.out_ids; float *od = p.out_dist; uint32_t *oc = p.out_count;
         KStats *stp = p.stats;
         uint32_t ipv = (flags & DR_F_IP) ? 1u : 0u;
-        void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp, &ipv, &qorig, &permp, &idm };
+        uint32_t topv = rerank_top;
+        void *rargs[] = { &vecp, &qpp, &nqv, &rkp, &rnp, &capv, &kv, &oi, &od, &oc, &stp, &ipv, &qorig, &permp, &idm, &topv };
         const size_t rlds = (ix->D > 256 ? (size_t)ix->D * 4 : 0) + (size_t)cap * 8;
         // (a handful of queries: eight wavefronts per query share its list's rows; a batch that fills the chip: one wavefront per query)
         const unsigned rblock = nq <= (uint32_t)ix->num_cu * 2 ? 512u : 64u;

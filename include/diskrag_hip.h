@@ -71,6 +71,12 @@ extern "C" {
 #define DR_F_POPS(n) (((uint32_t)(n) & 15u) << DR_F_POPS_SHIFT) /* DR_MODE_PQB: frontier entries expanded per step (DiskANN's beam): narrow rows
                           (R = 32) fill the 64 lanes two at a time, and a query needs half as many DEPENDENT steps;
                           0 = max(1, 64 / next_pow2(R)): as many rows as fill 64 neighbour slots */
+#define DR_F_RERANK_TOP_SHIFT 12u
+#define DR_F_RERANK_TOP_MASK 0x3FF000u
+#define DR_F_RERANK_TOP(n) (((uint32_t)(n) & 1023u) << DR_F_RERANK_TOP_SHIFT) /* DR_MODE_PQB | DR_F_RERANK (round 6): score only the n <= 1023 list
+                          entries with the smallest squared ADC (the list is in (ADC, id) order) instead of all L; 0 = the whole list. The traversal's list
+                          length L buys the ADC ranking its depth, the rerank's n what a 4 D-byte row read costs: at D = 1536 the rerank of an L = 250
+                          list is a third of the call (config c3). Restated in oracle/ (ORC_F_RERANK_TOP); stats.exact counts the rows scored. */
 #define DR_F_COSINE 8u /* M3 without DR_F_USE_PQ: the in-memory graph's distance_metric='cosine' -- compute_query_distance ->
                           cosine_similarity_cython (vamana_graph.py:324-329, cython_utils.pyx:53-70): 1 - cos, 0 when a norm is
                           0; out_dist = sqrt of it (vamana_graph.py:598). The reference sums in float32 under -ffast-math

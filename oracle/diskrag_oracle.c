@@ -51,6 +51,7 @@
 #define ORC_F_NO_VISITED_SET 64u /* ORC_PQ: the statement without a visited set (engine flag DR_F_NO_VISITED_SET): same ids and distances; the counters count evaluations */
 #define ORC_F_COSINE 32u  /* M3 without PQ: distance_metric='cosine' (cosine_similarity_cython, cython_utils.pyx:53-70) */
 #define ORC_F_IP 128u      /* with ORC_F_RERANK: engine flag DR_F_IP -- unit-norm data, the returned distance is |q - v|^2 / 2 = 1 - <q, v> (no reference counterpart) */
+#define ORC_F_RERANK_TOP_SHIFT 12u /* ORC_PQB with ORC_F_RERANK: bits 12..21 = rerank only the n list entries with the smallest ADC keys (0 = all), engine flag DR_F_RERANK_TOP(n) */
 #define ORC_F_POPS_SHIFT 8u /* ORC_PQB: bits 8..11 = frontier entries expanded per step (0 = 1), engine flag DR_F_POPS(n) */
 #define ORC_F_PAIRWISE 8u  /* squared-L2 modes: use the numpy pairwise order (what the device computes) instead of the
                              sequential Cython loop, whose -ffast-math order is unpinned anyway */
@@ -208,6 +209,8 @@ static int pqb_search_one(const orc_index *ix, const float *q, uint32_t k, uint3
 #undef PQB_ADC
     if (flags & ORC_F_RERANK) {
         if (!ix->vectors) { free(lut); free(list); free(popped); return -2; }
+        const uint32_t top = (flags >> ORC_F_RERANK_TOP_SHIFT) & 1023u;       /* the list is in (ADC, id) order: its first `top` entries */
+        if (top && n > top) n = top;
         for (size_t i = 0; i < n; i++) {
             const float e = pw_sqdiff_f32(ix->vectors + (size_t)list[i].id * D, q, D);
             memcpy(&list[i].db, &e, 4); nexact++;

@@ -17,6 +17,7 @@ PQ = 5    # engine mode DR_MODE_PQ (no reference counterpart): M1's loop on squa
 F_USE_PQ, F_CYTHON, F_QUERY_F64, F_PAIRWISE, F_RERANK, F_COSINE = 1, 2, 4, 8, 16, 32
 PQB = 6   # engine mode DR_MODE_PQB (no reference counterpart): the batch-per-step ADC beam search (diskrag_oracle.c pqb_search_one)
 def F_POPS(n): return (int(n) & 15) << 8     # PQB: frontier entries expanded per step
+def F_RERANK_TOP(n): return (int(n) & 1023) << 12     # PQB + F_RERANK: rerank only the n entries with the smallest ADC (engine flag DR_F_RERANK_TOP)
 F_IP = 128    # with F_RERANK: engine flag DR_F_IP (unit-norm data: distance = |q - v|^2 / 2 = 1 - <q, v>)
 F_NO_VISITED_SET = 64     # PQ mode: the statement without a visited set (engine flag DR_F_NO_VISITED_SET): same ids / distances, evaluation counters
 

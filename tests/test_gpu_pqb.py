@@ -18,8 +18,9 @@ def _stats4(st):
 def _check(eng, g, k, L, bw, pops, flags=0, tag=None):
     from diskrag_amd import _ffi
     from oracle import pyoracle as orc
+    top = (flags >> 12) & 1023
     w = orc.search_batch(g.vectors, g.adj, g.queries, g.medoid, orc.PQB, k, L=L, bw=bw,
-                         flags=orc.F_POPS(pops) | (orc.F_RERANK if flags & _ffi.F_RERANK else 0), codes=g.codes, codebook=g.codebook)
+                         flags=orc.F_POPS(pops) | (orc.F_RERANK if flags & _ffi.F_RERANK else 0) | orc.F_RERANK_TOP(top), codes=g.codes, codebook=g.codebook)
     ids, dist, cnt, st = eng.search_batch(g.queries, k, L=L, beam_width=bw, mode=_ffi.MODE_PQB, flags=flags | _ffi.F_POPS(pops))
     assert int(st["status"].max()) == 0, tag
     assert np.array_equal(ids, w[0]), tag
@@ -95,6 +96,24 @@ def test_pqb_the_same_node_through_several_rows_of_a_step():
         ix = get_index(name)
         for (L, bw, k) in ((100, 8, 10), (250, 0, 10), (40, 0, 10), (20, 2, 5)):
             _check(ix, g, k, L, bw, pops, tag=(name, pops, L, bw))
+
+
+def test_pqb_rerank_of_the_adc_top_of_the_list():
+    """DR_F_RERANK_TOP(n): only the n list entries with the smallest ADC are scored exactly (round 6: c3's rerank is a third of a call at D = 1536) --
+    ids, distance bits, counts and the exact-distance counter against the restatement; n >= L is the whole list; refused without DR_F_RERANK."""
+    from diskrag_amd import _ffi
+    for name in ("unit1536_R16_m32", "sift128_R64_m32", "deep96_R32_m16"):
+        g = load_golden(name)
+        ix = get_index(name)
+        for (L, bw, k, top) in ((100, 8, 10, 30), (250, 0, 10, 64), (64, 8, 20, 20), (100, 0, 10, 100), (100, 0, 10, 1000), (40, 0, 10, 5)):
+            _check(ix, g, k, L, bw, 0, flags=_ffi.F_RERANK | _ffi.F_RERANK_TOP(top), tag=(name, L, bw, k, top))
+        a = ix.search_batch(g.queries, 10, L=100, beam_width=8, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK | _ffi.F_RERANK_TOP(100))
+        b = ix.search_batch(g.queries, 10, L=100, beam_width=8, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1]))
+        with pytest.raises(_ffi.DiskragHipError):
+            ix.search_batch(g.queries, 10, L=100, beam_width=8, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK_TOP(10))
+        with pytest.raises(_ffi.DiskragHipError):
+            ix.search_batch(g.queries, 10, L=100, beam_width=8, mode=_ffi.MODE_PQ, flags=_ffi.F_RERANK | _ffi.F_RERANK_TOP(10))
 
 
 def test_pqb_through_the_pipelined_path():
