@@ -664,12 +664,21 @@ def worker_c2(args, rk):
     # ... and SURVEY.md 8d's literal metric: nq / wall time of ONE blocking dr_search_batch call (upload, search, tie order,
     # download, nothing overlapped), median over --blocking-calls calls rotating the distinct batches (pageable sources)
     ix.batch_select(15)             # (a blocking call uploads into the selected resident batch: keep it off the bench's)
-    call_s = []
+    call_s, call_pieces = [], []
     for i in range(0 if args.headline_only else max(3, args.blocking_calls) + 2):
         src = qb_pageable[i % len(qb_pageable)]
         t1 = time.perf_counter()
         ix.search_batch(src, k, L=args.L, beam_width=args.bw, mode=mode)
         call_s.append(time.perf_counter() - t1)
+        tmc = ix.timing()
+        call_pieces.append((call_s[-1] * 1e3, tmc["h2d_ms"], tmc["lut_kernel_ms"], tmc["search_kernel_ms"], tmc["finalize_kernel_ms"]))
+    # the pieces of the median call (device events; "host_and_gaps" = wall - their sum: the staging pass over the pageable batch that runs
+    # ahead of the copies, the bound kernels, launch gaps, the final synchronisation and the copy out of the page-locked slab)
+    blocking_pieces = None
+    if len(call_pieces) > 2:
+        mid = sorted(call_pieces[2:])[len(call_pieces[2:]) // 2]
+        blocking_pieces = {"wall": mid[0], "h2d_copy": mid[1], "table_kernel": mid[2], "search_kernel": mid[3], "tie_order_pass": mid[4],
+                           "host_and_gaps": mid[0] - sum(mid[1:])}
     call_s = sorted(call_s[2:]) or [float("inf")]     # (the first two calls size the slot's buffers)
     qps_one_call = nq / call_s[len(call_s) // 2]
     # the reference's real serving shape (search_engine.py:530-614, app.py:84-130): ONE query per blocking call, host buffer in, results out --
@@ -814,6 +823,7 @@ def worker_c2(args, rk):
                    "float32_rows_roofline_frac": float_rows["roofline_frac"] if float_rows else None,
                    "rows": args.rows,
                    "qps_blocking_call": None if args.headline_only else {"median": qps_one_call, "calls": len(call_s), "best": nq / call_s[0], "worst": nq / call_s[-1],
+                                         "ms_of_the_median_call": blocking_pieces,
                                          "note": "SURVEY.md 8d's literal metric: nq / wall time of one blocking dr_search_batch call "
                                                  "(pageable source; upload + search + tie order + download, nothing overlapped)"},
                    "per_query": {"expansions": float(st["steps"].mean()), "pq_distances": float(st["pq"].mean()),

@@ -77,6 +77,18 @@ const DimKernels *dr_dim_kernels(int D)
 struct dr_index;
 static int quiesce_locked(dr_index *ix);
 
+// A fill that has COMPLETED when the call returns. hipMemset on device memory queues a fill kernel on the null stream and may return before it has
+// run; the handle's streams are created hipStreamNonBlocking and do not wait for the null stream -- on a GPU shared with other processes (eight
+// bench ranks on one device) a kernel of the handle read or incremented a "zero-filled" counter BEFORE the fill landed: dr_build_vamana answered
+// "adjacency holds 100 neighbour ids >= N" about a healthy graph and once built a different one (round 6, scripts/stress_concurrent_builds.py:
+// 3 of 48 builds; none since).
+static inline hipError_t dr_memset_sync(void *p, int v, size_t bytes)
+{
+    hipError_t e = hipMemsetAsync(p, v, bytes, nullptr);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(nullptr);
+}
+
 template <class T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
@@ -97,7 +109,7 @@ template <class T> struct DevBuf {
         n = want;
         if (zero) {
             if (host) memset(p, 0, want * sizeof(T));
-            else { e = hipMemset(p, 0, want * sizeof(T)); if (e != hipSuccess) return fail(DR_E_NODEVICE, "hipMemset failed"); }
+            else { e = dr_memset_sync(p, 0, want * sizeof(T)); if (e != hipSuccess) return fail(DR_E_NODEVICE, "hipMemset failed"); }
         }
         return 0;
     }
@@ -335,8 +347,12 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     if (N == 0 || D == 0 || R == 0) return fail(DR_E_ARG, "N, D and R must be positive");
     if (medoid >= N) return fail(DR_E_ARG, "medoid %u out of range (N=%llu)", medoid, (unsigned long long)N);
     if (N >= 0xFFFFFFFFull) return fail(DR_E_UNSUPPORTED, "N must fit in 32-bit ids");
+    // Dimensions without compiled kernels (pydiskann's functions take any D; the facade's SUPPORTED_DIMENSIONS are all built): the index is
+    // created with its rows in original element order and searched by the generic traversal (search_f64.hpp, D = 0: the pairwise tree
+    // evaluated from D at run time) through dr_search_batch / dr_search_batch_f64 -- M1 ... M4; everything that needs a compiled
+    // dimension (builder, brute force, the engine's PQ traversals, resident and pipelined batches) answers DR_E_UNSUPPORTED.
     ix->kern = dr_dim_kernels((int)D);
-    if (!ix->kern) return fail(DR_E_UNSUPPORTED, "unsupported vector dimension %u (built: 32,64,96,128,256,768,960,1536)", D);
+    if (!ix->kern && D > 32768) return fail(DR_E_UNSUPPORTED, "vector dimension %u: at most 32768", D);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DR_E_NODEVICE, "no HIP device available");
     if (device < 0 || device >= ndev) return fail(DR_E_ARG, "device %d out of range (%d devices)", device, ndev);
@@ -354,7 +370,8 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     for (auto &pr : ix->kev) { HIPCHK(hipEventCreate(&pr[0])); HIPCHK(hipEventCreate(&pr[1])); HIPCHK(hipEventCreate(&pr[2])); }
     for (auto &bs : ix->sets) { HIPCHK(hipEventCreate(&bs.search_done)); HIPCHK(hipEventCreate(&bs.fin_start)); HIPCHK(hipEventCreate(&bs.fin_done)); }
     ix->h_perm.resize(D);
-    pw_build_perm_rec(0, D, ix->h_perm.data());
+    if (ix->kern) pw_build_perm_rec(0, D, ix->h_perm.data());
+    else for (uint32_t e = 0; e < D; e++) ix->h_perm[e] = e;
     if (ix->perm.reserve(D)) return DR_E_NODEVICE;
     HIPCHK(hipMemcpy(ix->perm.p, ix->h_perm.data(), D * sizeof(uint32_t), hipMemcpyHostToDevice));
     ix->has_vectors = with_vectors;
@@ -364,6 +381,13 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     if (ix->adj.reserve((size_t)N * R)) return DR_E_NODEVICE;
     if (ix->first.reserve((size_t)N * ((R + 63) / 64))) return DR_E_NODEVICE;
     return 0;
+}
+
+static int need_built_dim(const dr_index *ix, const char *what)
+{
+    if (ix->kern) return 0;
+    return fail(DR_E_UNSUPPORTED, "%s needs a compiled dimension (built: 32,64,96,128,256,768,960,1536); D = %u is served by the generic traversal of "
+                "dr_search_batch / dr_search_batch_f64 only (modes M1 ... M4)", what, ix->D);
 }
 
 static int need_vectors(const dr_index *ix, const char *what)
@@ -487,7 +511,9 @@ extern "C" int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_
 {
     if (!ix || !codebook || !codes) return fail(DR_E_ARG, "null argument");
     if (m == 0 || ix->D % m) return fail(DR_E_ARG, "n_subvectors %u must divide D=%u", m, ix->D);
-    if (ix->D / m > 128) return fail(DR_E_UNSUPPORTED, "sub_dim %u > 128", ix->D / m);
+    // (the table kernels of the batched paths hold a centroid of <= 128 elements; the generic traversal of an index without compiled kernels
+    //  walks numpy's tree at run time inside a table row too)
+    if (ix->D / m > 128 && ix->kern) return fail(DR_E_UNSUPPORTED, "sub_dim %u > 128", ix->D / m);
     std::lock_guard<std::mutex> lk(ix->mu);
     HIPCHK(hipSetDevice(ix->device));
     { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }     // queued searches still read the old codes
@@ -973,6 +999,7 @@ static const uint32_t DR_DIRECT_MAX = 256;      // dr_search_batch calls of at m
 static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_t mode, uint32_t policy, uint32_t flags,
                       const BuildOverride *ov = nullptr)
 {
+    { const int rcd = need_built_dim(ix, ov ? "the builder" : "this search path (resident / pipelined batches, DR_MODE_PQ / DR_MODE_PQB)"); if (rcd) return rcd; }
     if (ov) ix->cs->nq = ov->nq;
     if (ix->cs->nq == 0) return fail(DR_E_ARG, "no queries uploaded");
     if (ix->cs->nq > 65536 && !ov) return fail(DR_E_UNSUPPORTED, "resident batches are limited to 65536 queries (dr_search_batch chunks larger ones)");
@@ -1520,7 +1547,7 @@ static int sync_locked(dr_index *ix)
     if (ix->fin_stat.p && ix->last_nq >= 1024) {     // (small batches launch a small pass anyway: no blocking readback for them)
         uint32_t mx = 0;
         HIPCHK(hipMemcpy(&mx, ix->fin_stat.p, 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemset(ix->fin_stat.p, 0, 4));
+        HIPCHK(dr_memset_sync(ix->fin_stat.p, 0, 4));
         ix->fin_hint = std::max<uint32_t>(mx, 16);
     }
     dr_index::BatchSet &bs = ix->sets[ix->last_set];
@@ -1642,7 +1669,7 @@ extern "C" int dr_get_timing(dr_index *ix, dr_timing *out)
 
 
 static int seq_search_locked(dr_index *ix, const void *queries, bool f64, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width, uint32_t mode,
-                             uint32_t band_policy, uint32_t *out_ids, void *out_dist, uint32_t *out_count, dr_stats *stats);
+                             uint32_t band_policy, uint32_t *out_ids, void *out_dist, uint32_t *out_count, dr_stats *stats, uint32_t flags = 0, bool generic = false);
 
 extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t L,
                                uint32_t beam_width, uint32_t mode, uint32_t band_policy, uint32_t flags,
@@ -1652,6 +1679,12 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
     if (!out_ids || !out_dist || !out_count) return fail(DR_E_ARG, "null output buffer");
     if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
     std::lock_guard<std::mutex> lk(ix->mu);
+    // a dimension without compiled kernels (or DR_FORCE_GENERIC=1 on a built one: the test that holds the run-time tree to the compiled trees):
+    // the generic traversal, one wavefront per query
+    if (!ix->kern || getenv("DR_FORCE_GENERIC") != nullptr) {
+        if (mode < DR_MODE_M1 || mode > DR_MODE_M4) return fail(DR_E_UNSUPPORTED, "mode %u: the generic traversal (D = %u) serves M1 ... M4", mode, ix->D);
+        return seq_search_locked(ix, queries, false, nq, k, L, beam_width, mode, band_policy, out_ids, out_dist, out_count, stats, flags, true);
+    }
     if ((band_policy & 0xFFu) == 2u) {
         // the reference's coin flip itself (np.random.random() < 0.2 on numpy's MT19937 stream): a sequential walk, served by the literal kernel
         if (mode != DR_MODE_M1) return fail(DR_E_ARG, "band policy 2 (the literal coin flip) belongs to DR_MODE_M1");
@@ -1688,12 +1721,16 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
             return download_locked(ix, out_ids, out_dist, out_count, stats);
         }
         const bool eager_fin = nq > DR_DIRECT_MAX && ix->direct_fin;
+        bool fin_timed = false;
         if (eager_fin) {
             dr_index::BatchSet &bs = ix->sets[ix->last_set];
             const unsigned fgrid = (unsigned)std::min<uint64_t>(((uint64_t)nq + 3) / 4, (uint64_t)ix->num_cu * 8);
+            HIPCHK(hipEventRecord(bs.fin_start, ix->stream));
             hipLaunchKernelGGL(finalize_kernel, dim3(fgrid), dim3(256), 4 * ((size_t)ix->direct_f->cap + 2 + 64) * 8, ix->stream, *ix->direct_f);
             HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(bs.fin_done, ix->stream));
             HIPCHK(hipMemsetAsync(bs.counter.p + 1, 0, 4, ix->stream));
+            fin_timed = true;
         }
         HIPCHK(hipStreamSynchronize(ix->stream));
         const size_t b_ids = (size_t)nq * k * 4, b_cnt = (size_t)nq * 4, b_st = (size_t)nq * sizeof(KStats);
@@ -1746,8 +1783,16 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
         memcpy(out_dist, hp + b_ids, b_ids);
         memcpy(out_count, hp + 2 * b_ids, b_cnt);
         if (stats) memcpy(stats, hp + 2 * b_ids + b_cnt, b_st);
+        // the pieces of a blocking call (dr_get_timing): the batch's copy, the search kernel (+ table kernel), the tie-order pass queued behind it; the
+        // results were written into the page-locked slab by the kernels themselves (no download copies)
         ix->timing.d2h_ms = 0.0f; ix->timing.finalize_kernel_ms = 0.0f;
-        ix->timing.total_ms = ix->timing.lut_kernel_ms + ix->timing.search_kernel_ms;
+        if (fin_timed) {
+            float fms = 0;
+            const dr_index::BatchSet &bsf = ix->sets[ix->last_set];
+            if (hipEventElapsedTime(&fms, bsf.fin_start, bsf.fin_done) == hipSuccess) ix->timing.finalize_kernel_ms = fms;
+            (void)hipGetLastError();
+        }
+        ix->timing.total_ms = ix->timing.h2d_ms + ix->timing.lut_kernel_ms + ix->timing.search_kernel_ms + ix->timing.finalize_kernel_ms;
         return 0;
     }
     float h2d = 0, ker = 0, fin = 0, d2h = 0;
@@ -1774,29 +1819,37 @@ extern "C" int dr_search_batch(dr_index *ix, const float *queries, uint32_t nq, 
 // The literal sequential kernel (search_f64.hpp): float64 queries (the CLI hands np.array(list): diskrag.py:194, quirk Q8) -- M1 and M2, the two
 // searches the CLI reaches (search_engine.py:566-573) -- and, since round 5, float32 queries with the LITERAL coin flip of the rerank policy
 // (band_policy 2 | seed0 << 8: numpy's MT19937 stream, seeded with seed0 + query index). One wavefront per query, at most 64 queries per launch.
+// Round 6: `generic` = the D = 0 instantiation (the dimension a run-time parameter, numpy's tree walked at run time, M3 and M4 as well): what an
+// index without compiled kernels is searched with.
 static int seq_search_locked(dr_index *ix, const void *queries, bool f64, uint32_t nq, uint32_t k, uint32_t L, uint32_t beam_width, uint32_t mode,
-                             uint32_t band_policy, uint32_t *out_ids, void *out_dist, uint32_t *out_count, dr_stats *stats)
+                             uint32_t band_policy, uint32_t *out_ids, void *out_dist, uint32_t *out_count, dr_stats *stats, uint32_t flags, bool generic)
 {
-    const char *what = f64 ? "float64 search" : "band policy 2 (the literal coin flip)";
-    if (mode != DR_MODE_M1 && mode != DR_MODE_M2) return fail(DR_E_UNSUPPORTED, "%s: modes M1 and M2 only", what);
+    generic = generic || !ix->kern;
+    const char *what = generic ? "the generic traversal" : f64 ? "float64 search" : "band policy 2 (the literal coin flip)";
+    const bool m12 = mode == DR_MODE_M1 || mode == DR_MODE_M2;
+    if (!m12 && !(generic && !f64 && (mode == DR_MODE_M3 || mode == DR_MODE_M4))) return fail(DR_E_UNSUPPORTED, "%s: modes M1 and M2 only", what);
     if (k == 0) return fail(DR_E_ARG, "k must be positive");
     if ((band_policy & 0xFFu) > 2u) return fail(DR_E_ARG, "band policy %u", band_policy & 0xFFu);
-    { const int rcv = need_vectors(ix, what); if (rcv) return rcv; }
-    if (mode == DR_MODE_M1 && ix->m == 0) return fail(DR_E_NOPQ, "mode %u needs PQ data (dr_index_set_pq)", mode);
-    const uint32_t cap = (mode == DR_MODE_M2) ? beam_width : L;
+    if (generic && (flags & ~(DR_F_USE_PQ | DR_F_SQDIST))) return fail(DR_E_UNSUPPORTED, "%s takes DR_F_USE_PQ (M3) and DR_F_SQDIST (M4) only (flags %u)", what, flags);
+    const bool adc_only = mode == DR_MODE_M3 && (flags & DR_F_USE_PQ);
+    if (!adc_only) { const int rcv = need_vectors(ix, what); if (rcv) return rcv; }
+    if ((mode == DR_MODE_M1 || adc_only) && ix->m == 0) return fail(DR_E_NOPQ, "mode %u needs PQ data (dr_index_set_pq)", mode);
+    // result-heap capacity: M1 / M4 L (search_engine.py:468-474, vamana_graph.py:634-638), M2 beam_width (:746-750), M3 k (:586-590)
+    const uint32_t cap = (mode == DR_MODE_M2) ? beam_width : (mode == DR_MODE_M3) ? k : L;
     if (cap == 0) return fail(DR_E_ARG, "result-list capacity is zero (L / beam_width)");
     if (cap > 512) return fail(DR_E_UNSUPPORTED, "result-list capacity %u > 512", cap);
     HIPCHK(hipSetDevice(ix->device));
     { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }
     const uint32_t D = ix->D, CH = 64;
     const size_t esz = f64 ? 8 : 4;
-    const bool pq = (mode == DR_MODE_M1);
+    const bool pq = (mode == DR_MODE_M1) || adc_only;        // (the table sits in LDS)
     // LDS: 2 queries, both heaps, per-expansion arrays, the table, the generator's state; the candidates heap takes what is left
     const size_t fixed = (size_t)2 * D * esz + (size_t)(cap + 2) * (esz + 4) + 64 * esz + 64 * 4 + 64 * 4 + (pq ? (size_t)ix->m * 256 * 4 : 0) + 626 * 4 + 64;
     if (fixed + 1024 * (esz + 4) > 160 * 1024) return fail(DR_E_UNSUPPORTED, "%s does not fit in LDS (D=%u, m=%u, capacity %u)", what, D, ix->m, cap);
     const uint32_t cand_cap = (uint32_t)std::min<size_t>((160 * 1024 - fixed) / (esz + 4), 8192) & ~1u;
     const size_t lds = fixed + (size_t)cand_cap * (esz + 4);
-    const void *kfn = f64 ? ix->kern->search_f64 : ix->kern->search_seq_f32;
+    const void *kfn = generic ? (f64 ? reinterpret_cast<const void *>(&search_seq_kernel<0, double>) : reinterpret_cast<const void *>(&search_seq_kernel<0, float>))
+                              : f64 ? ix->kern->search_f64 : ix->kern->search_seq_f32;
     HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t vis_words = (uint32_t)((ix->N + 31) / 32);
     // scratch kept on the handle (the CLI asks one query per call: no allocation on its path after the first)
@@ -1814,7 +1867,8 @@ static int seq_search_locked(dr_index *ix, const void *queries, bool f64, uint32
         p.codebook = ix->codebook.p; p.perm = ix->perm.p; p.queries = dq.p;
         p.N = ix->N; p.D = D; p.R = ix->R; p.m = ix->m; p.sd = ix->sd; p.medoid = ix->medoid; p.nq = n;
         p.mode = mode; p.k = k; p.cap = cap; p.L = L; p.bw = beam_width; p.policy = band_policy; p.q0 = q0;
-        p.max_steps = pq ? (uint32_t)std::min<uint64_t>((uint64_t)L * 10, ix->N) : 0xFFFFFFFFu;
+        p.max_steps = mode == DR_MODE_M1 ? (uint32_t)std::min<uint64_t>((uint64_t)L * 10, ix->N) : 0xFFFFFFFFu;
+        p.flags = flags; p.chain_major = (generic && ix->kern) ? 1u : 0u;
         p.vis = dvis.p; p.vis_words = vis_words; p.cand_cap = cand_cap;
         p.out_ids = dids.p; p.out_dist = dd.p; p.out_count = dcnt.p; p.stats = dst.p;
         if (hipMemcpyAsync(dq.p, static_cast<const unsigned char *>(queries) + (size_t)q0 * D * esz, (size_t)n * D * esz, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
@@ -1853,7 +1907,8 @@ extern "C" int dr_search_batch_f64(dr_index *ix, const double *queries, uint32_t
     if (!out_ids || !out_dist || !out_count) return fail(DR_E_ARG, "null output buffer");
     if (!queries || nq == 0) return fail(DR_E_ARG, "empty query batch");
     std::lock_guard<std::mutex> lk(ix->mu);
-    return seq_search_locked(ix, queries, true, nq, k, L, beam_width, mode, band_policy, out_ids, out_dist, out_count, stats);
+    return seq_search_locked(ix, queries, true, nq, k, L, beam_width, mode, band_policy, out_ids, out_dist, out_count, stats, 0u,
+                             !ix->kern || getenv("DR_FORCE_GENERIC") != nullptr);
 }
 
 #include "entry_points.inc"

@@ -446,3 +446,76 @@ DEV double pw_run_lane64(const float *__restrict__ c, const double *q, int n)
     for (; i < n; i++) res = d_add(res, sqd64(c[i], q[i]));
     return res;
 }
+
+// ---- any length, the tree evaluated from n AT RUN TIME (round 6: dimensions that have no compiled tree) ------------------------------
+// numpy's pairwise routine literally (numpy/_core/src/umath/loops_utils.h.src @TYPE@_pairwise_sum; oracle/oracle_core.inc pw_sqdiff is the
+// same text): n < 8 sequential from 0; n <= 128 eight accumulators r[j] += a[8 t + j], combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the
+// n % 8 leftovers added one by one; above 128 split at n / 2 rounded down to a multiple of 8 -- the recursion kept on an explicit stack
+// (depth <= 8: n <= 32768). ONE LANE sums ONE run (the generic traversal scores 64 neighbours at a time, a lane each). `pos` (may be null):
+// element i of the run is stored at c[pos[i]] -- the chain-major rows of a built dimension, so that this routine and the compiled trees can
+// be held to each other on the same index (tests/test_gpu_shapes.py). The same bits as pw_row_stream<0, D, D> / pw_run_lane wherever those exist.
+template <typename REAL> DEV REAL rt_sqd(float v, REAL q);
+template <> DEV float rt_sqd<float>(float v, float q) { return sqd(v, q); }
+template <> DEV double rt_sqd<double>(float v, double q) { return sqd64(v, q); }
+DEV float rt_add(float a, float b) { return f_add(a, b); }
+DEV double rt_add(double a, double b) { return d_add(a, b); }
+
+template <typename REAL>
+DEV REAL pw_leaf_rt(const float *__restrict__ c, const u32 *pos, const REAL *q, int off, int n)
+{
+#define DR_RT_EL(i) rt_sqd<REAL>(c[pos ? pos[off + (i)] : (u32)(off + (i))], q[off + (i)])
+    if (n < 8) {
+        REAL res = 0;
+        for (int i = 0; i < n; i++) res = rt_add(res, DR_RT_EL(i));
+        return res;
+    }
+    REAL r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = DR_RT_EL(j);
+    int i = 8;
+    const int lim = n - (n % 8);
+    for (; i < lim; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = rt_add(r[j], DR_RT_EL(i + j));
+    }
+    REAL res = rt_add(rt_add(rt_add(r[0], r[1]), rt_add(r[2], r[3])), rt_add(rt_add(r[4], r[5]), rt_add(r[6], r[7])));
+    for (; i < n; i++) res = rt_add(res, DR_RT_EL(i));
+    return res;
+#undef DR_RT_EL
+}
+
+template <typename REAL>
+DEV REAL pw_run_rt(const float *__restrict__ c, const u32 *pos, const REAL *q, int n)
+{
+    if (n <= 128) return pw_leaf_rt<REAL>(c, pos, q, 0, n);
+    // frames of the recursion: (off, len, stage 0 = enter / 1 = left half running / 2 = right half running, left half's sum)
+    int f_off[9], f_len[9], f_stage[9];
+    REAL f_left[9];
+    int sp = 0;
+    f_off[0] = 0; f_len[0] = n; f_stage[0] = 0;
+    REAL ret = 0;
+    for (;;) {
+        if (f_len[sp] <= 128) {
+            ret = pw_leaf_rt<REAL>(c, pos, q, f_off[sp], f_len[sp]);
+            // return to the callers: a left half hands over to its right half, a right half adds and returns further up
+            for (;;) {
+                if (sp == 0) return ret;
+                sp--;
+                int n2 = f_len[sp] / 2; n2 -= n2 % 8;
+                if (f_stage[sp] == 1) {
+                    f_left[sp] = ret; f_stage[sp] = 2;
+                    f_off[sp + 1] = f_off[sp] + n2; f_len[sp + 1] = f_len[sp] - n2; f_stage[sp + 1] = 0;
+                    sp++;
+                    break;
+                }
+                ret = rt_add(f_left[sp], ret);
+            }
+        } else {
+            if (sp >= 7) return ret;        // (n > 32768: not reachable, the host refuses it)
+            int n2 = f_len[sp] / 2; n2 -= n2 % 8;
+            f_stage[sp] = 1;
+            f_off[sp + 1] = f_off[sp]; f_len[sp + 1] = n2; f_stage[sp + 1] = 0;
+            sp++;
+        }
+    }
+}

@@ -17,6 +17,14 @@
 // 2 | seed0 << 8 draws from the same generator -- init_genrand(seed0 + query index), 53-bit doubles from two 32-bit draws, exactly numpy's
 // legacy np.random.seed / np.random.random -- at the same points of the walk, for float32 (dr_search_batch) and float64
 // (dr_search_batch_f64) queries. Goldens: the reference run UNPATCHED (tests/golden/gen_golden_coinflip.py).
+//
+// Round 6: D = 0 is the GENERIC instantiation -- the dimension is a run-time parameter, the stored rows are in their original element order (or,
+// on an index of a built dimension, read through the chain-major position table), numpy's pairwise tree is evaluated from D at run time by
+// pw_run_rt (numerics.hpp), one LANE per neighbour, and the kernel serves all four reference traversals: M1, M2 and -- D = 0 only -- M3
+// (beam_search_with_pq, vamana_graph.py:535-605: k-sized heap, the trim that pops the BEST candidates, quirk Q9; with DR_F_USE_PQ the squared ADC
+// is the distance) and M4 (greedy_search, :607-640). It is what an index whose dimension has no compiled kernels is searched with
+// (pydiskann's functions take any D); DR_FORCE_GENERIC=1 runs it on a built dimension, where tests/test_gpu_shapes.py holds it bit for bit to
+// the compiled trees. Correct, not fast: one wavefront per query, lane-serial sums.
 #pragma once
 #include "search_kernel.hpp"
 
@@ -54,6 +62,8 @@ struct F64Params {
     u32 *vis; u32 vis_words; u32 cand_cap;
     u32 *out_ids; void *out_dist; u32 *out_count; KStats *stats;      // out_dist: REAL[nq][k]
     u32 q0;     // index of the launch's first query in the caller's batch (the coin flip is seeded per query)
+    u32 flags;  // DR_F_USE_PQ (M3), DR_F_SQDIST (M4): the generic instantiation (D = 0) serves every mode
+    u32 chain_major;   // generic instantiation: the stored rows are a built dimension's chain-major rows (read through perm) / 0: original element order
 };
 
 // (key, id) tuple order: first differing element decides (ids are unique inside a heap)
@@ -104,6 +114,7 @@ template <> struct SeqNum<double> {
     static DEV double mul(double a, double b) { return d_mul(a, b); }
     static DEV double sqrt_(double a) { return __builtin_sqrt(a); }
     static DEV double nan_() { return __longlong_as_double(0x7FF8000000000000ll); }
+    static DEV double root_of_sq(double a) { return __builtin_sqrt(a); }
 };
 template <> struct SeqNum<float> {
     template <int D> static DEV float row(const float *r, const float *q, int j) { return pw_row_stream<0, D, D, false>(r, nullptr, q, j); }
@@ -111,6 +122,7 @@ template <> struct SeqNum<float> {
     static DEV float mul(float a, float b) { return f_mul(a, b); }
     static DEV float sqrt_(float a) { return f_sqrt(a); }
     static DEV float nan_() { return __uint_as_float(0x7FC00000u); }
+    static DEV float root_of_sq(float a) { return (float)__builtin_sqrt((double)a); }      // M3 without PQ returns sqrt(d) taken in double (vamana_graph.py:598)
 };
 
 template <int D, typename REAL>
@@ -122,11 +134,18 @@ __global__ __launch_bounds__(64) void search_seq_kernel(const F64Params p)
     const int oct = lane >> 3, j = lane & 7;
     const u32 qi = blockIdx.x;
     if (qi >= p.nq) return;
+    constexpr bool GEN = (D == 0);
+    const int Dn = GEN ? (int)p.D : D;
     const bool pq = (p.mode == 1u);
+    // (the generic instantiation only) M3 / M4: their own capacity, stop rule, trim and result order; M3 with PQ scores by the squared ADC alone
+    const bool m3 = GEN && p.mode == 3u, m4 = GEN && p.mode == 4u;
+    const bool adc_only = m3 && (p.flags & 1u) != 0u;
+    const bool rooted = (p.mode == 2u) || (m4 && (p.flags & 2u) == 0u);          // np.linalg.norm: the square root of the pairwise sum
+    const bool need_lut = pq || adc_only;
     // LDS carve-up
     REAL *qperm = reinterpret_cast<REAL *>(smem64);                  // chain-major query
-    REAL *qorig = qperm + D;                                         // original order (table rows)
-    REAL *res_k = qorig + D;                                         // results heap: keys = -distance
+    REAL *qorig = qperm + Dn;                                        // original order (table rows)
+    REAL *res_k = qorig + Dn;                                        // results heap: keys = -distance
     REAL *cand_k = res_k + (p.cap + 2);                              // candidates heap: keys = distance   (cap + 2: keeps 8-byte alignment for either type)
     REAL *nb_e = cand_k + p.cand_cap;
     u32 *res_i = reinterpret_cast<u32 *>(nb_e + 64);
@@ -134,23 +153,36 @@ __global__ __launch_bounds__(64) void search_seq_kernel(const F64Params p)
     u32 *nb_id = cand_i + p.cand_cap;
     float *nb_pq = reinterpret_cast<float *>(nb_id + 64);
     float *lut = nb_pq + 64;                                         // m*256 floats when pq
-    u32 *mt = reinterpret_cast<u32 *>(lut + (pq ? (size_t)p.m * 256 : 0));   // [625] MT19937 state + position (the literal coin flip)
+    u32 *mt = reinterpret_cast<u32 *>(lut + (need_lut ? (size_t)p.m * 256 : 0));   // [625] MT19937 state + position (the literal coin flip)
     const bool coin = (p.policy & 0xFFu) == 2u;
     u32 *vbm = p.vis + (size_t)qi * p.vis_words;                     // zeroed by the host before the launch
 
-    for (int i = lane; i < D; i += 64) {
-        const REAL v = reinterpret_cast<const REAL *>(p.queries)[(size_t)qi * D + i];
+    for (int i = lane; i < Dn; i += 64) {
+        const REAL v = reinterpret_cast<const REAL *>(p.queries)[(size_t)qi * Dn + i];
         qorig[i] = v;
         qperm[p.perm[i]] = v;
     }
     WSYNC();
-    if (pq) {
+    if (need_lut) {
         // A2 in float64, stored as float32 (fast_pq.py:307-316)
         const u32 total = p.m * 256;
-        for (u32 e = lane; e < total; e += 64)
-            lut[e] = (float)NUM::run(p.codebook + (size_t)e * p.sd, qorig + (e >> 8) * p.sd, (int)p.sd);
+        for (u32 e = lane; e < total; e += 64) {
+            if constexpr (GEN) lut[e] = (float)pw_run_rt<REAL>(p.codebook + (size_t)e * p.sd, nullptr, qorig + (e >> 8) * p.sd, (int)p.sd);
+            else lut[e] = (float)NUM::run(p.codebook + (size_t)e * p.sd, qorig + (e >> 8) * p.sd, (int)p.sd);
+        }
         WSYNC();
     }
+    // squared ADC of a node, A3's strict order (fast_pq.py:320-328): one lane, one code word
+    auto adc_sq = [&](u32 node) -> float {
+        const u8 *code = p.codes + (size_t)node * p.m;
+        float s = 0.0f;
+        for (u32 jj = 0; jj < p.m; jj++) s = f_add(s, lut[jj * 256 + code[jj]]);
+        return s;
+    };
+    // (generic) the position table of a built dimension's chain-major rows, or none: rows in original order
+    const u32 *rowpos = nullptr;
+    if constexpr (GEN) rowpos = p.chain_major ? p.perm : nullptr;
+    const u32 cand_cap = p.cand_cap;
     if (coin && lane == 0) mt_seed(mt, (p.policy >> 8) + p.q0 + qi);     // np.random.seed(seed0 + query index)
 
     u32 steps = 0, nvisited = 0, nexact = 0, npq = 0, status = 0;
@@ -162,9 +194,15 @@ __global__ __launch_bounds__(64) void search_seq_kernel(const F64Params p)
         const u32 start = p.medoid;
         if (lane == 0) atomicOr(&vbm[start >> 5], 1u << (start & 31));
         nvisited = 1;
-        REAL d0 = NUM::template row<D>(p.vecp + (size_t)start * D, qperm, j);
-        if (!pq) d0 = NUM::sqrt_(d0);
-        nexact = 1;
+        REAL d0;
+        if constexpr (GEN) {
+            if (adc_only) { d0 = (REAL)adc_sq(start); npq = 1; }
+            else { d0 = pw_run_rt<REAL>(p.vecp + (size_t)start * Dn, rowpos, qorig, Dn); if (rooted) d0 = NUM::sqrt_(d0); nexact = 1; }
+        } else {
+            d0 = NUM::template row<(D > 0 ? D : 8)>(p.vecp + (size_t)start * D, qperm, j);
+            if (!pq) d0 = NUM::sqrt_(d0);
+            nexact = 1;
+        }
         if (lane == 0) { hq_push(cand_k, cand_i, cn, d0, start); hq_push(res_k, res_i, rn, -d0, start); }
         cn = 1; rn = 1;
         WSYNC();
@@ -179,7 +217,7 @@ __global__ __launch_bounds__(64) void search_seq_kernel(const F64Params p)
             hq_pop(cand_k, cand_i, n, ck, ci);
             const REAL W = -res_k[0];
             nb_id[0] = ci;
-            nb_id[1] = (rn >= cap && ck > W) ? 1u : 0u;
+            nb_id[1] = ((m4 || rn >= cap) && ck > W) ? 1u : 0u;      // (M4 stops on the worst distance whatever the list holds, vamana_graph.py:621-623)
         }
         cn--;
         WSYNC();
@@ -208,21 +246,27 @@ __global__ __launch_bounds__(64) void search_seq_kernel(const F64Params p)
             WSYNC();
             if (pq) {
                 // A3: strict sequential float32 sum over the sub-quantisers, then sqrt (fast_pq.py:320-333)
-                if (lane < nnew) {
-                    const u8 *code = p.codes + (size_t)nb_id[lane] * p.m;
-                    float s = 0.0f;
-                    for (u32 jj = 0; jj < p.m; jj++) s = f_add(s, lut[jj * 256 + code[jj]]);
-                    nb_pq[lane] = f_sqrt(s);
-                }
+                if (lane < nnew) nb_pq[lane] = f_sqrt(adc_sq(nb_id[lane]));
                 npq += nnew;
             }
-            // exact distances of all new neighbours, 8 per pass (the reference scores only those A4 lets through;
-            // scoring the others changes nothing but work, the counter below follows the reference)
-            for (int r0 = 0; r0 < nnew; r0 += 8) {
-                const int idx = min(r0 + oct, nnew - 1);
-                REAL ev = NUM::template row<D>(p.vecp + (size_t)nb_id[idx] * D, qperm, j);
-                if (!pq) ev = NUM::sqrt_(ev);
-                if (j == 0 && r0 + oct < nnew) nb_e[r0 + oct] = ev;
+            if constexpr (GEN) {
+                // one lane per new neighbour: its whole sum, the tree walked at run time (M3 with PQ: the squared ADC IS the distance)
+                if (lane < nnew) {
+                    REAL ev;
+                    if (adc_only) ev = (REAL)adc_sq(nb_id[lane]);
+                    else { ev = pw_run_rt<REAL>(p.vecp + (size_t)nb_id[lane] * Dn, rowpos, qorig, Dn); if (rooted) ev = NUM::sqrt_(ev); }
+                    nb_e[lane] = ev;
+                }
+                if (adc_only) npq += nnew;
+            } else {
+                // exact distances of all new neighbours, 8 per pass (the reference scores only those A4 lets through;
+                // scoring the others changes nothing but work, the counter below follows the reference)
+                for (int r0 = 0; r0 < nnew; r0 += 8) {
+                    const int idx = min(r0 + oct, nnew - 1);
+                    REAL ev = NUM::template row<(D > 0 ? D : 8)>(p.vecp + (size_t)nb_id[idx] * D, qperm, j);
+                    if (!pq) ev = NUM::sqrt_(ev);
+                    if (j == 0 && r0 + oct < nnew) nb_e[r0 + oct] = ev;
+                }
             }
             WSYNC();
             // the reference's neighbour loop, literally, on lane 0 (search_engine.py:449-474; vamana_graph.py:741-750)
@@ -240,10 +284,10 @@ __global__ __launch_bounds__(64) void search_seq_kernel(const F64Params p)
                         else pass = false;
                         if (!pass) continue;
                     }
-                    ex++;
+                    if (!adc_only) ex++;
                     const REAL e = nb_e[i];
                     if (n_r < cap || e < W) {
-                        if (n_c >= (int)p.cand_cap) { status |= DR_ST_CAND_OVERFLOW; continue; }
+                        if (n_c >= (int)cand_cap) { status |= DR_ST_CAND_OVERFLOW; continue; }
                         hq_push(cand_k, cand_i, n_c, e, nb_id[i]);
                         hq_push(res_k, res_i, n_r, -e, nb_id[i]);
                         if (n_r > cap) { REAL dk; u32 di; hq_pop(res_k, res_i, n_r, dk, di); }
@@ -257,7 +301,14 @@ __global__ __launch_bounds__(64) void search_seq_kernel(const F64Params p)
         }
         // candidates = heapq.nsmallest(beam_width, candidates); heapify (search_engine.py:477-479,
         // vamana_graph.py:753-755): the bw smallest tuples in ascending order, which already is a heap
-        if (p.bw != 0u && cn > (int)p.bw) {
+        if (m3) {
+            // vamana_graph.py:586-593: while len(candidates) > beam_width: heappop(candidates) -- the BEST candidates leave (quirk Q9)
+            if (cn > (int)p.bw) {
+                if (lane == 0) { int n = cn; while (n > (int)p.bw) { REAL dk; u32 di; hq_pop(cand_k, cand_i, n, dk, di); } }
+                cn = (int)p.bw;
+                WSYNC();
+            }
+        } else if (!m4 && p.bw != 0u && cn > (int)p.bw) {
             if (lane == 0) {
                 for (int a = 0; a < (int)p.bw; a++) {
                     int best = a;
@@ -275,16 +326,22 @@ __global__ __launch_bounds__(64) void search_seq_kernel(const F64Params p)
 
     // result extraction by lane 0: M1 stable sort of the heap ARRAY by distance only (search_engine.py:483-488);
     // M2 sorted() on full (distance, id) tuples (vamana_graph.py:758)
+    // (generic: M3 / M4 sort like M1 -- stable, by the key alone, vamana_graph.py:596-598 / :640; M3's key and returned distance are sqrt(d):
+    //  with PQ the float32 root, whose ties between different sums keep heap-array order; without, the root taken in double -- monotone and
+    //  injective on float32 sums, so the order is the sums' own and the root is applied afterwards)
+    const bool by_key = pq || m3 || m4;
     if (lane == 0) {
         for (int i = 0; i < rn; i++) res_k[i] = -res_k[i];
+        if (adc_only) for (int i = 0; i < rn; i++) res_k[i] = (REAL)f_sqrt((float)res_k[i]);
         for (int i = 1; i < rn; i++) {        // insertion sort: stable
             const REAL kk = res_k[i]; const u32 ii = res_i[i];
             int b = i - 1;
-            while (b >= 0 && (pq ? (res_k[b] > kk) : tup_lt(kk, ii, res_k[b], res_i[b]))) {
+            while (b >= 0 && (by_key ? (res_k[b] > kk) : tup_lt(kk, ii, res_k[b], res_i[b]))) {
                 res_k[b + 1] = res_k[b]; res_i[b + 1] = res_i[b]; b--;
             }
             res_k[b + 1] = kk; res_i[b + 1] = ii;
         }
+        if (m3 && !adc_only) for (int i = 0; i < rn; i++) res_k[i] = NUM::root_of_sq(res_k[i]);
     }
     WSYNC();
     const int kout = min(rn, (int)p.k);

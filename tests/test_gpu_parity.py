@@ -215,8 +215,14 @@ def test_error_behaviour():
         bad = g.adj.copy()
         bad[3, 2] = 1000
         HipIndex.create(g.vectors, bad, g.medoid)
-    with pytest.raises(DiskragHipError):       # unsupported dimension
-        HipIndex.create(np.zeros((4, 7), dtype=np.float32), np.zeros((4, 2), dtype=np.uint32), 0)
+    # a dimension without compiled kernels is served by the generic traversal since round 6 (tests/test_gpu_shapes.py); what needs a compiled one says so
+    odd = HipIndex.create(np.zeros((4, 7), dtype=np.float32), np.zeros((4, 2), dtype=np.uint32), 0)
+    with pytest.raises(DiskragHipError) as e:
+        odd.build_vamana(L_build=4)
+    assert e.value.code == _ffi.E_UNSUPPORTED
+    odd.close()
+    with pytest.raises(DiskragHipError):       # a dimension beyond the generic traversal's stack (32768)
+        HipIndex.create(np.zeros((1, 40000), dtype=np.float32), np.zeros((1, 2), dtype=np.uint32), 0)
 
 
 def test_large_batch_is_chunked():

@@ -97,3 +97,100 @@ def test_every_built_dimension(D, m):
                     _check(ix, x, adj, medoid, cb, codes, q, mode, k, L, bw, flags=fl, pol=pol)
         finally:
             ix.close()
+
+
+# ---- dimensions without compiled kernels (round 6): the generic traversal, numpy's pairwise tree evaluated from D at run time ------------------
+def _toy_index(N, D, m, R, seed, pad):
+    """a small kNN + random graph, a sampled codebook and its code words, all in numpy (the builder needs a compiled dimension; any graph serves a
+    parity test -- the oracle walks the same rows)"""
+    rs = np.random.RandomState(seed)
+    x = rs.randn(N, D).astype(np.float32)
+    x[: N // 2] += 2.0 * rs.randn(1, D).astype(np.float32)
+    q = (x[rs.choice(N, 24, replace=False)] + 0.1 * rs.randn(24, D)).astype(np.float32)
+    n2 = (x.astype(np.float64) ** 2).sum(1)
+    d2 = n2[:, None] + n2[None, :] - 2.0 * x.astype(np.float64) @ x.astype(np.float64).T
+    np.fill_diagonal(d2, np.inf)
+    knn = np.argsort(d2, axis=1)[:, : R - 5].astype(np.uint32)
+    adj = np.full((N, R), pad, dtype=np.uint32)
+    adj[:, : R - 5] = knn
+    adj[:, R - 5: R - 2] = rs.randint(0, N, size=(N, 3)).astype(np.uint32)          # (repeats of a kNN entry happen: first-occurrence masks at work)
+    medoid = int(np.argmin(((x - x.mean(0)) ** 2).sum(1)))
+    sd = D // m
+    cb = np.stack([x[rs.choice(N, 256, replace=False), j * sd:(j + 1) * sd] for j in range(m)]).astype(np.float32)       # [m][256][sd]
+    codes = np.empty((N, m), dtype=np.uint8)
+    for j in range(m):
+        sub = x[:, j * sd:(j + 1) * sd].astype(np.float64)
+        dd = (sub ** 2).sum(1)[:, None] + (cb[j].astype(np.float64) ** 2).sum(1)[None, :] - 2.0 * sub @ cb[j].astype(np.float64).T
+        codes[:, j] = np.argmin(dd, axis=1)
+    return x, q, adj, medoid, cb, codes
+
+
+GENERIC_CASES = ((1, 10, 40, 8, 0, 0), (1, 10, 40, 0, 1, 0), (1, 5, 12, 4, 0, 0), (2, 8, 0, 8, 0, 0), (2, 10, 0, 32, 0, 0),
+                 (3, 5, 5, 8, 0, 1), (3, 10, 10, 16, 0, 1), (3, 5, 5, 8, 0, 0), (4, 10, 30, 0, 0, 0), (4, 10, 30, 0, 0, 2))
+
+
+def _check_generic(ix, x, adj, medoid, cb, codes, q):
+    from oracle import pyoracle as orc
+    for (mode, k, L, bw, pol, fl) in GENERIC_CASES:
+        omode = {1: orc.M1, 2: orc.M2, 3: orc.M3, 4: orc.M4}[mode]
+        # (the device sums M3-without-PQ and the Cython twin of M4 in numpy's pairwise order: the reference's -ffast-math order is unpinned)
+        oflags = (orc.F_USE_PQ if (mode == 3 and fl & 1) else 0) | (orc.F_PAIRWISE if mode in (3, 4) else 0) | (orc.F_CYTHON if (mode == 4 and fl & 2) else 0)
+        ids, dist, cnt, st = ix.search_batch(q, k, L=L, beam_width=bw, mode=mode, band_policy=pol, flags=fl)
+        oi, od, oc, ost = orc.search_batch(x, adj, q, medoid, omode, k, L=L, bw=bw, policy=pol, flags=oflags, codes=codes, codebook=cb, nthreads=8)
+        tag = (x.shape[1], mode, k, L, bw, pol, fl)
+        assert (st["status"] == 0).all(), tag
+        assert np.array_equal(cnt, oc) and np.array_equal(ids, oi), tag
+        valid = oi != PAD
+        assert np.array_equal(dist[valid].view(np.uint32), od[valid].astype(np.float32).view(np.uint32)), tag       # every mode bit for bit: one summation order
+        assert np.array_equal(np.stack([st["steps"], st["visited"], st["exact"], st["pq"]], axis=1), ost), tag
+
+
+@pytest.mark.parametrize("D,m", [(48, 8), (100, 10), (384, 32), (512, 8), (1024, 4), (20, 4), (7, 1), (1000, 8)])
+def test_dimensions_without_compiled_kernels(D, m):
+    """pydiskann's searches take any D (vamana_graph.py:719-760, 535-640); the engine compiles eight. Any other dimension gets an index in original
+    element order and the generic traversal (search_f64.hpp, D = 0): M1 / M2 / M3 (PQ and exact) / M4 (norm and squared) against the oracle, ids,
+    distance bits, counts and counters -- D not a multiple of 8 (numpy's leftover elements), sub-vectors longer than 128 (the tree's recursion inside
+    a table row), D below 8 (the sequential form); float64 queries for M1 / M2 as the CLI hands them; what needs a compiled dimension says so."""
+    from diskrag_amd import HipIndex, _ffi
+    from oracle import pyoracle as orc
+    for pad in (0, int(PAD)):
+        x, q, adj, medoid, cb, codes = _toy_index(1200, D, m, 16, 100 + D, pad)
+        ix = HipIndex.create(x, adj, medoid)
+        ix.set_pq(cb, codes)
+        try:
+            _check_generic(ix, x, adj, medoid, cb, codes, q)
+            if pad == 0:
+                q64 = q.astype(np.float64) + 1e-9
+                for (mode, k, L, bw) in ((1, 10, 40, 8), (2, 8, 0, 8)):
+                    ids, dist, cnt, st = ix.search_batch_f64(q64, k, L=L, beam_width=bw, mode=mode)
+                    oi, od, oc, ost = orc.search_batch(x, adj, q64, medoid, {1: orc.M1, 2: orc.M2}[mode], k, L=L, bw=bw, codes=codes, codebook=cb, nthreads=8)
+                    assert np.array_equal(ids, oi) and np.array_equal(cnt, oc), (D, mode)
+                    assert np.array_equal(dist[oi != PAD].view(np.uint64), od[oi != PAD].view(np.uint64)), (D, mode)
+                for call in (lambda: ix.build_vamana(L_build=20), lambda: ix.bruteforce_topk(q, 5), lambda: ix.exact_distances(q, np.arange(4, dtype=np.uint32)),
+                             lambda: ix.search_batch(q, 5, L=20, mode=_ffi.MODE_PQB), lambda: ix.search_submit(q, 5, L=20).wait()):
+                    with pytest.raises(_ffi.DiskragHipError) as e:
+                        call()
+                    assert e.value.code == _ffi.E_UNSUPPORTED
+        finally:
+            ix.close()
+
+
+@pytest.mark.parametrize("D,m", [(32, 8), (64, 16), (96, 16), (128, 32), (256, 32), (768, 32), (960, 48), (1536, 32)])
+def test_the_run_time_tree_equals_the_compiled_trees(D, m, monkeypatch):
+    """On the eight built dimensions the generic traversal (DR_FORCE_GENERIC=1: rows read through the chain-major position table) and the compiled
+    kernels return the same ids, distance bits and counters -- and both equal the oracle."""
+    from diskrag_amd import HipIndex
+    x, q, adj, medoid, cb, codes = _toy_index(1200, D, m, 16, 300 + D, 0)
+    ix = HipIndex.create(x, adj, medoid)
+    ix.set_pq(cb, codes)
+    try:
+        monkeypatch.setenv("DR_FORCE_GENERIC", "1")
+        _check_generic(ix, x, adj, medoid, cb, codes, q)
+        a = {c: ix.search_batch(q, c[1], L=c[2], beam_width=c[3], mode=c[0], band_policy=c[4], flags=c[5]) for c in GENERIC_CASES}
+        monkeypatch.delenv("DR_FORCE_GENERIC")
+        for c, (ids, dist, cnt, st) in a.items():
+            i2, d2, c2, s2 = ix.search_batch(q, c[1], L=c[2], beam_width=c[3], mode=c[0], band_policy=c[4], flags=c[5])
+            assert np.array_equal(ids, i2) and np.array_equal(dist.view(np.uint32), d2.view(np.uint32)) and np.array_equal(cnt, c2), (D, c)
+            assert all(np.array_equal(st[f], s2[f]) for f in ("steps", "visited", "exact", "pq")), (D, c)
+    finally:
+        ix.close()
