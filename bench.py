@@ -44,6 +44,14 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy reaches
 
+# (L, beam_width, rerank depth; 0 = the whole list) of DR_MODE_PQB | DR_F_RERANK at recall@10 >= 0.95: "bench" = the default bench-scale index
+# (c3 1M, c4 4M points), "full" = the configuration's own size (from `full_from` points on) -- scripts/op_rerank_top.py, profiles/r06/
+# c3 1M: L = 100 no trim, rerank of the ADC top 72: 3.46 M QPS resident / 3.65-3.73 M as a stream at recall 0.959 (the whole list: 0.977 at 3.1 M);
+# c3 10M: the rerank depth IS the recall (top 200 of L = 250: 0.936; 250: 0.9504; L = 300 top 200: 0.943): L = 250 whole list, 1.10 M / 1.25 M;
+# c4 4M: L = 200, beam_width 8: 4.8 M / 6.65 M at 0.955 (96-d rows: the rerank is a tenth of the call, its depth buys nothing)
+OPERATING_POINTS = {"c3": {"bench": (100, 0, 72), "full": (250, 0, 0), "full_from": 5_000_000},
+                    "c4": {"bench": (200, 8, 0), "full": (400, 32, 0), "full_from": 50_000_000}}
+
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
@@ -84,17 +92,33 @@ def parse_args(argv=None):
                          "--num-queries batches, every batch cut into contiguous slices of nq/N queries, one per rank")
     ap.add_argument("--pq-scan-codes", type=int, default=64_000_000, help="code words of the isolated PQ-scan measurement (config.pq_scan)")
     ap.add_argument("--blocking-calls", type=int, default=24, help="blocking dr_search_batch calls timed for config.qps_blocking_call (median)")
+    ap.add_argument("--rerank-top", dest="rerank_top", type=int, default=None,
+                    help="c3 / c4: rerank only the n list entries with the smallest ADC (DR_F_RERANK_TOP); default: the operating point's; 0 = the whole list")
+    ap.add_argument("--full-size", action="store_true",
+                    help="c3 / c4 / c5: the configuration's own size on ONE MI355X (c3 10 000 000 x 1536: ~9 min of set-up; c4 100 000 000 x 96: ~12 min; "
+                         "c5 one 125 000 000-point shard of the 1B x 1536 shape: ~25 min) instead of the bench-scale default")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
     # the shape of the configuration (BASELINE.json configs[1] / configs[4]) unless given
     dflt = {"c2": dict(dim=128, R=64, L=100, bw=8, L_build=100), "c5": dict(dim=1536, R=128, L=100, bw=32, L_build=128),
-            # (the operating points of the full-size runs, profiles/r04/op_c3_*.jsonl / op_c4_*.jsonl and profiles/r05/)
-            "c3": dict(dim=1536, R=64, L=250, bw=0, L_build=100), "c4": dict(dim=96, R=64, L=400, bw=32, L_build=100)}[args.config]
+            "c3": dict(dim=1536, R=64, L_build=100), "c4": dict(dim=96, R=64, L_build=100)}[args.config]
+    given = argv if argv is not None else sys.argv
     if args.config in ("c3", "c4"):
-        if args.n == 1_000_000 and "--num-vectors" not in (argv if argv is not None else sys.argv):
+        if args.n == 1_000_000 and "--num-vectors" not in given:
             args.n = 1_000_000 if args.config == "c3" else 4_000_000
-        if args.config == "c4" and "--m" not in (argv if argv is not None else sys.argv):
+        if args.full_size:
+            args.n = 10_000_000 if args.config == "c3" else 100_000_000
+        if args.config == "c4" and "--m" not in given:
             args.m = 16
+        # The metric reads "QPS @ recall@10 >= 0.95": the default (L, beam_width, rerank depth) is the fastest measured point at or above 0.95 of
+        # an index of THIS size (profiles/r06/op_rerank_top_*.jsonl; the bench-scale index reaches the bar with a shorter list than the full-size one)
+        op = OPERATING_POINTS[args.config]
+        pt = op["full"] if args.n >= op["full_from"] else op["bench"]
+        if args.L is None: args.L = pt[0]
+        if args.bw is None: args.bw = pt[1]
+        if args.rerank_top is None: args.rerank_top = pt[2] if (args.L, args.bw) == (pt[0], pt[1]) else 0
+    if args.config == "c5" and args.full_size:
+        args.n = 125_000_000
     for name, v in dflt.items():
         if getattr(args, name) is None:
             setattr(args, name, v)
@@ -707,13 +731,16 @@ def worker_c2(args, rk):
 
     # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 read
     # correction applied): collected offline on this same workload by scripts/profile_run.sh, committed under profiles/
-    traffic, traffic_src = None, None
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    traffic, traffic_src, traffic_2 = None, None, None
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         pmc = ROOT / "profiles" / rnd / ("pmc_traffic.json" if args.rows == "auto" else "pmc_traffic_f32_rows.json")
         if traffic is None and pmc.exists() and (args.n, nq, D, args.R, args.L, args.m) == (1_000_000, 10_000, 128, 64, 100, 32):
-            rec = json.loads(pmc.read_text()).get("beam_width_%d" % args.bw)
+            doc = json.loads(pmc.read_text())
+            rec = doc.get("beam_width_%d" % args.bw)
             if rec and (rnd != "r01" or variant == 13):
                 traffic = rec["hbm_bytes_per_launch"]
+                # (round 6: the counters were also collected with TWO batches per launch, the shape of the bench's coalesced launches)
+                traffic_2 = (doc.get("queries_per_launch_20000") or {}).get("hbm_bytes_per_launch") if args.bw == 8 else None
                 traffic_src = ("profiles/%s/" + pmc.name + ": rocprofv3 --pmc read requests by size (TCC_EA0_RDREQ_32B/64B/128B; FETCH_SIZE x2 before round 4) + WRITE_SIZE, separate passes over scripts/pmc_target.py "
                                "-- the same workload and build, collected by scripts/profile_run.sh in ANOTHER run on another box of the pool (a PMC pass "
                                "cannot share a process with the timed region), one batch per launch there: scaled by this run's batches per launch "
@@ -726,7 +753,8 @@ def worker_c2(args, rk):
     alg_kernel_1 = (a_k - 4 * 256 * D) / nb + 4 * 256 * D
     achieved = alg_kernel / (k_ms * 1e-3) / 1e9
     if traffic is not None:
-        traffic = traffic * per_launch      # the PMC passes run one batch per launch; the counters are linear in the queries of a launch
+        # the PMC passes ran one (and, since round 6, two) batches per launch; this run's launches hold `per_launch` batches: linear in between
+        traffic = traffic + (per_launch - 1.0) * (traffic_2 - traffic) if traffic_2 else traffic * per_launch
     # one launch per batch, PIPE_DEPTH in flight (how rounds 2-3 ran the headline): the same stream without coalescing
     one_per_launch = None
     if not args.headline_only:
@@ -955,8 +983,13 @@ def worker_shape(args, rk):
         del x
     qn = np.linalg.norm(q_all[:64].astype(np.float64), axis=1)
     ip = _ffi.F_IP if c3 and np.abs(qn * qn - 1.0).max() < 5e-4 else 0       # c3 is named an inner-product config: unit-norm rows and queries
-    kw = dict(L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK | ip)
-    kw2 = dict(L=500, beam_width=64, mode=_ffi.MODE_M1) if not c3 else None      # c4: the reference-faithful M1 beside it
+    top = int(args.rerank_top or 0)
+    kw = dict(L=args.L, beam_width=args.bw, mode=_ffi.MODE_PQB, flags=_ffi.F_RERANK | ip | _ffi.F_RERANK_TOP(top if top < args.L else 0))
+    # the reference-faithful M1 (_pq_accelerated_graph_search, search_engine.py:398-506) beside it, at ITS recall-0.95 point of the full-size index
+    # (c4 100M: L = 500, beam_width 64; c3 10M: L = 200, beam_width 64 -- profiles/r04/op_c4_100M_d96_m1fine.jsonl, op_c3_10M_d1536_bwsweep.jsonl)
+    kw2 = dict(L=500, beam_width=64, mode=_ffi.MODE_M1) if not c3 else dict(L=200, beam_width=64, mode=_ffi.MODE_M1)
+    if args.no_secondary:
+        kw2 = None
     qb = []
     for b in range(nb):
         a = _ffi.pinned_empty((nq, D), np.float32)
@@ -1008,12 +1041,34 @@ def worker_shape(args, rk):
     # the rerank pass of c3 runs in its own kernel: its rows are not the traversal kernel's
     alg_search_launch = float((per_q - X * 4.0 * D).mean()) * qpl + 4.0 * 256 * D
     achieved = alg_search_launch / (k_ms * 1e-3) / 1e9
+    # one resident launch per batch, nothing overlapped: where a batch's time goes (traversal kernel, table kernel, rerank pass + the rest)
+    ix.batch_select(15); ix.batch_upload(qb[0])
+    ix.batch_run(k, **kw); ix.batch_sync()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        ix.batch_run(k, **kw)
+    ix.batch_sync()
+    res_ms = (time.perf_counter() - t1) / 3 * 1e3
+    tmr = ix.timing()
+    resident_pieces = {"ms_per_batch": res_ms, "traversal_kernel": float(tmr["search_kernel_ms"]), "table_kernel": float(tmr["lut_kernel_ms"]),
+                       "rerank_pass_and_rest": res_ms - float(tmr["search_kernel_ms"]) - float(tmr["lut_kernel_ms"]), "qps_resident": nq / (res_ms * 1e-3),
+                       "rows_reranked_per_query": float(X.mean())}
+    ix.batch_select(0)
+    # HBM traffic of the traversal kernel from the PMC counters, collected offline on this workload (scripts/profile_run_r06.sh, separate --pmc passes;
+    # one 10 000-query batch per launch there: scaled by this run's queries per launch)
+    traffic, traffic_src = None, None
+    pmc = ROOT / "profiles" / "r06" / ("pmc_pqb_%s.json" % args.config)
+    if pmc.exists():
+        rec = json.loads(pmc.read_text())
+        if (rec.get("N"), rec.get("L"), rec.get("bw")) == (n, args.L, args.bw) and rec.get("hbm_bytes_per_launch"):
+            traffic = rec["hbm_bytes_per_launch"] * qpl / 10000.0
+            traffic_src = "profiles/r06/%s: rocprofv3 --pmc TCC_EA0_RDREQ by size + WRITE_SIZE over scripts/pmc_target_shape.py (same index recipe, 10 000 queries per launch), scaled to this run's queries per launch" % pmc.name
     m1_ref = None
     if kw2 is not None:
         stream(2 * depth, kw2); ix.batch_sync()
         el2, _ = stream(max(8, n_sub // 2), kw2); ix.batch_sync()
         o2 = [ix.search_batch(qb[b], k, **kw2) for b in range(min(nb, 2))]
-        m1_ref = {"what": "DR_MODE_M1 L=500 beam_width=64: the reference-faithful _pq_accelerated_graph_search at ITS recall-0.95 point of the full-size index",
+        m1_ref = {"what": "DR_MODE_M1 L=%d beam_width=%d: the reference-faithful _pq_accelerated_graph_search at ITS recall-0.95 point of the full-size index" % (kw2["L"], kw2["beam_width"]),
                   "qps": nq * max(8, n_sub // 2) / el2, "recall_at_10": recall_at_k(np.concatenate([o[0] for o in o2]), gt, k),
                   "kernel_ms_per_launch": float(ix.timing()["search_kernel_ms"]), "variant": ix.timing()["variant"]}
     out = {"metric": "QPS @ recall@10>=0.95, %s, PQ traversal + full-precision rerank, batch=%d" % ("d=1536 unit-norm (inner product = L2)" if c3
@@ -1024,7 +1079,7 @@ def worker_shape(args, rk):
            "config": {"workload": "%s-shaped synthetic (BASELINE configs[%d]): N=%d d=%d unit-norm mixture (4096 clusters), R=%d, PQ m=%d, %s L=%d beam_width=%s, k=%d, "
                                   "batch=%d queries; a step = %d batches; host memory -> host memory (dr_search_submit/wait, %d submits in flight, %.0f queries per launch); "
                                   "index built on the device (dr_build_vamana L_build=%d); full size = %d points"
-                                  % (args.config, 2 if c3 else 3, n, D, R, m, "DR_MODE_PQB | DR_F_RERANK" + (" | DR_F_IP" if ip else ""), args.L, args.bw or None, k, nq, bps, depth, qpl,
+                                  % (args.config, 2 if c3 else 3, n, D, R, m, "DR_MODE_PQB | DR_F_RERANK" + (" | DR_F_IP" if ip else "") + (" | DR_F_RERANK_TOP(%d)" % top if 0 < top < args.L else ""), args.L, args.bw or None, k, nq, bps, depth, qpl,
                                      args.L_build, 10_000_000 if c3 else 100_000_000),
                       "recall_at_10": float(np.mean(recalls)), "build_seconds": build_s, "pq_seconds": pq_s, "parallelism": "query-sharded replicas x%d" % rk.world,
                       "per_rank_seconds": times, "queries_per_launch": qpl, "kernel_ms_per_launch": k_ms, "kernel_ms_per_10k_queries": k_ms * 10000.0 / qpl,
@@ -1032,9 +1087,11 @@ def worker_shape(args, rk):
                       "per_query": {"expansions": float(S.mean()), "code_words_scored": float(V.mean()), "full_precision_rows_scored": float(X.mean()),
                                     "algorithmic_bytes": float(per_q.mean())},
                       "launch": {k_: tm[k_] for k_ in ("variant", "grid", "block", "lds_bytes", "waves_per_cu")},
+                      "rerank_top": top if 0 < top < args.L else args.L, "one_resident_batch_ms": resident_pieces,
                       "m1_reference_faithful": m1_ref},
            "roofline": {"bound": "hbm", "kernel": "pqb_search_kernel (DR_MODE_PQB traversal; the rerank pass is its own kernel)",
-                        "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                        "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                        "hbm_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_search_launch, "queries_per_launch": qpl,
                         "whole_call_algorithmic_bytes_per_launch": alg_launch,
                         "note": "algorithmic bytes = SURVEY 8d's B_q from the engine's per-query counters x the queries of a launch; these traversals are bound by "
@@ -1045,7 +1102,7 @@ def worker_shape(args, rk):
         adj = ix.get_adjacency()
         ns = min(args.cpu_sample, nq)
         q0 = np.array(qb[0][:ns])
-        omode, oflags = orc.PQB, orc.F_RERANK | (orc.F_IP if ip else 0)
+        omode, oflags = orc.PQB, orc.F_RERANK | (orc.F_IP if ip else 0) | orc.F_RERANK_TOP(top if top < args.L else 0)
         t2 = time.perf_counter()
         oids, odist, ocnt, ost = orc.search_batch(x, adj, q0, medoid, omode, k, L=args.L, bw=args.bw, flags=oflags, codes=codes, codebook=cb, nthreads=cores)
         cpu_s = time.perf_counter() - t2
@@ -1186,6 +1243,42 @@ def worker_c5(args, rk):
                                         "waves_per_cu": tm["waves_per_cu"]}}}
     if recall < args.min_recall:
         raise RuntimeError(f"c5: recall@{k} vs the brute-force ADC ranking = {recall:.4f} is below {args.min_recall}")
+    # What a USABLE PQ-only index costs: at m = 32 a 1536-d code word keeps recall@10 against the exact neighbours at the quantiser's
+    # ceiling (0.2-0.5); the same shard with m = 64 (sub-vectors of 24 elements, 64-byte code words, a 64-KiB table per query: the kernel with 32
+    # table rows in registers and 32 in LDS) -- one rank, the same stream, points regenerated from the stream (bench scale only)
+    m64 = None
+    if rk.world == 1 and not args.no_secondary and m == 32 and n_s <= 8_000_000:
+        t0 = time.time()
+        sample = gen.draw(0, min(262144, stride))
+        tmp = HipIndex.create_empty(sample, R=R, device=device)
+        cb64, _ = tmp.pq_train_ex(64, n_sample=50000, max_iter=15, n_init=1, seed=5)
+        tmp.close()
+        del sample
+        sh64 = HipIndex.create_codes_empty(n_s, D, R, cb64, device=device)
+        for r0 in range(0, n_s, ch):
+            sh64.encode_rows(gen.draw(rk.rank * stride + r0, min(ch, n_s - r0)), r0)
+        _, b64 = sh64.build_vamana_pq(L_build=args.L_build, alpha=1.2, passes=2, seed=7)
+        g64, _, _ = sh64.pq_scan_topk(q[:ngt], k)
+        sh64.batch_upload(q)
+        pts = []
+        for (L64, bw64) in ((args.L, args.bw), (150, 32), (200, 32)):
+            kw64 = dict(L=L64, beam_width=bw64, mode=_ffi.MODE_PQB)
+            sh64.batch_run(k, **kw64); sh64.batch_sync()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                sh64.batch_run(k, **kw64)
+            sh64.batch_sync()
+            dt = (time.perf_counter() - t1) / 3
+            i64 = sh64.batch_download()[0]
+            t64 = sh64.timing()
+            pts.append({"L": L64, "beam_width": bw64, "qps_resident": nq / dt, "kernel_ms": t64["search_kernel_ms"], "table_kernel_ms": t64["lut_kernel_ms"],
+                        "waves_per_cu": t64["waves_per_cu"], "recall_at_10_vs_bruteforce_adc": recall_at_k(i64[:ngt], g64.astype(np.uint32), k),
+                        "recall_at_10_vs_exact_neighbours": recall_at_k((i64[:ngt].astype(np.int64) + base).astype(np.uint32), gt_exact, k)})
+        m64 = {"m": 64, "code_bytes": 64, "setup_seconds": time.time() - t0, "graph_build_seconds": b64,
+               "adc_ranking_recall_at_10_vs_exact_neighbours": recall_at_k((g64.astype(np.int64) + base).astype(np.uint32), gt_exact, k), "points": pts,
+               "m32_same_launch_shape": {"note": "the m = 32 shard of this line, one resident 10k launch", "kernel_ms": tm["search_kernel_ms"], "waves_per_cu": tm["waves_per_cu"]}}
+        sh64.close()
+    out["config"]["m64"] = m64
     comm.close()
     sh.close()
     if rk.rank == 0:

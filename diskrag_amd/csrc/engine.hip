@@ -267,6 +267,19 @@ struct dr_index {
     bool hold_always = false;     // dr_debug_hold: submits are only launched when full / flushed / waited for (tests)
     uint64_t pipe_launches = 0, pipe_tickets = 0, pipe_max_tickets = 0, pipe_queries = 0;   // dr_pipeline_stats
     hipStream_t up_stream = nullptr, down_stream = nullptr;
+    // A second search lane (DR_TWO_LANES=1; A/B of round 6, VERDICT r5 item 2 ii): consecutive launches of the pipelined path alternate between
+    // `stream` and `stream2`, each lane with its own visited words and table scratch, so that the tail of one launch -- persistent
+    // wavefronts running out of tickets -- is filled by the head of the next. A launch takes lane 1 only when it repeats the parameters of
+    // the lane-0 launch before it (nothing to prepare: byte rows, bit order, regime are settled) and is ordered behind that launch's
+    // preparation by `prep_ev`, recorded on lane 0 right before its search kernel.
+    hipStream_t stream2 = nullptr;
+    hipEvent_t prep_ev = nullptr;
+    bool two_lanes = false, prep_recorded = false;
+    int lane_req = 0;             // lane of the launch being queued (set by launch_group_locked around run_locked)
+    uint64_t lane0_sig = 0;       // parameters of the last launch queued on lane 0 (0: none)
+    uint32_t lane_toggle = 0;
+    DevBuf<uint32_t> vis2, vis_epoch2;
+    DevBuf<float> lut2;
     uint32_t last_nq = 0;         // batch size of the last launch (dr_batch_download)
     DevBuf<uint32_t> vis, vis_epoch;   // visited words [slots][vis_words] + the per-slot query stamp (search_kernel.hpp)
     // Disk tier of the full-precision rows (dr_index_attach_row_file; the reference's MMapNodeReader, io/diskann_persist.py:201-234): a PQ-only index
@@ -365,6 +378,8 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     HIPCHK(hipStreamCreateWithFlags(&ix->fstream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ix->up_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ix->down_stream, hipStreamNonBlocking));
+    ix->two_lanes = getenv("DR_TWO_LANES") != nullptr;
+    if (ix->two_lanes) { HIPCHK(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&ix->prep_ev, hipEventDisableTiming)); }
     for (auto &gr : ix->groups) { HIPCHK(hipEventCreateWithFlags(&gr.up_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&gr.down_done, hipEventDisableTiming)); }
     for (auto &e : ix->ev) HIPCHK(hipEventCreate(&e));
     for (auto &pr : ix->kev) { HIPCHK(hipEventCreate(&pr[0])); HIPCHK(hipEventCreate(&pr[1])); HIPCHK(hipEventCreate(&pr[2])); }
@@ -565,8 +580,10 @@ extern "C" void dr_index_close(dr_index *ix)
     if (ix && ix->row_pin) { (void)hipHostFree(ix->row_pin); ix->row_pin = nullptr; }
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) if (st) (void)hipStreamSynchronize(st);
-    ix->lut.release();
+    for (hipStream_t st : { ix->up_stream, ix->stream, ix->stream2, ix->fstream, ix->down_stream }) if (st) (void)hipStreamSynchronize(st);
+    ix->lut.release(); ix->lut2.release(); ix->vis2.release(); ix->vis_epoch2.release();
+    if (ix->prep_ev) (void)hipEventDestroy(ix->prep_ev);
+    if (ix->stream2) (void)hipStreamDestroy(ix->stream2);
     ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release(); ix->nbcodes.release(); ix->sdc.release();
     ix->perm.release(); ix->vis.release(); ix->vis_epoch.release();
     for (auto &qs : ix->slots) qs.release();
@@ -1044,8 +1061,10 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // ONE search stream per handle. (Round 3 tried a second one for small pipelined batches, with its own visited-set scratch:
     // slower -- profiles/r03/ab/ab_small_batches_two_search_lanes.json, and the kernel trace of it in profiles/r04/ -- and removed;
     // small submits are coalesced into one launch instead, dr_search_submit.)
-    hipStream_t st = ix->stream;
-    DevBuf<uint32_t> &vis = ix->vis, &vis_epoch = ix->vis_epoch;
+    const int lane1 = (!ov && ix->two_lanes && ix->lane_req == 1) ? 1 : 0;
+    hipStream_t st = lane1 ? ix->stream2 : ix->stream;
+    DevBuf<uint32_t> &vis = lane1 ? ix->vis2 : ix->vis, &vis_epoch = lane1 ? ix->vis_epoch2 : ix->vis_epoch;
+    if (lane1 && ix->prep_recorded) HIPCHK(hipStreamWaitEvent(st, ix->prep_ev, 0));
 
     const int sc = cap <= 64 ? 0 : cap <= 128 ? 1 : cap <= 256 ? 2 : cap <= 512 ? 3 : 4;
     // kernel variant (variants.hpp): the first available variant of the mode's preference list whose LDS footprint
@@ -1308,6 +1327,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     p.res_keys = bs.res_keys.p; p.res_n = bs.res_n.p; p.stats = bs.stats.p;
     p.tie_list = bs.tie.p; p.tie_count = bs.counter.p + 1;
     p.log = bs.log.p; p.logcap = logcap;
+    if (getenv("DR_NO_LOG") != nullptr) p.logcap = 0;      // timing / counter experiment only (with DR_SKIP_FINALIZE=1): no insert log is written, the tie order of tied queries is then wrong
     p.out_ids = bs.out_ids.p; p.out_dist = bs.out_dist.p; p.out_count = bs.out_count.p;
     // (small blocking call: outputs land in the page-locked slab -- not on the one call per list-size class whose counters are read back below)
     const bool direct = ix->direct && !ov && !(mode == DR_MODE_M1 && ix->adc_live_sc[sc] < 0);
@@ -1373,17 +1393,18 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     if (lat) ix->lat_sc = sc;
     if (!lat) bs.ticket_base += nq;      // (variant 18 walks its queries by workgroup index: no tickets drawn)
     if (!ov && ix->kev_pending == dr_index::KEV) harvest_kernel_times(ix, false);
-    if (!ov && ix->kev_pending == dr_index::KEV) { HIPCHK(hipStreamSynchronize(ix->stream)); harvest_kernel_times(ix, false); }
+    if (!ov && ix->kev_pending == dr_index::KEV) { HIPCHK(hipStreamSynchronize(ix->stream)); if (ix->stream2) HIPCHK(hipStreamSynchronize(ix->stream2)); harvest_kernel_times(ix, false); }
     p.lut_g = nullptr;
     const bool want_lut = kd_desc.lut && !(ov && ov->sdc);
     if (want_lut) {
         // The per-query tables T[q][j][c] (A2, fast_pq.py:294-318) of the whole batch, built at full occupancy right
         // before the search kernel that lands them in LDS (engine_kernels.hpp lut_build_kernel). Built by EVERY search --
         // a table is part of its query's search, not of the upload -- and timed separately (dr_timing.lut_kernel_ms).
-        if (ix->lut.reserve((size_t)nq * ix->m * 256)) return DR_E_NODEVICE;
+        DevBuf<float> &lutb = lane1 ? ix->lut2 : ix->lut;
+        if (lutb.reserve((size_t)nq * ix->m * 256)) return DR_E_NODEVICE;
         if (!ov) HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][2], st));
-        { const int rcl = launch_lut_build(ix, ix->cs->q.p, nq, ix->lut.p, st); if (rcl) return rcl; }
-        p.lut_g = ix->lut.p;
+        { const int rcl = launch_lut_build(ix, ix->cs->q.p, nq, lutb.p, st); if (rcl) return rcl; }
+        p.lut_g = lutb.p;
     }
     PqbParams pp;
     if (pqb) {
@@ -1396,6 +1417,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         pp.phase = p.phase;
     }
     void *args[] = { pqb ? (void *)&pp : (void *)&p };
+    if (!ov && ix->two_lanes && !lane1) { HIPCHK(hipEventRecord(ix->prep_ev, st)); ix->prep_recorded = true; }      // (everything this index state needed has been queued on lane 0 by now)
     if (!ov) { ix->kev_lut[ix->kev_pending] = want_lut; HIPCHK(hipEventRecord(ix->kev[ix->kev_pending][0], st)); }
     {
         const hipError_t le = hipLaunchKernel(kfn, dim3(grid), dim3(64 * NW), args, lds, st);
@@ -1536,6 +1558,7 @@ static int sync_locked(dr_index *ix)
 {
     HIPCHK(hipStreamSynchronize(ix->up_stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
+    if (ix->stream2) HIPCHK(hipStreamSynchronize(ix->stream2));
     HIPCHK(hipStreamSynchronize(ix->fstream));
     HIPCHK(hipStreamSynchronize(ix->down_stream));
     harvest_kernel_times(ix, true);
@@ -1612,7 +1635,8 @@ static int quiesce_locked(dr_index *ix)
     int rc_first = 0; std::string msg;
     for (int j = 0; j < DR_MAX_JOBS; j++)
         if (ix->jobs[j].active) { const int rc = finish_job_locked(ix, j); if (rc && !rc_first) { rc_first = rc; msg = g_err; } }
-    for (hipStream_t st : { ix->up_stream, ix->stream, ix->fstream, ix->down_stream }) HIPCHK(hipStreamSynchronize(st));
+    for (hipStream_t st : { ix->up_stream, ix->stream, ix->stream2, ix->fstream, ix->down_stream }) if (st) HIPCHK(hipStreamSynchronize(st));
+    ix->lane0_sig = 0;
     if (rc_first) { g_err = msg; return rc_first; }
     return 0;
 }

@@ -27,6 +27,7 @@
 // then computed without a walk -- see "decisions" in the main loop: counts against the old list by binary search,
 // counts against earlier neighbours by bit masks, and a fixed point that converges in one or two ballots.
 #pragma once
+#include "variants.hpp"
 #include "numerics.hpp"
 
 // A wavefront's LDS operations execute in issue order, so cross-lane hand-offs through LDS inside ONE wave only
@@ -1934,7 +1935,7 @@ template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0
 // 32-KiB table or the row pipeline's buffers: 1)
 // the register-table variant exists to run two wavefronts per SIMD: 256 registers each; the 4-wavefront workgroups of the
 // byte-row landing variants (16, 17) sit four to a CU like the 16 wavefronts of ONE workgroup of 11 / 13: 4 per SIMD, 128 registers)
-__global__ __launch_bounds__(64 * NW, ((NW == 1 && D <= 256) || TREG > 0) ? 2 : (NW == 4 && RB > 0 && U8) ? 4 : 1) void search_kernel(const SearchParams p)
+__global__ __launch_bounds__(64 * NW, ((NW == 1 && D <= 256) || TREG > 0) ? 2 : (NW == 4 && RB > 0 && U8) ? (QB ? DR_AB_MINW17 : 4) : 1) void search_kernel(const SearchParams p)
 {
     search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB, U8, QB, TREG>(p);
 }

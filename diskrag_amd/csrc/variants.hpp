@@ -29,6 +29,14 @@
 // (tried in round 2 and removed: 16-wave forms of 3 and 5 for D <= 96 -- twice the queries in flight, 30 % slower than the
 //  per-query table at the c4 shape: that kernel is bound by its number of memory requests, not by latency)
 // sizeclass: result capacity <= 64 / 128 / 256 / 512 / 1024 (the last one: one-wavefront-per-workgroup variants only)
+// A/B build (VERDICT r5 item 2 i: "more requests in flight"): -DDR_AB_RB17=32 -DDR_AB_MINW17=6 turns variant 17 (byte rows + byte queries in
+// 4-wavefront workgroups) into a 24-wavefronts-per-CU form -- bursts of 32 rows (4 KiB landing area per wavefront), six workgroups per CU, 80 VGPRs.
+#ifndef DR_AB_RB17
+#define DR_AB_RB17 64
+#endif
+#ifndef DR_AB_MINW17
+#define DR_AB_MINW17 4
+#endif
 struct KindDesc {
     int id;
     int nw;       // wavefronts per workgroup
@@ -53,7 +61,7 @@ static const KindDesc DR_KINDS[] = {
     { 14, 16, false, 64, false, false, true, true, 0 },
     { 15, 1, false, 0, true, true, false, false, 16 },
     { 16, 4, false, 64, false, true, true, false, 0 },
-    { 17, 4, false, 64, false, true, true, true, 0 },
+    { 17, 4, false, DR_AB_RB17, false, true, true, true, 0 },
 };
 #define DR_NUM_KINDS ((int)(sizeof(DR_KINDS) / sizeof(DR_KINDS[0])))
 #define DR_MAX_KIND_ID 17

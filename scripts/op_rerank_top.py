@@ -35,8 +35,8 @@ gt, _ = ix.bruteforce_topk(q, 10)
 emit({"setup": {"shape": shape, "N": n, "D": D, "m": m, "build_s": bsec, "setup_s": time.perf_counter() - t0}})
 del x
 ix.batch_upload(q)
-grid = {"c3": [(L, bw) for L in (150, 200, 250, 300, 400) for bw in (0, 128)], "c4": [(L, bw) for L in (200, 300, 400, 500) for bw in (32, 64)]}[shape]
-tops = {"c3": (0, 200, 150, 100, 64, 48, 32), "c4": (0, 200, 100, 64, 32)}[shape]
+grid = {"c3": [(L, bw) for L in (100, 125, 150, 200, 250, 300) for bw in (0, 128)], "c4": [(L, bw) for L in (100, 150, 200, 300, 400) for bw in (8, 32, 64)]}[shape]
+tops = {"c3": (0, 200, 150, 125, 100, 80, 72, 64), "c4": (0, 100, 64, 48, 32, 24, 16)}[shape]
 good = []
 for L, bw in grid:
     for top in tops:

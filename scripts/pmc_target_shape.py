@@ -13,8 +13,11 @@ D, m, ncl, latent = {"c3": (1536, 32, 4096, 64), "c4": (96, 16, 4096, 32), "c5s"
 R = 32 if shape == "c5s" else 64
 import os
 mode = _ffi.MODE_PQ if shape == "c5s" else _ffi.MODE_M1
-if shape == "c5s" and os.environ.get("PMC_MODE") == "pqb":
+flags = 0
+if os.environ.get("PMC_MODE") == "pqb":
     mode = _ffi.MODE_PQB                # round 5: the batch-per-step traversal (csrc/pqb_kernel.hpp), default pops
+    if shape != "c5s":
+        flags = _ffi.F_RERANK           # c3 / c4: PQ traversal + exact rerank of the L list (bench.py --config c3 | c4)
 gen = unit_mixture_parallel if n * D >= (1 << 32) else unit_mixture
 x, q = gen(n, D, n_queries=10000, n_clusters=ncl, seed=11, latent=latent)
 ix = HipIndex.create_empty(x, R=R)
@@ -25,10 +28,11 @@ if os.environ.get("DR_INLINE") == "1":
 ix.bruteforce_topk(q[:1], 10)           # calibration: streams the whole vector table once
 ix.batch_upload(q)
 for _ in range(4):
-    ix.batch_run(10, L=L, beam_width=bw, mode=mode)
+    ix.batch_run(10, L=L, beam_width=bw, mode=mode, flags=flags)
 ids, dist, cnt, st = ix.batch_download()
 S, V, X = st["steps"].astype(np.float64), st["pq_evaluated"].astype(np.float64), st["exact"].astype(np.float64)
 print("ALG_BYTES_PER_LAUNCH", float((4 * D + S * 4 * R + V * m + X * 4 * D + 80).sum() + 4 * 256 * D))
 print("CALIB_BYTES", n * D * 4)
+print("N", n); print("L", L); print("BW", bw)
 print("KERNEL_MS", ix.timing()["search_kernel_ms"], "VARIANT", ix.timing()["variant"])
 print("PER_QUERY steps %.1f exact %.1f pq_eval %.1f" % (S.mean(), X.mean(), V.mean()))
