@@ -10,11 +10,9 @@ struct PqbTable { int m16, treg; const void *fn[5][3]; };
 const PqbTable *dr_pqb_table_m0_t0();
 const PqbTable *dr_pqb_table_m1_t0();
 const PqbTable *dr_pqb_table_m1_t8();
-const PqbTable *dr_pqb_table_m2_t0();
 const PqbTable *dr_pqb_table_m2_t16();
 const PqbTable *dr_pqb_table_m2_t24();
 const PqbTable *dr_pqb_table_m3_t16();
-const PqbTable *dr_pqb_table_m4_t16();
 const PqbTable *dr_pqb_table_m4_t32();
 
 // sc: size class of the list (0..4); nc: passes per step (1, 2, 4); m: sub-quantisers; treg_pref: -1 = the engine's choice
@@ -25,11 +23,13 @@ static inline PqbChoice dr_pqb_choose(int sc, int nc, uint32_t m, int treg_pref)
     // m = 32: 24 rows in registers = 12 wavefronts per CU at 168 registers each (c5s 4M, L = 100, beam_width 8, two pops: 1.42 -> 1.27 ms
     // against 16 rows / 9 wavefronts, profiles/r05/ab/); four passes per step or 1024-entry lists do not fit 168 registers: 16 rows
     else if (m == 32) {
-        const int tr = treg_pref >= 0 ? treg_pref : (nc <= 2 && sc <= 3) ? 24 : 16;
-        t = tr == 0 ? dr_pqb_table_m2_t0() : tr == 24 ? dr_pqb_table_m2_t24() : dr_pqb_table_m2_t16();
+        // (round 6: the all-LDS form of m = 32 -- 4 wavefronts per CU, 1.6x slower -- and the 16-register-row form of m = 64 were reachable through
+        //  DR_PQB_TREG only and are no longer built; m not a multiple of 16 still runs with its whole table in LDS: m0_t0)
+        const int tr = treg_pref == 16 ? 16 : treg_pref == 24 ? 24 : (nc <= 2 && sc <= 3) ? 24 : 16;
+        t = tr == 24 ? dr_pqb_table_m2_t24() : dr_pqb_table_m2_t16();
     }
     else if (m == 48) t = dr_pqb_table_m3_t16();
-    else if (m == 64) t = treg_pref == 16 ? dr_pqb_table_m4_t16() : dr_pqb_table_m4_t32();
+    else if (m == 64) t = dr_pqb_table_m4_t32();
     else if (m <= 128) t = dr_pqb_table_m0_t0();
     PqbChoice c = { nullptr, 0, 0, 1 };
     if (!t) return c;

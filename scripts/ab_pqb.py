@@ -43,7 +43,7 @@ for pops in (2, 4):       # steps of several passes: the visited filter + compac
         if m == 32: variants.append((f"PQB_pops{pops}_treg24", dict(mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(pops)), {"DR_PQB_TREG": "24"}))
 best_pops = 2 if R <= 64 else 1
 if m == 32:
-    for treg in ("0", "24"):
+    for treg in ("16", "24"):
         variants.append((f"PQB_pops{best_pops}_treg{treg}", dict(mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(best_pops)), {"DR_PQB_TREG": treg}))
 if n * R * m <= 40e9:
     variants.append((f"PQB_pops{best_pops}_inline", dict(mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(best_pops)), {"inline": 1}))

@@ -76,9 +76,9 @@ def test_pqb_eight_pops_and_wide_rows():
         ix.search_batch(g.queries, 10, L=50, beam_width=8, mode=_ffi.MODE_PQB, flags=_ffi.F_POPS(8))
 
 
-@pytest.mark.parametrize("treg", ["0", "16", "24"])
+@pytest.mark.parametrize("treg", ["16", "24"])
 def test_pqb_table_layouts_return_the_same_bits(treg, monkeypatch):
-    """m = 32: the table rows in LDS / the last 16 / the last 24 in registers (ds_bpermute lookups) -- the same sums in the same order."""
+    """m = 32: the last 16 / the last 24 table rows in registers (ds_bpermute lookups), the rest in LDS -- the same sums in the same order (the oracle's)."""
     monkeypatch.setenv("DR_PQB_TREG", treg)
     for name in ("unit1536_R16_m32", "sift128_R64_m32"):
         g = load_golden(name)
