@@ -448,8 +448,7 @@ DEV double pw_run_lane64(const float *__restrict__ c, const double *q, int n)
 }
 
 // ---- any length, the tree evaluated from n AT RUN TIME (round 6: dimensions that have no compiled tree) ------------------------------
-// numpy's pairwise routine literally (numpy/_core/src/umath/loops_utils.h.src @TYPE@_pairwise_sum; oracle/oracle_core.inc pw_sqdiff is the
-// same text): n < 8 sequential from 0; n <= 128 eight accumulators r[j] += a[8 t + j], combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the
+// numpy's pairwise routine literally (numpy/_core/src/umath/loops_utils.h.src @TYPE@_pairwise_sum): n < 8 sequential from 0; n <= 128 eight accumulators r[j] += a[8 t + j], combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the
 // n % 8 leftovers added one by one; above 128 split at n / 2 rounded down to a multiple of 8 -- the recursion kept on an explicit stack
 // (depth <= 8: n <= 32768). ONE LANE sums ONE run (the generic traversal scores 64 neighbours at a time, a lane each). `pos` (may be null):
 // element i of the run is stored at c[pos[i]] -- the chain-major rows of a built dimension, so that this routine and the compiled trees can
