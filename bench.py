@@ -981,6 +981,11 @@ def worker_shape(args, rk):
     log(rk, f"graph in {build_s:.1f}s, PQ m={m} in {pq_s:.1f}s, ground truth done")
     if not want_cpu:
         del x
+    # c4's 16-byte code words cost a 128-byte line each when gathered (6.2x traffic, profiles/r06/pmc_pqb_c4.json): beside the adjacency row they are
+    # one contiguous read per expansion (dr_index_inline_codes: N R m bytes -- 4 GB at 4M points, 102 GB at 100M; same results, +6.5 % at 100M in round 5)
+    inline = (not c3) and n * R * m <= 120e9 and not os.environ.get("DR_BENCH_NO_INLINE")
+    if inline:
+        ix.inline_codes(True)
     qn = np.linalg.norm(q_all[:64].astype(np.float64), axis=1)
     ip = _ffi.F_IP if c3 and np.abs(qn * qn - 1.0).max() < 5e-4 else 0       # c3 is named an inner-product config: unit-norm rows and queries
     top = int(args.rerank_top or 0)
@@ -1087,7 +1092,7 @@ def worker_shape(args, rk):
                       "per_query": {"expansions": float(S.mean()), "code_words_scored": float(V.mean()), "full_precision_rows_scored": float(X.mean()),
                                     "algorithmic_bytes": float(per_q.mean())},
                       "launch": {k_: tm[k_] for k_ in ("variant", "grid", "block", "lds_bytes", "waves_per_cu")},
-                      "rerank_top": top if 0 < top < args.L else args.L, "one_resident_batch_ms": resident_pieces,
+                      "rerank_top": top if 0 < top < args.L else args.L, "one_resident_batch_ms": resident_pieces, "inline_neighbour_codes": bool(inline),
                       "m1_reference_faithful": m1_ref},
            "roofline": {"bound": "hbm", "kernel": "pqb_search_kernel (DR_MODE_PQB traversal; the rerank pass is its own kernel)",
                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
