@@ -982,8 +982,9 @@ def worker_shape(args, rk):
     if not want_cpu:
         del x
     # c4's 16-byte code words cost a 128-byte line each when gathered (6.2x traffic, profiles/r06/pmc_pqb_c4.json): beside the adjacency row they are
-    # one contiguous read per expansion (dr_index_inline_codes: N R m bytes -- 4 GB at 4M points, 102 GB at 100M; same results, +6.5 % at 100M in round 5)
-    inline = (not c3) and n * R * m <= 120e9 and not os.environ.get("DR_BENCH_NO_INLINE")
+    # one contiguous read per expansion (dr_index_inline_codes: N R m bytes -- 102 GB at 100M; same results, +6.5 % at 100M in round 5)
+    # (at 4M points the two forms measure the same: 6.65 against 6.67 M QPS, profiles/r06 -- the footprint only pays where the gathers leave the caches)
+    inline = (not c3) and n >= 50_000_000 and n * R * m <= 120e9 and not os.environ.get("DR_BENCH_NO_INLINE")
     if inline:
         ix.inline_codes(True)
     qn = np.linalg.norm(q_all[:64].astype(np.float64), axis=1)

@@ -338,16 +338,30 @@ DEV float pw_run_regs(const float (&c)[N], const float *q)
         for (int i = 0; i < N; i++) res = f_add(res, sqd(c[i], q[i]));
         return res;
     } else {
-        float r[8];
+        // the eight accumulator chains as four PAIRS (round 6): difference, square and add of two neighbouring chains are one packed instruction each
+        // (v_pk_add_f32 with a negated operand, v_pk_mul_f32, v_pk_add_f32) -- the same IEEE operations on the same values in the same order per
+        // chain, 72 instead of 96 instructions per table entry at sub_dim 48 (the compiler packed the squares and adds but left 48 scalar
+        // subtractions: the query pair is a scalar-register operand)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 r[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) r[j] = sqd(c[j], q[j]);
+        for (int jj = 0; jj < 4; jj++) {
+            const f2 cc = { c[2 * jj], c[2 * jj + 1] }, qq = { q[2 * jj], q[2 * jj + 1] };
+            const f2 d = cc - qq;
+            r[jj] = d * d;
+        }
         constexpr int lim = N - (N % 8);
 #pragma unroll
         for (int i = 8; i < lim; i += 8) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) r[j] = f_add(r[j], sqd(c[i + j], q[i + j]));
+            for (int jj = 0; jj < 4; jj++) {
+                const f2 cc = { c[i + 2 * jj], c[i + 2 * jj + 1] }, qq = { q[i + 2 * jj], q[i + 2 * jj + 1] };
+                const f2 d = cc - qq;
+                const f2 sq = d * d;
+                r[jj] = r[jj] + sq;
+            }
         }
-        float res = f_add(f_add(f_add(r[0], r[1]), f_add(r[2], r[3])), f_add(f_add(r[4], r[5]), f_add(r[6], r[7])));
+        float res = f_add(f_add(f_add(r[0].x, r[0].y), f_add(r[1].x, r[1].y)), f_add(f_add(r[2].x, r[2].y), f_add(r[3].x, r[3].y)));
 #pragma unroll
         for (int i = lim; i < N; i++) res = f_add(res, sqd(c[i], q[i]));
         return res;

@@ -21,8 +21,9 @@
 // DR_MODE_PQ spends half of its instructions deciding what the reference's neighbour-by-neighbour loop would have done (three
 // binary searches over the list, candidate masks, a fixed point, the insert log for the tie-order pass), a step here is
 //   pop (scalar bit operations on the live masks) -> rows -> code words -> ADC -> one ballot against the largest key ->
-//   every lane's rank in the list (first level against list entries read out of the registers, two or three 4-ary levels over the
-//   staged list) -> its rank among the accepted keys (a loop over the accepted lanes, keys by v_readlane) -> ONE scatter / gather merge.
+//   per surviving candidate: its rank in the list (a 4-ary search over the staged list) and among the accepted keys -> ONE scatter / gather merge
+//   through LDS. (-DPQB_CANDIDATES_V2: round 6's form of that phase -- first search level out of the registers, membership folded into the last
+//   level, the accepted keys ranked by a v_readlane loop: 2 dependent LDS round trips instead of 5, measured 0-3 % slower.)
 // Expanding several frontier entries per step (pops; DiskANN's beam) fills the 64 lanes when rows are narrow (R = 32: two rows
 // per ADC pass) and halves the number of DEPENDENT memory round trips per query.
 //
@@ -265,6 +266,116 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
             }
             PH(4);
 
+#ifndef PQB_CANDIDATES_V2
+            // ---- candidates (key below the list's largest key, or any while the list fills), all lanes at once:
+            // (1) rank in the list = binary search over the staged list; the entry found there says whether the node is IN the list;
+            // (2) several rows per step: the same node through two rows -- the later copy leaves (a loop over the compacted keys);
+            // (3) the accepted keys are compacted into LDS; every accepted lane counts the accepted keys below its own (broadcast
+            //     reads, no dependency between them), and a histogram of the list ranks, prefix-summed, tells every list entry how
+            //     many accepted keys lie below it;
+            // (4) ONE scatter / gather merge through the staged list.
+            if (anyc != 0ull) {
+                constexpr int QIT = (NCHR == 1) ? 3 : (NCHR <= 4) ? 4 : 5;      // 4^QIT >= NCHR * 64
+                u64 acc[NC];
+                int lb[NC], ci[NC];
+                int nacc = 0;
+#pragma unroll
+                for (int t = 0; t < NC; t++) {
+                    // #(list keys < key): a 4-ary search over the staged list padded with +inf to 4^QIT entries -- three independent
+                    // LDS reads per level, QIT DEPENDENT round trips instead of the 2 QIT of a binary search
+                    int lo = 0;
+                    bool inl = false;
+                    if (rn > 0) {
+#pragma unroll
+                        for (int it = 0; it < QIT; it++) {
+                            const int st = 1 << (2 * (QIT - 1 - it));
+                            const int i1 = lo + st - 1, i2 = lo + 2 * st - 1, i3 = lo + 3 * st - 1;
+                            const u64 v1 = mk[min(i1, rn - 1)], v2 = mk[min(i2, rn - 1)], v3 = mk[min(i3, rn - 1)];
+                            const int c1 = (i1 < rn && v1 < key[t]) ? 1 : 0, c2 = (i2 < rn && v2 < key[t]) ? 1 : 0, c3 = (i3 < rn && v3 < key[t]) ? 1 : 0;
+                            lo += (c1 + c2 + c3) * st;
+                        }
+                        const u64 vv = mk[min(lo, rn - 1)];
+                        inl = lo < rn && (vv ^ key[t]) <= 1ull;
+                    }
+                    lb[t] = lo;
+                    acc[t] = cm[t] & __ballot(!inl);
+                    ci[t] = nacc + __popcll(acc[t] & lanemask_lt());
+                    nacc += __popcll(acc[t]);
+                }
+                if (np > 1 && nacc > 1) {
+                    // the same node through two of the step's rows: only its first copy (in lane order) stays
+#pragma unroll
+                    for (int t = 0; t < NC; t++) if ((acc[t] >> lane) & 1ull) cbuf[ci[t]] = key[t];
+                    WSYNC();
+                    bool dup[NC];
+#pragma unroll
+                    for (int t = 0; t < NC; t++) dup[t] = false;
+#pragma unroll 8
+                    for (int jq = 0; jq < nacc; jq++) {
+                        const u64 kj = cbuf[jq];
+#pragma unroll
+                        for (int t = 0; t < NC; t++) dup[t] = dup[t] || (kj == key[t] && jq < ci[t]);
+                    }
+                    WSYNC();
+                    nacc = 0;
+#pragma unroll
+                    for (int t = 0; t < NC; t++) {
+                        acc[t] &= ~__ballot(dup[t]);
+                        ci[t] = nacc + __popcll(acc[t] & lanemask_lt());
+                        nacc += __popcll(acc[t]);
+                    }
+                }
+                if (nacc > 0) {
+                    bool isacc[NC];
+#pragma unroll
+                    for (int t = 0; t < NC; t++) {
+                        isacc[t] = ((acc[t] >> lane) & 1ull) != 0ull;
+                        if (isacc[t]) { cbuf[ci[t]] = key[t]; atomicAdd(&hist[lb[t]], 1u); }
+                    }
+                    if (lane < 4) cbuf[nacc + lane] = ~0ull;          // (the count loop below reads four keys per trip)
+                    WSYNC();
+                    u32 rA[NC];
+#pragma unroll
+                    for (int t = 0; t < NC; t++) rA[t] = 0u;
+#pragma unroll 1
+                    for (int jq = 0; jq < nacc; jq += 4) {
+                        const u64 k0 = cbuf[jq], k1 = cbuf[jq + 1], k2 = cbuf[jq + 2], k3 = cbuf[jq + 3];
+#pragma unroll
+                        for (int t = 0; t < NC; t++)
+                            rA[t] += (k0 < key[t] ? 1u : 0u) + (k1 < key[t] ? 1u : 0u) + (k2 < key[t] ? 1u : 0u) + (k3 < key[t] ? 1u : 0u);
+                    }
+                    // list entry i moves up by the accepted keys below it = those whose list rank is <= i
+                    u32 carry = 0u;
+#pragma unroll
+                    for (int c = 0; c < NCHR; c++) {
+                        const int idx = c * 64 + lane;
+                        const u32 inc = wave_incl_scan_u32(hist[idx]) + carry;
+                        hist[idx] = 0u;
+                        carry = readlane32(inc, 63);
+                        const int npos = idx + (int)inc;
+                        const u64 nl = ((live[c] >> lane) & 1ull) ? 0ull : PQB_NOTLIVE;
+                        if (idx < rn && npos < cap) mk[npos] = rk.v[c] | nl;
+                    }
+#pragma unroll
+                    for (int t = 0; t < NC; t++) {
+                        const int npos = lb[t] + (int)rA[t];
+                        if (isacc[t] && npos < cap) mk[npos] = key[t];
+                    }
+                    WSYNC();
+                    const int rn2 = min(rn + nacc, cap);
+#pragma unroll
+                    for (int c = 0; c < NCHR; c++) {
+                        const int idx = c * 64 + lane;
+                        const u64 v = (idx < rn2) ? mk[idx] : ~0ull;
+                        live[c] = __ballot(idx < rn2 && (v & PQB_NOTLIVE) == 0ull);
+                        rk.v[c] = (idx < rn2) ? (v & ~PQB_NOTLIVE) : ~0ull;
+                    }
+                    WSYNC();
+                    rn = rn2;
+                    nins += (u32)nacc;
+                }
+            }
+#else      // A/B of round 6 (profiles/r06/ab/ab_pqb_candidates_phase_*.jsonl): fewer dependent LDS round trips, 0-3 % SLOWER -- not the default
             // ---- candidates (key below the list's largest key, or any while the list fills), all lanes at once:
             // (1) rank in the list. First level WITHOUT a memory access: the list is sorted in the registers, its entries at the fixed positions
             //     SEG - 1, 2 SEG - 1, ... are read out with v_readlane (wave-uniform: scalar operands of the compares) and cut the list into K0
@@ -292,21 +403,6 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
                     int lo = 0;
                     bool inl = false;
                     if (rn > 0) {
-#ifdef PQB_SEARCH_V1      // A/B: round 5's search -- QIT 4-ary levels over the staged list from the top, the entry at the rank read afterwards
-                        constexpr int QIT = (NCHR == 1) ? 3 : (NCHR <= 4) ? 4 : 5;
-#pragma unroll
-                        for (int it = 0; it < QIT; it++) {
-                            const int st = 1 << (2 * (QIT - 1 - it));
-                            const int i1 = lo + st - 1, i2 = lo + 2 * st - 1, i3 = lo + 3 * st - 1;
-                            const u64 v1 = mk[min(i1, rn - 1)], v2 = mk[min(i2, rn - 1)], v3 = mk[min(i3, rn - 1)];
-                            const int c1 = (i1 < rn && v1 < key[t]) ? 1 : 0, c2 = (i2 < rn && v2 < key[t]) ? 1 : 0, c3 = (i3 < rn && v3 < key[t]) ? 1 : 0;
-                            lo += (c1 + c2 + c3) * st;
-                        }
-                        const u64 vv1 = mk[min(lo, rn - 1)];
-                        inl = lo < rn && (vv1 ^ key[t]) <= 1ull;
-                    }
-                    if (false) {
-#endif
 #pragma unroll
                         for (int i = 0; i < K0 - 1; i++) lo += (spl[i] < key[t]) ? SEG : 0;
 #pragma unroll
@@ -428,6 +524,7 @@ __global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 
                     nins += (u32)nacc;
                 }
             }
+#endif
             PH(5);
             seed = false;
             // frontier trim: only the beam_width smallest live entries stay live
