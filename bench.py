@@ -47,9 +47,11 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s i
 # (L, beam_width, rerank depth; 0 = the whole list) of DR_MODE_PQB | DR_F_RERANK at recall@10 >= 0.95: "bench" = the default bench-scale index
 # (c3 1M, c4 4M points), "full" = the configuration's own size (from `full_from` points on) -- scripts/op_rerank_top.py, profiles/r06/
 # c3 1M: L = 100 no trim, rerank of the ADC top 72: 3.46 M QPS resident / 3.65-3.73 M as a stream at recall 0.959 (the whole list: 0.977 at 3.1 M);
-# c3 10M: the rerank depth IS the recall (top 200 of L = 250: 0.936; 250: 0.9504; L = 300 top 200: 0.943): L = 250 whole list, 1.10 M / 1.25 M;
+# c3 10M: the rerank depth IS the recall (top 200 of L = 250: 0.936; L = 300 top 200: 0.943), and on 20 000 queries L = 250 reads 0.9476, L = 256
+# 0.9497 (round 5's 0.9504 was a 10 000-query sample): the first points safely above the bar are L = 264 (0.9528, 1.01 M) and L = 272, beam_width 128
+# (0.9539, 1.12 M resident and as a stream; op_rerank_top_c3_10000000_fine.jsonl) -- lists beyond 256 entries are the next kernel size class;
 # c4 4M: L = 200, beam_width 8: 4.8 M / 6.65 M at 0.955 (96-d rows: the rerank is a tenth of the call, its depth buys nothing)
-OPERATING_POINTS = {"c3": {"bench": (100, 0, 72), "full": (250, 0, 0), "full_from": 5_000_000},
+OPERATING_POINTS = {"c3": {"bench": (100, 0, 72), "full": (272, 128, 0), "full_from": 5_000_000},
                     "c4": {"bench": (200, 8, 0), "full": (400, 32, 0), "full_from": 50_000_000}}
 
 

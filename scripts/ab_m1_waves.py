@@ -22,7 +22,8 @@ cb = ix.pq_train(32, n_sample=100_000, iters=8)
 ix.pq_encode(cb)
 for b in range(4):
     ix.batch_select(b); ix.batch_upload(q[b * nq:(b + 1) * nq])
-for kind in (13, 17, 13, 17):
+import os
+for kind in [int(v) for v in os.environ.get("AB_KINDS", "13,17,13,17").split(",")]:
     ix.debug_force_kind(kind)
     for i in range(4):
         ix.batch_select(i % 4); ix.batch_run(10, L=100, beam_width=8, mode=_ffi.MODE_M1)

@@ -15,8 +15,9 @@ from diskrag_amd.synth import unit_mixture, unit_mixture_parallel, recall_at_k  
 shape, n = sys.argv[1], int(sys.argv[2])
 bar = float(sys.argv[3]) if len(sys.argv) > 3 else 0.95
 D, m, ncl, latent = {"c3": (1536, 32, 4096, 64), "c4": (96, 16, 4096, 32)}[shape]
-nq = 10000
-out = open(f"gpurun_out/op_rerank_top_{shape}_{n}.jsonl", "w")
+import os
+nq = int(os.environ.get("OP_NQ", "10000"))
+out = open(f"gpurun_out/op_rerank_top_{shape}_{n}{os.environ.get('OP_TAG', '')}.jsonl", "w")
 
 
 def emit(rec):
@@ -37,6 +38,9 @@ del x
 ix.batch_upload(q)
 grid = {"c3": [(L, bw) for L in (100, 125, 150, 200, 250, 300) for bw in (0, 128)], "c4": [(L, bw) for L in (100, 150, 200, 300, 400) for bw in (8, 32, 64)]}[shape]
 tops = {"c3": (0, 200, 150, 125, 100, 80, 72, 64), "c4": (0, 100, 64, 48, 32, 24, 16)}[shape]
+if os.environ.get("OP_GRID"):        # "L:bw,L:bw,..." and OP_TOPS="0,200,..." override the shape's grid
+    grid = [tuple(int(v) for v in g.split(":")) for g in os.environ["OP_GRID"].split(",")]
+    tops = tuple(int(v) for v in os.environ.get("OP_TOPS", "0").split(","))
 good = []
 for L, bw in grid:
     for top in tops:

@@ -197,3 +197,23 @@ def test_pin_to_gpu_socket_on_a_fake_tree_of_eight_devices_on_two_sockets(tmp_pa
         assert os.sched_getaffinity(0) == set(have)
     finally:
         os.sched_setaffinity(0, have)
+
+
+def test_c3_c4_default_to_the_recall_095_point_of_the_size_they_build():
+    """`--config c3 | c4` run at the fastest measured recall >= 0.95 point of an index of THAT size (bench scale / --full-size)"""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    a = bench.parse_args(["--config", "c3"])
+    assert (a.n, a.dim, a.L, a.bw, a.rerank_top) == (1_000_000, 1536, 100, 0, 72)
+    a = bench.parse_args(["--config", "c3", "--full-size"])
+    assert (a.n, a.L, a.bw, a.rerank_top) == (10_000_000, 272, 128, 0)
+    a = bench.parse_args(["--config", "c4"])
+    assert (a.n, a.dim, a.m, a.L, a.bw, a.rerank_top) == (4_000_000, 96, 16, 200, 8, 0)
+    a = bench.parse_args(["--config", "c4", "--full-size"])
+    assert (a.n, a.L, a.bw) == (100_000_000, 400, 32)
+    a = bench.parse_args(["--config", "c3", "--L", "300"])          # an explicit list length: no rerank cut unless asked for
+    assert (a.L, a.bw, a.rerank_top) == (300, 0, 0)
+    a = bench.parse_args(["--config", "c5", "--full-size"])
+    assert a.n == 125_000_000 and a.R == 128
+    a = bench.parse_args([])
+    assert (a.n, a.dim, a.R, a.L, a.bw, a.m) == (1_000_000, 128, 64, 100, 8, 32)
