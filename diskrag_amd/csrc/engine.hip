@@ -279,8 +279,6 @@ struct dr_index {
     uint64_t lane0_sig = 0;       // parameters of the last launch queued on lane 0 (0: none)
     uint32_t lane_toggle = 0;
     DevBuf<uint32_t> vis2, vis_epoch2;
-    DevBuf<uint32_t> vish, vish_epoch;     // the visited-id hash sets of variants 22 / 23 (search_kernel.hpp VH): [slots][DR_VH_WORDS] + stamps
-    bool vh_skip = false;                  // the re-run of a call whose query outgrew its id set: the bitmap variants serve it
     DevBuf<float> lut2;
     uint32_t last_nq = 0;         // batch size of the last launch (dr_batch_download)
     DevBuf<uint32_t> vis, vis_epoch;   // visited words [slots][vis_words] + the per-slot query stamp (search_kernel.hpp)
@@ -583,7 +581,7 @@ extern "C" void dr_index_close(dr_index *ix)
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     for (hipStream_t st : { ix->up_stream, ix->stream, ix->stream2, ix->fstream, ix->down_stream }) if (st) (void)hipStreamSynchronize(st);
-    ix->lut.release(); ix->lut2.release(); ix->vis2.release(); ix->vis_epoch2.release(); ix->vish.release(); ix->vish_epoch.release();
+    ix->lut.release(); ix->lut2.release(); ix->vis2.release(); ix->vis_epoch2.release();
     if (ix->prep_ev) (void)hipEventDestroy(ix->prep_ev);
     if (ix->stream2) (void)hipStreamDestroy(ix->stream2);
     ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release(); ix->nbcodes.release(); ix->sdc.release();
@@ -1065,7 +1063,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     // small submits are coalesced into one launch instead, dr_search_submit.)
     const int lane1 = (!ov && ix->two_lanes && ix->lane_req == 1) ? 1 : 0;
     hipStream_t st = lane1 ? ix->stream2 : ix->stream;
-    DevBuf<uint32_t> &vis_bm = lane1 ? ix->vis2 : ix->vis, &vis_epoch_bm = lane1 ? ix->vis_epoch2 : ix->vis_epoch;
+    DevBuf<uint32_t> &vis = lane1 ? ix->vis2 : ix->vis, &vis_epoch = lane1 ? ix->vis_epoch2 : ix->vis_epoch;
     if (lane1 && ix->prep_recorded) HIPCHK(hipStreamWaitEvent(st, ix->prep_ev, 0));
 
     const int sc = cap <= 64 ? 0 : cap <= 128 ? 1 : cap <= 256 ? 2 : cap <= 512 ? 3 : 4;
@@ -1086,21 +1084,18 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         return (d.cb ? (size_t)256 * ix->D * 4 : 0) + (size_t)d.nw * pw;
     };
     if (!ov && ix->vec8_state == 0) { const int rcb8 = build_byte_rows(ix); if (rcb8) return rcb8; }
-    const bool vh_enabled = [] { const char *e = getenv("DR_VHASH"); return e != nullptr && e[0] == '1'; }();      // (read per call: the tests and A/Bs run both forms in one process)
     auto usable = [&](int kd) {
         const int pos = dr_kind_pos(kd);
         if (pos < 0 || ix->kern->search[pos][sc] == nullptr || lds_of(kd) > 160 * 1024) return false;
         const KindDesc &d = DR_KINDS[pos];
         if (d.treg && ((ix->m & 15u) != 0 || ix->m < 32u || ix->m > 64u)) return false;     // (register rows: the last whole 16-byte code piece)
-        // (22 / 23: ids must fit 24 bits beside the stamp; lane 0 only; DR_VHASH=0 switches them off, the re-run of an overflowed call skips them)
-        if (d.vh && (ix->N > (1ull << 24) || lane1 || ix->vh_skip || ov || !vh_enabled)) return false;
         return (!d.u8 || ix->vec8_state == 1) && (!d.qb || (ix->cs->q_u8 && !ov));
     };
     // ADC-only traversals: shared codebook (D <= 128) > table split between LDS and registers (15: twice the wavefronts
     // per CU of 2 at m = 32; DR_NO_TREG=1 switches it off for A/B) > table in LDS
     static const bool no_treg = getenv("DR_NO_TREG") != nullptr;
-    static const int PREF_M1[] = { 22, 13, 11, 9, 3, 0 }, PREF_ADC[] = { 5, 15, 2 }, PREF_ADC_NOTREG[] = { 5, 2, 2 }, PREF_EX[] = { 14, 12, 8, 1 }, PREF_BUILD[] = { 1, 8 };
-    static const int PREF_M1_LIVE_LUT[] = { 0, 3, 13, 11, 9, 9 }, PREF_M1_LIVE_CB[] = { 3, 0, 13, 11, 9, 9 };
+    static const int PREF_M1[] = { 13, 11, 9, 3, 0 }, PREF_ADC[] = { 5, 15, 2 }, PREF_ADC_NOTREG[] = { 5, 2, 2 }, PREF_EX[] = { 14, 12, 8, 1 }, PREF_BUILD[] = { 1, 8 };
+    static const int PREF_M1_LIVE_LUT[] = { 0, 3, 13, 11, 9 }, PREF_M1_LIVE_CB[] = { 3, 0, 13, 11, 9 };
     const bool k_m1 = (mode == DR_MODE_M1), k_adc = pq_only;
     // M1 has two regimes. On SIFT-scale data the rerank policy A4 is provably true for almost every expansion (Q1),
     // the ADC is skipped and the kernel is a pure row gather: vectors landed in LDS, table never built (9, 6).
@@ -1117,7 +1112,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     const bool adc_table_first = k_adc && !(ov && ov->sdc) && lds_of(2) * 6 <= 160 * 1024;
     const int *pref = k_m1 ? PREF_M1 : (ov && ov->sdc) ? (no_treg ? PREF_BUILD_PQ_NOTREG : PREF_BUILD_PQ)
                     : k_adc ? (adc_table_first ? (no_treg ? PREF_ADC_TABLE_NOTREG : PREF_ADC_TABLE) : (no_treg ? PREF_ADC_NOTREG : PREF_ADC)) : ov ? PREF_BUILD : PREF_EX;
-    const int npref = k_m1 ? 6 : (ov && ov->sdc) ? 2 : k_adc ? 3 : ov ? 2 : 4;
+    const int npref = k_m1 ? 5 : (ov && ov->sdc) ? 2 : k_adc ? 3 : ov ? 2 : 4;
     // (round 4: the per-query table wins with as few as five or six wavefronts per CU -- c4 shape, lists of 300-500 entries: 1.38x over
     // the shared codebook at eight, profiles/r04/ab/ab_c4_long_lists_table_vs_codebook.jsonl; it used to need eight to be preferred)
     if (ix->adc_live < 0) { for (int &v : ix->adc_live_sc) v = -1; for (int &v : ix->lat_adc_live) v = -1; }      // (codes / adjacency / rows changed: every class is measured again)
@@ -1131,7 +1126,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
         if (!env_read) { const char *e = getenv("DR_FORCE_KIND"); if (e && !g_force_kind_set) g_force_kind = atoi(e); env_read = true; }
         const int g = g_force_kind;
         if (g >= 0 && g <= DR_MAX_KIND_ID && !pqb && usable(g) && !(ov && ov->sdc)) {
-            const bool g_m1 = (g == 0 || g == 3 || g == 9 || g == 11 || g == 13 || g == 16 || g == 17 || g == 22 || g == 23), g_adc = (g == 2 || g == 5 || g == 15), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
+            const bool g_m1 = (g == 0 || g == 3 || g == 9 || g == 11 || g == 13 || g == 16 || g == 17), g_adc = (g == 2 || g == 5 || g == 15), g_ex = (g == 1 || g == 8 || g == 12 || g == 14);
             if ((g_m1 && k_m1) || (g_adc && k_adc) || (g_ex && !k_m1 && !k_adc)) kind = g;
         }
     }
@@ -1234,9 +1229,7 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
     uint64_t max_steps = capped ? std::min<uint64_t>((uint64_t)L * 10, ix->N) : 0xFFFFFFFFull;
     // visited set: per wavefront slot one word per 24 bit positions (+ an 8-bit query stamp: nothing is cleared
     // between queries, search_kernel.hpp) and the slot's stamp counter
-    const bool vh = !ov && !pqb && !lat && kind >= 0 && DR_KINDS[dr_kind_pos(kind)].vh;      // the visited-id hash set: its own scratch (another word layout)
-    DevBuf<uint32_t> &vis = vh ? ix->vish : vis_bm, &vis_epoch = vh ? ix->vish_epoch : vis_epoch_bm;
-    const uint32_t vis_words = vh ? DR_VH_WORDS : (uint32_t)(((ix->N + 23) / 24 + 3) & ~3ull);
+    const uint32_t vis_words = (uint32_t)(((ix->N + 23) / 24 + 3) & ~3ull);
     // DR_F_NO_VISITED_SET (DR_MODE_PQ): the traversal keeps NO visited set (SearchParams::novis) -- no visited words (20 MB per
     // wavefront slot on a 1.25e8-point shard), no bit-position twin of the adjacency; same results, more evaluations.
     if ((flags & DR_F_NO_VISITED_SET) && mode != DR_MODE_PQ) return fail(DR_E_ARG, "DR_F_NO_VISITED_SET goes with DR_MODE_PQ");
@@ -1271,10 +1264,10 @@ static int run_locked(dr_index *ix, uint32_t k, uint32_t L, uint32_t bw, uint32_
 
     SearchParams p;
     memset(&p, 0, sizeof p);
-    if (!ov && !novis && !pqb && !lat && !vh && !ix->adjr_valid) { const int rcb = build_bit_order(ix); if (rcb) return rcb; }      // (DR_MODE_PQB's filter is indexed by id)
+    if (!ov && !novis && !pqb && !lat && !ix->adjr_valid) { const int rcb = build_bit_order(ix); if (rcb) return rcb; }      // (DR_MODE_PQB's filter is indexed by id)
     if (!ov && ix->inline_codes && !ix->nbcodes_valid && ix->codes.p && (mode == DR_MODE_M1 || pq_only)) { const int rci = build_inline_codes(ix); if (rci) return rci; }
     p.vecp = ix->vecp.p; p.adj = ix->adj.p; p.first = ix->first.p; p.codes = ix->codes.p; p.codebook = ix->codebook.p;
-    p.adjr = (!ov && !novis && !vh && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
+    p.adjr = (!ov && !novis && ix->use_adjr) ? ix->adjr.p : nullptr; p.medoid_pos = ix->medoid_pos;
     const bool rowpre = getenv("DR_PQ_ROW_PREFETCH") != nullptr;      // A/B (round 4): ids of the predicted next pop's row landed in LDS
     p.novis = novis ? (1u | (rowpre && !(ov && ov->sdc) ? 2u : 0u)) : 0u;
     if (const char *e = getenv("DR_REPREFETCH")) { if (e[0] == '1') p.novis |= 4u; }      // A/B (round 4): the adjacency prefetch with a second chance (1 % slower)

@@ -61,9 +61,6 @@
 #define PHD(i) do {} while (0)
 #endif
 
-#ifndef DR_ST_VIS_OVERFLOW
-#define DR_ST_VIS_OVERFLOW 1u      // dr_stats.status bit 0: a visited-id set ran out (latency_kernel.hpp's, or the VH variants' below)
-#endif
 #define DR_ST_CAND_OVERFLOW 2u
 #define DR_ST_LOG_OVERFLOW 4u
 #define DR_ST_INTERNAL 8u      // a loop guard fired (never expected; bounds every loop so a bug cannot hang the GPU)
@@ -670,21 +667,9 @@ DEV void write_results(const SearchParams &p, u32 qi, int cap, u32 kmode, bool h
     }
 }
 
-// VH (round 6, variants 22 / 23 = 13 / 17): the visited set as an exact HASH SET OF IDS instead of the stamped bitmap over all N positions. Per wavefront
-// slot 1024 buckets of eight 32-bit entries (stamp << 24 | id; N <= 2^24) + a 120-entry overflow list = 32.5 KiB instead of N / 6 bytes (167 KB at 1M points):
-// the 4096 slots' tables are 133 MB, rewritten in place query after query -- they live in the Infinity Cache (256 MiB) instead of streaming 22 % of the
-// kernel's read lines and ALL of its write requests (37 % of its memory requests) through HBM; and the adjacency's bit-position twin (2 of the 5 lines
-// of a row's load group) is not read at all. One 32-byte bucket load per tested neighbour (one round trip, as the bitmap word's); a lane inserts at the
-// bucket's live count (+ its rank among the lanes of the same instruction that hit the same bucket: grouped through LDS as the bitmap's words are);
-// a full bucket spills into the overflow list (scanned by the wave when a lane meets a full bucket: rare), a full list sets DR_ST_VIS_OVERFLOW and
-// the host serves the call again with the bitmap variant. Same visited SET, hence the same results and counters.
-#define DR_VH_BUCKETS 1024u
-#define DR_VH_OVF 120u
-#define DR_VH_WORDS (DR_VH_BUCKETS * 8u + 128u)
-template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false, int TREG = 0, bool VH = false>
+template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false, int TREG = 0>
 DEV void search_body(const SearchParams &p)
 {
-    static_assert(!VH || (QB && FILTER && KIND == DIST_EXACT), "the visited-id hash set serves the byte-row M1 variants");
     static_assert(TREG == 0 || (TREG == 16 && KIND == DIST_ADC_SQ && !FILTER && !CBLDS && RB == 0), "register table rows: the ADC-only per-query-table variant");
     constexpr bool QREG = (D <= 256);
     constexpr bool SPLIT = QREG && split_form_ok<D>();
@@ -902,8 +887,7 @@ DEV void search_body(const SearchParams &p)
         u32 pre_id = 0xFFFFFFFFu;   // node whose adjacency row is (being) landed in pre_buf; none at query start
         u32 pre_db = 0xFFFFFFFFu;   // distance bits of that node (the prediction a better new neighbour replaces)
         u32 npre_hit = 0;
-        const bool pre_on = ADJPRE && has_first && (VH || p.adjr != nullptr) && p.R == 64u;
-        u32 vh_novf = 0u;       // (VH) entries of this query in the slot's overflow list
+        const bool pre_on = ADJPRE && has_first && p.adjr != nullptr && p.R == 64u;
 #ifdef DR_TRACE_VIS
         u32 trn = 0;
 #endif
@@ -929,9 +913,6 @@ DEV void search_body(const SearchParams &p)
         // ---- start node (search_engine.py:416-426)
         {
             const u32 start = p.medoid;
-            if constexpr (VH) {
-                if (lane == 0) vbm[(((start * 0x9E3779B1u) >> 22) << 3)] = vtag | start;      // (a new stamp: the bucket holds nothing live)
-            } else
             if (lane == 0 && !novis) {
                 const u32 sp = p.adjr ? p.medoid_pos : start;
                 const u32 sw = __umulhi(sp, 0xAAAAAAABu) >> 4;            // sp / 24
@@ -1052,7 +1033,7 @@ DEV void search_body(const SearchParams &p)
                     aux_w = *reinterpret_cast<const u64 *>(pre_buf + 128);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // read before the next prefetch reuses the area
                 } else if (rowpre_hit) { nbid_l = cbase ? hit_ids1 : hit_ids0; nbpos_l = 0u; aux_w = auxp[0]; }
-                else { nbid_l = idrow[sl]; nbpos_l = (novis || VH) ? 0u : posrow[sl]; aux_w = auxp[0]; }
+                else { nbid_l = idrow[sl]; nbpos_l = novis ? 0u : posrow[sl]; aux_w = auxp[0]; }
                 if constexpr (SPEC_CODES) { if (codes_with_row) adc_load_codes(cw0, cw1, cw2, cw3, p.nbcodes + ((size_t)cur * p.R + sl) * p.m, p.m); }
                 // Predict the next pop -- the best frontier entry that is left now (this expansion's neighbours may still
                 // beat it) -- and land ITS adjacency row in LDS: no VGPR destination, nobody waits for it, and when the
@@ -1066,14 +1047,11 @@ DEV void search_body(const SearchParams &p)
                         const u64 kn = ka2 <= kb2 ? ka2 : kb2;
                         if (kn != ~0ull) {
                             pre_id = (u32)kn; pre_db = (u32)(kn >> 32);
-                            const u32 *gi = p.adj + (size_t)pre_id * 64 + lane;
+                            const u32 *gi = p.adj + (size_t)pre_id * 64 + lane, *gp = p.adjr + (size_t)pre_id * 64 + lane;
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gi,
                                 (__attribute__((address_space(3))) void *)pre_buf, 4, 0, 0);
-                            if constexpr (!VH) {
-                                const u32 *gp = p.adjr + (size_t)pre_id * 64 + lane;
-                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
-                                    (__attribute__((address_space(3))) void *)(pre_buf + 64), 4, 0, 0);
-                            }
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
+                                (__attribute__((address_space(3))) void *)(pre_buf + 64), 4, 0, 0);
                             if (lane < 2) {
                                 const u32 *gm = reinterpret_cast<const u32 *>(p.first + (size_t)pre_id) + lane;
                                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gm,
@@ -1119,21 +1097,9 @@ DEV void search_body(const SearchParams &p)
                 u32 vraw = 0u;
                 const u32 hsh = vw * 0x9E3779B1u;
                 const u32 bh = hsh >> 20;                                // filter bit of this word
-                bool vneed = active && !novis && !VH;
+                bool vneed = active && !novis;
                 if constexpr (VB_BITS > 0) vneed = vneed && ((blm[bh >> 5] >> (bh & 31)) & 1u) != 0u;
                 if (vneed) vraw = __hip_atomic_load(&vbm[vw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // (VH) the neighbour's bucket: eight entries, four 8-byte loads served by the L2 (this wavefront is the table's only writer)
-                const u32 vh_b = (nbid * 0x9E3779B1u) >> 22;
-                u64 vhw0 = 0ull, vhw1 = 0ull, vhw2 = 0ull, vhw3 = 0ull;
-                if constexpr (VH) {
-                    if (active) {
-                        const u64 *bp = reinterpret_cast<const u64 *>(vbm + (vh_b << 3));
-                        vhw0 = __hip_atomic_load(bp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vhw1 = __hip_atomic_load(bp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vhw2 = __hip_atomic_load(bp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vhw3 = __hip_atomic_load(bp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
                 // Code words of the row's neighbours fetched BESIDE the visited test instead of after it (one dependent
                 // round trip less per expansion) whenever their ADC may be needed: always for the ADC traversals; for M1
                 // unless the bound that lets the expansion skip the ADC already holds with every active lane counted as
@@ -1159,57 +1125,7 @@ DEV void search_body(const SearchParams &p)
                     if (spec && codelane && !codes_with_row) adc_load_codes(cw0, cw1, cw2, cw3, mycode, p.m);
                 }
                 if (novis) isnew = active;      // every neighbour is scored; the list itself says which are already in it (decisions)
-                else if constexpr (VH) {
-                    const u32 want = vtag | nbid;
-                    const u32 ent[8] = { (u32)vhw0, (u32)(vhw0 >> 32), (u32)vhw1, (u32)(vhw1 >> 32), (u32)vhw2, (u32)(vhw2 >> 32), (u32)vhw3, (u32)(vhw3 >> 32) };
-                    bool found = false;
-                    u32 nlive = 0u;       // (entries of this query fill a bucket from position 0: always inserted at the live count)
-#pragma unroll
-                    for (int e = 0; e < 8; e++) { found = found || ent[e] == want; nlive += ((ent[e] >> 24) == vstamp) ? 1u : 0u; }
-                    // a full bucket that does not hold the id: the slot's overflow list decides (rare: the wave scans it together)
-                    if (vh_novf != 0u && __ballot(active && !found && nlive == 8u) != 0ull) {
-                        const u32 *ol = vbm + DR_VH_BUCKETS * 8u;
-#pragma unroll 1
-                        for (u32 i = 0; i < vh_novf; i++) found = found || (__hip_atomic_load(ol + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nbid && nlive == 8u);
-                    }
-                    isnew = active && !found;
-                    // lanes of this instruction that insert into the SAME bucket take consecutive positions: grouped by bucket through LDS (the
-                    // bitmap's word grouping: a lane that reads back its own bucket number has found its group's leader), ranked by an LDS atomic
-                    u32 vldr = (u32)lane, vrank = 0u;
-                    u32 *vacc = reinterpret_cast<u32 *>(nb_e);         // idle until the distances are written
-                    u64 *vtab = reinterpret_cast<u64 *>(mk);           // idle until the rows land / the merge
-                    vacc[lane] = 0u;
-                    bool vpend = isnew;
-                    u64 pendm = __ballot(vpend);
-                    const u32 hsb = vh_b * 0x85EBCA6Bu;
-#pragma unroll 1
-                    for (int vr = 0; vr < 2 && pendm != 0ull; vr++) {
-                        const u32 hb = (hsb >> (vr ? 8 : 20)) & (u32)(VT - 1);
-                        if (vpend) vtab[hb] = ((u64)vh_b << 32) | (u32)lane;
-                        WSYNC();
-                        const u64 entg = vtab[hb];
-                        WSYNC();
-                        if (vpend && (u32)(entg >> 32) == vh_b) { vldr = (u32)entg; vpend = false; vrank = atomicAdd(&vacc[vldr], 1u); }
-                        pendm = __ballot(vpend);
-                    }
-#pragma unroll 1
-                    while (pendm != 0ull) {      // leftovers (two hash collisions in a row): one group per trip
-                        const int f = __ffsll((long long)pendm) - 1;
-                        const u32 bf = readlane32(vh_b, f);
-                        if (vpend && vh_b == bf) { vldr = (u32)f; vpend = false; vrank = atomicAdd(&vacc[f], 1u); }
-                        pendm = __ballot(vpend);
-                    }
-                    WSYNC();
-                    const u32 vpos = nlive + vrank;
-                    if (isnew && vpos < 8u) vbm[(vh_b << 3) + vpos] = want;
-                    const u64 ovm = __ballot(isnew && vpos >= 8u);
-                    if (ovm != 0ull) {
-                        const u32 oi = vh_novf + (u32)__popcll(ovm & lanemask_lt());
-                        if (isnew && vpos >= 8u && oi < DR_VH_OVF) vbm[DR_VH_BUCKETS * 8u + oi] = nbid;
-                        vh_novf += (u32)__popcll(ovm);
-                        if (vh_novf > DR_VH_OVF) { status |= DR_ST_VIS_OVERFLOW; vh_novf = DR_VH_OVF; }
-                    }
-                } else {
+                else {
                     u32 vldr = (u32)lane;
                     u32 *vacc = reinterpret_cast<u32 *>(nb_e);         // idle until the distances are written
                     u64 *vtab = reinterpret_cast<u64 *>(mk);           // idle until the rows land / the merge
@@ -2013,7 +1929,7 @@ DEV void search_body(const SearchParams &p)
     if (lane == 0 && !novis) p.vis_epoch[slot_id] = vstamp;
 }
 
-template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false, int TREG = 0, bool VH = false>
+template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0, bool U8 = false, bool QB = false, int TREG = 0>
 // (minimum wavefronts per SIMD: 2 for the one-wavefront workgroups at D <= 256, which are register-limited -- forcing 3 on
 // the exact traversals (168 VGPRs, 25 spilled) measured 0...+5 % slower at the c4 shape; the large dimensions hold a
 // 32-KiB table or the row pipeline's buffers: 1)
@@ -2021,5 +1937,5 @@ template <int D, bool FILTER, int KIND, int NCHR, int NW, bool CBLDS, int RB = 0
 // byte-row landing variants (16, 17) sit four to a CU like the 16 wavefronts of ONE workgroup of 11 / 13: 4 per SIMD, 128 registers)
 __global__ __launch_bounds__(64 * NW, ((NW == 1 && D <= 256) || TREG > 0) ? 2 : (NW == 4 && RB > 0 && U8) ? (QB ? DR_AB_MINW17 : 4) : 1) void search_kernel(const SearchParams p)
 {
-    search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB, U8, QB, TREG, VH>(p);
+    search_body<D, FILTER, KIND, NCHR, NW, CBLDS, RB, U8, QB, TREG>(p);
 }

@@ -26,8 +26,6 @@
 //  16 = 11, 17 = 13 in workgroups of FOUR wavefronts (same code, same 16 wavefronts per CU as four workgroups): a batch
 //     smaller than the chip's 4096 wavefront slots -- the 1250-query slice of an 8-GPU strong-scaling job, a coalesced
 //     handful of requests -- spreads over all 256 CUs instead of filling ceil(nq / 16) of them (round 4)
-//  22 = 13, 23 = 17 with the visited set as a HASH SET OF IDS per wavefront slot (32.5 KiB, rewritten in place: on-die) instead of the stamped bitmap
-//     over all N positions (round 6; N <= 2^24; a query that outgrows its set is served again by 13 / 17)
 // (tried in round 2 and removed: 16-wave forms of 3 and 5 for D <= 96 -- twice the queries in flight, 30 % slower than the
 //  per-query table at the c4 shape: that kernel is bound by its number of memory requests, not by latency)
 // sizeclass: result capacity <= 64 / 128 / 256 / 512 / 1024 (the last one: one-wavefront-per-workgroup variants only)
@@ -48,7 +46,6 @@ struct KindDesc {
     bool pq;      // reads PQ data
     bool u8, qb;  // byte rows, byte queries
     int treg;     // table rows (sub-quantisers) held in registers instead of LDS
-    bool vh;      // visited set = a hash set of ids per wavefront slot (search_kernel.hpp VH) instead of the stamped bitmap
 };
 static const KindDesc DR_KINDS[] = {
     { 0, 1, false, 0, true, true, false, false, 0 },
@@ -65,11 +62,9 @@ static const KindDesc DR_KINDS[] = {
     { 15, 1, false, 0, true, true, false, false, 16 },
     { 16, 4, false, 64, false, true, true, false, 0 },
     { 17, 4, false, DR_AB_RB17, false, true, true, true, 0 },
-    { 22, 16, false, 64, false, true, true, true, 0, true },
-    { 23, 4, false, 64, false, true, true, true, 0, true },
 };
 #define DR_NUM_KINDS ((int)(sizeof(DR_KINDS) / sizeof(DR_KINDS[0])))
-#define DR_MAX_KIND_ID 23
+#define DR_MAX_KIND_ID 17
 #define DR_NUM_SIZECLASS 5
 #define DR_MAX_CAPACITY 1024u
 // position of variant `id` in DR_KINDS (= its row in DimKernels::search), or -1
@@ -79,7 +74,7 @@ static inline int dr_kind_pos(int id)
     return -1;
 }
 // the small-workgroup twin of a variant (same kernel in 4-wavefront workgroups), or -1
-static inline int dr_small_twin(int id) { return id == 11 ? 16 : id == 13 ? 17 : id == 22 ? 23 : -1; }
+static inline int dr_small_twin(int id) { return id == 11 ? 16 : id == 13 ? 17 : -1; }
 struct DimKernels {
     int D;
     const void *search[sizeof(DR_KINDS) / sizeof(DR_KINDS[0])][DR_NUM_SIZECLASS];     // [position in DR_KINDS][sizeclass]; nullptr: not built for this dimension

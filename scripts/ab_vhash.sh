@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B (GPU box): the visited set of the c2 M1 kernel as a hash set of ids per wavefront slot (variants 22 / 23, DR_VHASH=1) against the stamped bitmap (13 / 17)
+# A/B (GPU box; RECORD: runs only on commit 2cfb1e0, where variants 22 / 23 exist): the visited set of the c2 M1 kernel as a hash set of ids per wavefront
+# slot (DR_VHASH=1) against the stamped bitmap (13 / 17). Result: profiles/r06/ab/ab_visited_id_hash_set.jsonl (bit-identical, 40-48 % slower); removed after.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/ab; rm -f gpurun_out/ab/vhash.jsonl
 export DR_VHASH=1
 DR_VHASH=1 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_live_regime.py tests/test_gpu_coalesce.py -x -q 2>&1 | tail -3
