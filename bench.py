@@ -741,12 +741,15 @@ def worker_c2(args, rk):
             rec = doc.get("beam_width_%d" % args.bw)
             if rec and (rnd != "r01" or variant == 13):
                 traffic = rec["hbm_bytes_per_launch"]
-                # (round 6: the counters were also collected with TWO batches per launch, the shape of the bench's coalesced launches)
-                traffic_2 = (doc.get("queries_per_launch_20000") or {}).get("hbm_bytes_per_launch") if args.bw == 8 else None
+                # (round 6: the counters were also collected with two / three batches per launch, the shape of the bench's coalesced launches)
+                for nq2 in (30000, 20000):
+                    t2 = (doc.get("queries_per_launch_%d" % nq2) or {}).get("hbm_bytes_per_launch") if args.bw == 8 else None
+                    if t2 and traffic_2 is None:
+                        traffic_2 = (t2, nq2 / 10000.0)
                 traffic_src = ("profiles/%s/" + pmc.name + ": rocprofv3 --pmc read requests by size (TCC_EA0_RDREQ_32B/64B/128B; FETCH_SIZE x2 before round 4) + WRITE_SIZE, separate passes over scripts/pmc_target.py "
-                               "-- the same workload and build, collected by scripts/profile_run.sh in ANOTHER run on another box of the pool (a PMC pass "
-                               "cannot share a process with the timed region), one batch per launch there: scaled by this run's batches per launch "
-                               "(the counters are linear in the queries of a launch); hbm_frac divides it by THIS run's kernel time") % rnd
+                               "-- the same workload and search kernel (the file carries the library's hash), collected by scripts/profile_run_r06.sh in ANOTHER run on another "
+                               "box of the pool (a PMC pass cannot share a process with the timed region) with one AND three batches per launch (round 6; one only before): "
+                               "interpolated to this run's batches per launch; hbm_frac divides it by THIS run's kernel time") % rnd
 
     byte_rows = variant in (11, 13)
     # the kernel's own necessary bytes: a scored vector is D bytes for the byte-row variants, 4D for float rows
@@ -756,7 +759,7 @@ def worker_c2(args, rk):
     achieved = alg_kernel / (k_ms * 1e-3) / 1e9
     if traffic is not None:
         # the PMC passes ran one (and, since round 6, two) batches per launch; this run's launches hold `per_launch` batches: linear in between
-        traffic = traffic + (per_launch - 1.0) * (traffic_2 - traffic) if traffic_2 else traffic * per_launch
+        traffic = traffic + (per_launch - 1.0) * (traffic_2[0] - traffic) / (traffic_2[1] - 1.0) if traffic_2 else traffic * per_launch
     # one launch per batch, PIPE_DEPTH in flight (how rounds 2-3 ran the headline): the same stream without coalescing
     one_per_launch = None
     if not args.headline_only:

@@ -726,6 +726,7 @@ static int build_rank(dr_index *ix)
     if (!ix->rank_valid) {
         uint64_t P = (uint64_t)(1.5e13 / ((double)N * D * 3.0));
         P = std::min<uint64_t>(std::min<uint64_t>(P, 4096), N / 64) & ~7ull;
+        if (const char *ep = getenv("DR_BITORDER_P")) P = std::min<uint64_t>((uint64_t)atoll(ep), N / 64) & ~7ull;      // A/B: pivots (cells) of the locality order
         if (P < 64) return 0;
         std::vector<uint32_t> h(P);
         for (uint64_t i = 0; i < P; i++) h[i] = (uint32_t)(i * (N / P));
@@ -747,7 +748,8 @@ static int build_rank(dr_index *ix)
         static const bool flat = getenv("DR_BITORDER_FLAT") != nullptr;
         std::vector<uint32_t> cell_order(P);
         for (uint64_t c = 0; c < P; c++) cell_order[c] = (uint32_t)c;
-        const uint64_t S = 64;
+        uint64_t S = 64;
+        if (const char *es = getenv("DR_BITORDER_S")) S = std::max<uint64_t>(8, (uint64_t)atoll(es));      // A/B: super cells the cells are grouped by
         if (!flat && P >= S * 8) {
             DevBuf<uint32_t> spid, slabel;
             DevBuf<float> spiv;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence of round 6 (run on the GPU box through gpurun). Output: gpurun_out/prof6/ -> copied to profiles/r06/ by hand.
 #   1. the headline kernel (c2, variant 13): --kernel-trace --stats of `bench.py --headline-only`; PMC traffic (separate --pmc passes) in the
-#      shape of the bench's COALESCED launches (PMC_NQ=20000 queries per launch) and with one batch per launch; the library's hash in every file
+#      shape of the bench's COALESCED launches (PMC_NQ=30000 queries per launch) and with one batch per launch; the library's hash in every file
 #   2. where the written bytes go (VERDICT r5 item 2 iii): the same passes with DR_NO_LOG=1 DR_SKIP_FINALIZE=1 (no insert log) -- WRITE_SIZE and the
 #      kernel's duration with and without
 #   3. SQ counters of the occupancy A/B (variant 17 at 16 wavefronts per CU against the 24-wavefront build, when that library is present)
@@ -24,14 +24,14 @@ for part in $PARTS; do case $part in
   rm -rf $OUT/stats_c2
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c2 -- python3 bench.py --steps 5 --warmup 1 --headline-only > $OUT/bench_under_rocprof.json 2> $OUT/stats_c2.err
   cp $(ls $OUT/stats_c2/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv; rm -rf $OUT/stats_c2
-  for nq in 20000 10000; do
+  for nq in 30000 10000; do
     export PMC_NQ=$nq
     pmc rd_$nq "$RD" scripts/pmc_target.py 8
     pmc wr_$nq "$WR" scripts/pmc_target.py 8
     unset PMC_NQ
   done ;;
 2)
-  export PMC_NQ=20000 DR_NO_LOG=1 DR_SKIP_FINALIZE=1
+  export PMC_NQ=30000 DR_NO_LOG=1 DR_SKIP_FINALIZE=1
   pmc wr_nolog "$WR" scripts/pmc_target.py 8
   pmc rd_nolog "$RD" scripts/pmc_target.py 8
   unset PMC_NQ DR_NO_LOG DR_SKIP_FINALIZE ;;
@@ -96,11 +96,11 @@ def traffic(rd_tag, wr_tag, sub):
     return o
 src = "scripts/profile_run_r06.sh: rocprofv3 --pmc TCC_EA0_RDREQ_{sum,32B,64B,128B} and WRITE_SIZE + TCC_EA0_WRREQ (separate passes), mean of the last 3 launches, MI355X, ROCm 7.2; read bytes = 128 / 64 / 32 per request of each size (profiles/r04/tcc_calibration.json), WRITE_SIZE in KiB"
 c2 = {"source": src + "; target scripts/pmc_target.py 8 (the bench workload, resident launches)"}
-for nq in (20000, 10000):
+for nq in (30000, 20000, 10000):
     t = traffic(f"rd_{nq}", f"wr_{nq}", "search_kernel<128, true")
     if t: c2["queries_per_launch_%d" % nq] = t
 t = traffic("rd_nolog", "wr_nolog", "search_kernel<128, true")
-if t: c2["queries_per_launch_20000_no_insert_log"] = dict(t, note="DR_NO_LOG=1 DR_SKIP_FINALIZE=1: the insert log is not written (tie order wrong: counters and timing only)")
+if t: c2["queries_per_launch_30000_no_insert_log"] = dict(t, note="DR_NO_LOG=1 DR_SKIP_FINALIZE=1: the insert log is not written (tie order wrong: counters and timing only)")
 if len(c2) > 1:
     # bench.py reads beam_width_8 (one batch per launch, scaled by its batches per launch) -- kept for that reader
     if "queries_per_launch_10000" in c2: c2["beam_width_8"] = dict(c2["queries_per_launch_10000"], queries_per_launch=10000)
