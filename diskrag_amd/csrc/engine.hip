@@ -375,9 +375,20 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     ix->num_cu = prop.multiProcessorCount;
     ix->device = device; ix->N = N; ix->D = D; ix->R = R; ix->medoid = medoid;
     HIPCHK(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+    if (getenv("DR_COMPANION_PRIORITY") != nullptr) {
+        // A/B (round 6): the companions of the search kernel (tie-order pass, bound kernels, copies) on high-priority streams, so that their few
+        // wavefronts are dispatched ahead of a queued search kernel's workgroups when slots free up
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        const int which = atoi(getenv("DR_COMPANION_PRIORITY"));       // 1: all three, 2: tie order + download, 3: tie order only, 4: upload only
+        HIPCHK(hipStreamCreateWithPriority(&ix->fstream, hipStreamNonBlocking, which != 4 ? hi : lo));
+        HIPCHK(hipStreamCreateWithPriority(&ix->up_stream, hipStreamNonBlocking, (which == 1 || which == 4) ? hi : lo));
+        HIPCHK(hipStreamCreateWithPriority(&ix->down_stream, hipStreamNonBlocking, (which == 1 || which == 2) ? hi : lo));
+    } else {
     HIPCHK(hipStreamCreateWithFlags(&ix->fstream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ix->up_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ix->down_stream, hipStreamNonBlocking));
+    }
     ix->two_lanes = getenv("DR_TWO_LANES") != nullptr;
     if (ix->two_lanes) { HIPCHK(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&ix->prep_ev, hipEventDisableTiming)); }
     for (auto &gr : ix->groups) { HIPCHK(hipEventCreateWithFlags(&gr.up_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&gr.down_done, hipEventDisableTiming)); }
