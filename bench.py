@@ -99,6 +99,7 @@ def parse_args(argv=None):
     ap.add_argument("--full-size", action="store_true",
                     help="c3 / c4 / c5: the configuration's own size on ONE MI355X (c3 10 000 000 x 1536: ~9 min of set-up; c4 100 000 000 x 96: ~12 min; "
                          "c5 one 125 000 000-point shard of the 1B x 1536 shape: ~25 min) instead of the bench-scale default")
+    ap.add_argument("--coalesce", type=int, default=65536, help="c2: queries one launch of the pipelined path may hold (dr_set_coalesce; the library's own default is 32768)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
     # the shape of the configuration (BASELINE.json configs[1] / configs[4]) unless given
@@ -558,9 +559,17 @@ def worker_c2(args, rk):
     ix.batch_select(0)
     ix.debug_force_kind(base_kind)
 
+    # Launches of the pipelined path hold up to `coalesce` queries: the library's default is 32 768 (three 10 000-query batches); the bench asks for
+    # 65 536 (dr_set_coalesce: six batches per launch) -- a launch on 4096 persistent wavefronts ends about one query (0.3 ms) after its ideal finish
+    # whatever it holds, so twice the queries per launch is 0.98 -> 0.94 ms of kernel per 10 000 queries and +3 % host -> host, four of four interleaved
+    # rounds (profiles/r06/ab/ab_launches_of_up_to_65536_queries.jsonl); the price is latency: a batch spends ~25 ms in the stream instead of ~14
+    # (--coalesce 32768 restores the default, 10240 one batch per launch)
+    coalesce = args.coalesce
+    ix.set_coalesce(coalesce)
+
     def tickets_in_flight(n_q):
-        """submits a caller keeps in flight: PIPE_DEPTH launches' worth (a launch coalesces submits up to 32768 queries) + 2"""
-        return min(_ffi.MAX_TICKETS - 2, _ffi.PIPE_DEPTH * max(1, 32768 // n_q) + 2)
+        """submits a caller keeps in flight: PIPE_DEPTH launches' worth (a launch coalesces submits up to `coalesce` queries) + 2"""
+        return min(_ffi.MAX_TICKETS - 2, _ffi.PIPE_DEPTH * max(1, coalesce // n_q) + 2)
 
     # ---------------------------------------------------------------- the headline: host memory -> host memory, pipelined
     def run_pipelined(n_launch, sources, depth=_ffi.PIPE_DEPTH):
@@ -770,7 +779,7 @@ def worker_c2(args, rk):
         ix.batch_sync()
         one_per_launch = {"qps": nq * max(40, launches // 2) / el_1, "kernel_ms": float(ix.timing()["search_kernel_ms"]),
                           "tickets_in_flight": _ffi.PIPE_DEPTH}
-        ix.set_coalesce(32768)
+        ix.set_coalesce(coalesce)
     secondary = float_rows = float_queries = unrounded = None
     if not args.no_secondary and rk.world == 1:
         n_sec = max(40, launches // 4)
@@ -839,7 +848,8 @@ def worker_c2(args, rk):
                    "rank_cpu_affinity": pinned_to if rk.world > 1 else None,
                    "per_rank_setup": setup_all,
                    "per_rank_slice": slices if strong else None,
-                   "tickets_in_flight": depth_head, "queries_per_launch": q_per_launch, "submits_per_launch": submits_per_launch,
+                   "tickets_in_flight": depth_head, "coalesce_cap_queries": coalesce, "queries_per_launch": q_per_launch, "submits_per_launch": submits_per_launch,
+                   "ms_a_batch_spends_in_the_stream": depth_head * nq / (value / rk.world) * 1e3 if value else None,
                    "kernel_launches_in_timed_region": n_kernel_launches, "kernel_ms_per_batch": k_ms / per_launch,
                    "one_launch_per_batch": one_per_launch,
                    "ms_per_batch": elapsed_job / launches * 1e3, "timed_region_s": elapsed_job, "per_rank_seconds": times,

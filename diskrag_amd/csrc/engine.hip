@@ -76,6 +76,7 @@ const DimKernels *dr_dim_kernels(int D)
 
 struct dr_index;
 static int quiesce_locked(dr_index *ix);
+static const uint32_t DR_MAX_GROUP = 65536;     // queries ONE launch of the pipelined path may hold (dr_set_coalesce; the default is 32768): a launch's scratch is sized by its queries
 
 // A fill that has COMPLETED when the call returns. hipMemset on device memory queues a fill kernel on the null stream and may return before it has
 // run; the handle's streams are created hipStreamNonBlocking and do not wait for the null stream -- on a GPU shared with other processes (eight
@@ -390,6 +391,7 @@ static int index_alloc_common(dr_index *ix, uint64_t N, uint32_t D, uint32_t R, 
     HIPCHK(hipStreamCreateWithFlags(&ix->down_stream, hipStreamNonBlocking));
     }
     ix->two_lanes = getenv("DR_TWO_LANES") != nullptr;
+    if (const char *ec = getenv("DR_COALESCE_CAP")) ix->coalesce_cap = std::min<uint32_t>((uint32_t)atoi(ec), DR_MAX_GROUP);      // A/B: the default of dr_set_coalesce
     if (ix->two_lanes) { HIPCHK(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&ix->prep_ev, hipEventDisableTiming)); }
     for (auto &gr : ix->groups) { HIPCHK(hipEventCreateWithFlags(&gr.up_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&gr.down_done, hipEventDisableTiming)); }
     for (auto &e : ix->ev) HIPCHK(hipEventCreate(&e));
