@@ -99,7 +99,7 @@ def parse_args(argv=None):
     ap.add_argument("--full-size", action="store_true",
                     help="c3 / c4 / c5: the configuration's own size on ONE MI355X (c3 10 000 000 x 1536: ~9 min of set-up; c4 100 000 000 x 96: ~12 min; "
                          "c5 one 125 000 000-point shard of the 1B x 1536 shape: ~25 min) instead of the bench-scale default")
-    ap.add_argument("--coalesce", type=int, default=65536, help="c2: queries one launch of the pipelined path may hold (dr_set_coalesce; the library's own default is 32768)")
+    ap.add_argument("--coalesce", type=int, default=65536, help="c2 / c3 / c4: queries one launch of the pipelined path may hold (dr_set_coalesce; the library's own default is 32768)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
     # the shape of the configuration (BASELINE.json configs[1] / configs[4]) unless given
@@ -1016,7 +1016,8 @@ def worker_shape(args, rk):
         a = _ffi.pinned_empty((nq, D), np.float32)
         a[:] = q_all[b * nq:(b + 1) * nq]
         qb.append(a)
-    depth = min(_ffi.MAX_TICKETS - 2, _ffi.PIPE_DEPTH * max(1, 32768 // nq) + 2)
+    ix.set_coalesce(args.coalesce)          # (launches of up to 65 536 queries: worker_c2 has the measurement)
+    depth = min(_ffi.MAX_TICKETS - 2, _ffi.PIPE_DEPTH * max(1, args.coalesce // nq) + 2)
 
     def stream(n_sub, kw_):
         jobs, done, last = [], 0, None

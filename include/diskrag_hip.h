@@ -311,7 +311,7 @@ int dr_search_submit(dr_index *ix, const float *queries, uint32_t nq, uint32_t k
                      uint32_t *out_count, dr_stats *stats, uint64_t *out_ticket);
 int dr_search_wait(dr_index *ix, uint64_t ticket);
 int dr_search_flush(dr_index *ix);                       /* launches whatever dr_search_submit is holding back */
-int dr_set_coalesce(dr_index *ix, uint32_t max_queries); /* queries per coalesced launch (<= 32768); 0: no coalescing */
+int dr_set_coalesce(dr_index *ix, uint32_t max_queries); /* queries per coalesced launch (<= 65536 since round 6; default 32768); 0: no coalescing */
 int dr_pipeline_stats(dr_index *ix, uint64_t *out4);     /* [0] launches of the pipelined path, [1] tickets they carried, [2] most tickets in one launch, [3] queries */
 int dr_debug_hold(dr_index *ix, int on);                 /* test hook: held submits launch only when full / flushed / waited for */
 void *dr_host_alloc(uint64_t bytes); /* page-locked host memory (NULL on failure) */
