@@ -263,3 +263,42 @@ def test_large_groups_full_batches_share_a_launch(name, params):
     finally:
         ix.debug_hold(False)
     ix.batch_sync()
+
+
+def test_bulk_groups_collect_towards_the_launch_capacity():
+    """Round 6: a group that already holds >= 8192 queries keeps collecting while ONE search is running, for as long as another such batch fits its
+    capacity (dr_set_coalesce, now up to 65 536): a stream of 9000-query submits rides in launches of several submits, mixed with small requests, any
+    wait order -- and every ticket still carries the bits of a blocking call of its own; a lone bulk submit is launched at once (nothing in flight)."""
+    from diskrag_amd import HipIndex, _ffi
+    from diskrag_amd.synth import sift_like
+    x, q = sift_like(60000, 128, n_queries=9000, n_clusters=128, seed=31, query_seed=32)
+    ix = HipIndex.create_empty(x, R=32)
+    ix.build_vamana(L_build=60, alpha=1.2, passes=2, seed=3, pad_with_zero=True)
+    ix.pq_encode(ix.pq_train(32, n_sample=20000, iters=3))
+    kw = dict(L=60, beam_width=8, mode=_ffi.MODE_M1)
+    try:
+        want = ix.search_batch(q, 10, **kw)
+        lone = ix.search_submit(q, 10, **kw)                       # nothing in flight: launched at once
+        assert _same(lone.wait(), want)
+        for cap in (32768, 65536):
+            ix.set_coalesce(cap)
+            before = ix.pipeline_stats()
+            rs = np.random.RandomState(cap)
+            jobs, sizes = [], []
+            for i in range(22):
+                n = 9000 if i % 4 else int(rs.choice([1, 7, 300]))
+                a = int(rs.randint(0, len(q) - n + 1))
+                sizes.append((a, n))
+                jobs.append(ix.search_submit(q[a:a + n], 10, **kw))
+            for i in rs.permutation(len(jobs)):
+                a, n = sizes[i]
+                got = jobs[i].wait()
+                assert _same(got, tuple(w[a:a + n] for w in want)), (cap, i, a, n)
+            after = ix.pipeline_stats()
+            assert after["tickets"] - before["tickets"] == 22
+            assert 1 <= after["launches"] - before["launches"] <= 22          # (how many submits share a launch depends on timing: the bits must not)
+        with pytest.raises(_ffi.DiskragHipError):
+            ix.set_coalesce(65537)
+        ix.set_coalesce(32768)
+    finally:
+        ix.close()
