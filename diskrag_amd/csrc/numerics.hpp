@@ -464,7 +464,7 @@ DEV double pw_run_lane64(const float *__restrict__ c, const double *q, int n)
 // ---- any length, the tree evaluated from n AT RUN TIME (round 6: dimensions that have no compiled tree) ------------------------------
 // numpy's pairwise routine literally (numpy/_core/src/umath/loops_utils.h.src @TYPE@_pairwise_sum): n < 8 sequential from 0; n <= 128 eight accumulators r[j] += a[8 t + j], combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the
 // n % 8 leftovers added one by one; above 128 split at n / 2 rounded down to a multiple of 8 -- the recursion kept on an explicit stack
-// (depth <= 8: n <= 32768). ONE LANE sums ONE run (the generic traversal scores 64 neighbours at a time, a lane each). `pos` (may be null):
+// (n <= 32768: nine frames; twelve are there). ONE LANE sums ONE run (the generic traversal scores 64 neighbours at a time, a lane each). `pos` (may be null):
 // element i of the run is stored at c[pos[i]] -- the chain-major rows of a built dimension, so that this routine and the compiled trees can
 // be held to each other on the same index (tests/test_gpu_shapes.py). The same bits as pw_row_stream<0, D, D> / pw_run_lane wherever those exist.
 template <typename REAL> DEV REAL rt_sqd(float v, REAL q);
@@ -502,8 +502,8 @@ DEV REAL pw_run_rt(const float *__restrict__ c, const u32 *pos, const REAL *q, i
 {
     if (n <= 128) return pw_leaf_rt<REAL>(c, pos, q, 0, n);
     // frames of the recursion: (off, len, stage 0 = enter / 1 = left half running / 2 = right half running, left half's sum)
-    int f_off[9], f_len[9], f_stage[9];
-    REAL f_left[9];
+    int f_off[12], f_len[12], f_stage[12];
+    REAL f_left[12];
     int sp = 0;
     f_off[0] = 0; f_len[0] = n; f_stage[0] = 0;
     REAL ret = 0;
@@ -524,7 +524,7 @@ DEV REAL pw_run_rt(const float *__restrict__ c, const u32 *pos, const REAL *q, i
                 ret = rt_add(f_left[sp], ret);
             }
         } else {
-            if (sp >= 7) return ret;        // (n > 32768: not reachable, the host refuses it)
+            if (sp >= 10) return ret;       // (frames halve: n <= 32768 needs 9; the host refuses longer runs)
             int n2 = f_len[sp] / 2; n2 -= n2 % 8;
             f_stage[sp] = 1;
             f_off[sp + 1] = f_off[sp]; f_len[sp + 1] = n2; f_stage[sp + 1] = 0;

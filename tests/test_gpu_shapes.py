@@ -194,3 +194,23 @@ def test_the_run_time_tree_equals_the_compiled_trees(D, m, monkeypatch):
             assert all(np.array_equal(st[f], s2[f]) for f in ("steps", "visited", "exact", "pq")), (D, c)
     finally:
         ix.close()
+
+
+def test_a_very_long_vector_through_the_generic_traversal():
+    """D = 17 000 (nine levels of numpy's pairwise recursion; the queries' two copies take 136 KB of the kernel's LDS): the exact traversals against the oracle"""
+    from diskrag_amd import HipIndex
+    from oracle import pyoracle as orc
+    rs = np.random.RandomState(5)
+    N, D, R = 300, 17000, 8
+    x = rs.randn(N, D).astype(np.float32)
+    q = (x[:6] + 0.05 * rs.randn(6, D)).astype(np.float32)
+    adj = np.stack([rs.permutation(N)[:R] for _ in range(N)]).astype(np.uint32)
+    ix = HipIndex.create(x, adj, 0)
+    try:
+        for (mode, omode, k, L, bw, oflags) in ((2, orc.M2, 5, 0, 8, 0), (4, orc.M4, 5, 20, 0, orc.F_PAIRWISE)):
+            ids, dist, cnt, st = ix.search_batch(q, k, L=L, beam_width=bw, mode=mode)
+            oi, od, oc, ost = orc.search_batch(x, adj, q, 0, omode, k, L=L, bw=bw, flags=oflags, nthreads=4)
+            assert np.array_equal(ids, oi) and np.array_equal(cnt, oc), mode
+            assert np.array_equal(dist[oi != PAD].view(np.uint32), od[oi != PAD].astype(np.float32).view(np.uint32)), mode
+    finally:
+        ix.close()
