@@ -240,6 +240,8 @@ struct dr_index {
     DevBuf<uint8_t> codes;
     DevBuf<uint8_t> nbcodes;      // [N][R][m] inline neighbour codes (dr_index_inline_codes), rebuilt before the next search when stale
     bool inline_codes = false, nbcodes_valid = false;
+    DevBuf<uint8_t> scan_codes;   // the code words in the skewed flat scan's order (pq_scan_order_kernel), built by the first one-query dr_pq_scan_best
+    bool scan_valid = false;
     DevBuf<float> codebook;
     DevBuf<float> sdc;            // centroid-pair table [m][256][256] (PQ-only builder), built on first use FOR THE CODEBOOK IN PLACE:
     uint64_t codebook_gen = 0, sdc_gen = ~0ull;   // every codebook / m change bumps codebook_gen; ensure_sdc rebuilds a table of another generation
@@ -531,7 +533,7 @@ extern "C" int dr_index_set_adjacency(dr_index *ix, const uint32_t *adj)
     HIPCHK(hipSetDevice(ix->device));
     { const int rcq = quiesce_locked(ix); if (rcq) return rcq; }     // queued searches still read the old rows
     HIPCHK(hipMemcpy(ix->adj.p, adj, (size_t)ix->N * ix->R * 4, hipMemcpyHostToDevice));
-    ix->adc_live = -1; ix->nbcodes_valid = false;
+    ix->adc_live = -1; ix->nbcodes_valid = false; ix->scan_valid = false;
     return build_first_masks(ix);
 }
 
@@ -551,7 +553,7 @@ extern "C" int dr_index_set_pq(dr_index *ix, const float *codebook, const uint8_
     HIPCHK(hipMemcpy(ix->codebook.p, codebook, (size_t)256 * ix->D * 4, hipMemcpyHostToDevice));
     ix->m = m; ix->sd = ix->D / m; ix->codebook_gen++;
     for (auto &qs : ix->slots) qs.pq_ub_valid = false;
-    ix->adc_live = -1; ix->nbcodes_valid = false;
+    ix->adc_live = -1; ix->nbcodes_valid = false; ix->scan_valid = false;
     return 0;
 }
 
@@ -597,7 +599,7 @@ extern "C" void dr_index_close(dr_index *ix)
     ix->lut.release(); ix->lut2.release(); ix->vis2.release(); ix->vis_epoch2.release();
     if (ix->prep_ev) (void)hipEventDestroy(ix->prep_ev);
     if (ix->stream2) (void)hipStreamDestroy(ix->stream2);
-    ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->codebook.release(); ix->nbcodes.release(); ix->sdc.release();
+    ix->vecp.release(); ix->adj.release(); ix->first.release(); ix->codes.release(); ix->scan_codes.release(); ix->scan_valid = false; ix->codebook.release(); ix->nbcodes.release(); ix->sdc.release();
     ix->perm.release(); ix->vis.release(); ix->vis_epoch.release();
     for (auto &qs : ix->slots) qs.release();
     for (auto &jb : ix->jobs) if (jb.pin_in) (void)hipHostFree(jb.pin_in);

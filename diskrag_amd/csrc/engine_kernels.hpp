@@ -398,6 +398,184 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(const float *__restrict__ 
     }
 }
 
+// ---- the skewed flat scan (round 6): pq_scan_kernel's pace is the LDS array -- the 32 lanes of a lane group look up ONE table row at random
+// code bytes, 3.15 LDS cycles per group on average instead of 1 (68 % of the cycles are bank conflicts). Here lane l looks up row
+// (p + l) mod m at step p: the 32 lanes of a group sit on 32 different rows, and with the table stored entry-major --
+// slot x = p + (l & 31) of code byte c at word c * S + x, holding row x mod m; S = 64 (m <= 32) or 128 words -- on 32 different banks:
+// every ds_read_b32 is conflict-free. A lane therefore meets the rows of its code words in the reference's order (A3: strict sequential float
+// sum over j = 0 .. m - 1, fast_pq.py:325-326) but with the word boundary at its own step m - psi (psi = (l & 31) mod m): the rows psi .. m - 1 of
+// the word of 64-point row g - 1, then the rows 0 .. psi - 1 of the word of row g. The code bytes come in that order from a scan-order copy
+// of the code words (pq_scan_order_kernel: record (g, l) = m bytes, g = 0 .. ceil(N / 64), stored by 16-byte quarters: a wavefront load is 1 KiB contiguous), so the loads are coalesced
+// and any split of the rows into contiguous ranges costs one extra record per wavefront. Two running sums per lane: fma(t, 1.0f, s) is
+// the float add s + t and fma(t, 0.0f, s) is s for finite t, so sA takes the steps before the boundary and sB those after it with two
+// loop-invariant masks per step and no select; a table with a non-finite entry (pq_scan_skew_table_kernel flags it) takes the body with
+// selects instead (SAFE), which is exact for any value. The same bits as pq_scan_kernel.
+template <int M16>
+__global__ __launch_bounds__(256) void pq_scan_order_kernel(const u8 *__restrict__ codes, u64 n, u8 *__restrict__ out)
+{
+    constexpr u32 m = 16u * M16;
+    const u64 G = (n + 63) / 64, recs = (G + 1) * 64;
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < recs; r += (u64)gridDim.x * blockDim.x) {
+        const u64 g = r >> 6;
+        const u32 l = (u32)(r & 63), psi = (l & 31u) % m;
+        const u64 pa = g * 64 + l - 64, pb = g * 64 + l;
+        const bool va = g >= 1 && pa < n, vb = g < G && pb < n;
+        u32 w[m / 4];
+#pragma unroll
+        for (u32 d = 0; d < m / 4; d++) {
+            u32 v = 0;
+#pragma unroll
+            for (u32 b = 0; b < 4; b++) {
+                const u32 p = d * 4 + b;
+                u32 byte = 0;
+                if (p + psi < m) { if (va) byte = codes[pa * m + psi + p]; }
+                else if (vb) byte = codes[pb * m + p + psi - m];
+                v |= byte << (8 * b);
+            }
+            w[d] = v;
+        }
+        uint4 *o = reinterpret_cast<uint4 *>(out) + g * (m / 16) * 64 + l;      // quarter d of the 64 records of row g: 1 KiB contiguous
+#pragma unroll
+        for (u32 d = 0; d < m / 16; d++) o[d * 64] = make_uint4(w[4 * d], w[4 * d + 1], w[4 * d + 2], w[4 * d + 3]);
+    }
+}
+
+// the table of one query in the skewed scan's LDS image: out[q][c * S + x] = lut[q][(x mod m) * 256 + c] for x < m + 31; flag[q] != 0: a non-finite entry
+__global__ __launch_bounds__(256) void pq_scan_skew_table_kernel(const float *__restrict__ lut_g, u32 m, u32 S, float *__restrict__ out, u32 *__restrict__ flag)
+{
+    const u32 q = blockIdx.y;
+    const float *src = lut_g + (size_t)q * m * 256;
+    float *dst = out + (size_t)q * 256 * S;
+    bool bad = false;
+    for (u32 e = blockIdx.x * blockDim.x + threadIdx.x; e < 256u * S; e += gridDim.x * blockDim.x) {
+        const u32 c = e / S, x = e % S;
+        float v = 0.0f;
+        if (x < m + 31u) { v = src[(x % m) * 256 + c]; bad |= !(fabsf(v) <= 3.402823466e38f); }
+        dst[e] = v;
+    }
+    if (bad) atomicOr(flag + q, 1u);
+}
+
+// DEPTH records in flight per lane (registers; refilled as soon as a record's lookups are issued, never behind a branch: the loads past a
+// wavefront's range repeat its last record): one record ahead -- pq_scan_kernel's form -- leaves 16 wavefronts x 2 KiB per CU in flight, a
+// third of what the HBM latency needs, and that, not the LDS, was the pace of the first skewed form (0.66-0.69 of the peak at m = 32).
+#ifdef PQ_SKEW_PLAIN_LOADS
+#define PQ_SKEW_LOAD(p) (*(p))
+#else
+#define PQ_SKEW_LOAD(p) __builtin_nontemporal_load(p)
+#endif
+#ifndef PQ_SKEW_DEPTH32
+#define PQ_SKEW_DEPTH32 2
+#endif
+#ifndef PQ_SKEW_DEPTH16
+#define PQ_SKEW_DEPTH16 2
+#endif
+#ifndef PQ_SKEW_DEPTH64
+#define PQ_SKEW_DEPTH64 2
+#endif
+#ifndef PQ_SKEW_THREADS32
+#define PQ_SKEW_THREADS32 512
+#endif
+// (OUT: every distance is written. A store in the loop makes the compiler wait for ALL loads in flight once per DEPTH records -- loads and stores
+// share gfx950's vmcnt and complete in no order relative to each other -- so the scan that wants the nearest code word only has none.)
+template <int M16, int THREADS, int DEPTH, bool OUT>
+__global__ __launch_bounds__(THREADS) void pq_scan_skew_kernel(const float *__restrict__ lut_skew, const u32 *__restrict__ flag, const u8 *__restrict__ scan_codes,
+                                                              u64 n, float *__restrict__ out_sq, u64 *__restrict__ out_best)
+{
+    constexpr u32 m = 16u * M16, S = m <= 32 ? 64u : 128u;
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const u32 qi = blockIdx.y;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(lut_skew + (size_t)qi * 256 * S);
+        float4 *dst = reinterpret_cast<float4 *>(smem);
+        for (u32 e = threadIdx.x; e < 64u * S; e += THREADS) dst[e] = src[e];
+    }
+    const bool safe = flag[qi] != 0;
+    if ((u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();      // the lookups below address the LDS from 0
+    __syncthreads();
+    const u32 lane = threadIdx.x & 63u, phi = lane & 31u, psi = phi % m;
+    const u64 G = (n + 63) / 64;
+    const u64 W = (u64)gridDim.x * (THREADS / 64), gw = (u64)blockIdx.x * (THREADS / 64) + (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    auto uniform64 = [](u64 v) { return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v); };
+    const u64 g0 = uniform64(G * gw / W), g1 = uniform64(G * (gw + 1) / W);      // (scalar registers: the loop counter, the range tests and the record addresses are scalar code)
+    const u32 n32 = (u32)(n > 0xFFFFFFFFull ? 0xFFFFFFFFull : n);
+    u32 bs = ~0u, bi = ~0u;      // the lane's nearest code word: sum bits (sums are >= +0: their bits order as the values do, NaN last), id
+    if (g0 < g1) {
+        const u32x4 *recs = reinterpret_cast<const u32x4 *>(scan_codes);      // record g, quarter w, lane l: recs[(g * M16 + w) * 64 + l]
+        u32x4 buf[DEPTH][M16];
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const u64 gl = g0 + d < g1 ? g0 + d : g1;
+#pragma unroll
+            for (int w = 0; w < M16; w++) buf[d][w] = PQ_SKEW_LOAD(recs + (gl * M16 + w) * 64 + lane);
+        }
+        float mA[m], mB[m];
+#pragma unroll
+        for (u32 p = 0; p < m; p++) {
+            mA[p] = (p + psi < m) ? 1.0f : 0.0f;
+            mB[p] = 1.0f - mA[p];
+            asm volatile("" : "+v"(mB[p]));      // (kept in a register: re-derived from mA it is a third instruction per step)
+        }
+        const u32 lanebase = phi * 4u;
+        float sA = 0.0f;
+        for (u64 g = g0; g <= g1; g += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) {
+                const u64 gg = g + d;      // (gg > g1 in a wavefront's last group: the repeated last record is looked up and dropped -- an exit here
+                                           //  makes the compiler wait for every load in flight at the loop's head)
+                // the lookups of a 16-byte quarter are in flight while the sums take the quarter before it
+                float t[2][16];
+                auto look = [&](int w, float (&tt)[16]) {
+                    const u32 words[4] = { buf[d][w].x, buf[d][w].y, buf[d][w].z, buf[d][w].w };
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const int p = w * 16 + u * 4 + b;
+                            u32 addr;
+                            if constexpr (S == 64) addr = __builtin_amdgcn_perm(words[u], lanebase, 0x0C0C0400u | ((u32)b << 8));      // (c << 8) | lanebase
+                            else addr = (((words[u] >> (8 * b)) & 255u) << 9) + lanebase;
+                            tt[u * 4 + b] = *(const __attribute__((address_space(3))) float *)(uintptr_t)(addr + 4 * p);      // (the image starts at LDS address 0: checked above)
+                        }
+                };
+                look(0, t[0]);
+                float sB = 0.0f;
+#pragma unroll
+                for (int w = 0; w < M16; w++) {
+                    if (w + 1 < M16) look(w + 1, t[(w + 1) & 1]);
+                    else {
+                        const u64 gl = gg + DEPTH < g1 ? gg + DEPTH : g1;
+#pragma unroll
+                        for (int w2 = 0; w2 < M16; w2++) buf[d][w2] = PQ_SKEW_LOAD(recs + (gl * M16 + w2) * 64 + lane);
+                    }
+                    if (!safe) {
+#pragma unroll
+                        for (int e = 0; e < 16; e++) { sA = __builtin_fmaf(t[w & 1][e], mA[w * 16 + e], sA); sB = __builtin_fmaf(t[w & 1][e], mB[w * 16 + e], sB); }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; e++) { const bool inA = (u32)(w * 16 + e) + psi < m; sA = f_add(sA, inA ? t[w & 1][e] : 0.0f); sB = f_add(sB, inA ? 0.0f : t[w & 1][e]); }
+                    }
+                }
+                if (gg > g0 && gg <= g1) {      // the word that ended in this record: point (gg - 1) * 64 + lane (ids ascend along a lane: "<" keeps the smallest id of equal sums)
+                    const u32 i = (u32)gg * 64u - 64u + lane, sb = __float_as_uint(sA);
+                    if constexpr (OUT) { if (i < n32) out_sq[(size_t)qi * n + i] = sA; }
+                    const bool better = sb < bs && i < n32;
+                    bs = better ? sb : bs;
+                    bi = better ? i : bi;
+                }
+                sA = sB;
+            }
+        }
+    }
+    if (out_best) {
+        u64 best = ((u64)bs << 32) | bi;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const u64 other = __shfl_xor(best, o); best = other < best ? other : best; }
+        if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(reinterpret_cast<unsigned long long *>(out_best + qi), (unsigned long long)best);
+    }
+}
+
 // Flat PQ scan keeping the k nearest code words per query (brute-force ADC search: the ground truth of the PQ-only
 // traversals, and what a PQ-only shard falls back to when no graph exists). Tables come from lut_build_kernel (global
 // memory, landed in LDS once per block); every wavefront keeps its own ascending list of k keys (distance bits << 32 | id:
