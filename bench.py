@@ -400,9 +400,10 @@ def alg_bytes(st, D, R, m, k, row_bytes=None):
 
 
 def isolated_pq_scan(device, n_codes=64_000_000, m=32, D=128, nq=4):
-    """north_star's "PQ-scan kernel >= 40 % of the HBM-read roofline": the isolated ADC kernel (pq_scan_kernel: table in LDS,
-    code words streamed, strict sequential float sum) over a table of random code words far larger than L2 + Infinity
-    Cache (2 GB); algorithmic bytes = N*m per query, duration from HIP events around the launch."""
+    """north_star's "PQ-scan kernel >= 40 % of the HBM-read roofline": the isolated ADC kernel (round 6: pq_scan_skew_kernel -- table image
+    in LDS with every lane of a lane group on its own table row, code words streamed from the scan-order copy, strict sequential float sum;
+    `previous_kernel`: pq_scan_kernel, DR_PQ_SCAN_NO_SKEW=1) over a table of random code words far larger than L2 + Infinity Cache (2 GB);
+    algorithmic bytes = N*m per query, duration from HIP events around the table-image kernel + the scan launch."""
     from diskrag_amd import HipIndex
     rs = np.random.default_rng(5)
     codes = rs.integers(0, 256, size=(n_codes, m), dtype=np.uint8)
@@ -412,13 +413,19 @@ def isolated_pq_scan(device, n_codes=64_000_000, m=32, D=128, nq=4):
     del codes
     sc.pq_scan_best(q)
     ms = sorted(sc.pq_scan_best(q[:1])[2] for _ in range(5))          # one query: the code stream against the HBM peak
+    os.environ["DR_PQ_SCAN_NO_SKEW"] = "1"
+    try:
+        ms_old = sorted(sc.pq_scan_best(q[:1])[2] for _ in range(5))
+    finally:
+        del os.environ["DR_PQ_SCAN_NO_SKEW"]
     msn = sorted(sc.pq_scan_best(q)[2] for _ in range(5))             # nq queries sharing the pass (pq_scan_multi_kernel: 4 per group at m <= 32)
     sc.close()
     gbps = n_codes * m / (ms[2] * 1e-3) / 1e9
     per_pass = 4 if m <= 32 and nq > 2 else 2
     passes = -(-nq // per_pass)
-    return {"kernel": "pq_scan_kernel<2>", "code_bytes_per_launch": n_codes * m, "kernel_ms_median": ms[2], "GBps": gbps,
+    return {"kernel": "pq_scan_skew_table_kernel + pq_scan_skew_kernel<2, 512, 2, false>", "code_bytes_per_launch": n_codes * m, "kernel_ms_median": ms[2], "GBps": gbps,
             "frac": gbps / HBM_PEAK_GBPS, "queries_per_launch": 1,
+            "previous_kernel": {"kernel": "pq_scan_kernel<2>", "kernel_ms_median": ms_old[2], "frac": n_codes * m / (ms_old[2] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             "shared_pass": {"kernel": "pq_scan_multi_kernel<2, 4, 768>", "queries_per_launch": nq, "queries_per_pass": per_pass, "kernel_ms_median": msn[2],
                             "ms_per_query": msn[2] / nq, "GBps_algorithmic": nq * n_codes * m / (msn[2] * 1e-3) / 1e9,
                             "code_stream_GBps": passes * n_codes * m / (msn[2] * 1e-3) / 1e9,

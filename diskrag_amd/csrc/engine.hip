@@ -242,6 +242,7 @@ struct dr_index {
     bool inline_codes = false, nbcodes_valid = false;
     DevBuf<uint8_t> scan_codes;   // the code words in the skewed flat scan's order (pq_scan_order_kernel), built by the first one-query dr_pq_scan_best
     bool scan_valid = false;
+    uint32_t scan_streams = 0, scan_rows = 0, scan_interleaved = 1;      // the copy's layout: V streams of at most L rows, record t of stream k at t * V + k
     DevBuf<float> codebook;
     DevBuf<float> sdc;            // centroid-pair table [m][256][256] (PQ-only builder), built on first use FOR THE CODEBOOK IN PLACE:
     uint64_t codebook_gen = 0, sdc_gen = ~0ull;   // every codebook / m change bumps codebook_gen; ensure_sdc rebuilds a table of another generation

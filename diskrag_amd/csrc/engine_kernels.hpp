@@ -398,28 +398,35 @@ __global__ __launch_bounds__(256) void pq_scan_kernel(const float *__restrict__ 
     }
 }
 
-// ---- the skewed flat scan (round 6): pq_scan_kernel's pace is the LDS array -- the 32 lanes of a lane group look up ONE table row at random
-// code bytes, 3.15 LDS cycles per group on average instead of 1 (68 % of the cycles are bank conflicts). Here lane l looks up row
-// (p + l) mod m at step p: the 32 lanes of a group sit on 32 different rows, and with the table stored entry-major --
-// slot x = p + (l & 31) of code byte c at word c * S + x, holding row x mod m; S = 64 (m <= 32) or 128 words -- on 32 different banks:
-// every ds_read_b32 is conflict-free. A lane therefore meets the rows of its code words in the reference's order (A3: strict sequential float
-// sum over j = 0 .. m - 1, fast_pq.py:325-326) but with the word boundary at its own step m - psi (psi = (l & 31) mod m): the rows psi .. m - 1 of
-// the word of 64-point row g - 1, then the rows 0 .. psi - 1 of the word of row g. The code bytes come in that order from a scan-order copy
-// of the code words (pq_scan_order_kernel: record (g, l) = m bytes, g = 0 .. ceil(N / 64), stored by 16-byte quarters: a wavefront load is 1 KiB contiguous), so the loads are coalesced
-// and any split of the rows into contiguous ranges costs one extra record per wavefront. Two running sums per lane: fma(t, 1.0f, s) is
-// the float add s + t and fma(t, 0.0f, s) is s for finite t, so sA takes the steps before the boundary and sB those after it with two
-// loop-invariant masks per step and no select; a table with a non-finite entry (pq_scan_skew_table_kernel flags it) takes the body with
-// selects instead (SAFE), which is exact for any value. The same bits as pq_scan_kernel.
+// ---- the skewed flat scan (round 6; one query per block row). pq_scan_kernel looks up ONE table row per step in all 64 lanes at random code
+// bytes: 3.15 LDS cycles per 32-lane group on average instead of 1 (68 % of the LDS cycles are bank conflicts), and keeps one code word ahead per
+// lane. Here lane l looks up row (p + l) mod m at step p, from a table image stored entry-major: slot x = p + (l & 31) of code byte c sits at word
+// c * S + x and holds row x mod m (S = 64 words for m <= 32, 128 above). The 32 lanes of a group are on 32 different slots, so on 32 different
+// banks: every ds_read_b32 is conflict-free, and the address is one v_perm_b32 ((c << 8) | 4 (l & 31), the step in the offset field).
+// A lane still meets the rows of a code word in the reference's order (A3: strict sequential float sum over j = 0 .. m - 1, fast_pq.py:325-326)
+// but with the word boundary at its own step m - psi, psi = (l & 31) mod m: a record of m bytes holds the rows psi .. m - 1 of the word of one
+// 64-point row (part A) and then the rows 0 .. psi - 1 of the word of the next row (part B). The bytes come in that order from a scan-order copy of
+// the code words (pq_scan_order_kernel), stored by 16-byte quarters so that a wavefront load is 1 KiB contiguous.
+// Two running sums per lane, sA for part A and sB for part B: fma(t, 1.0f, s) is the float add s + t and fma(t, 0.0f, s) is s for finite t, so two
+// loop-invariant masks per step select the sum without a select instruction; a table image with a non-finite entry (every block checks its image as
+// it lands) takes the body with selects instead, which is exact for any value. After a record sA is the finished sum of part A's word and sB carries
+// on as the next record's sA. The same bits as pq_scan_kernel (tests/test_gpu_pq_scan_skew.py).
+// The copy is cut into V streams of consecutive 64-point rows (stream k: rows G k / V .. G (k + 1) / V - 1, G = ceil(N / 64), plus one closing
+// record: a stream of len rows is len + 1 records), one stream per wavefront of a launch that fills the device. il != 0: record t of stream k sits
+// at position t * V + k -- the wavefronts of a launch read one moving window of the copy instead of V distant ones (1-4 % faster); il == 0
+// (DR_PQ_SCAN_CONTIGUOUS_STREAMS, A/B): at k * (L + 1) + t, L = ceil(G / V).
 template <int M16>
-__global__ __launch_bounds__(256) void pq_scan_order_kernel(const u8 *__restrict__ codes, u64 n, u8 *__restrict__ out)
+__global__ __launch_bounds__(256) void pq_scan_order_kernel(const u8 *__restrict__ codes, u64 n, u32 V, u32 L, u32 il, u8 *__restrict__ out)
 {
     constexpr u32 m = 16u * M16;
-    const u64 G = (n + 63) / 64, recs = (G + 1) * 64;
+    const u64 G = (n + 63) / 64, recs = (u64)(L + 1) * V * 64;
     for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < recs; r += (u64)gridDim.x * blockDim.x) {
-        const u64 g = r >> 6;
+        const u64 pos = r >> 6;
         const u32 l = (u32)(r & 63), psi = (l & 31u) % m;
-        const u64 pa = g * 64 + l - 64, pb = g * 64 + l;
-        const bool va = g >= 1 && pa < n, vb = g < G && pb < n;
+        const u32 k = il ? (u32)(pos % V) : (u32)(pos / (L + 1)), t = il ? (u32)(pos / V) : (u32)(pos % (L + 1));
+        const u64 r0 = G * k / V, len = G * (k + 1) / V - r0;
+        const u64 pa = (r0 + t) * 64 + l - 64, pb = (r0 + t) * 64 + l;      // part A: the word of row r0 + t - 1, part B: of row r0 + t
+        const bool va = t >= 1 && t <= len && pa < n, vb = t < len && pb < n;
         u32 w[m / 4];
 #pragma unroll
         for (u32 d = 0; d < m / 4; d++) {
@@ -434,99 +441,94 @@ __global__ __launch_bounds__(256) void pq_scan_order_kernel(const u8 *__restrict
             }
             w[d] = v;
         }
-        uint4 *o = reinterpret_cast<uint4 *>(out) + g * (m / 16) * 64 + l;      // quarter d of the 64 records of row g: 1 KiB contiguous
+        uint4 *o = reinterpret_cast<uint4 *>(out) + pos * (m / 16) * 64 + l;      // quarter d of the 64 lanes of a record: 1 KiB contiguous
 #pragma unroll
         for (u32 d = 0; d < m / 16; d++) o[d * 64] = make_uint4(w[4 * d], w[4 * d + 1], w[4 * d + 2], w[4 * d + 3]);
     }
 }
 
-// the table of one query in the skewed scan's LDS image: out[q][c * S + x] = lut[q][(x mod m) * 256 + c] for x < m + 31; flag[q] != 0: a non-finite entry
-__global__ __launch_bounds__(256) void pq_scan_skew_table_kernel(const float *__restrict__ lut_g, u32 m, u32 S, float *__restrict__ out, u32 *__restrict__ flag)
+// the table of one query in the skewed scan's LDS image, straight from the codebook: out[q][c * S + x] = T_q[x mod m][c] for x < m + 31 (0 beyond),
+// every entry by pw_run_lane -- numpy's pairwise order, the bits of lut_build_kernel (A2: fast_pq.py:294-318)
+__global__ __launch_bounds__(256) void pq_scan_skew_table_kernel(const float *__restrict__ codebook, const float *__restrict__ queries, u32 D, u32 m, u32 sd, u32 S,
+                                                                 float *__restrict__ out)
 {
     const u32 q = blockIdx.y;
-    const float *src = lut_g + (size_t)q * m * 256;
     float *dst = out + (size_t)q * 256 * S;
-    bool bad = false;
     for (u32 e = blockIdx.x * blockDim.x + threadIdx.x; e < 256u * S; e += gridDim.x * blockDim.x) {
-        const u32 c = e / S, x = e % S;
-        float v = 0.0f;
-        if (x < m + 31u) { v = src[(x % m) * 256 + c]; bad |= !(fabsf(v) <= 3.402823466e38f); }
-        dst[e] = v;
+        const u32 c = e / S, x = e % S, j = x % m;
+        dst[e] = x < m + 31u ? pw_run_lane(codebook + ((size_t)j * 256 + c) * sd, queries + (size_t)q * D + j * sd, (int)sd) : 0.0f;
     }
-    if (bad) atomicOr(flag + q, 1u);
 }
 
-// DEPTH records in flight per lane (registers; refilled as soon as a record's lookups are issued, never behind a branch: the loads past a
-// wavefront's range repeat its last record): one record ahead -- pq_scan_kernel's form -- leaves 16 wavefronts x 2 KiB per CU in flight, a
-// third of what the HBM latency needs, and that, not the LDS, was the pace of the first skewed form (0.66-0.69 of the peak at m = 32).
-#ifdef PQ_SKEW_PLAIN_LOADS
-#define PQ_SKEW_LOAD(p) (*(p))
-#else
-#define PQ_SKEW_LOAD(p) __builtin_nontemporal_load(p)
-#endif
-#ifndef PQ_SKEW_DEPTH32
-#define PQ_SKEW_DEPTH32 2
-#endif
-#ifndef PQ_SKEW_DEPTH16
-#define PQ_SKEW_DEPTH16 2
-#endif
-#ifndef PQ_SKEW_DEPTH64
-#define PQ_SKEW_DEPTH64 2
-#endif
-#ifndef PQ_SKEW_THREADS32
-#define PQ_SKEW_THREADS32 512
-#endif
+// DEPTH records in flight per lane (registers; a record is refilled as soon as its last lookups are issued, never behind a branch: the loads past a
+// stream's end repeat its closing record). Measured at 64M code words: 2 in flight at 16 (m <= 32) or 8 wavefronts per CU beat 1 (-5 %), 3, 4 and
+// 6 (-4 .. -10 %: profiles/r06/ab/pq_scan_skew_*.jsonl); a read-only streaming kernel on the same device reaches 6.4-7.2 TB/s
+// (scripts/micro/hbm_stream.hip), this one 6.4 at m = 32.
 // (OUT: every distance is written. A store in the loop makes the compiler wait for ALL loads in flight once per DEPTH records -- loads and stores
 // share gfx950's vmcnt and complete in no order relative to each other -- so the scan that wants the nearest code word only has none.)
 template <int M16, int THREADS, int DEPTH, bool OUT>
-__global__ __launch_bounds__(THREADS) void pq_scan_skew_kernel(const float *__restrict__ lut_skew, const u32 *__restrict__ flag, const u8 *__restrict__ scan_codes,
-                                                              u64 n, float *__restrict__ out_sq, u64 *__restrict__ out_best)
+__global__ __launch_bounds__(THREADS) void pq_scan_skew_kernel(const float *__restrict__ lut_skew, const u8 *__restrict__ scan_codes,
+                                                              u64 n, u32 V, u32 L, u32 il, float *__restrict__ out_sq, u64 *__restrict__ out_best)
 {
     constexpr u32 m = 16u * M16, S = m <= 32 ? 64u : 128u;
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const u32 qi = blockIdx.y;
+    bool safe;
     {
         const float4 *src = reinterpret_cast<const float4 *>(lut_skew + (size_t)qi * 256 * S);
         float4 *dst = reinterpret_cast<float4 *>(smem);
-        for (u32 e = threadIdx.x; e < 64u * S; e += THREADS) dst[e] = src[e];
+        bool bad = false;
+        for (u32 e = threadIdx.x; e < 64u * S; e += THREADS) {
+            const float4 v = src[e];
+            dst[e] = v;
+            bad |= !(fabsf(v.x) <= 3.402823466e38f && fabsf(v.y) <= 3.402823466e38f && fabsf(v.z) <= 3.402823466e38f && fabsf(v.w) <= 3.402823466e38f);
+        }
+        if ((u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();      // the lookups below address the LDS from 0
+        // a non-finite entry anywhere: the body with selects. The vote goes through slot S - 1 of code byte 0, which no lookup reads (x <= m + 30) and
+        // the image holds as 0 (__syncthreads_or would bring a static LDS word of its own and move the image off address 0)
+        u32 *vote = reinterpret_cast<u32 *>(smem) + (S - 1);
+        __syncthreads();
+        if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0) atomicOr(vote, 1u);
+        __syncthreads();
+        safe = *vote != 0u;
     }
-    const bool safe = flag[qi] != 0;
-    if ((u32)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();      // the lookups below address the LDS from 0
-    __syncthreads();
     const u32 lane = threadIdx.x & 63u, phi = lane & 31u, psi = phi % m;
     const u64 G = (n + 63) / 64;
-    const u64 W = (u64)gridDim.x * (THREADS / 64), gw = (u64)blockIdx.x * (THREADS / 64) + (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const u32 W = gridDim.x * (THREADS / 64), gw = blockIdx.x * (THREADS / 64) + (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     auto uniform64 = [](u64 v) { return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v); };
-    const u64 g0 = uniform64(G * gw / W), g1 = uniform64(G * (gw + 1) / W);      // (scalar registers: the loop counter, the range tests and the record addresses are scalar code)
     const u32 n32 = (u32)(n > 0xFFFFFFFFull ? 0xFFFFFFFFull : n);
     u32 bs = ~0u, bi = ~0u;      // the lane's nearest code word: sum bits (sums are >= +0: their bits order as the values do, NaN last), id
-    if (g0 < g1) {
-        const u32x4 *recs = reinterpret_cast<const u32x4 *>(scan_codes);      // record g, quarter w, lane l: recs[(g * M16 + w) * 64 + l]
+    float mA[m], mB[m];
+#pragma unroll
+    for (u32 p = 0; p < m; p++) {
+        mA[p] = (p + psi < m) ? 1.0f : 0.0f;
+        mB[p] = 1.0f - mA[p];
+        asm volatile("" : "+v"(mB[p]));      // (kept in a register: re-derived from mA it is a third instruction per step)
+    }
+    const u32 lanebase = phi * 4u;
+    const u32x4 *recs = reinterpret_cast<const u32x4 *>(scan_codes);      // record at position pos, quarter w, lane l: recs[(pos * M16 + w) * 64 + l]
+    for (u32 k = gw; k < V; k += W) {      // (the default launch: W == V, one stream per wavefront)
+        // (scalar registers: the loop counter, the range tests and the record addresses are scalar code)
+        const u64 r0 = uniform64(G * k / V), len = uniform64(G * (k + 1) / V) - r0;
+        if (len == 0) continue;
+        const u64 p0 = il ? (u64)k : (u64)k * (L + 1), pstep = il ? (u64)V : 1ull;      // record t at position p0 + t * pstep
         u32x4 buf[DEPTH][M16];
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) {
-            const u64 gl = g0 + d < g1 ? g0 + d : g1;
+            const u64 tl = (u64)d < len ? (u64)d : len;
 #pragma unroll
-            for (int w = 0; w < M16; w++) buf[d][w] = PQ_SKEW_LOAD(recs + (gl * M16 + w) * 64 + lane);
+            for (int w = 0; w < M16; w++) buf[d][w] = __builtin_nontemporal_load(recs + ((p0 + tl * pstep) * M16 + w) * 64 + lane);
         }
-        float mA[m], mB[m];
-#pragma unroll
-        for (u32 p = 0; p < m; p++) {
-            mA[p] = (p + psi < m) ? 1.0f : 0.0f;
-            mB[p] = 1.0f - mA[p];
-            asm volatile("" : "+v"(mB[p]));      // (kept in a register: re-derived from mA it is a third instruction per step)
-        }
-        const u32 lanebase = phi * 4u;
         float sA = 0.0f;
-        for (u64 g = g0; g <= g1; g += DEPTH) {
+        for (u64 t0 = 0; t0 <= len; t0 += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; d++) {
-                const u64 gg = g + d;      // (gg > g1 in a wavefront's last group: the repeated last record is looked up and dropped -- an exit here
+                const u64 tt = t0 + d;      // (tt > len in a stream's last group: the repeated closing record is looked up and dropped -- an exit here
                                            //  makes the compiler wait for every load in flight at the loop's head)
                 // the lookups of a 16-byte quarter are in flight while the sums take the quarter before it
                 float t[2][16];
-                auto look = [&](int w, float (&tt)[16]) {
+                auto look = [&](int w, float (&tq)[16]) {
                     const u32 words[4] = { buf[d][w].x, buf[d][w].y, buf[d][w].z, buf[d][w].w };
 #pragma unroll
                     for (int u = 0; u < 4; u++)
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(THREADS) void pq_scan_skew_kernel(const float *__re
                             u32 addr;
                             if constexpr (S == 64) addr = __builtin_amdgcn_perm(words[u], lanebase, 0x0C0C0400u | ((u32)b << 8));      // (c << 8) | lanebase
                             else addr = (((words[u] >> (8 * b)) & 255u) << 9) + lanebase;
-                            tt[u * 4 + b] = *(const __attribute__((address_space(3))) float *)(uintptr_t)(addr + 4 * p);      // (the image starts at LDS address 0: checked above)
+                            tq[u * 4 + b] = *(const __attribute__((address_space(3))) float *)(uintptr_t)(addr + 4 * p);      // (the image starts at LDS address 0: checked above)
                         }
                 };
                 look(0, t[0]);
@@ -545,9 +547,9 @@ __global__ __launch_bounds__(THREADS) void pq_scan_skew_kernel(const float *__re
                 for (int w = 0; w < M16; w++) {
                     if (w + 1 < M16) look(w + 1, t[(w + 1) & 1]);
                     else {
-                        const u64 gl = gg + DEPTH < g1 ? gg + DEPTH : g1;
+                        const u64 tl = tt + DEPTH < len ? tt + DEPTH : len;
 #pragma unroll
-                        for (int w2 = 0; w2 < M16; w2++) buf[d][w2] = PQ_SKEW_LOAD(recs + (gl * M16 + w2) * 64 + lane);
+                        for (int w2 = 0; w2 < M16; w2++) buf[d][w2] = __builtin_nontemporal_load(recs + ((p0 + tl * pstep) * M16 + w2) * 64 + lane);
                     }
                     if (!safe) {
 #pragma unroll
@@ -557,8 +559,8 @@ __global__ __launch_bounds__(THREADS) void pq_scan_skew_kernel(const float *__re
                         for (int e = 0; e < 16; e++) { const bool inA = (u32)(w * 16 + e) + psi < m; sA = f_add(sA, inA ? t[w & 1][e] : 0.0f); sB = f_add(sB, inA ? 0.0f : t[w & 1][e]); }
                     }
                 }
-                if (gg > g0 && gg <= g1) {      // the word that ended in this record: point (gg - 1) * 64 + lane (ids ascend along a lane: "<" keeps the smallest id of equal sums)
-                    const u32 i = (u32)gg * 64u - 64u + lane, sb = __float_as_uint(sA);
+                if (tt >= 1 && tt <= len) {      // the word that ended in this record: point (r0 + tt - 1) * 64 + lane (ids ascend along a lane: "<" keeps the smallest id of equal sums)
+                    const u32 i = (u32)(r0 + tt) * 64u - 64u + lane, sb = __float_as_uint(sA);
                     if constexpr (OUT) { if (i < n32) out_sq[(size_t)qi * n + i] = sA; }
                     const bool better = sb < bs && i < n32;
                     bs = better ? sb : bs;

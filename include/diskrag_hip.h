@@ -329,7 +329,10 @@ int dr_adc(dr_index *ix, const float *queries, uint32_t nq, const uint32_t *node
 int dr_pq_scan(dr_index *ix, const float *queries, uint32_t nq, float *out_sq /*[nq][N]*/, float *kernel_ms);
 /* The same scan, also returning the nearest code word per query (smallest id among equal sums): the isolated
  * ADC kernel of the path, benched against the HBM roofline on a code table far larger than the caches
- * (scripts/bench_pq_scan.py). out_sq may be null. */
+ * (scripts/bench_pq_scan.py). out_sq may be null. One query (and DR_PQ_SCAN_PER_QUERY=1), n_subvectors in {16, 32, 48, 64}:
+ * the scan reads a second copy of the code words in its own order (N * m bytes of device memory, built by the first such call
+ * and rebuilt after the code words change; without room for it, or with DR_PQ_SCAN_NO_SKEW=1, the scan reads the code words
+ * themselves at 0.6 of the speed). Same results either way. */
 int dr_pq_scan_best(dr_index *ix, const float *queries, uint32_t nq, float *out_sq, uint32_t *out_best_id,
                     float *out_best_sq, float *kernel_ms);
 /* Brute-force ADC search: the k (<= 64) nearest code words per query by a flat scan of all N code words, in (distance, id)

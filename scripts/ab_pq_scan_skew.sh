@@ -1,12 +1,13 @@
 #!/bin/bash
-# interleaved A/B of the one-query flat PQ scan (round 6): the skewed kernel (in-tree build) against pq_scan_kernel (DR_PQ_SCAN_NO_SKEW=1) and
+# interleaved A/B of the one-query flat PQ scan (round 6): the skewed kernel (in-tree build; 'contiguous': every stream of the scan-order copy in one
+# piece, DR_PQ_SCAN_CONTIGUOUS_STREAMS=1) against pq_scan_kernel (DR_PQ_SCAN_NO_SKEW=1) and
 # against other builds of the skewed kernel (given as DR_LIB paths: -DPQ_SKEW_PLAIN_LOADS, -DPQ_SKEW_DEPTH32=2|6; m = 32 only).
 # usage: ab_pq_scan_skew.sh OUT [lib ...]     -> JSON lines (scripts/bench_pq_scan.py: 64M code words, one query, m = 32 and m = 16)
 out=$1; shift
 for round in 1 2; do
-  for v in skew noskew "$@"; do
-    unset DR_LIB DR_PQ_SCAN_NO_SKEW
-    case $v in skew) ;; noskew) export DR_PQ_SCAN_NO_SKEW=1 ;; *) export DR_LIB=$PWD/$v ;; esac
+  for v in skew contiguous noskew "$@"; do
+    unset DR_LIB DR_PQ_SCAN_NO_SKEW DR_PQ_SCAN_CONTIGUOUS_STREAMS
+    case $v in skew) ;; contiguous) export DR_PQ_SCAN_CONTIGUOUS_STREAMS=1 ;; noskew) export DR_PQ_SCAN_NO_SKEW=1 ;; *) export DR_LIB=$PWD/$v ;; esac
     ms="32 16 64"
     for m in $ms; do
       echo "{\"variant\": \"$(basename $v .so)\", \"round\": $round, \"m\": $m, \"run\": $(timeout 600 python scripts/bench_pq_scan.py 64000000 $m 1 128 2>>$out.err)}" >> $out
