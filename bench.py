@@ -1225,7 +1225,7 @@ def worker_c5(args, rk):
     # Exchanges of --c5-group submits (a count, never a timing: every rank forms the same exchanges), three exchanges' worth of submits in
     # flight: a 10k-query launch of this kernel is 4.9 queries per wavefront slot and ends in a tail of idle slots
     # (profiles/r04/scale_c5_shard_R128_stream.json: 1.44 -> 1.76 M QPS on the full-size shard with 26.7 k queries per launch)
-    grp = max(1, min(16, args.c5_group, 32768 // max(1, nq)))
+    grp = max(1, min(16, args.c5_group, 65536 // max(1, nq)))
     _ffi.sharded_set_group(sh, grp)
     depth_c5 = 2 if grp == 1 else 3 * grp
 
@@ -1243,6 +1243,17 @@ def worker_c5(args, rk):
     stream(max(2 * depth_c5, args.warmup))
     rk.barrier()
     el, (ids, dist, status, _), ms = stream(args.steps)
+    group_ab = None
+    if os.environ.get("DR_BENCH_C5_GROUPS"):      # A/B of the exchange size in ONE process (one index): "3,6,3,6" -> QPS of a stream of 2 * steps batches per entry
+        group_ab = []
+        for g in [int(v) for v in os.environ["DR_BENCH_C5_GROUPS"].split(",")]:
+            _ffi.sharded_set_group(sh, g)
+            depth_c5 = 2 if g == 1 else 3 * g
+            stream(2 * depth_c5)
+            rk.barrier()
+            el_g = stream(2 * args.steps)[0]
+            group_ab.append({"submits_per_exchange": g, "qps": nq * 2 * args.steps / max(rk.gather("t_c5_g%d" % len(group_ab), el_g))})
+        depth_c5 = 2 if grp == 1 else 3 * grp
     _ffi.sharded_set_group(sh, 1)
     times = rk.gather("t_c5", el)
     if int(status.max()) != 0:
@@ -1266,7 +1277,7 @@ def worker_c5(args, rk):
                       "adc_ranking_recall_at_10_vs_exact_neighbours": recall_at_k(gt, gt_exact, k),
                       "ground_truth_queries": ngt, "rccl_ranks": rk.world, "exact_ground_truth_seconds": ex_s,
                       "build_seconds": build_s, "encode_seconds": enc_s, "codebook_seconds": cb_s,
-                      "per_rank_seconds": times, "exchange_bytes_per_rank_per_batch": (nq * k + 1) * 8, "submits_per_exchange": grp, "submits_in_flight": depth_c5,
+                      "per_rank_seconds": times, "exchange_bytes_per_rank_per_batch": (nq * k + 1) * 8, "submits_per_exchange": grp, "submits_in_flight": depth_c5, "exchange_size_ab": group_ab,
                       "one_blocking_call_ms": {"search": float(ms1[0]), "all_gather": float(ms1[1]), "merge": float(ms1[2])},
                       "search_kernel": {"variant": tm["variant"], "kernel_ms": tm["search_kernel_ms"], "table_kernel_ms": tm["lut_kernel_ms"],
                                         "waves_per_cu": tm["waves_per_cu"]}}}

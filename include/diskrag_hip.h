@@ -224,7 +224,7 @@ int dr_sharded_submit(dr_index *const *shards, const uint32_t *id_base, uint32_t
                       float *out_ms, uint64_t *out_ticket);
 int dr_sharded_wait(dr_index *first_shard, uint64_t ticket);
 /* Submits per EXCHANGE (1 ... 16; default 1). With n > 1 the searches of n consecutive dr_sharded_submit calls (same shards, communicator and
- * parameters; <= 32768 queries together) run as ONE launch per shard and their lists travel in ONE all-gather: a 10 000-query launch of the
+ * parameters; <= 65536 queries together since round 6) run as ONE launch per shard and their lists travel in ONE all-gather: a 10 000-query launch of the
  * PQ-only traversal is 4.9 queries per wavefront slot and ends in a tail of idle slots (one 1.25e8-point shard: 1.44 -> 1.76 M QPS at 26.7 k
  * queries per launch). The rule is a COUNT, never a timing, so that every rank forms the same exchanges: an exchange is launched when it holds
  * n submits, when the next submit does not fit or differs, when one of its tickets is waited for, or by dr_sharded_flush; every ticket gets
