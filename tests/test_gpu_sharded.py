@@ -213,6 +213,17 @@ def test_grouped_exchanges_carry_several_submits():
                 assert ei.value.code == _ffi.E_NOPQ
             _ffi.sharded_set_group(shards[0], 1)
             assert same(_ffi.sharded_submit(shards, bases, batches[0], k, comm=c, **kw).wait(), want[0])
+        # round 6: an exchange holds up to 65536 queries (32768 before): five 12000-query submits ride in ONE launch per shard, a sixth
+        # would not fit next to them and opens the next exchange; every ticket still gets the bits of its own rows
+        big = np.ascontiguousarray(np.tile(q, (100, 1)))
+        wantb = _ffi.sharded_search(shards, bases, big, k, comm=None, **kw)
+        _ffi.sharded_set_group(shards[0], 6)
+        jobs = [_ffi.sharded_submit(shards, bases, big, k, comm=None, **kw) for _ in range(6)]
+        got = [j.wait() for j in jobs]
+        for g in got:
+            assert same(g, wantb)
+        assert np.array_equal(got[0][3], got[4][3]) and not np.array_equal(got[0][3], got[5][3])      # five of 12000 in one exchange (60000 <= 65536), the sixth alone
+        _ffi.sharded_set_group(shards[0], 1)
         with pytest.raises(_ffi.DiskragHipError):
             _ffi.sharded_set_group(shards[0], 17)
     finally:
