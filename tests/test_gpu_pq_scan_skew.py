@@ -90,3 +90,25 @@ def test_the_scan_order_copy_follows_the_code_words():
         assert np.array_equal(bits(c[0]), bits(orc.adc(orc.build_lut(cb3, q[0]), codes3)[0]))
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("contiguous", [False, True])
+def test_several_streams_per_wavefront_and_both_layouts_of_the_copy(contiguous, monkeypatch):
+    """three block rows share the device (fewer wavefronts than streams of the scan-order copy: a wavefront walks several streams); the interleaved
+    layout and DR_PQ_SCAN_CONTIGUOUS_STREAMS=1 (the A/B layout: every stream in one piece) give the same bits"""
+    from oracle import pyoracle as orc
+    if contiguous:
+        monkeypatch.setenv("DR_PQ_SCAN_CONTIGUOUS_STREAMS", "1")
+    ix, cb, codes, rs = _index(300007, 128, 32, 23)
+    try:
+        q = rs.randn(3, 128).astype(np.float32)
+        _, _, _, a = ix.pq_scan_best(q[:1], want_output=True)
+        monkeypatch.setenv("DR_PQ_SCAN_PER_QUERY", "1")
+        bid, bsq, _, b = ix.pq_scan_best(q, want_output=True)
+        for qi in range(3):
+            want = orc.adc(orc.build_lut(cb, q[qi]), codes)[0]
+            assert np.array_equal(bits(b[qi]), bits(want))
+            assert int(bid[qi]) == int(np.flatnonzero(want == want.min())[0])
+        assert np.array_equal(bits(a[0]), bits(b[0]))
+    finally:
+        ix.close()
