@@ -419,12 +419,16 @@ def isolated_pq_scan(device, n_codes=64_000_000, m=32, D=128, nq=4):
     finally:
         del os.environ["DR_PQ_SCAN_NO_SKEW"]
     msn = sorted(sc.pq_scan_best(q)[2] for _ in range(5))             # nq queries sharing the pass (pq_scan_multi_kernel: 4 per group at m <= 32)
+    sc.pq_scan_topk(q[:1], 10)
+    mst = sorted(sc.pq_scan_topk(q[:1], 10)[2] for _ in range(5))     # the brute-force ADC search of ONE query (the skewed kernel with a list of k keys per wavefront)
     sc.close()
     gbps = n_codes * m / (ms[2] * 1e-3) / 1e9
     per_pass = 4 if m <= 32 and nq > 2 else 2
     passes = -(-nq // per_pass)
     return {"kernel": "pq_scan_skew_table_kernel + pq_scan_skew_kernel<2, 512, 2, false>", "code_bytes_per_launch": n_codes * m, "kernel_ms_median": ms[2], "GBps": gbps,
             "frac": gbps / HBM_PEAK_GBPS, "queries_per_launch": 1,
+            "brute_force_adc_top10_one_query": {"kernel": "pq_scan_skew_kernel<2, 512, 2, false, true> (dr_pq_scan_topk)", "kernel_ms_median": mst[2],
+                                                "frac": n_codes * m / (mst[2] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             "previous_kernel": {"kernel": "pq_scan_kernel<2>", "kernel_ms_median": ms_old[2], "frac": n_codes * m / (ms_old[2] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
             "shared_pass": {"kernel": "pq_scan_multi_kernel<2, 4, 768>", "queries_per_launch": nq, "queries_per_pass": per_pass, "kernel_ms_median": msn[2],
                             "ms_per_query": msn[2] / nq, "GBps_algorithmic": nq * n_codes * m / (msn[2] * 1e-3) / 1e9,

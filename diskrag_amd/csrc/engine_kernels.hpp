@@ -466,9 +466,13 @@ __global__ __launch_bounds__(256) void pq_scan_skew_table_kernel(const float *__
 // (scripts/micro/hbm_stream.hip), this one 6.4 at m = 32.
 // (OUT: every distance is written. A store in the loop makes the compiler wait for ALL loads in flight once per DEPTH records -- loads and stores
 // share gfx950's vmcnt and complete in no order relative to each other -- so the scan that wants the nearest code word only has none.)
-template <int M16, int THREADS, int DEPTH, bool OUT>
+// (TOPK: the brute-force ADC search of one query -- dr_pq_scan_topk. Every wavefront keeps an ascending list of k keys (distance bits << 32 | id) in
+// LDS behind the table image and a wave-uniform threshold, as pq_scan_topk_kernel does; its list goes to part[query][wavefront of the launch][k] and
+// topk_merge_kernel folds the lists.)
+template <int M16, int THREADS, int DEPTH, bool OUT, bool TOPK = false>
 __global__ __launch_bounds__(THREADS) void pq_scan_skew_kernel(const float *__restrict__ lut_skew, const u8 *__restrict__ scan_codes,
-                                                              u64 n, u32 V, u32 L, u32 il, float *__restrict__ out_sq, u64 *__restrict__ out_best)
+                                                              u64 n, u32 V, u32 L, u32 il, float *__restrict__ out_sq, u64 *__restrict__ out_best,
+                                                              u32 k, u64 *__restrict__ part)
 {
     constexpr u32 m = 16u * M16, S = m <= 32 ? 64u : 128u;
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
@@ -499,6 +503,10 @@ __global__ __launch_bounds__(THREADS) void pq_scan_skew_kernel(const float *__re
     auto uniform64 = [](u64 v) { return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v); };
     const u32 n32 = (u32)(n > 0xFFFFFFFFull ? 0xFFFFFFFFull : n);
     u32 bs = ~0u, bi = ~0u;      // the lane's nearest code word: sum bits (sums are >= +0: their bits order as the values do, NaN last), id
+    u64 *klist = reinterpret_cast<u64 *>(smem + (size_t)256 * S * 4) + (threadIdx.x >> 6) * 64;      // TOPK: the wavefront's k smallest keys, ascending
+    u64 Wk = ~0ull;              // ... and its k-th smallest key so far (wave-uniform)
+    int kn = 0;
+    if constexpr (TOPK) { klist[lane] = ~0ull; WSYNC(); }
     float mA[m], mB[m];
 #pragma unroll
     for (u32 p = 0; p < m; p++) {
@@ -508,11 +516,11 @@ __global__ __launch_bounds__(THREADS) void pq_scan_skew_kernel(const float *__re
     }
     const u32 lanebase = phi * 4u;
     const u32x4 *recs = reinterpret_cast<const u32x4 *>(scan_codes);      // record at position pos, quarter w, lane l: recs[(pos * M16 + w) * 64 + l]
-    for (u32 k = gw; k < V; k += W) {      // (the default launch: W == V, one stream per wavefront)
+    for (u32 ks = gw; ks < V; ks += W) {      // (the default launch: W == V, one stream per wavefront)
         // (scalar registers: the loop counter, the range tests and the record addresses are scalar code)
-        const u64 r0 = uniform64(G * k / V), len = uniform64(G * (k + 1) / V) - r0;
+        const u64 r0 = uniform64(G * ks / V), len = uniform64(G * (ks + 1) / V) - r0;
         if (len == 0) continue;
-        const u64 p0 = il ? (u64)k : (u64)k * (L + 1), pstep = il ? (u64)V : 1ull;      // record t at position p0 + t * pstep
+        const u64 p0 = il ? (u64)ks : (u64)ks * (L + 1), pstep = il ? (u64)V : 1ull;      // record t at position p0 + t * pstep
         u32x4 buf[DEPTH][M16];
 #pragma unroll
         for (int d = 0; d < DEPTH; d++) {
@@ -562,15 +570,38 @@ __global__ __launch_bounds__(THREADS) void pq_scan_skew_kernel(const float *__re
                 if (tt >= 1 && tt <= len) {      // the word that ended in this record: point (r0 + tt - 1) * 64 + lane (ids ascend along a lane: "<" keeps the smallest id of equal sums)
                     const u32 i = (u32)(r0 + tt) * 64u - 64u + lane, sb = __float_as_uint(sA);
                     if constexpr (OUT) { if (i < n32) out_sq[(size_t)qi * n + i] = sA; }
-                    const bool better = sb < bs && i < n32;
-                    bs = better ? sb : bs;
-                    bi = better ? i : bi;
+                    if constexpr (TOPK) {
+                        const u64 key = ((u64)sb << 32) | i;
+                        u64 cmk = __ballot(i < n32 && key < Wk);
+                        while (cmk) {      // (rare once the list has warmed up: the threshold is the k-th smallest of what this wavefront has seen)
+                            const int f = __ffsll((long long)cmk) - 1;
+                            cmk &= cmk - 1;
+                            const u64 kf = readlane64(key, f);
+                            if (kf < Wk) {
+                                const u64 mine = ((int)lane < kn) ? klist[lane] : ~0ull;
+                                const int pos = __popcll(__ballot((int)lane < kn && mine < kf));
+                                WSYNC();
+                                if ((int)lane < kn && (int)lane >= pos && lane + 1 < k) klist[lane + 1] = mine;
+                                if (lane == 0) klist[pos] = kf;
+                                WSYNC();
+                                if (kn < (int)k) kn++;
+                                if (kn == (int)k) Wk = klist[k - 1];
+                            }
+                        }
+                    } else {
+                        const bool better = sb < bs && i < n32;
+                        bs = better ? sb : bs;
+                        bi = better ? i : bi;
+                    }
                 }
                 sA = sB;
             }
         }
     }
-    if (out_best) {
+    if constexpr (TOPK) {
+        WSYNC();
+        if (lane < k) part[((size_t)qi * W + gw) * k + lane] = ((int)lane < kn) ? klist[lane] : ~0ull;
+    } else if (out_best) {
         u64 best = ((u64)bs << 32) | bi;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { const u64 other = __shfl_xor(best, o); best = other < best ? other : best; }

@@ -112,3 +112,34 @@ def test_several_streams_per_wavefront_and_both_layouts_of_the_copy(contiguous, 
         assert np.array_equal(bits(a[0]), bits(b[0]))
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("D,m", [(64, 16), (128, 32), (96, 48), (128, 64)])
+def test_brute_force_adc_search_of_one_query_on_the_skewed_kernel(D, m, monkeypatch):
+    """dr_pq_scan_topk with one query (and one block row per query): the k smallest (distance, id) pairs of the flat scan, the smaller id first among
+    equal sums; == pq_scan_topk_kernel (DR_PQ_SCAN_NO_SKEW=1)"""
+    for n in (50, 4097, 250003):
+        ix, cb, codes, rs = _index(n, D, m, 7 * m + n % 89)
+        try:
+            if n > 200:
+                codes[17] = codes[n - 3]; codes[n // 2] = codes[n - 3]      # equal sums
+                ix.set_pq(cb, codes)
+            q = rs.randn(3, D).astype(np.float32)
+            full = ix.pq_scan_best(q, want_output=True)[3]
+            for k in (1, 10, 64):
+                got1 = ix.pq_scan_topk(q[:1], k)
+                monkeypatch.setenv("DR_PQ_SCAN_PER_QUERY", "1")
+                got3 = ix.pq_scan_topk(q, k)
+                monkeypatch.setenv("DR_PQ_SCAN_NO_SKEW", "1")
+                old3 = ix.pq_scan_topk(q, k)
+                monkeypatch.delenv("DR_PQ_SCAN_NO_SKEW")
+                monkeypatch.delenv("DR_PQ_SCAN_PER_QUERY")
+                assert np.array_equal(got3[0], old3[0]) and np.array_equal(bits(got3[1]), bits(old3[1]))
+                assert np.array_equal(got1[0][0], got3[0][0]) and np.array_equal(bits(got1[1][0]), bits(got3[1][0]))
+                for qi in range(3):
+                    order = np.lexsort((np.arange(n), full[qi]))[:k]
+                    kk = min(k, n)
+                    assert np.array_equal(got3[0][qi][:kk], order.astype(np.uint32)[:kk]), (n, k, qi)
+                    assert np.array_equal(bits(got3[1][qi][:kk]), bits(full[qi][order][:kk]))
+        finally:
+            ix.close()
