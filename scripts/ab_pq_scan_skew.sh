@@ -1,8 +1,8 @@
 #!/bin/bash
 # interleaved A/B of the one-query flat PQ scan (round 6): the skewed kernel (in-tree build; 'contiguous': every stream of the scan-order copy in one
 # piece, DR_PQ_SCAN_CONTIGUOUS_STREAMS=1) against pq_scan_kernel (DR_PQ_SCAN_NO_SKEW=1) and
-# against other builds of the skewed kernel (given as DR_LIB paths: -DPQ_SKEW_PLAIN_LOADS, -DPQ_SKEW_DEPTH32=2|6; m = 32 only).
-# usage: ab_pq_scan_skew.sh OUT [lib ...]     -> JSON lines (scripts/bench_pq_scan.py: 64M code words, one query, m = 32 and m = 16)
+# against other builds of the library (given as DR_LIB paths: the round's variants were builds with other block sizes, records in flight and load kinds).
+# usage: ab_pq_scan_skew.sh OUT [lib ...]     -> JSON lines (scripts/bench_pq_scan.py: 64M code words, one query, m = 32, 16 and 64)
 out=$1; shift
 for round in 1 2; do
   for v in skew contiguous noskew "$@"; do
