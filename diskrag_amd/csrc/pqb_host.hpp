@@ -13,7 +13,9 @@ const PqbTable *dr_pqb_table_m1_t8();
 const PqbTable *dr_pqb_table_m2_t16();
 const PqbTable *dr_pqb_table_m2_t24();
 const PqbTable *dr_pqb_table_m3_t16();
+const PqbTable *dr_pqb_table_m3_t32();
 const PqbTable *dr_pqb_table_m4_t32();
+const PqbTable *dr_pqb_table_m4_t48();
 
 // sc: size class of the list (0..4); nc: passes per step (1, 2, 4); m: sub-quantisers; treg_pref: -1 = the engine's choice
 static inline PqbChoice dr_pqb_choose(int sc, int nc, uint32_t m, int treg_pref)
@@ -28,8 +30,11 @@ static inline PqbChoice dr_pqb_choose(int sc, int nc, uint32_t m, int treg_pref)
         const int tr = treg_pref == 16 ? 16 : treg_pref == 24 ? 24 : (nc <= 2 && sc <= 3) ? 24 : 16;
         t = tr == 24 ? dr_pqb_table_m2_t24() : dr_pqb_table_m2_t16();
     }
-    else if (m == 48) t = dr_pqb_table_m3_t16();
-    else if (m == 64) t = dr_pqb_table_m4_t32();
+    // m = 48 / 64 (round 6): the LDS rows set the wavefronts per CU (32 rows: 4, 16 rows: 8), so as many rows as the 256 registers of two wavefronts per
+    // SIMD hold go to registers -- m = 64, L = 100, beam_width 32 on 1M x 1536: 32 / 40 / 48 rows 4.31 / 4.15 / 3.67 ms per 10 000 queries, m = 48: 16 / 32 rows 3.23 / 2.70 (and at m = 64 8.5 ms
+    // before, when the 32-row form was compiled for three wavefronts per SIMD and spilled); four passes per step keep the 32-row form (no scratch)
+    else if (m == 48) t = (treg_pref == 16 || (treg_pref != 32 && nc > 2)) ? dr_pqb_table_m3_t16() : dr_pqb_table_m3_t32();
+    else if (m == 64) t = (treg_pref == 32 || (treg_pref != 48 && nc > 2)) ? dr_pqb_table_m4_t32() : dr_pqb_table_m4_t48();
     else if (m <= 128) t = dr_pqb_table_m0_t0();
     PqbChoice c = { nullptr, 0, 0, 1 };
     if (!t) return c;

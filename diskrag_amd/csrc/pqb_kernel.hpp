@@ -129,11 +129,12 @@ static inline size_t pqb_lds_bytes(uint32_t m, int treg, int nchr, int nc)
 
 template <int NCHR, int NC, int M16, int TREG>
 // (wavefronts per SIMD the registers must allow: 3 with 24 of 32 rows in registers -- 8 KiB of LDS per wavefront, 12 per CU --; 4 for the
-// small table of m = 16 with half of it in registers)
+// small table of m = 16 with half of it in registers; m = 64: the LDS rows decide -- 32 of 64 rows in LDS are 4 wavefronts per CU, one per SIMD, so the
+// registers need not be cut to 168 (round 6: that cap cost 64-970 bytes of scratch per lane), 24 / 16 rows in LDS are 6 / 8 per CU at <= 256 registers)
 #ifdef PQB_FORCE_WAVES4      // A/B: the <= 128-register form -- four wavefronts per SIMD whatever it spills
 __global__ __launch_bounds__(64, 4) void pqb_search_kernel(const PqbParams p)
 #else
-__global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (TREG >= 24) ? 3 : 2) void pqb_search_kernel(const PqbParams p)
+__global__ __launch_bounds__(64, (M16 == 1 && TREG == 8) ? 4 : (M16 == 4) ? ((TREG >= 48) ? 2 : 1) : (M16 == 3) ? ((TREG >= 32) ? 2 : 1) : (TREG >= 24) ? 3 : 2) void pqb_search_kernel(const PqbParams p)
 #endif
 {
     static_assert(TREG == 0 || (M16 > 0 && TREG <= M16 * 16 && TREG % 8 == 0), "register rows need a compile-time m");
