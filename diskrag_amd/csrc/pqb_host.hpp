@@ -34,7 +34,7 @@ static inline PqbChoice dr_pqb_choose(int sc, int nc, uint32_t m, int treg_pref)
     // SIMD hold go to registers -- m = 64, L = 100, beam_width 32 on 1M x 1536: 32 / 40 / 48 rows 4.31 / 4.15 / 3.67 ms per 10 000 queries, m = 48: 16 / 32 rows 3.23 / 2.70 (and at m = 64 8.5 ms
     // before, when the 32-row form was compiled for three wavefronts per SIMD and spilled); four passes per step keep the 32-row form (no scratch)
     else if (m == 48) t = (treg_pref == 16 || (treg_pref != 32 && nc > 2)) ? dr_pqb_table_m3_t16() : dr_pqb_table_m3_t32();
-    else if (m == 64) t = (treg_pref == 32 || (treg_pref != 48 && nc > 2)) ? dr_pqb_table_m4_t32() : dr_pqb_table_m4_t48();
+    else if (m == 64) t = (treg_pref == 32 || (treg_pref != 48 && (nc > 2 || (nc == 2 && sc >= 3)))) ? dr_pqb_table_m4_t32() : dr_pqb_table_m4_t48();      // (two passes per step with lists beyond 256 entries: the 48-row form spills 900 bytes)
     else if (m <= 128) t = dr_pqb_table_m0_t0();
     PqbChoice c = { nullptr, 0, 0, 1 };
     if (!t) return c;
